@@ -1,0 +1,303 @@
+"""CPU oracle of the NLT model: channel schedule, two-path U-Net, warp, losses, train step.
+
+ORACLE = test infrastructure (see oracle/__init__.py); never imported by the product.
+Follows, in order: nlt/util/net.py:18-56 -> nlt/networks/convnet.py:30-90 ->
+nlt/networks/elements.py:26-39,69-78 -> nlt/models/nlt.py:39-64,89-199 ->
+nlt/util/img.py:74-120,179-185 -> nlt/losses.py:39-53,90-118 -> nlt/trainvali.py:272-281.
+"""
+import math
+
+import numpy as np
+import torch
+
+from . import tf_ops as T
+from . import barron as B
+
+
+# ----------------------------------------------------------------------------
+# nlt/util/net.py:18-56
+# ----------------------------------------------------------------------------
+def gen_feat_n(min_n, max_n, final_n=3):
+    assert max_n >= min_n and max_n >= final_n
+    n_ch = [2 ** i for i in range(int(np.log2(min_n)) + 1, int(np.log2(max_n)) + 1)]
+    if not n_ch or n_ch[0] != min_n:
+        n_ch = [min_n] + n_ch
+    if not n_ch or n_ch[-1] != max_n:
+        n_ch.append(max_n)
+    n_ch += n_ch[::-1]
+    n_ch += [2 ** i for i in range(int(np.log2(n_ch[-1])) - 1, int(np.log2(final_n)), -1)]
+    while n_ch and n_ch[-1] < final_n:
+        n_ch.pop()
+    n_ch.append(final_n)
+    return n_ch
+
+
+# ----------------------------------------------------------------------------
+# nlt/networks/convnet.py:30-90 (released branch: norm=None, pool=None)
+# ----------------------------------------------------------------------------
+def build_layers(depth0, depth, kernel=2, stride=2):
+    """Returns (layers, is_contracting, spatsize_changes); a layer is a dict
+    {'kind': 'conv1x1'|'down'|'up', 'n': out_channels, 'act': bool}."""
+    n_feat = gen_feat_n(depth0, depth)
+    layers, is_c, ssc = [], [], []
+    layers.append({'kind': 'conv1x1', 'n': n_feat[0], 'act': False})   # :44
+    is_c.append(True); ssc.append(1)
+    prev_n = 0
+    for n in n_feat[:-1]:
+        if n >= prev_n:                                                # :49-64
+            layers.append({'kind': 'down', 'n': n, 'act': True, 'k': kernel, 's': stride})
+            is_c.append(True); ssc.append(1 / stride)
+        else:                                                          # :66-81
+            layers.append({'kind': 'up', 'n': n, 'act': True, 'k': kernel, 's': stride})
+            is_c.append(False); ssc.append(stride)
+        prev_n = n
+    layers.append({'kind': 'conv1x1', 'n': n_feat[-1], 'act': False})  # :85
+    is_c.append(False); ssc.append(1)
+    assert np.cumprod(ssc)[-1] == 1, "Resolution doesn't return to the original value"  # :88-90
+    return layers, is_c, ssc
+
+
+def _layer_in_channels(layers, is_c, cin_query, cin_obs, use_obs=True):
+    """Channel count entering each query/obs layer under Model._call's concat
+    rules (nlt/models/nlt.py:141-199), including the bottleneck self-concat."""
+    q_in, o_in = [], []
+    qc, oc = cin_query, cin_obs
+    stack = []
+    for L, c in zip(layers, is_c):
+        if c:
+            q_in.append(qc); o_in.append(oc)
+            oc = L['n']
+            qc = L['n'] + (L['n'] if use_obs else 0)
+            stack.append(qc)
+        else:
+            if stack:
+                qc = qc + stack.pop()
+            q_in.append(qc); o_in.append(None)
+            qc = L['n']
+    return q_in, o_in
+
+
+def init_weights(layers, in_channels, rng, bias_range=0.1, contracting_only=None):
+    """Keras-layout weights.  conv: (kh,kw,Cin,Cout); deconv: (kh,kw,Cout,Cin).
+    Kernels glorot-uniform (Keras default); biases U(-bias_range,bias_range) instead of
+    Keras' zeros so the bias path is exercised."""
+    ws = []
+    for i, (L, cin) in enumerate(zip(layers, in_channels)):
+        if contracting_only is not None and not contracting_only[i]:
+            break
+        n = L['n']
+
+        def bias():
+            return rng.uniform(-bias_range, bias_range, size=(n,)).astype(np.float32)
+        if L['kind'] == 'conv1x1':
+            ws.append([(T.glorot_uniform(rng, (1, 1, cin, n)), bias())])
+        elif L['kind'] == 'down':
+            k = L['k']
+            ws.append([(T.glorot_uniform(rng, (k, k, cin, n)), bias()),
+                       (T.glorot_uniform(rng, (k, k, n, n)), bias())])
+        else:
+            k = L['k']
+            ws.append([(T.glorot_uniform(rng, (k, k, n, cin)), bias()),
+                       (T.glorot_uniform(rng, (k, k, n, n)), bias())])
+    return ws
+
+
+def apply_layer(L, w, x):
+    """One entry of Network.layers (convnet.py:44,50-59,67-76,85)."""
+    if L['kind'] == 'conv1x1':
+        return T.conv2d_same(x, w[0][0], w[0][1], 1)
+    if L['kind'] == 'down':
+        y = T.leaky_relu(T.conv2d_same(x, w[0][0], w[0][1], L['s']))
+        return T.leaky_relu(T.conv2d_same(y, w[1][0], w[1][1], 1))
+    y = T.leaky_relu(T.conv2d_transpose_same(x, w[0][0], w[0][1], L['s']))
+    return T.leaky_relu(T.conv2d_transpose_same(y, w[1][0], w[1][1], 1))
+
+
+class OracleModel:
+    """nlt/models/nlt.py Model, restated.  Weights are torch-CPU leaf tensors."""
+
+    def __init__(self, depth0=16, depth=256, kernel=2, stride=2, uvh=512, uvw=512, imh=512,
+                 imw=512, use_obs=True, skip_connect_base=True, loss='l2', seed=0, dtype=torch.float32):
+        self.layers, self.is_contracting, _ = build_layers(depth0, depth, kernel, stride)
+        self.uvh, self.uvw, self.imh, self.imw = uvh, uvw, imh, imw
+        self.use_obs, self.skip_connect_base = use_obs, skip_connect_base
+        self.loss_spec = loss
+        q_in, o_in = _layer_in_channels(self.layers, self.is_contracting, 5, 3, use_obs)
+        rng = np.random.default_rng(seed)
+        wq = init_weights(self.layers, q_in, rng)
+        wo = init_weights(self.layers, o_in, rng, contracting_only=self.is_contracting)
+        tt = lambda a: torch.tensor(a, dtype=dtype, requires_grad=True)
+        self.wq = [[(tt(k), tt(b)) for k, b in lw] for lw in wq]
+        self.wo = [[(tt(k), tt(b)) for k, b in lw] for lw in wo]   # obs net keeps contracting layers only (nlt.py:57-59)
+
+    # -- flat parameter order shared with the product: query layers, then obs layers; kernel then bias
+    def parameters(self):
+        out = []
+        for net in (self.wq, self.wo):
+            for lw in net:
+                for k, b in lw:
+                    out += [k, b]
+        return out
+
+    def numpy_weights(self):
+        conv = lambda net: [[(k.detach().numpy().copy(), b.detach().numpy().copy()) for k, b in lw] for lw in net]
+        return {'query': conv(self.wq), 'obs': conv(self.wo)}
+
+    # -- nlt/models/nlt.py:141-199
+    def _call(self, query_x, obs_xs, obs_weights=None, obs_override=None, return_feats=False):
+        feats = []
+        if obs_weights is not None:
+            obs_weights = obs_weights.reshape(obs_weights.shape[0], 1, 1, 1, -1)
+        stack = []
+        query_y = None
+        for i, (L, c) in enumerate(zip(self.layers, self.is_contracting)):
+            if c:
+                obs_ys = [apply_layer(L, self.wo[i], x) for x in obs_xs]       # :154-155
+                obs_agg = torch.stack(obs_ys, -1)                               # :161
+                if obs_weights is not None:
+                    obs_agg = obs_weights * obs_agg                             # :162-163
+                obs_agg = obs_agg.mean(-1)                                      # :164
+                obs_xs = obs_ys                                                 # :166
+                query_y = apply_layer(L, self.wq[i], query_x)                   # :168
+                if self.use_obs:
+                    if obs_override is not None:
+                        obs_agg = obs_override[i]                               # :172-173
+                    query_x = torch.cat((query_y, obs_agg), -1)                 # :174
+                else:
+                    query_x = query_y
+                stack.append(query_x)                                           # :180
+                feats.append(obs_agg)
+            else:
+                if stack:
+                    query_x = torch.cat((query_x, stack.pop()), -1)             # :184-190
+                query_y = apply_layer(L, self.wq[i], query_x)                   # :195
+                query_x = query_y
+        return (query_y, feats) if return_feats else query_y
+
+    # -- nlt/models/nlt.py:89-139
+    def call(self, batch, mode='train', obs_override=None, nn_list=None):
+        """batch = the reference 11-tuple (ids may be None).  `nn_list`, if given, is a
+        list of (nn_base, nn_rgb) pairs and replaces the single neighbour of the
+        reference (k>1 observation maps; _call already takes a list, nlt.py:154-164)."""
+        if mode not in ('train', 'vali', 'test'):
+            raise ValueError(mode)
+        _, base, cvis, lvis, warp, rgb, rgb_camspc, _, nn_base, nn_rgb, _ = batch
+        x = torch.cat((base, cvis, lvis), 3)                                    # :95
+        if nn_list is None:
+            y_obs = [nn_rgb - nn_base]                                          # :96
+        else:
+            y_obs = [r - b for b, r in nn_list]
+        pred = self._call(x, y_obs, obs_override=obs_override)
+        if self.skip_connect_base:
+            pred = pred + base                                                  # :101-102
+        warp_px = torch.stack((warp[..., 0] * self.uvw, warp[..., 1] * self.uvh), 3)  # :104-106
+        fg = T.set_left_top_corner(torch.ones_like(pred), 0)                    # :107-108
+        base0 = T.set_left_top_corner(base, 0)
+        pred = T.set_left_top_corner(pred, 0)
+        fg_c = T.resize_bilinear(T.resampler(fg, warp_px), self.imh, self.imw)  # :112-120
+        base_c = T.resize_bilinear(T.resampler(base0, warp_px), self.imh, self.imw)
+        pred_c = T.resize_bilinear(T.resampler(pred, warp_px), self.imh, self.imw)
+        to_vis = {'base_camspc': base_c, 'pred': pred, 'pred_camspc': pred_c, 'fg_camspc': fg_c,
+                  'warp_px': warp_px}
+        if mode in ('train', 'vali'):
+            gt_c = T.alpha_blend(rgb_camspc, fg_c)                              # :132-133
+            to_vis['gt_camspc'] = gt_c
+            return pred_c, gt_c, {}, to_vis
+        return pred_c, None, None, to_vis
+
+    # -- nlt/models/base.py:63-77 + nlt/models/nlt.py:66-87,201-205
+    def compute_loss(self, pred, gt, keep_batch=True):
+        total = 0
+        for term in self.loss_spec.split(','):
+            name, weight = parse_loss_and_weight(term)
+            if name == 'l2':
+                val = l2_loss(gt, pred, keep_batch)
+            elif name == 'barron':
+                val = B.barron_loss(gt, pred, keep_batch)
+            else:
+                raise NotImplementedError(name)
+            total = total + weight * val
+        return total
+
+
+def parse_loss_and_weight(s):
+    """nlt/models/base.py:63-77: longest float prefix is the weight."""
+    for i in range(len(s), -1, -1):
+        try:
+            weight = float(s[:i])
+        except ValueError:
+            continue
+        return s[i:], weight
+    return s, 1.
+
+
+def l2_loss(gt, pred, keep_batch=False):
+    """nlt/losses.py:39-53: MeanSquaredError(reduction='none') = mean over C, then
+    mean over H,W (per example) or over everything."""
+    loss = ((gt - pred) ** 2).mean(-1)
+    return loss.mean(dim=(1, 2)) if keep_batch else loss.mean()
+
+
+# ----------------------------------------------------------------------------
+# Keras Adam(amsgrad=True), TF 2.2 OptimizerV2     nlt/trainvali.py:122-127,280
+# ----------------------------------------------------------------------------
+class KerasAdamAMSGrad:
+    def __init__(self, params, lr, beta1=0.9, beta2=0.999, eps=1e-7):
+        self.params = params
+        self.lr, self.b1, self.b2, self.eps = lr, beta1, beta2, eps
+        self.t = 0
+        self.m = [torch.zeros_like(p) for p in params]
+        self.v = [torch.zeros_like(p) for p in params]
+        self.vhat = [torch.zeros_like(p) for p in params]
+
+    def step(self, grads):
+        self.t += 1
+        lr_t = self.lr * math.sqrt(1 - self.b2 ** self.t) / (1 - self.b1 ** self.t)
+        with torch.no_grad():
+            for p, g, m, v, vh in zip(self.params, grads, self.m, self.v, self.vhat):
+                m.mul_(self.b1).add_(g, alpha=1 - self.b1)
+                v.mul_(self.b2).addcmul_(g, g, value=1 - self.b2)
+                torch.maximum(vh, v, out=vh)
+                p.sub_(lr_t * m / (vh.sqrt() + self.eps))
+
+
+def train_step(model, opt, batch, global_bs, nn_list=None):
+    """nlt/trainvali.py:272-281 on one replica: per-example loss -> sum/global_bs ->
+    grads -> Adam-AMSGrad.  Returns (weighted_loss, grads)."""
+    pred, gt, kw, _ = model.call(batch, 'train', nn_list=nn_list)
+    per_example = model.compute_loss(pred, gt, keep_batch=True)
+    weighted = per_example.sum() / global_bs                 # tf.nn.compute_average_loss
+    params = model.parameters()
+    grads = torch.autograd.grad(weighted, params)
+    opt.step(grads)
+    return weighted.detach(), grads
+
+
+# ----------------------------------------------------------------------------
+# synthetic batches
+# ----------------------------------------------------------------------------
+def synth_batch(n, uvh, uvw, hc, wc, imh, imw, k=1, seed=0, identity_warp=False, fg_frac=0.7,
+                quantize_vis=False):
+    """Seeded stand-in for datasets/nlt.py:_load_data outputs.  Returns (batch11, nn_list)."""
+    rng = np.random.default_rng(seed)
+    U = lambda *s: rng.random(s, dtype=np.float32)
+    base, rgb = U(n, uvh, uvw, 3), U(n, uvh, uvw, 3)
+    cvis, lvis = U(n, uvh, uvw, 1), U(n, uvh, uvw, 1)
+    if quantize_vis:
+        cvis = np.floor(255 * cvis) / np.float32(255); lvis = np.floor(255 * lvis) / np.float32(255)
+    rgb_c = U(n, imh, imw, 3)
+    if identity_warp:
+        jj, ii = np.meshgrid(np.arange(wc, dtype=np.float32), np.arange(hc, dtype=np.float32))
+        warp = np.stack((jj / np.float32(wc), ii / np.float32(hc)), -1)[None].repeat(n, 0)
+        warp = warp.astype(np.float32)
+    else:
+        warp = U(n, hc, wc, 2).astype(np.float16).astype(np.float32)   # save_float16_npy (data_gen/util.py:67-70)
+        bg = rng.random((n, hc, wc)) >= fg_frac
+        warp[bg] = 0                                                   # render.py:155
+    nn_list = [(U(n, uvh, uvw, 3), U(n, uvh, uvw, 3)) for _ in range(k)]
+    nn_rgb_c = U(n, imh, imw, 3)
+    tt = torch.from_numpy
+    batch = (None, tt(base), tt(cvis), tt(lvis), tt(warp), tt(rgb), tt(rgb_c), None,
+             tt(nn_list[0][0]), tt(nn_list[0][1]), tt(nn_rgb_c))
+    nn_t = [(tt(b), tt(r)) for b, r in nn_list]
+    return batch, nn_t
