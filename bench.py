@@ -1,0 +1,190 @@
+#!/usr/bin/env python
+"""bench.py -- rendered Mtexels/s of the NLT hot path on MI355X (BASELINE.json metric).
+
+One "step" = one full `Model.call` forward (buffers -> two-path U-Net -> pred -> UV->camera warp)
+over one batch of synthetic frames already resident in HBM.  Workload at every N: BASELINE
+config 3 per GPU -- depth0 16 / depth 256, 4 frames, 1024^2 UV, k = 4 neighbour observation
+maps, 512^2 camera-space warp (70 % foreground via fp16, 30 % background = (0,0)); frames shard
+data-parallel across ranks with no data-path collective in the forward (weak scaling).
+
+    python bench.py --gpus 1 --steps 20 --warmup 5
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+Prints ONE JSON line on rank 0.  `roofline` is for the dominant kernel (largest share of the
+step's GPU time), timed live with HIP events on the launch stream inside the timed region;
+`cpu_baseline` is the CPU oracle (a port: TensorFlow cannot run here) on the host cores, N=1 only.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0          # MI355X HBM3E peak (MI355X_MICROARCH.md)
+BYTES_PER_TEXEL = {1: 961.5, 4: 1755.75}   # SURVEY.md 8d, fp32 layer-wise algorithmic bytes
+
+
+def algorithmic_bytes_per_texel(k):
+    return 4.0 * (123.8125 + 34.5625 * k + 50.375 + 31.625 * k)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=20)
+    ap.add_argument('--warmup', type=int, default=5)
+    ap.add_argument('--uv', type=int, default=1024)
+    ap.add_argument('--cam', type=int, default=512)
+    ap.add_argument('--frames', type=int, default=4, help='frames (light x view pairs) per GPU')
+    ap.add_argument('--k', type=int, default=4, help='neighbour observation maps per frame')
+    ap.add_argument('--depth', type=int, default=256)
+    ap.add_argument('--algo', type=str, default='auto', choices=['auto', 'direct'])
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--per-op', action='store_true', help='print a per-launch timing table to stderr')
+    ap.add_argument('--dominant', type=str, default=None, help='label of the kernel to time in the timed region')
+    return ap.parse_args()
+
+
+def synth_device_batch(n, uv, cam, k, device, seed):
+    import torch
+    g = torch.Generator(device=device).manual_seed(seed)
+    U = lambda *s: torch.rand(s, device=device, generator=g)
+    base, rgb, cvis, lvis = U(n, uv, uv, 3), U(n, uv, uv, 3), U(n, uv, uv, 1), U(n, uv, uv, 1)
+    warp = U(n, cam, cam, 2).half().float()                       # save_float16_npy quantisation
+    warp[U(n, cam, cam) >= 0.7] = 0                               # background -> texel (0,0)
+    nn_base, nn_rgb = U(n, k, uv, uv, 3), U(n, k, uv, uv, 3)
+    rgb_c, nn_rgb_c = U(n, cam, cam, 3), U(n, cam, cam, 3)
+    return (None, base, cvis, lvis, warp, rgb, rgb_c, None, nn_base, nn_rgb, nn_rgb_c)
+
+
+def cpu_baseline(args):
+    """CPU oracle forward on the host cores: one frame of the same workload (bounded sample)."""
+    import torch
+    from oracle import nlt_oracle as O
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    om = O.OracleModel(depth=args.depth, uvh=args.uv, uvw=args.uv, imh=args.cam, imw=args.cam, seed=0)
+    batch, nn = O.synth_batch(1, args.uv, args.uv, args.cam, args.cam, args.cam, args.cam, k=args.k, seed=3)
+    times = []
+    with torch.no_grad():
+        om.call(batch, 'test', nn_list=nn)                         # warm-up
+        for _ in range(9):
+            t0 = time.perf_counter()
+            om.call(batch, 'test', nn_list=nn)
+            times.append(time.perf_counter() - t0)
+    t = sorted(times)[len(times) // 2]
+    return {"value": round(args.uv * args.uv / t / 1e6, 3), "unit": "Mtexels/s", "cores": cores, "kind": "port",
+            "sample": "CPU oracle (torch-CPU restatement of the TF2 path; TensorFlow not installable here), "
+                      "1 frame %dx%d UV, k=%d, full forward + warp, median of 9 after 1 warm-up" % (args.uv, args.uv, args.k)}
+
+
+def main():
+    args = parse()
+    import torch
+    import torch.distributed as dist
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if world != args.gpus and world > 1:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    torch.cuda.set_device(local_rank)
+    device = torch.device('cuda', local_rank)
+    if world > 1:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group('nccl', device_id=device)
+
+    import nlt_amd
+    from nlt_amd import capi
+    from nlt_amd.engine import OpTimer
+    from nlt_amd.models import get_model_class
+    cfg = nlt_amd.make_config(depth=args.depth, uvh=args.uv, uvw=args.uv, imh=args.cam, imw=args.cam)
+    model = get_model_class('nlt')(cfg).build(device)
+    # random-init weights of the released architecture; non-zero biases so the bias path is live
+    g = torch.Generator(device=device).manual_seed(1234)          # same weights on every rank
+    for v in model.register_trainable() or model.trainable_variables:
+        if v.dim() == 1:
+            v.data.uniform_(-0.1, 0.1, generator=g)
+    if args.algo == 'direct':
+        model.conv_algo = capi.ALGO_DIRECT
+    batch = synth_device_batch(args.frames, args.uv, args.cam, args.k, device, seed=100 + rank)
+
+    def step():
+        return model.call(batch, 'test')
+
+    # per-launch survey (outside the timed region) -> dominant kernel
+    for _ in range(2):
+        step()
+    timer = OpTimer()
+    model.plan.timer = timer
+    for _ in range(3):
+        step()
+    rec = timer.collect()
+    model.plan.timer = None
+    table = sorted(((r[1] / r[0], l, r[2]) for l, r in rec.items()), reverse=True)
+    if args.per_op and rank == 0:
+        tot = sum(t for t, _, _ in table)
+        sys.stderr.write("%-12s %10s %7s %10s\n" % ("launch", "ms", "%", "algGB/s"))
+        for t, l, nb in table:
+            sys.stderr.write("%-12s %10.4f %6.1f%% %10.1f\n" % (l, t, 100 * t / tot, nb / t / 1e6))
+        sys.stderr.write("sum of launches %.3f ms\n" % tot)
+    dominant = args.dominant or table[0][1]
+
+    for _ in range(args.warmup):
+        step()
+    dom = OpTimer(); dom.only = {dominant}
+    model.plan.timer = dom
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    model.plan.timer = None
+    if world > 1:
+        te = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        dist.all_reduce(te, op=dist.ReduceOp.MAX)
+        elapsed = float(te.item())
+    drec = dom.collect()[dominant]
+    dom_ms = drec[1] / drec[0]
+    dom_bytes = drec[2]
+
+    if rank == 0:
+        texels = world * args.frames * args.uv * args.uv * args.steps
+        value = texels / elapsed / 1e6
+        ach = dom_bytes / (dom_ms * 1e-3) / 1e9
+        bpt = algorithmic_bytes_per_texel(args.k)
+        out = {
+            "metric": "rendered Mtexels/s at %d^2 UV (full Model.call forward: U-Net + UV->camera warp)" % args.uv,
+            "value": round(value, 2), "unit": "Mtexels/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 4),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+            "data": "synthetic (seeded random texel buffers, random-init weights of the released architecture)",
+            "config": {"workload": "BASELINE config 3: dragon_specular relight+view-synth, depth0 16/depth %d, "
+                                   "%d frames/GPU, %d^2 UV, k=%d obs maps, %d^2 camera warp"
+                                   % (args.depth, args.frames, args.uv, args.k, args.cam),
+                       "frames_per_gpu": args.frames, "uv": args.uv, "k": args.k, "cam": args.cam,
+                       "conv_algo": args.algo, "parallelism": "dp%d (frames sharded, no forward collective)" % world},
+            "roofline": {"bound": "hbm", "kernel": dominant, "achieved": round(ach, 1), "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None,
+                         "launch_ms": round(dom_ms, 4), "algorithmic_bytes_per_launch": int(dom_bytes)},
+            "roofline_whole_pass": {"algorithmic_bytes_per_texel": bpt,
+                                    "achieved": round(value / world * 1e6 * bpt / 1e9, 1), "unit": "GB/s per GPU",
+                                    "frac": round(value / world * 1e6 * bpt / 1e9 / HBM_PEAK_GBS, 4)},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

@@ -1,0 +1,151 @@
+/*
+ * nlt_hip.h -- C ABI of libnlt_hip.so: the MI355X (gfx950) hot path of
+ * google/neural-light-transport's UV-texture-space renderer.
+ *
+ * The reference has NO native boundary: every op below is executed today by a
+ * TensorFlow-2.2 / TF-Addons kernel reached from Python.  Each
+ * entry point names the reference call site it replaces (paths relative to the
+ * reference tree).  A reference-side binding is therefore a Python ctypes stub; see
+ * INTEGRATION.md.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer owned by the caller; tensors are NHWC,
+ *     fp32, densely packed unless a per-texel stride (`ld*`, in floats) says otherwise;
+ *   - every call is asynchronous on `stream` (a hipStream_t passed as void*; NULL =
+ *     the default stream), re-entrant per stream, keeps no global state and never
+ *     throws: it returns NLT_OK or a negative nlt_status;
+ *   - sizes are ints; tensors hold < 2^31 elements.
+ */
+#ifndef NLT_HIP_H_
+#define NLT_HIP_H_
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum {
+  NLT_OK = 0,
+  NLT_ERR_BAD_ARG = -1,      /* null pointer, non-positive size, misaligned pointer/stride */
+  NLT_ERR_UNSUPPORTED = -2,  /* shape/algorithm combination this build does not implement */
+  NLT_ERR_LAUNCH = -3        /* hipGetLastError() != hipSuccess after the launch */
+} nlt_status;
+
+/* Conv families of nlt/networks/elements.py:26-39 as Keras/TF execute them with
+ * padding='same' (SURVEY.md 8a rows a-C1..a-D3).  (h, w) below are INPUT dims. */
+typedef enum {
+  NLT_CONV1X1 = 0,     /* Conv2D k1 s1: out (h,w);   W keras (1,1,Cin,Cout)                       */
+  NLT_CONV_K2S2 = 1,   /* Conv2D k2 s2: out (h/2,w/2), h,w even; W keras (2,2,Cin,Cout)            */
+  NLT_CONV_K2S1 = 2,   /* Conv2D k2 s1: out (h,w), zero pad bottom/right; W keras (2,2,Cin,Cout)   */
+  NLT_DECONV_K2S2 = 3, /* Conv2DTranspose k2 s2: out (2h,2w); W keras (2,2,Cout,Cin)               */
+  NLT_DECONV_K2S1 = 4  /* Conv2DTranspose k2 s1: out (h,w), zero pad top/left; W (2,2,Cout,Cin)    */
+} nlt_conv_mode;
+
+typedef enum {
+  NLT_ALGO_AUTO = 0,
+  NLT_ALGO_DIRECT = 1, /* one thread per texel x 4 outputs, fp32 FMA; reads Keras-layout weights  */
+  NLT_ALGO_MFMA = 2    /* implicit GEMM on v_mfma_f32_16x16x4_f32; reads nlt_pack_conv_weights()  */
+} nlt_conv_algo;
+
+const char* nlt_version(void);
+const char* nlt_status_string(int status);
+
+/* Number of floats nlt_pack_conv_weights() writes for (mode, c0, c1, cout). */
+long nlt_packed_weight_floats(int mode, int c0, int c1, int cout);
+
+/* Re-lays a Keras kernel for the MFMA path: [K/16][N/16][64 lanes][4] fragments, each
+ * K segment (tap x source) zero-padded to a multiple of 16.  Replaces nothing in the
+ * reference (Keras keeps HWIO / HWOI); call it whenever the weights change. */
+int nlt_pack_conv_weights(int mode, const float* w_keras, int c0, int c1, int cout,
+                          float* w_packed, void* stream);
+
+/*
+ * One conv / transposed-conv layer with fused bias, LeakyReLU and "virtual concat".
+ *   replaces: tf.keras Conv2D / Conv2DTranspose / LeakyReLU as called through
+ *             nlt/networks/elements.py:26-39,72-73 (layer stacks of convnet.py:44-85) and
+ *             the tf.concat of nlt/models/nlt.py:174,190 (the two sources ARE the concat).
+ * Input channels [0,c0) come from src0 (per-texel stride ld0 floats), [c0,c0+c1) from src1
+ * (stride ld1; c1 = 0 and src1 = NULL for a single source); both are [n,h,w,*].  The
+ * output goes to out[texel*ldo + 0..cout) so a layer can write a channel slice of a wider
+ * interleaved tensor.  act != 0 applies LeakyReLU(alpha) (elements.py:72-73: alpha = 0.3).
+ * Backward-data reuse: mask_src (stride ldm) != NULL multiplies the result by
+ * (mask_src > 0 ? 1 : alpha) instead of activating it, and accumulate != 0 adds the old
+ * contents of `out` before masking.
+ * algo DIRECT needs w_keras, MFMA needs w_packed; AUTO uses MFMA when it can.
+ * tile_hint: 0 = auto, else 16*RT + CT (wave tile = 16*RT texels x 16*CT outputs).
+ */
+int nlt_conv_forward(int mode, int algo, int tile_hint,
+                     const float* src0, int ld0, int c0,
+                     const float* src1, int ld1, int c1,
+                     int n, int h, int w,
+                     const float* w_keras, const float* w_packed, const float* bias,
+                     int cout, float* out, int ldo,
+                     int act, float alpha,
+                     const float* mask_src, int ldm, int accumulate,
+                     void* stream);
+
+/*
+ * L0 of both paths, fused (the original-resolution 1x1 convs, no activation).
+ *   replaces: nlt/models/nlt.py:95-96 (tf.concat of base|cvis|lvis; nn_rgb - nn_base),
+ *             layer 0 of net['query'] and net['obs'] (convnet.py:44), and the first
+ *             observation mean + concat (nlt.py:161-164,174).
+ * nn_rgb / nn_base: [n,k,h,w,3] (k observations per frame); obs_weights: [n,k] or NULL.
+ * fm0 [n,h,w,2*c]: channels [0,c) = query L0, [c,2c) = mean_k(obs L0 (* weight)).
+ * obs0 [n,k,h,w,c]: per-observation L0 outputs (input of obs layer 1).
+ * Weights Keras layout: wq (1,1,5,c), wo (1,1,3,c).
+ */
+int nlt_stem_forward(const float* base, const float* cvis, const float* lvis,
+                     const float* nn_rgb, const float* nn_base, const float* obs_weights,
+                     int n, int k, int h, int w, int c,
+                     const float* wq, const float* bq, const float* wo, const float* bo,
+                     float* fm0, float* obs0, void* stream);
+
+/*
+ * Mean over the k observation feature maps of a level, written into a channel slice.
+ *   replaces: nlt/models/nlt.py:161-164 (expand_dims, concat, obs_weights product, reduce_mean).
+ * obs [n,k,h,w,c]; obs_weights [n,k] or NULL; out[texel*ldo + 0..c) = sum_i w_i*obs_i / k.
+ */
+int nlt_obs_mean_forward(const float* obs, const float* obs_weights, int n, int k, int hw, int c,
+                         float* out, int ldo, void* stream);
+
+/*
+ * Output head: 1x1 conv over the virtual concat [dec | skip] -> 3 channels, + base,
+ * texel (0,0) of every frame forced to 0.
+ *   replaces: last layer of net['query'] (convnet.py:85), nlt/models/nlt.py:99-102
+ *             (pred += base) and :110 (imgutil.set_left_top_corner(pred, 0)).
+ * dec [n,h,w,*] stride ldd, cd channels; skip stride lds, cs channels; w keras (1,1,cd+cs,3).
+ * base may be NULL (skip_connect_base = False).  pred [n,h,w,3].
+ */
+int nlt_head_forward(const float* dec, int ldd, int cd, const float* skip, int lds, int cs,
+                     const float* w_keras, const float* bias, const float* base,
+                     int n, int h, int w, float* pred, void* stream);
+
+/*
+ * UV -> camera bilinear gather of the three buffers the model warps, in one pass.
+ *   replaces: nlt/models/nlt.py:104-114: warp * (uvw, uvh); fg = ones with texel (0,0)
+ *             zeroed; set_left_top_corner(base, 0); three tfa.image.resampler calls
+ *             (TF-Addons 0.10.0 resampler op).
+ * pred, base [n,uvh,uvw,3] (base's texel (0,0) is treated as 0; pred must already have it
+ * zeroed, as nlt_head_forward leaves it; base may be NULL); warp [n,hc,wc,2] in [0,1] UV
+ * units, x first.  Outputs [n,hc,wc,3] each (any may be NULL).  idx_out (optional)
+ * [n,hc,wc,4] int32 = (fx, fy, inside, 0): the integer UV indices of the gather, for the
+ * bit-exact parity check.
+ */
+int nlt_warp_forward(const float* pred, const float* base, const float* warp,
+                     int n, int uvh, int uvw, int hc, int wc,
+                     float* pred_cam, float* base_cam, float* fg_cam, int* idx_out, void* stream);
+
+/*
+ * Bilinear resize, half-pixel centres, no antialias.
+ *   replaces: tf.image.resize via nlt/util/img.py:92-120 (nlt/models/nlt.py:116-120).
+ */
+int nlt_resize_bilinear_forward(const float* x, int n, int h, int w, int c, int oh, int ow,
+                                float* out, void* stream);
+
+/* out = a * b elementwise (imgutil.alpha_blend with tensor2=None, nlt/util/img.py:74-89;
+ * nlt/models/nlt.py:132-133). */
+int nlt_mul_forward(const float* a, const float* b, long count, float* out, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NLT_HIP_H_ */

@@ -1,0 +1,231 @@
+// Implicit-GEMM conv on the fp32 matrix cores (v_mfma_f32_16x16x4_f32, exact fp32).
+//
+// D[cout][texel] = W^T[cout][K] * X^T[K][texel]: the WEIGHTS are the MFMA "A" operand and the
+// TEXELS the "B" operand, so each lane ends up holding 4 consecutive output channels of one
+// texel -> one 16-byte NHWC store per lane, bias/LeakyReLU applied in registers.
+//
+// Lane l = (kk = l>>4, i = l&15).  Inside a K-chunk of 16 the k index is permuted so that lane
+// kk owns channels 4kk..4kk+3: both operands are then fetched with ONE 16-byte load per lane
+// (texels straight from the NHWC tensor, weights from the pre-packed fragment array) and feed
+// four consecutive MFMA k-steps.  No LDS, no barriers: every texel element is used by exactly
+// one wave (register-level reuse across its CT column tiles) and the weights are L2-resident.
+#include "nlt_common.h"
+
+namespace {
+
+__host__ __device__ inline int chunks16(int c) { return (c + 15) >> 4; }
+
+template <int MODE>
+__device__ __forceinline__ int keras_widx(int t, int c, int ncol, int cin, int cout) {
+  if (MODE == NLT_CONV1X1 || MODE == NLT_CONV_K2S2 || MODE == NLT_CONV_K2S1) return (t * cin + c) * cout + ncol;
+  if (MODE == NLT_DECONV_K2S1) return (t * cout + ncol) * cin + c;
+  return ncol * cin + c;
+}
+
+template <int MODE>
+__global__ void pack_weights_kernel(const float* __restrict__ wk, int c0, int c1, int cout, int N,
+                                    int ntiles, long total, float* __restrict__ wp) {
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= total) return;
+  const int s4 = idx & 3;
+  const int lane = (idx >> 2) & 63;
+  const long tile = idx >> 8;
+  const int nt = tile % ntiles;
+  const int kc = tile / ntiles;
+  const int ch0 = chunks16(c0), ch1 = chunks16(c1);
+  const int t = kc / (ch0 + ch1);
+  const int r = kc % (ch0 + ch1);
+  const int s = r >= ch0;
+  const int cl = (s ? r - ch0 : r) * 16 + 4 * (lane >> 4) + s4;
+  const int cs = s ? c1 : c0;
+  const int ncol = nt * 16 + (lane & 15);
+  float v = 0.f;
+  if (cl < cs && ncol < N) v = wk[keras_widx<MODE>(t, (s ? c0 : 0) + cl, ncol, c0 + c1, cout)];
+  wp[idx] = v;
+}
+
+template <int MODE, int RT, int CT>
+__global__ __launch_bounds__(256) void conv_mfma_kernel(ConvP p, int mtiles, int ngroups, int ntiles) {
+  constexpr int TAPS = ConvTraits<MODE>::TAPS;
+  const int lane = threadIdx.x & 63;
+  const int wave = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int ng = wave % ngroups;
+  const int mt = wave / ngroups;
+  if (mt >= mtiles) return;
+  const int px = lane & 15, kk = lane >> 4;
+
+  int rf[RT], ry[RT], rx[RT], rm[RT];
+  bool rv[RT];
+#pragma unroll
+  for (int rt = 0; rt < RT; ++rt) {
+    const int m = (mt * RT + rt) * 16 + px;
+    rv[rt] = m < p.M;
+    const int mc = rv[rt] ? m : p.M - 1;
+    rm[rt] = mc;
+    rx[rt] = mc % p.gw;
+    ry[rt] = (mc / p.gw) % p.gh;
+    rf[rt] = mc / (p.gw * p.gh);
+  }
+
+  f32x4 acc[RT][CT];
+#pragma unroll
+  for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct) acc[rt][ct] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  const f32x4* __restrict__ wp = reinterpret_cast<const f32x4*>(p.wgt) + (size_t)(ng * CT) * 64 + lane;
+  const size_t wstride = (size_t)ntiles * 64;   // f32x4 per K-chunk
+
+  int kc = 0;
+  for (int t = 0; t < TAPS; ++t) {
+    int tex[RT];
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt) tex[rt] = rv[rt] ? conv_tap_texel<MODE>(p, rf[rt], ry[rt], rx[rt], t) : -1;
+    for (int s = 0; s < 2; ++s) {
+      const int cs = s ? p.c1 : p.c0;
+      if (cs == 0) continue;
+      const float* __restrict__ src = s ? p.src1 : p.src0;
+      const int ld = s ? p.ld1 : p.ld0;
+      const float* rp[RT];
+#pragma unroll
+      for (int rt = 0; rt < RT; ++rt) rp[rt] = src + (size_t)(tex[rt] < 0 ? 0 : tex[rt]) * ld + 4 * kk;
+      for (int k0 = 0; k0 < cs; k0 += 16, ++kc) {
+        const bool kin = (k0 + 4 * kk) < cs;
+        f32x4 b[RT], a[CT];
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) {
+          b[rt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+          if (kin && tex[rt] >= 0) b[rt] = *reinterpret_cast<const f32x4*>(rp[rt] + k0);
+        }
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct) a[ct] = wp[(size_t)kc * wstride + ct * 64];
+#pragma unroll
+        for (int s4 = 0; s4 < 4; ++s4)
+#pragma unroll
+          for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+            for (int ct = 0; ct < CT; ++ct)
+              acc[rt][ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[ct][s4], b[rt][s4], acc[rt][ct], 0, 0, 0);
+      }
+    }
+  }
+
+  // Epilogue: lane holds outputs [ncol, ncol+4) of texel px for every (rt, ct).
+#pragma unroll
+  for (int ct = 0; ct < CT; ++ct) {
+    const int ncol = (ng * CT + ct) * 16 + kk * 4;
+    if (ncol >= p.N) continue;
+    int oc = ncol, ab = 0;
+    if (MODE == NLT_DECONV_K2S2) { ab = ncol / p.cout; oc = ncol - ab * p.cout; }
+    const f32x4 bv = *reinterpret_cast<const f32x4*>(p.bias + oc);
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt) {
+      if (!rv[rt]) continue;
+      int otex = rm[rt];
+      if (MODE == NLT_DECONV_K2S2) otex = (rf[rt] * p.oh + 2 * ry[rt] + (ab >> 1)) * p.ow + 2 * rx[rt] + (ab & 1);
+      f32x4 v = acc[rt][ct] + bv;
+      f32x4* o = reinterpret_cast<f32x4*>(p.out + (size_t)otex * p.ldo + oc);
+      if (p.accumulate) v += *o;
+      if (p.mask_src) {
+        const f32x4 mk = *reinterpret_cast<const f32x4*>(p.mask_src + (size_t)otex * p.ldm + oc);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] *= (mk[j] > 0.f) ? 1.f : p.alpha;
+      } else if (p.act) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = v[j] > 0.f ? v[j] : p.alpha * v[j];
+      }
+      *o = v;
+    }
+  }
+}
+
+template <int MODE, int RT, int CT>
+int launch_tile(const ConvP& p, hipStream_t s) {
+  const int ntiles = (p.N + 15) >> 4;
+  const int ngroups = ntiles / CT;
+  const int mtiles = (p.M + 16 * RT - 1) / (16 * RT);
+  const long waves = (long)mtiles * ngroups;
+  const unsigned blocks = (unsigned)((waves + 3) / 4);
+  hipLaunchKernelGGL((conv_mfma_kernel<MODE, RT, CT>), dim3(blocks), dim3(256), 0, s, p, mtiles, ngroups, ntiles);
+  NLT_CHECK_LAUNCH();
+  return NLT_OK;
+}
+
+template <int MODE>
+int launch_mode(const ConvP& p, int tile_hint, hipStream_t s) {
+  const int ntiles = (p.N + 15) >> 4;
+  int RT = 0, CT = 0;
+  if (tile_hint > 0) { RT = tile_hint >> 4; CT = tile_hint & 15; }
+  else {
+    // largest wave tile that still gives the chip >= 2 waves per SIMD (1024 SIMDs)
+    static const int cand[9][2] = {{4, 4}, {2, 4}, {4, 2}, {2, 2}, {1, 4}, {4, 1}, {1, 2}, {2, 1}, {1, 1}};
+    RT = 1; CT = 1;
+    for (int i = 0; i < 9; ++i) {
+      const int r = cand[i][0], c = cand[i][1];
+      if (ntiles % c) continue;
+      const long waves = (long)((p.M + 16 * r - 1) / (16 * r)) * (ntiles / c);
+      if (waves >= 2048) { RT = r; CT = c; break; }
+    }
+  }
+  if (CT <= 0 || ntiles % CT) return NLT_ERR_UNSUPPORTED;
+#define NLT_TILE(R, C) if (RT == R && CT == C) return launch_tile<MODE, R, C>(p, s);
+  NLT_TILE(4, 4) NLT_TILE(2, 4) NLT_TILE(4, 2) NLT_TILE(2, 2) NLT_TILE(1, 4)
+  NLT_TILE(4, 1) NLT_TILE(1, 2) NLT_TILE(2, 1) NLT_TILE(1, 1)
+#undef NLT_TILE
+  return NLT_ERR_UNSUPPORTED;
+}
+
+int taps_of(int mode) { return (mode == NLT_CONV1X1 || mode == NLT_DECONV_K2S2) ? 1 : 4; }
+
+}  // namespace
+
+bool nlt_conv_mfma_supported(int mode, const ConvP& p) {
+  (void)mode;
+  if ((p.c0 & 3) || (p.c1 & 3) || (p.cout & 3) || (p.ld0 & 3) || (p.ldo & 3)) return false;
+  if (p.c1 && (p.ld1 & 3)) return false;
+  if (p.mask_src && (p.ldm & 3)) return false;
+  if (!nlt_aligned16(p.src0) || !nlt_aligned16(p.out) || !nlt_aligned16(p.bias) || !nlt_aligned16(p.wgt)) return false;
+  if (p.c1 && !nlt_aligned16(p.src1)) return false;
+  if (p.mask_src && !nlt_aligned16(p.mask_src)) return false;
+  return true;
+}
+
+int nlt_conv_mfma_launch(int mode, const ConvP& p, int tile_hint, hipStream_t s) {
+  if (!nlt_conv_mfma_supported(mode, p)) return NLT_ERR_UNSUPPORTED;
+  switch (mode) {
+    case NLT_CONV1X1: return launch_mode<NLT_CONV1X1>(p, tile_hint, s);
+    case NLT_CONV_K2S2: return launch_mode<NLT_CONV_K2S2>(p, tile_hint, s);
+    case NLT_CONV_K2S1: return launch_mode<NLT_CONV_K2S1>(p, tile_hint, s);
+    case NLT_DECONV_K2S2: return launch_mode<NLT_DECONV_K2S2>(p, tile_hint, s);
+    case NLT_DECONV_K2S1: return launch_mode<NLT_DECONV_K2S1>(p, tile_hint, s);
+  }
+  return NLT_ERR_BAD_ARG;
+}
+
+extern "C" long nlt_packed_weight_floats(int mode, int c0, int c1, int cout) {
+  if (mode < NLT_CONV1X1 || mode > NLT_DECONV_K2S1 || c0 <= 0 || c1 < 0 || cout <= 0) return -1;
+  const int N = (mode == NLT_DECONV_K2S2) ? 4 * cout : cout;
+  return (long)taps_of(mode) * (chunks16(c0) + chunks16(c1)) * ((N + 15) >> 4) * 256;
+}
+
+extern "C" int nlt_pack_conv_weights(int mode, const float* w_keras, int c0, int c1, int cout,
+                                     float* w_packed, void* stream) {
+  if (!w_keras || !w_packed) return NLT_ERR_BAD_ARG;
+  const long total = nlt_packed_weight_floats(mode, c0, c1, cout);
+  if (total <= 0) return NLT_ERR_BAD_ARG;
+  const int N = (mode == NLT_DECONV_K2S2) ? 4 * cout : cout;
+  const int ntiles = (N + 15) >> 4;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const unsigned blocks = (unsigned)((total + 255) / 256);
+#define NLT_PACK(MODE) hipLaunchKernelGGL(pack_weights_kernel<MODE>, dim3(blocks), dim3(256), 0, s, w_keras, c0, c1, cout, N, ntiles, total, w_packed)
+  switch (mode) {
+    case NLT_CONV1X1: NLT_PACK(NLT_CONV1X1); break;
+    case NLT_CONV_K2S2: NLT_PACK(NLT_CONV_K2S2); break;
+    case NLT_CONV_K2S1: NLT_PACK(NLT_CONV_K2S1); break;
+    case NLT_DECONV_K2S2: NLT_PACK(NLT_DECONV_K2S2); break;
+    case NLT_DECONV_K2S1: NLT_PACK(NLT_DECONV_K2S1); break;
+  }
+#undef NLT_PACK
+  NLT_CHECK_LAUNCH();
+  return NLT_OK;
+}

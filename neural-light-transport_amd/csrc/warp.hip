@@ -1,0 +1,106 @@
+// UV -> camera bilinear gather (tfa.image.resampler semantics) for pred/base/fg in one pass,
+// and the TF2 half-pixel bilinear resize.  Gather kernels: one thread per camera pixel; the
+// UV taps are served by L2 (neighbouring camera pixels hit neighbouring texels).
+#include "nlt_common.h"
+
+namespace {
+
+// Arithmetic is kept un-contracted (no FMA fusion) and in the TFA kernel's order so that the
+// fp32 result equals the oracle's NumPy float32 restatement operation for operation.
+#pragma clang fp contract(off)
+__global__ __launch_bounds__(256) void warp_kernel(const float* __restrict__ pred, const float* __restrict__ base,
+                                                   const float* __restrict__ warp, int uvh, int uvw, int hcwc,
+                                                   long total, float* __restrict__ pred_cam,
+                                                   float* __restrict__ base_cam, float* __restrict__ fg_cam,
+                                                   int* __restrict__ idx_out) {
+  const long p = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= total) return;
+  const int f = p / hcwc;
+  const float x = warp[p * 2 + 0] * (float)uvw;     // nlt/models/nlt.py:104-106
+  const float y = warp[p * 2 + 1] * (float)uvh;
+  const bool inside = x > -1.f && y > -1.f && x < (float)uvw && y < (float)uvh;
+  const int fx = (int)floorf(x), fy = (int)floorf(y);
+  if (idx_out) {
+    idx_out[p * 4 + 0] = fx; idx_out[p * 4 + 1] = fy; idx_out[p * 4 + 2] = inside ? 1 : 0; idx_out[p * 4 + 3] = 0;
+  }
+  float op[3] = {0.f, 0.f, 0.f}, ob[3] = {0.f, 0.f, 0.f}, og = 0.f;
+  if (inside) {
+    const int cx = fx + 1, cy = fy + 1;
+    const float dx = (float)cx - x, dy = (float)cy - y;
+    const float wts[4] = {dx * dy, (1.f - dx) * (1.f - dy), dx * (1.f - dy), (1.f - dx) * dy};
+    const int xs[4] = {fx, cx, fx, cx};
+    const int ys[4] = {fy, cy, cy, fy};
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const int xi = xs[t], yi = ys[t];
+      const bool ok = xi >= 0 && yi >= 0 && xi <= uvw - 1 && yi <= uvh - 1;
+      const bool corner = (xi == 0 && yi == 0);      // set_left_top_corner(., 0): nlt.py:108-110
+      const long tex = ((long)f * uvh + (ok ? yi : 0)) * uvw + (ok ? xi : 0);
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        const float vp = (ok && pred) ? pred[tex * 3 + c] : 0.f;
+        const float vb = (ok && !corner && base) ? base[tex * 3 + c] : 0.f;
+        op[c] = op[c] + wts[t] * vp;
+        ob[c] = ob[c] + wts[t] * vb;
+      }
+      og = og + wts[t] * ((ok && !corner) ? 1.f : 0.f);
+    }
+  }
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    if (pred_cam) pred_cam[p * 3 + c] = op[c];
+    if (base_cam) base_cam[p * 3 + c] = ob[c];
+    if (fg_cam) fg_cam[p * 3 + c] = og;
+  }
+}
+
+__global__ __launch_bounds__(256) void resize_kernel(const float* __restrict__ x, int n, int h, int w, int c,
+                                                     int oh, int ow, long total, float* __restrict__ out) {
+  const long p = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= total) return;
+  const int ox = p % ow;
+  const int oy = (p / ow) % oh;
+  const int f = p / ((long)ow * oh);
+  const float sy = (float)h / (float)oh, sx = (float)w / (float)ow;
+  const float srcy = ((float)oy + 0.5f) * sy - 0.5f;
+  const float srcx = ((float)ox + 0.5f) * sx - 0.5f;
+  const float fly = floorf(srcy), flx = floorf(srcx);
+  const int ylo = max((int)fly, 0), yhi = min((int)ceilf(srcy), h - 1);
+  const int xlo = max((int)flx, 0), xhi = min((int)ceilf(srcx), w - 1);
+  const float ly = srcy - fly, lx = srcx - flx;
+  const float* tl = x + (((long)f * h + ylo) * w + xlo) * c;
+  const float* tr = x + (((long)f * h + ylo) * w + xhi) * c;
+  const float* bl = x + (((long)f * h + yhi) * w + xlo) * c;
+  const float* br = x + (((long)f * h + yhi) * w + xhi) * c;
+  for (int ch = 0; ch < c; ++ch) {
+    const float top = tl[ch] + (tr[ch] - tl[ch]) * lx;
+    const float bot = bl[ch] + (br[ch] - bl[ch]) * lx;
+    out[p * c + ch] = top + (bot - top) * ly;
+  }
+}
+
+}  // namespace
+
+extern "C" int nlt_warp_forward(const float* pred, const float* base, const float* warp,
+                                int n, int uvh, int uvw, int hc, int wc,
+                                float* pred_cam, float* base_cam, float* fg_cam, int* idx_out, void* stream) {
+  if (!warp || n <= 0 || uvh <= 0 || uvw <= 0 || hc <= 0 || wc <= 0) return NLT_ERR_BAD_ARG;
+  if (pred_cam && !pred) return NLT_ERR_BAD_ARG;
+  if (!pred_cam && !base_cam && !fg_cam && !idx_out) return NLT_ERR_BAD_ARG;
+  const long total = (long)n * hc * wc;
+  hipLaunchKernelGGL(warp_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), pred, base, warp, uvh, uvw, hc * wc, total,
+                     pred_cam, base_cam, fg_cam, idx_out);
+  NLT_CHECK_LAUNCH();
+  return NLT_OK;
+}
+
+extern "C" int nlt_resize_bilinear_forward(const float* x, int n, int h, int w, int c, int oh, int ow,
+                                           float* out, void* stream) {
+  if (!x || !out || n <= 0 || h <= 0 || w <= 0 || c <= 0 || oh <= 0 || ow <= 0) return NLT_ERR_BAD_ARG;
+  const long total = (long)n * oh * ow;
+  hipLaunchKernelGGL(resize_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), x, n, h, w, c, oh, ow, total, out);
+  NLT_CHECK_LAUNCH();
+  return NLT_OK;
+}

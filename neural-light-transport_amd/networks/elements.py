@@ -1,0 +1,204 @@
+"""Layer factories with the reference's names and semantics (nlt/networks/elements.py:26-125),
+executed by libnlt_hip.so.  Weights live in Keras layouts (conv: (kh,kw,Cin,Cout); deconv:
+(kh,kw,Cout,Cin)) as torch CUDA tensors so checkpoints / oracles exchange arrays unchanged.
+
+Released-config branch only (conv, deconv, leakyrelu/relu, iden, norm/pool 'none'); the other
+norm / pool / act / upconv branches raise NotImplementedError.
+"""
+import math
+
+import torch
+
+from .. import _capi as C
+
+_seed_counter = [0]
+
+
+def _glorot_uniform(shape, device, seed):
+    """Keras default kernel initialiser: U(-l, l), l = sqrt(6 / (fan_in + fan_out)) with the
+    receptive field folded into both fans."""
+    kh, kw, a, b = shape
+    limit = math.sqrt(6.0 / (kh * kw * a + kh * kw * b))
+    g = torch.Generator().manual_seed(seed)
+    return ((torch.rand(shape, generator=g) * 2 - 1) * limit).to(device)
+
+
+class Layer:
+    built = True
+    trainable = ()
+
+    def build(self, cin, device):
+        return cin
+
+    def variables(self):
+        return []
+
+
+class Conv2D(Layer):
+    """tf.keras.layers.Conv2D / Conv2DTranspose(n_ch_out, kernel_size, strides, padding='same')."""
+
+    def __init__(self, n_ch_out, kernel_size, stride, transpose=False):
+        if kernel_size not in (1, 2) or stride not in (1, 2) or (kernel_size == 1 and (stride != 1 or transpose)):
+            raise NotImplementedError("kernel %d stride %d" % (kernel_size, stride))
+        self.n_ch_out, self.kernel_size, self.stride, self.transpose = n_ch_out, kernel_size, stride, transpose
+        if kernel_size == 1:
+            self.mode = C.CONV1X1
+        elif transpose:
+            self.mode = C.DECONV_K2S2 if stride == 2 else C.DECONV_K2S1
+        else:
+            self.mode = C.CONV_K2S2 if stride == 2 else C.CONV_K2S1
+        self.built = False
+        self.kernel = self.bias = None
+        self.cin = None
+        self._packed = {}
+
+    def build(self, cin, device='cuda', seed=None):
+        if not self.built:
+            if seed is None:
+                _seed_counter[0] += 1
+                seed = _seed_counter[0]
+            k, n = self.kernel_size, self.n_ch_out
+            shape = (k, k, n, cin) if self.transpose else (k, k, cin, n)
+            self.kernel = _glorot_uniform(shape, device, seed).requires_grad_(True)
+            self.bias = torch.zeros(n, device=device, requires_grad=True)   # Keras: zeros
+            self.cin = cin
+            self.built = True
+        return self.n_ch_out
+
+    def set_weights(self, kernel, bias):
+        kernel = torch.as_tensor(kernel, dtype=torch.float32)
+        bias = torch.as_tensor(bias, dtype=torch.float32)
+        cin = kernel.shape[3] if self.transpose else kernel.shape[2]
+        dev = self.kernel.device if self.built else 'cuda'
+        self.kernel = kernel.to(dev).contiguous().requires_grad_(True)
+        self.bias = bias.to(dev).contiguous().requires_grad_(True)
+        self.cin, self.built = cin, True
+        self._packed = {}
+
+    def variables(self):
+        return [self.kernel, self.bias]
+
+    def packed(self, c0, c1):
+        """MFMA fragment layout of the kernel for a (c0 | c1) input split; re-packed when the
+        kernel tensor has been written (optimizer step / set_weights)."""
+        key = (c0, c1)
+        ent = self._packed.get(key)
+        ver = (self.kernel.data_ptr(), self.kernel._version)
+        if ent is None or ent[0] != ver:
+            ent = (ver, C.pack_conv_weights(self.mode, self.kernel.detach(), c0, c1, self.n_ch_out))
+            self._packed[key] = ent
+        return ent[1]
+
+    def out_hw(self, h, w):
+        if self.mode == C.CONV_K2S2:
+            return h // 2, w // 2
+        if self.mode == C.DECONV_K2S2:
+            return 2 * h, 2 * w
+        return h, w
+
+    def __call__(self, x, act=None):
+        """x [N,H,W,Cin] dense -> [N,H',W',Cout]; `act` (an Act layer) is fused when given."""
+        n, h, w, cin = x.shape
+        self.build(cin, x.device)
+        assert cin == self.cin, "layer built for %d input channels, got %d" % (self.cin, cin)
+        oh, ow = self.out_hw(h, w)
+        out = torch.empty((n, oh, ow, self.n_ch_out), device=x.device, dtype=torch.float32)
+        use_mfma = cin % 4 == 0 and self.n_ch_out % 4 == 0
+        C.conv_forward(self.mode, x.contiguous(), cin, cin, None, 0, 0, n, h, w,
+                       self.kernel.detach(), self.packed(cin, 0) if use_mfma else None, self.bias.detach(),
+                       self.n_ch_out, out, self.n_ch_out, act=act is not None,
+                       alpha=act.alpha if act is not None else 0.0)
+        return out
+
+
+class Act(Layer):
+    def __init__(self, alpha):
+        self.alpha = alpha
+
+    def __call__(self, x):
+        raise NotImplementedError(
+            "activations run fused into the preceding conv kernel; call the enclosing Sequential")
+
+
+class Identity(Layer):
+    def __call__(self, x):
+        return x
+
+
+class Sequential(Layer):
+    """tf.keras.Sequential over the layer kinds above; conv -> (identities) -> act is executed as
+    one fused kernel launch."""
+
+    def __init__(self, layers):
+        self.layers = list(layers)
+
+    @property
+    def built(self):
+        return all(l.built for l in self.layers)
+
+    def build(self, cin, device='cuda'):
+        for l in self.layers:
+            cin = l.build(cin, device)
+        return cin
+
+    def variables(self):
+        return [v for l in self.layers for v in l.variables()]
+
+    def convs(self):
+        """[(Conv2D, Act or None)] in execution order."""
+        out, i = [], 0
+        L = self.layers
+        while i < len(L):
+            if isinstance(L[i], Conv2D):
+                j = i + 1
+                while j < len(L) and isinstance(L[j], Identity):
+                    j += 1
+                act = L[j] if j < len(L) and isinstance(L[j], Act) else None
+                out.append((L[i], act))
+                i = j + 1 if act is not None else j
+            elif isinstance(L[i], Identity):
+                i += 1
+            else:
+                raise NotImplementedError("stand-alone %s" % type(L[i]).__name__)
+        return out
+
+    def __call__(self, x):
+        for conv_, act_ in self.convs():
+            x = conv_(x, act=act_)
+        return x
+
+
+def conv(kernel_size, n_ch_out, stride=1):
+    return Conv2D(n_ch_out, kernel_size, stride)
+
+
+def deconv(kernel_size, n_ch_out, stride=1):
+    return Conv2D(n_ch_out, kernel_size, stride, transpose=True)
+
+
+def upconv(n_ch_out):
+    raise NotImplementedError("upconv (bilinear x2 + 2x2 conv) is only reached with pool != None")
+
+
+def norm(type_):
+    if type_ is None or type_.lower() == 'none':
+        return iden()
+    raise NotImplementedError(type_)
+
+
+def act(type_):
+    if type_ == 'relu':
+        return Act(0.0)                 # tf.keras.layers.ReLU(negative_slope=0)
+    if type_ == 'leakyrelu':
+        return Act(0.3)                 # tf.keras.layers.LeakyReLU(alpha=0.3)
+    raise NotImplementedError(type_)
+
+
+def pool(type_):
+    if type_ is None or type_.lower() == 'none':
+        return iden()
+    raise NotImplementedError(type_)
+
+
+def iden():
+    return Identity()

@@ -1,0 +1,110 @@
+"""-m gpu: full Model.call forward (fused RenderPlan on HIP kernels) vs the CPU oracle.
+Tolerance (BASELINE.json): rel-L2 <= 1e-4 on the rendered texels; integer UV indices bit-exact."""
+import os
+import numpy as np
+import pytest
+import torch
+
+from nlt_amd import capi as C
+from oracle import nlt_oracle as O
+from oracle import tf_ops as T
+from gpu_util import rel_l2, make_pair, to_device_batch
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-4
+G = os.path.join(os.path.dirname(__file__), 'golden')
+
+
+def _compare(om, pm, batch, nn, algo=C.ALGO_AUTO, mode='train'):
+    with torch.no_grad():
+        o_pred_c, o_gt_c, _, o_vis = om.call(batch, mode, nn_list=nn)
+    pm.conv_algo = algo
+    p_pred_c, p_gt_c, _, p_vis = pm.call(to_device_batch(batch, nn), mode, want_indices=True)
+    torch.cuda.synchronize()
+    assert rel_l2(p_vis['pred'].cpu(), o_vis['pred']) <= TOL
+    assert rel_l2(p_pred_c.cpu(), o_pred_c) <= TOL
+    assert rel_l2(p_vis['base_camspc'].cpu(), o_vis['base_camspc']) <= 1e-6
+    if mode != 'test':
+        assert rel_l2(p_gt_c.cpu(), o_gt_c) <= 1e-6
+    fx, fy, inside = T.resampler_indices(o_vis['warp_px'].numpy(), om.uvh, om.uvw)
+    idx = p_vis['uv_indices'].cpu().numpy()
+    np.testing.assert_array_equal(idx[..., 0], fx)
+    np.testing.assert_array_equal(idx[..., 1], fy)
+    np.testing.assert_array_equal(idx[..., 2], inside.astype(np.int32))
+    return p_vis
+
+
+@pytest.mark.parametrize('k', [1, 2, 4])
+@pytest.mark.parametrize('algo', [C.ALGO_AUTO, C.ALGO_DIRECT])
+def test_forward_depth256_64(k, algo):
+    om, pm = make_pair(depth=256, uv=64, im=32, seed=k)
+    batch, nn = O.synth_batch(2, 64, 64, 32, 32, 32, 32, k=k, seed=10 + k)
+    _compare(om, pm, batch, nn, algo)
+
+
+def test_forward_relight_only_identity_warp_128():
+    # BASELINE config 2 shape family (relight only: identity warp), reduced to 128^2 for the CPU oracle
+    om, pm = make_pair(depth=256, uv=128, im=128, seed=3)
+    batch, nn = O.synth_batch(2, 128, 128, 128, 128, 128, 128, k=1, seed=4, identity_warp=True)
+    vis = _compare(om, pm, batch, nn)
+    # identity warp: camera-space prediction is the UV prediction itself
+    np.testing.assert_array_equal(vis['pred_camspc'].cpu().numpy(), vis['pred'].cpu().numpy())
+
+
+def test_forward_resized_camera_space_and_test_mode():
+    om, pm = make_pair(depth=256, uv=64, im=48, seed=5)      # warp res 32 != im res 48 -> resize path
+    batch, nn = O.synth_batch(1, 64, 64, 32, 32, 48, 48, k=1, seed=6)
+    _compare(om, pm, batch, nn, mode='test')
+    with pytest.raises(ValueError):
+        pm.call(to_device_batch(batch, nn), 'bogus')
+
+
+def test_forward_depth1024_config1_shape():
+    # BASELINE config 1 (dragon_sss, depth 1024, 256^2 UV), one frame to keep the oracle quick
+    om, pm = make_pair(depth=1024, uv=256, im=256, seed=7)
+    batch, nn = O.synth_batch(1, 256, 256, 256, 256, 256, 256, k=1, seed=8, identity_warp=True)
+    _compare(om, pm, batch, nn)
+
+
+def test_no_obs_and_no_skip_base():
+    om, pm = make_pair(depth=256, uv=64, im=64, seed=9, use_obs=False, skip_connect_base=False)
+    batch, nn = O.synth_batch(1, 64, 64, 64, 64, 64, 64, k=1, seed=9)
+    _compare(om, pm, batch, nn)
+
+
+def test_layerwise_call_matches_fused_plan_and_oracle():
+    """Model._call (reference structure, materialised concats, generic layer objects) ==
+    fused plan == oracle."""
+    om, pm = make_pair(depth=256, uv=64, im=64, seed=11)
+    batch, nn = O.synth_batch(1, 64, 64, 64, 64, 64, 64, k=2, seed=12)
+    db = to_device_batch(batch, nn)
+    x = torch.cat((db[1], db[2], db[3]), 3)
+    y_obs = [(db[9][:, i] - db[8][:, i]).contiguous() for i in range(2)]
+    got = pm._call(x, y_obs)
+    with torch.no_grad():
+        ref = om._call(torch.cat((batch[1], batch[2], batch[3]), 3), [r - b for b, r in nn])
+    assert rel_l2(got.cpu(), ref) <= TOL
+
+
+def test_obs_override_path():
+    om, pm = make_pair(depth=256, uv=64, im=64, seed=13)
+    batch, nn = O.synth_batch(2, 64, 64, 64, 64, 64, 64, k=1, seed=14)
+    with torch.no_grad():
+        x = torch.cat((batch[1], batch[2], batch[3]), 3)
+        _, feats = om._call(x, [nn[0][1] - nn[0][0]], return_feats=True)
+        override = [f.mean(0, keepdim=True) for f in feats]          # nlt_test.py:118-126 style aggregate
+        o_pred_c, _, _, o_vis = om.call(batch, 'test', obs_override=[f.expand(2, -1, -1, -1) for f in override],
+                                        nn_list=nn)
+    p_pred_c, _, _, p_vis = pm.call(to_device_batch(batch, nn), 'test', obs_override=[f.cuda() for f in override])
+    assert rel_l2(p_vis['pred'].cpu(), o_vis['pred']) <= TOL
+
+
+def test_golden_fixture_64():
+    """Committed oracle outputs (tests/golden/make_forward_golden.py) -- guards the oracle AND
+    the kernels against drifting together."""
+    g = np.load(os.path.join(G, 'nlt_forward_64.npz'))
+    om, pm = make_pair(depth=256, uv=64, im=32, seed=int(g['weight_seed']))
+    batch, nn = O.synth_batch(2, 64, 64, 32, 32, 32, 32, k=2, seed=int(g['batch_seed']))
+    p_pred_c, _, _, p_vis = pm.call(to_device_batch(batch, nn), 'train')
+    assert rel_l2(p_vis['pred'].cpu(), g['pred']) <= TOL
+    assert rel_l2(p_pred_c.cpu(), g['pred_camspc']) <= TOL

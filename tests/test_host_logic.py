@@ -1,0 +1,71 @@
+"""CPU: host-side mirror of the reference's plugin surface (no device calls)."""
+import os
+import re
+import subprocess
+import sys
+
+import pytest
+
+import nlt_amd
+from nlt_amd.models import get_model_class
+from nlt_amd.networks import convnet, elements
+from nlt_amd.util.net import gen_feat_n
+from oracle import nlt_oracle as O
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_gen_feat_n_matches_oracle():
+    for a, b, c in [(16, 256, 3), (16, 1024, 3), (8, 64, 3), (16, 16, 3), (12, 100, 3), (32, 64, 1)]:
+        assert gen_feat_n(a, b, c) == O.gen_feat_n(a, b, c)
+    with pytest.raises(AssertionError):
+        gen_feat_n(64, 16)
+
+
+def test_convnet_structure():
+    net = convnet.Network(16, 256, 2, 2, norm_type='None', act_type='leakyrelu', pool_type='None')
+    assert len(net.layers) == 14
+    assert net.is_contracting == [True] * 7 + [False] * 7
+    assert net.spatsize_changes == [1] + [0.5] * 6 + [2] * 6 + [1]
+    (c1, a1), (c2, a2) = net.layers[1].convs()
+    assert (c1.mode, c2.mode) == (nlt_amd.capi.CONV_K2S2, nlt_amd.capi.CONV_K2S1) and a1.alpha == 0.3
+    (d1, _), (d2, _) = net.layers[7].convs()
+    assert (d1.mode, d2.mode) == (nlt_amd.capi.DECONV_K2S2, nlt_amd.capi.DECONV_K2S1) and d1.n_ch_out == 128
+    assert convnet.Network(16, 1024, 2, 2, act_type='relu').layers[1].convs()[0][1].alpha == 0.0
+    with pytest.raises(AssertionError):
+        convnet.Network(8, 64, 2, 2)                       # depth0 must be 16
+    for bad in (dict(norm_type='batch'), dict(pool_type='max'), dict(act_type='elu')):
+        with pytest.raises(NotImplementedError):
+            convnet.Network(16, 256, 2, 2, **bad)
+    assert convnet.Network.str2none('None') is None and convnet.Network.str2none('x') == 'x'
+
+
+def test_model_registry_and_contract():
+    Model = get_model_class('nlt')
+    m = Model(nlt_amd.make_config(uvh=64, uvw=64, imh=64, imw=64, loss='barron,2e+0l2'))
+    assert len(m.net['query'].layers) == 14 and len(m.net['obs'].layers) == 7     # decoder dropped from obs
+    assert [w for w, _ in m.wloss] == [1.0, 2.0]
+    assert m._parse_loss_and_weight('1e+0lpips') == ('lpips', 1.0)
+    with pytest.raises(AssertionError):
+        m.trainable_variables
+    m.register_trainable()
+    assert hasattr(m, 'net_query_layer13') and hasattr(m, 'net_obs_layer6') and not hasattr(m, 'net_obs_layer7')
+    with pytest.raises(ValueError):
+        m._validate_mode('infer')
+    with pytest.raises(NotImplementedError):
+        Model(nlt_amd.make_config(loss='barron,1e+0lpips'))     # frozen AlexNet blob missing upstream
+    with pytest.raises(ModuleNotFoundError):
+        get_model_class('nope')
+
+
+def test_product_never_imports_oracle():
+    """The shipped package must not route through the CPU oracle (or /root/reference)."""
+    pkg = os.path.join(ROOT, 'neural-light-transport_amd')
+    for dp, _, fs in os.walk(pkg):
+        for f in fs:
+            if f.endswith(('.py', '.hip', '.h', '.cpp')):
+                src = open(os.path.join(dp, f)).read()
+                assert not re.search(r'^\s*(from|import)\s+oracle\b', src, flags=re.M), f
+                assert '/root/reference' not in src, f
+    code = "import sys; sys.path.insert(0, %r); import nlt_amd; assert 'oracle' not in sys.modules" % ROOT
+    subprocess.run([sys.executable, '-c', code], check=True)

@@ -1,0 +1,105 @@
+"""CPU: the host orchestration of the product (fused RenderPlan: interleaved feature maps,
+channel-slice outputs, dual-source virtual concat, bottleneck self-concat, obs_override; the
+layer-wise Model._call; Model.call's warp/resize/blend sequence) driven through a TEST-ONLY
+emulation of the C-ABI adapters (tests/fake_capi.py) and compared with the oracle.  The real
+kernels are checked by the -m gpu tests; this guards the Python plumbing on machines without a GPU."""
+import numpy as np
+import pytest
+import torch
+
+import nlt_amd
+from nlt_amd.models import get_model_class
+from oracle import nlt_oracle as O
+import fake_capi
+
+
+def rel_l2(a, b):
+    return float(np.linalg.norm(a.numpy().astype(np.float64) - b.numpy()) / np.linalg.norm(b.numpy()))
+
+
+def make(depth, uv, im, **kw):
+    om = O.OracleModel(depth=depth, uvh=uv, uvw=uv, imh=im, imw=im, seed=1, **kw)
+    pm = get_model_class('nlt')(nlt_amd.make_config(depth=depth, uvh=uv, uvw=uv, imh=im, imw=im, **kw))
+    # CPU weights (the fake adapters take CPU tensors)
+    for name in ('query', 'obs'):
+        for layer, lw in zip(pm.net[name].layers, om.numpy_weights()[name]):
+            convs = [layer] if hasattr(layer, 'set_weights') else [c for c, _ in layer.convs()]
+            for c, (k, b) in zip(convs, lw):
+                c.kernel, c.bias = torch.tensor(k), torch.tensor(b)
+                c.cin = k.shape[3] if c.transpose else k.shape[2]
+                c.built = True
+    return om, pm
+
+
+def cpu_batch(batch, nn):
+    b = list(batch)
+    b[8] = torch.stack([x[0] for x in nn], 1); b[9] = torch.stack([x[1] for x in nn], 1)
+    return tuple(b)
+
+
+@pytest.mark.parametrize('depth,uv,k', [(256, 64, 1), (256, 64, 3), (1024, 256, 1)])
+def test_fused_plan_matches_oracle(monkeypatch, depth, uv, k):
+    fake_capi.install(monkeypatch)
+    om, pm = make(depth, uv, 32)
+    batch, nn = O.synth_batch(1, uv, uv, 16, 16, 32, 32, k=k, seed=2)
+    with torch.no_grad():
+        ref_c, ref_gt, _, ref_vis = om.call(batch, 'train', nn_list=nn)
+    got_c, got_gt, kw, vis = pm.call(cpu_batch(batch, nn), 'train', want_indices=True)
+    assert kw == {}
+    assert rel_l2(vis['pred'], ref_vis['pred']) < 1e-5
+    assert rel_l2(got_c, ref_c) < 1e-5 and rel_l2(got_gt, ref_gt) < 1e-5
+    assert got_c.shape == (1, 32, 32, 3)                     # warp res 16 -> image res 32 (resize path)
+
+
+def test_layerwise_call_and_override_and_flags(monkeypatch):
+    fake_capi.install(monkeypatch)
+    om, pm = make(256, 64, 64)
+    batch, nn = O.synth_batch(2, 64, 64, 64, 64, 64, 64, k=2, seed=3)
+    x = torch.cat((batch[1], batch[2], batch[3]), 3)
+    with torch.no_grad():
+        ref, feats = om._call(x, [r - b for b, r in nn], return_feats=True)
+        got = pm._call(x, [r - b for b, r in nn])
+        assert rel_l2(got, ref) < 1e-5
+        override = [f.mean(0, keepdim=True) for f in feats]
+        ref_o = om.call(batch, 'test', obs_override=[f.expand(2, -1, -1, -1) for f in override], nn_list=nn)[3]['pred']
+    got_o = pm.call(cpu_batch(batch, nn), 'test', obs_override=override)[3]['pred']
+    assert rel_l2(got_o, ref_o) < 1e-5
+    w = torch.rand(2, 2)
+    with torch.no_grad():
+        ref_w = om._call(x, [r - b for b, r in nn], obs_weights=w)
+    pred_w, _ = pm.plan.forward(batch[1], batch[2], batch[3], cpu_batch(batch, nn)[9], cpu_batch(batch, nn)[8],
+                                obs_weights=w, skip_connect_base=False)
+    ref_w = ref_w.clone(); ref_w[:, 0, 0, :] = 0
+    assert rel_l2(pred_w, ref_w) < 1e-5
+
+
+def test_no_obs_no_skip(monkeypatch):
+    fake_capi.install(monkeypatch)
+    om, pm = make(256, 64, 64, use_obs=False, skip_connect_base=False)
+    batch, nn = O.synth_batch(1, 64, 64, 64, 64, 64, 64, k=1, seed=4)
+    with torch.no_grad():
+        ref = om.call(batch, 'vali', nn_list=nn)[3]['pred']
+    assert rel_l2(pm.call(cpu_batch(batch, nn), 'vali')[3]['pred'], ref) < 1e-5
+
+
+def test_op_labels_and_algorithmic_bytes(monkeypatch):
+    """Per-launch algorithmic bytes sum to SURVEY 8d's per-texel figure (961.5 B k=1; 1755.75 B k=4)."""
+    fake_capi.install(monkeypatch)
+    from nlt_amd.engine import OpTimer
+
+    class Rec(OpTimer):
+        def launch(self, label, nbytes, fn, *a, **kw):
+            self.records[label] = [1, 0.0, nbytes]
+            fn(*a, **kw)
+    for k, per_texel in ((1, 961.5), (4, 1755.75)):
+        om, pm = make(256, 64, 64)
+        pm.plan.timer = Rec()
+        batch, nn = O.synth_batch(1, 64, 64, 64, 64, 64, 64, k=k, seed=5)
+        pm.call(cpu_batch(batch, nn), 'test')
+        total = sum(r[2] for r in pm.plan.timer.records.values())
+        # the fused plan adds the explicit obs-mean launches and the stem's raw-input reads /
+        # mean write on top of the layer-wise accounting; everything else must match exactly
+        extra = sum(r[2] for l, r in pm.plan.timer.records.items() if l.endswith('.o.mean'))
+        extra += 4 * 64 * 64 * (3 * k + 16) + 4 * 64 * 64 * 3        # stem: second raw obs input + mean write; head: base read
+        assert abs((total - extra) / (64 * 64) - per_texel) < 1e-6, (k, (total - extra) / 4096)
+        assert len(pm.plan.timer.records) == 1 + 6 * 5 + 6 * 2 + 1
