@@ -46,6 +46,8 @@ def parse():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--per-op', action='store_true', help='print a per-launch timing table to stderr')
     ap.add_argument('--dominant', type=str, default=None, help='label of the kernel to time in the timed region')
+    ap.add_argument('--train-steps', type=int, default=-1, help='train steps to time for the train_step field (-1: steps//2, 0: skip)')
+    ap.add_argument('--train-loss', type=str, default='l2')
     return ap.parse_args()
 
 
@@ -80,6 +82,48 @@ def cpu_baseline(args):
     return {"value": round(args.uv * args.uv / t / 1e6, 3), "unit": "Mtexels/s", "cores": cores, "kind": "port",
             "sample": "CPU oracle (torch-CPU restatement of the TF2 path; TensorFlow not installable here), "
                       "1 frame %dx%d UV, k=%d, full forward + warp, median of 9 after 1 warm-up" % (args.uv, args.uv, args.k)}
+
+
+def bench_train(args, device, world, rank, n_steps):
+    """BASELINE config 4 per GPU: 4 frames, 1024^2 UV, k=1, loss l2, Keras Adam-AMSGrad, ONE RCCL
+    all-reduce(sum) of the flat fp32 gradient bucket per step.  Reported beside the headline."""
+    import torch
+    import torch.distributed as dist
+    import nlt_amd
+    from nlt_amd import trainvali
+    from nlt_amd.models import get_model_class
+    cfg = nlt_amd.make_config(depth=args.depth, uvh=args.uv, uvw=args.uv, imh=args.cam, imw=args.cam,
+                              loss=args.train_loss, lr=1e-3)
+    model = get_model_class('nlt')(cfg).build(device)
+    model.register_trainable()
+    g = torch.Generator(device=device).manual_seed(4321)
+    with torch.no_grad():
+        for c in model._conv_layers():
+            c.bias.uniform_(-0.1, 0.1, generator=g)
+    opt = trainvali.make_optimizer(model, cfg)
+    batch = synth_device_batch(args.frames, args.uv, args.cam, 1, device, seed=200 + rank)
+    gbs = world * args.frames
+    for _ in range(3):
+        trainvali.distributed_train_step(model, batch, opt, gbs)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(n_steps):
+        loss, _ = trainvali.distributed_train_step(model, batch, opt, gbs)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    el = time.perf_counter() - t0
+    if world > 1:
+        te = torch.tensor([el], device=device, dtype=torch.float64)
+        dist.all_reduce(te, op=dist.ReduceOp.MAX)
+        el = float(te.item())
+    return {"value": round(world * args.frames * args.uv * args.uv * n_steps / el / 1e6, 2), "unit": "Mtexels/s",
+            "ms_per_step": round(1e3 * el / n_steps, 3), "steps": n_steps, "global_batch": gbs,
+            "workload": "BASELINE config 4: %d frames/GPU, %d^2 UV, k=1, loss %s, Adam-AMSGrad, flat %d-float "
+                        "gradient bucket all-reduce" % (args.frames, args.uv, args.train_loss, model.flat_params.numel()),
+            "final_loss": float(loss)}
 
 
 def main():
@@ -156,6 +200,11 @@ def main():
     dom_ms = drec[1] / drec[0]
     dom_bytes = drec[2]
 
+    train = None
+    n_train = args.steps // 2 if args.train_steps < 0 else args.train_steps
+    if n_train > 0:
+        train = bench_train(args, device, world, rank, n_train)
+
     if rank == 0:
         texels = world * args.frames * args.uv * args.uv * args.steps
         value = texels / elapsed / 1e6
@@ -179,6 +228,8 @@ def main():
                                     "achieved": round(value / world * 1e6 * bpt / 1e9, 1), "unit": "GB/s per GPU",
                                     "frac": round(value / world * 1e6 * bpt / 1e9 / HBM_PEAK_GBS, 4)},
         }
+        if train is not None:
+            out["train_step"] = train
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args)
         print(json.dumps(out), flush=True)

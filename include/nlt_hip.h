@@ -145,6 +145,80 @@ int nlt_resize_bilinear_forward(const float* x, int n, int h, int w, int c, int 
  * nlt/models/nlt.py:132-133). */
 int nlt_mul_forward(const float* a, const float* b, long count, float* out, void* stream);
 
+/* ======================= train step (nlt/trainvali.py:272-281) ======================= */
+
+/*
+ * Weight and bias gradients of one conv layer: dW += X^T dPre, db += sum dPre, accumulated into
+ * Keras-layout buffers (zero them first).  X is given exactly as to nlt_conv_forward (sources,
+ * strides, input dims); dpre [n,oh,ow,*] (stride ldp) is the gradient w.r.t. the layer's
+ * PRE-activation output.
+ *   replaces: tape.gradient(loss, layer.kernel / layer.bias) for tf.keras Conv2D / Conv2DTranspose
+ *             (nlt/trainvali.py:279; layers built in nlt/networks/elements.py:26-39).
+ * Backward-DATA needs no extra entry point: it is nlt_conv_forward in the adjoint mode
+ * (CONV_K2Sx <-> DECONV_K2Sx) on the SAME Keras kernel array, with mask_src / accumulate.
+ */
+int nlt_conv_backward_weights(int mode, int algo,
+                              const float* src0, int ld0, int c0,
+                              const float* src1, int ld1, int c1,
+                              int n, int h, int w,
+                              const float* dpre, int ldp, int cout,
+                              float* dw_keras, float* dbias, void* stream);
+
+/* out = g * (y > 0 ? 1 : alpha): LeakyReLU backward from the saved OUTPUT y (elements.py:72-73). */
+int nlt_lrelu_backward(const float* g, int ldg, const float* y, int ldy, int c, long texels, float alpha,
+                       float* out, int ldo, void* stream);
+
+/* Backward of nlt_obs_mean_forward fused with the observation layer's LeakyReLU backward:
+ * dpre_obs[f,i] = (dobs_partial[f,i] + dmean[f] * w_i / k) * lrelu'(obs_y[f,i]); obs_y / obs_weights /
+ * dobs_partial may be NULL (no activation / unit weights / no other consumer).  nlt/models/nlt.py:161-166. */
+int nlt_obs_mean_backward(const float* dmean, int ldm, const float* obs_y, const float* obs_weights,
+                          const float* dobs_partial, int n, int k, int hw, int c, float alpha,
+                          float* dpre_obs, void* stream);
+
+/* Backward of nlt_stem_forward: accumulates dwq (5,c), dbq (c), dwo (3,c), dbo (c) from
+ * dfm0 [n,h,w,2c] and the per-observation partial dobs0 [n,k,h,w,c] (may be NULL). */
+int nlt_stem_backward(const float* base, const float* cvis, const float* lvis, const float* nn_rgb,
+                      const float* nn_base, const float* obs_weights, int n, int k, int h, int w, int c,
+                      const float* dfm0, const float* dobs0_partial,
+                      float* dwq, float* dbq, float* dwo, float* dbo, void* stream);
+
+/* Backward of nlt_head_forward: d_dec / d_skip (written), dw (cd+cs,3) and db (3) accumulated;
+ * the gradient of texel (0,0) is dropped (set_left_top_corner). */
+int nlt_head_backward(const float* dec, int ldd, int cd, const float* skip, int lds, int cs,
+                      const float* w_keras, const float* dpred, int n, int h, int w,
+                      float* d_dec, int ldgd, float* d_skip, int ldgs, float* dw, float* db, void* stream);
+
+/* Gradient of nlt_warp_forward w.r.t. pred: 4-corner scatter-add (the TFA resampler gradient,
+ * nlt/models/nlt.py:114 under the tape); dpred [n,uvh,uvw,3] is zero-filled first; texel (0,0) gets none. */
+int nlt_warp_backward(const float* dpred_cam, const float* warp, int n, int uvh, int uvw, int hc, int wc,
+                      float* dpred, void* stream);
+
+/* Gradient of nlt_resize_bilinear_forward w.r.t. x (zero-filled first). */
+int nlt_resize_bilinear_backward(const float* dout, int n, int h, int w, int c, int oh, int ow, float* dx,
+                                 void* stream);
+
+/* losses.L2 with keep_batch=True (nlt/losses.py:39-53): loss[f] = mean over H,W,C of (gt-pred)^2. */
+int nlt_l2_loss_forward(const float* pred, const float* gt, int n, long per_example, float* loss, void* stream);
+int nlt_l2_loss_backward(const float* pred, const float* gt, const float* gloss, int n, long per_example,
+                         float* dpred, void* stream);
+
+/* losses.Barron with keep_batch=True (nlt/losses.py:90-118; robust_loss adaptive.py:453-538 with
+ * alpha = 1, scale = 0.01, CDF9/7, 5 levels, sYUV): loss[f]; if dpred_unit != NULL also
+ * d loss[f] / d pred (multiply by the upstream per-example gradient with nlt_scale_rows).
+ * workspace: nlt_barron_workspace_floats(n,h,w) floats.  min(h,w) >= 17. */
+long nlt_barron_workspace_floats(int n, int h, int w);
+int nlt_barron_loss(const float* pred, const float* gt, int n, int h, int w, float* workspace,
+                    float* loss, float* dpred_unit, void* stream);
+
+/* out[f,:] = x[f,:] * scale[f] */
+int nlt_scale_rows(const float* x, const float* scale, int n, long per_row, float* out, void* stream);
+
+/* One fused Keras Adam(amsgrad=True) step over a flat parameter bucket (TF 2.2 OptimizerV2:
+ * p -= lr_t * m / (sqrt(vhat) + eps), lr_t = lr*sqrt(1-b2^t)/(1-b1^t) computed by the caller).
+ *   replaces: optimizer.apply_gradients (nlt/trainvali.py:124-127,280). */
+int nlt_adam_amsgrad_step(float* param, const float* grad, float* m, float* v, float* vhat, long count,
+                          float lr_t, float beta1, float beta2, float eps, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

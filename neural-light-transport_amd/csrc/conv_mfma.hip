@@ -75,38 +75,54 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvP p, int mtiles, int
 
   const f32x4* __restrict__ wp = reinterpret_cast<const f32x4*>(p.wgt) + (size_t)(ng * CT) * 64 + lane;
   const size_t wstride = (size_t)ntiles * 64;   // f32x4 per K-chunk
+  const int ch0 = chunks16(p.c0), ch1 = chunks16(p.c1);
+  const int cps = ch0 + ch1;                    // K-chunks per tap: source 0 then source 1
 
+  // Fragment loads are UNCONDITIONAL (clamped addresses, value selected afterwards): a predicated
+  // load becomes an exec-masked branch per load and serialises the wave's memory requests.
+  // The next chunk's fragments are requested before the current chunk's MFMAs are issued.
   int kc = 0;
   for (int t = 0; t < TAPS; ++t) {
-    int tex[RT];
+    bool tv[RT];
+    const float* p0[RT];
+    const float* p1[RT];
 #pragma unroll
-    for (int rt = 0; rt < RT; ++rt) tex[rt] = rv[rt] ? conv_tap_texel<MODE>(p, rf[rt], ry[rt], rx[rt], t) : -1;
-    for (int s = 0; s < 2; ++s) {
-      const int cs = s ? p.c1 : p.c0;
-      if (cs == 0) continue;
-      const float* __restrict__ src = s ? p.src1 : p.src0;
-      const int ld = s ? p.ld1 : p.ld0;
-      const float* rp[RT];
+    for (int rt = 0; rt < RT; ++rt) {
+      const int tex = rv[rt] ? conv_tap_texel<MODE>(p, rf[rt], ry[rt], rx[rt], t) : -1;
+      tv[rt] = tex >= 0;
+      const size_t tx = tv[rt] ? (size_t)tex : 0;
+      p0[rt] = p.src0 + tx * p.ld0 + 4 * kk;
+      p1[rt] = p.c1 ? p.src1 + tx * p.ld1 + 4 * kk : p0[rt];
+    }
+    auto load_frags = [&](int r, int kci, f32x4 (&a)[CT], f32x4 (&b)[RT]) {
+      const bool s = r >= ch0;
+      const int k0 = (s ? r - ch0 : r) << 4;
+      const bool kin = (k0 + 4 * kk) < (s ? p.c1 : p.c0);
+      const int koff = kin ? k0 : -4 * kk;      // out-of-segment lanes re-read the row start
 #pragma unroll
-      for (int rt = 0; rt < RT; ++rt) rp[rt] = src + (size_t)(tex[rt] < 0 ? 0 : tex[rt]) * ld + 4 * kk;
-      for (int k0 = 0; k0 < cs; k0 += 16, ++kc) {
-        const bool kin = (k0 + 4 * kk) < cs;
-        f32x4 b[RT], a[CT];
-#pragma unroll
-        for (int rt = 0; rt < RT; ++rt) {
-          b[rt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-          if (kin && tex[rt] >= 0) b[rt] = *reinterpret_cast<const f32x4*>(rp[rt] + k0);
-        }
-#pragma unroll
-        for (int ct = 0; ct < CT; ++ct) a[ct] = wp[(size_t)kc * wstride + ct * 64];
-#pragma unroll
-        for (int s4 = 0; s4 < 4; ++s4)
-#pragma unroll
-          for (int rt = 0; rt < RT; ++rt)
-#pragma unroll
-            for (int ct = 0; ct < CT; ++ct)
-              acc[rt][ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[ct][s4], b[rt][s4], acc[rt][ct], 0, 0, 0);
+      for (int rt = 0; rt < RT; ++rt) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>((s ? p1[rt] : p0[rt]) + koff);
+        const bool ok = kin && tv[rt];
+        b[rt] = (f32x4){ok ? v[0] : 0.f, ok ? v[1] : 0.f, ok ? v[2] : 0.f, ok ? v[3] : 0.f};
       }
+#pragma unroll
+      for (int ct = 0; ct < CT; ++ct) a[ct] = wp[(size_t)kci * wstride + ct * 64];
+    };
+    f32x4 a_cur[CT], b_cur[RT], a_nxt[CT], b_nxt[RT];
+    load_frags(0, kc, a_cur, b_cur);
+    for (int r = 0; r < cps; ++r, ++kc) {
+      if (r + 1 < cps) load_frags(r + 1, kc + 1, a_nxt, b_nxt);
+#pragma unroll
+      for (int s4 = 0; s4 < 4; ++s4)
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+          for (int ct = 0; ct < CT; ++ct)
+            acc[rt][ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_cur[ct][s4], b_cur[rt][s4], acc[rt][ct], 0, 0, 0);
+#pragma unroll
+      for (int ct = 0; ct < CT; ++ct) a_cur[ct] = a_nxt[ct];
+#pragma unroll
+      for (int rt = 0; rt < RT; ++rt) b_cur[rt] = b_nxt[rt];
     }
   }
 

@@ -14,6 +14,8 @@ HBM buffers:
   conv kernels' dual-source "virtual concat" (nlt.py:190), including the bottleneck self-concat
   quirk (first decoder layer sees concat(fm[D], fm[D])).
 """
+import os
+
 import torch
 
 from . import _capi as C
@@ -47,7 +49,11 @@ class RenderPlan:
     def __init__(self, net_query, net_obs, use_obs=True):
         self.timer = None               # set to an OpTimer (or a set of labels via timer.only) to time launches
         self.q, self.o, self.use_obs = net_query, net_obs, use_obs
-        self.tile_hints = {}            # label -> 16*RT+CT override (tuning aid)
+        self.tile_hints = {}            # label -> 16*RT+CT wave tile ('*' = every launch)
+        self.algo_hints = {}            # label -> C.ALGO_DIRECT for the few tiny-channel layers where it wins
+        self.autotune = os.environ.get('NLT_AUTOTUNE', '1') != '0'
+        self._trial_direct = False
+        self._ran_direct = set()
         is_c = net_query.is_contracting
         self.n_down = sum(is_c) - 1                      # contracting Sequential blocks
         self.n_up = len(is_c) - sum(is_c) - 1            # expanding Sequential blocks
@@ -94,6 +100,10 @@ class RenderPlan:
     def _conv(self, label, layer, act, src0, c0, ld0, src1, c1, ld1, n, h, w, out, ldo, algo=C.ALGO_AUTO):
         layer.build(c0 + c1, src0.device)
         assert layer.cin == c0 + c1, (layer.cin, c0, c1)
+        small = (c0 + c1) * layer.n_ch_out <= 1024
+        if self.algo_hints.get(label) == C.ALGO_DIRECT or (self._trial_direct and small):
+            algo = C.ALGO_DIRECT
+            self._ran_direct.add(label)
         ok = c0 % 4 == 0 and c1 % 4 == 0 and layer.n_ch_out % 4 == 0 and algo != C.ALGO_DIRECT
         oh, ow = layer.out_hw(h, w)
         # SURVEY 8d accounting: every input element read once, every output element written once
@@ -107,6 +117,39 @@ class RenderPlan:
                        act=act is not None, alpha=act.alpha if act is not None else 0.0,
                        algo=algo if ok else C.ALGO_DIRECT, tile_hint=tile_hint if ok else 0)
 
+    # ------------------------------------------------------------------ autotune
+    def _autotune(self, run):
+        """Plan-creation-time choice of the MFMA wave tile (RT x CT) per launch: streaming layers
+        want many small waves (memory-level parallelism), deep layers big register tiles (MFMA
+        bound); a few 4/8-channel layers are faster on the direct kernel.  Times every candidate
+        with HIP events on this shape and keeps the fastest."""
+        saved = (self.timer, dict(self.tile_hints), dict(self.algo_hints))
+        results = {}
+        trials = [('tile', 16 * r + c) for r in (1, 2, 4) for c in (1, 2, 4)] + [('direct', 0)]
+        for kind, hint in trials:
+            self.tile_hints = {'*': hint} if kind == 'tile' else {}
+            self.algo_hints = {}
+            self._trial_direct = kind == 'direct'
+            self._ran_direct = set()
+            self.timer = None
+            run()
+            self.timer = OpTimer()
+            run(); run()
+            for label, r in self.timer.collect().items():
+                if kind == 'tile' or label in self._ran_direct:
+                    results.setdefault(label, []).append((r[1] / r[0], kind, hint))
+        self._trial_direct = False
+        self.timer, self.tile_hints, self.algo_hints = saved
+        for label, res in results.items():
+            if '.s1' not in label and '.s2' not in label and label != 'L0.q':
+                continue
+            t, kind, hint = min(res)
+            if kind == 'direct':
+                self.algo_hints.setdefault(label, C.ALGO_DIRECT)
+            else:
+                self.tile_hints.setdefault(label, hint)
+        self.tuned = results
+
     # ------------------------------------------------------------------ forward
     def forward(self, base, cvis, lvis, nn_rgb, nn_base, obs_weights=None, obs_override=None,
                 skip_connect_base=True, algo=C.ALGO_AUTO):
@@ -116,6 +159,10 @@ class RenderPlan:
         k = nn_rgb.shape[1]
         dev = base.device
         b = self._buffers(n, k, h, w, dev)
+        if self.autotune and not b.get('tuned') and base.is_cuda:
+            b['tuned'] = True
+            self._autotune(lambda: self.forward(base, cvis, lvis, nn_rgb, nn_base, obs_weights, obs_override,
+                                                skip_connect_base, algo))
         q, o, D, cl = self.q, self.o, self.n_down, b['C']
         mult = 2 if self.use_obs else 1
         run_obs = self.use_obs and obs_override is None
@@ -177,3 +224,118 @@ class RenderPlan:
                      x, cx, cx, b['fm'][0], cs, cs, head.kernel.detach(), head.bias.detach(),
                      base if skip_connect_base else None, n, h, w, b['pred'])
         return b['pred'], b
+
+    # ------------------------------------------------------------------ backward
+    def _grad_buffers(self, b):
+        g = b.get('grads')
+        if g is None:
+            Z = torch.empty_like
+            g = {'fm': [Z(t) for t in b['fm']], 'obs': [Z(t) for t in b['obs']],
+                 'qtmp': [None] + [Z(t) for t in b['qtmp'][1:]], 'otmp': [None] + [Z(t) for t in b['otmp'][1:]],
+                 'dtmp': [Z(t) for t in b['dtmp']], 'dec': [Z(t) for t in b['dec']],
+                 'zero_bias': torch.zeros(4096, device=b['pred'].device)}
+            b['grads'] = g
+        return g
+
+    def _wgrad(self, label, layer, src0, c0, ld0, src1, c1, ld1, n, h, w, dpre, ldp):
+        oh, ow = layer.out_hw(h, w)
+        nbytes = 4 * (n * h * w * (c0 + c1) + n * oh * ow * layer.n_ch_out)
+        self._launch(label, nbytes, C.conv_backward_weights, layer.mode, src0, c0, ld0, src1, c1, ld1, n, h, w,
+                     dpre, ldp, layer.n_ch_out, layer.dkernel, layer.dbias)
+
+    def _dgrad(self, label, layer, lo, hi, dpre, ldp, n, oh, ow, out, ldo, mask_src=None, ldm=0, mask_alpha=0.3,
+               accumulate=False, zero_bias=None):
+        """Backward-data of `layer` w.r.t. its input channels [lo,hi): the adjoint conv family on
+        the gradient w.r.t. the layer's pre-activation output dpre [n,oh,ow,cout].  mask_src (the
+        saved activation the result corresponds to) turns the result into the gradient w.r.t. the
+        PRODUCER's pre-activation."""
+        packed, ks = layer.packed_adjoint(lo, hi)
+        adj = layer.ADJOINT[layer.mode]
+        out_px = n * oh * ow * (4 if adj == C.DECONV_K2S2 else 1) // (4 if adj == C.CONV_K2S2 else 1)
+        nbytes = 4 * (n * oh * ow * layer.n_ch_out + out_px * (hi - lo))
+        self._launch(label, nbytes, C.conv_forward, adj, dpre, layer.n_ch_out, ldp, None, 0, 0, n, oh, ow, ks, packed,
+                     zero_bias, hi - lo, out, ldo, act=False, alpha=mask_alpha, algo=C.ALGO_MFMA,
+                     mask_src=mask_src, ldm=ldm, accumulate=accumulate)
+
+    def backward(self, dpred, base, cvis, lvis, nn_rgb, nn_base, obs_weights=None):
+        """Gradient of everything `forward` computed, given dpred = dL/d(pred) [N,H,W,3]; uses the
+        activations the last forward left in the plan's buffers.  Weight gradients are ACCUMULATED
+        into each layer's dkernel / dbias (views of the model's flat gradient bucket: zero it first)."""
+        if not self.use_obs:
+            raise NotImplementedError("training with use_obs = False")
+        n, h, w, _ = base.shape
+        k = nn_rgb.shape[1]
+        b = self._buffers(n, k, h, w, base.device)
+        g = self._grad_buffers(b)
+        q, o, D, U, cl = self.q, self.o, self.n_down, self.n_up, b['C']
+        zb = g['zero_bias']
+
+        # ---- head
+        head = q.layers[-1]
+        x_last = b['dec'][U - 1]
+        cx = x_last.shape[-1]
+        cs = 2 * cl[0]
+        self._launch('bwd.head', 4 * n * h * w * (2 * (cx + cs) + 3), C.head_backward, x_last, cx, cx, b['fm'][0], cs, cs,
+                     head.kernel.detach(), dpred, n, h, w, g['dec'][U - 1], cx, g['fm'][0], cs, head.dkernel, head.dbias)
+
+        # ---- decoder (expanding blocks), last to first
+        hh, ww = h, w
+        for j in range(U - 1, -1, -1):
+            (da, act_a), (db, act_b) = q.layers[D + 1 + j].convs()
+            nl = db.n_ch_out
+            lab = 'bwd.L%d.q' % (D + 1 + j)
+            # s1:  dec[j] = act(deconv_s1(dtmp[j]))
+            self._launch(lab + '.s1.act', 12 * n * hh * ww * nl, C.lrelu_backward, g['dec'][j], nl, b['dec'][j], nl, nl,
+                         n * hh * ww, act_b.alpha, g['dec'][j], nl)
+            self._wgrad(lab + '.s1.wgrad', db, b['dtmp'][j], nl, nl, None, 0, 0, n, hh, ww, g['dec'][j], nl)
+            self._dgrad(lab + '.s1.dgrad', db, 0, nl, g['dec'][j], nl, n, hh, ww, g['dtmp'][j], nl,
+                        mask_src=b['dtmp'][j], ldm=nl, mask_alpha=act_a.alpha, zero_bias=zb)
+            # s2:  dtmp[j] = act(deconv_s2(concat(x, skip)))
+            if j > 0:
+                x, cxj = b['dec'][j - 1], b['dec'][j - 1].shape[-1]
+                dx = g['dec'][j - 1]
+            else:
+                x, cxj = b['fm'][D], 2 * cl[D]
+                dx = g['fm'][D]
+            skip, csj, dskip = b['fm'][D - j], 2 * cl[D - j], g['fm'][D - j]
+            self._wgrad(lab + '.s2.wgrad', da, x, cxj, cxj, skip, csj, csj, n, hh // 2, ww // 2, g['dtmp'][j], nl)
+            self._dgrad(lab + '.s2.dgrad.x', da, 0, cxj, g['dtmp'][j], nl, n, hh, ww, dx, cxj, zero_bias=zb)
+            self._dgrad(lab + '.s2.dgrad.skip', da, cxj, cxj + csj, g['dtmp'][j], nl, n, hh, ww, dskip, csj,
+                        accumulate=(j == 0), zero_bias=zb)
+            hh, ww = hh // 2, ww // 2
+
+        # ---- encoder (contracting blocks), deepest first; hh, ww = dims of level D
+        for l in range(D, 0, -1):
+            (qa, qact_a), (qb, qact_b) = q.layers[l].convs()
+            (oa, oact_a), (ob, oact_b) = o.layers[l].convs()
+            c, cp = cl[l], cl[l - 1]
+            lab = 'bwd.L%d' % l
+            # query half of dfm[l] -> gradient w.r.t. the pre-activation of q.s1
+            self._launch(lab + '.q.s1.act', 12 * n * hh * ww * c, C.lrelu_backward, g['fm'][l], 2 * c, b['fm'][l], 2 * c,
+                         c, n * hh * ww, qact_b.alpha, g['fm'][l], 2 * c)
+            # observation half: distribute the mean's gradient, add the obs path's own, activation backward
+            self._launch(lab + '.o.mean', 4 * n * hh * ww * c * (1 + 3 * k), C.obs_mean_backward,
+                         g['fm'][l].view(-1)[c:], 2 * c, b['obs'][l], obs_weights, g['obs'][l] if l < D else None,
+                         n, k, hh * ww, c, oact_b.alpha, g['obs'][l])
+            # q.s1 / q.s2
+            self._wgrad(lab + '.q.s1.wgrad', qb, b['qtmp'][l], c, c, None, 0, 0, n, hh, ww, g['fm'][l], 2 * c)
+            self._dgrad(lab + '.q.s1.dgrad', qb, 0, c, g['fm'][l], 2 * c, n, hh, ww, g['qtmp'][l], c,
+                        mask_src=b['qtmp'][l], ldm=c, mask_alpha=qact_a.alpha, zero_bias=zb)
+            self._wgrad(lab + '.q.s2.wgrad', qa, b['fm'][l - 1], 2 * cp, 2 * cp, None, 0, 0, n, 2 * hh, 2 * ww,
+                        g['qtmp'][l], c)
+            self._dgrad(lab + '.q.s2.dgrad', qa, 0, 2 * cp, g['qtmp'][l], c, n, hh, ww, g['fm'][l - 1], 2 * cp,
+                        accumulate=True, zero_bias=zb)
+            # o.s1 / o.s2 (n*k observation frames)
+            self._wgrad(lab + '.o.s1.wgrad', ob, b['otmp'][l], c, c, None, 0, 0, n * k, hh, ww, g['obs'][l], c)
+            self._dgrad(lab + '.o.s1.dgrad', ob, 0, c, g['obs'][l], c, n * k, hh, ww, g['otmp'][l], c,
+                        mask_src=b['otmp'][l], ldm=c, mask_alpha=oact_a.alpha, zero_bias=zb)
+            self._wgrad(lab + '.o.s2.wgrad', oa, b['obs'][l - 1], cp, cp, None, 0, 0, n * k, 2 * hh, 2 * ww,
+                        g['otmp'][l], c)
+            self._dgrad(lab + '.o.s2.dgrad', oa, 0, cp, g['otmp'][l], c, n * k, hh, ww, g['obs'][l - 1], cp, zero_bias=zb)
+            hh, ww = hh * 2, ww * 2
+
+        # ---- L0 (both paths)
+        q0, o0 = q.layers[0], o.layers[0]
+        self._launch('bwd.L0.stem', 4 * n * h * w * (5 + 6 * k + 2 * cl[0] + k * cl[0]), C.stem_backward,
+                     base, cvis, lvis, nn_rgb, nn_base, obs_weights, n, k, h, w, cl[0], g['fm'][0], g['obs'][0],
+                     q0.dkernel, q0.dbias, o0.dkernel, o0.dbias)

@@ -11,6 +11,41 @@ from ..networks import convnet
 from .base import Model as BaseModel
 
 
+class _RenderFn(torch.autograd.Function):
+    """torch-autograd glue around the hand-written forward/backward plans: `flat_params` is the
+    model's single parameter bucket; its gradient is the flat gradient bucket the backward plan
+    fills (one tensor -> one RCCL all-reduce, one fused Adam launch)."""
+
+    @staticmethod
+    def forward(ctx, flat_params, model, inputs, want_indices):
+        base, cvis, lvis, warp, nn_rgb, nn_base, obs_weights = inputs
+        out = model._render(base, cvis, lvis, warp, nn_rgb, nn_base, obs_weights, None, want_indices)
+        ctx.model, ctx.inputs = model, inputs
+        pred, pred_c, base_c, fg_c, idx = out
+        nd = [t for t in (pred, base_c, fg_c) if t is not None]
+        ctx.mark_non_differentiable(*nd)
+        ctx.set_materialize_grads(False)
+        if idx is None:
+            idx = torch.empty(0, dtype=torch.int32, device=pred.device)
+        ctx.mark_non_differentiable(idx)
+        return pred_c, pred, base_c, fg_c, idx
+
+    @staticmethod
+    def backward(ctx, d_pred_c, *unused):
+        model = ctx.model
+        base, cvis, lvis, warp, nn_rgb, nn_base, obs_weights = ctx.inputs
+        n, hc, wc, _ = warp.shape
+        model.flat_grads.zero_()
+        if d_pred_c is not None:
+            d_pred_c = d_pred_c.contiguous()
+            if (hc, wc) != (model.imh, model.imw):
+                d_pred_c = C.resize_bilinear_backward(d_pred_c, hc, wc)
+            dpred = torch.empty((n, model.uvh, model.uvw, 3), device=base.device, dtype=torch.float32)
+            C.warp_backward(d_pred_c, warp, n, model.uvh, model.uvw, hc, wc, dpred)
+            model.plan.backward(dpred, base, cvis, lvis, nn_rgb, nn_base, obs_weights)
+        return model.flat_grads, None, None, None
+
+
 class Model(BaseModel):
     def __init__(self, config):
         # needed by the Barron loss
@@ -67,7 +102,50 @@ class Model(BaseModel):
                 if stack:
                     cin_q += stack.pop()
                 cin_q = layer.build(cin_q, device)
+        self._flatten(device)
         return self
+
+    def _conv_layers(self):
+        """Every Conv2D of both nets in the flat-bucket order: query layers, then obs layers."""
+        out = []
+        for name in ('query', 'obs'):
+            for layer in self.net[name].layers:
+                out += [layer] if hasattr(layer, 'set_weights') else [c for c, _ in layer.convs()]
+        return out
+
+    def _flatten(self, device):
+        """Moves every kernel / bias into ONE flat fp32 parameter bucket (16-byte aligned slots)
+        with a matching flat gradient bucket; layers keep views.  One bucket = one RCCL all-reduce
+        and one fused Adam launch per step."""
+        convs = self._conv_layers()
+        slots, off = [], 0
+        for c in convs:
+            for t in (c.kernel, c.bias):
+                slots.append((off, t.numel(), tuple(t.shape)))
+                off += (t.numel() + 3) // 4 * 4
+        flat = torch.zeros(off, device=device, dtype=torch.float32)
+        it = iter(slots)
+        for c in convs:
+            for name in ('kernel', 'bias'):
+                o, n, shp = next(it)
+                flat[o:o + n].copy_(getattr(c, name).detach().reshape(-1))
+        self.flat_params = flat.requires_grad_(True)
+        self.flat_grads = torch.zeros_like(flat)
+        self.n_params = sum(n for _, n, _ in slots)
+        self._epoch = [0]
+        it = iter(slots)
+        for c in convs:
+            for name in ('kernel', 'bias'):
+                o, n, shp = next(it)
+                setattr(c, name, self.flat_params.detach()[o:o + n].view(shp))
+                setattr(c, 'd' + name, self.flat_grads[o:o + n].view(shp))
+            c._epoch = self._epoch
+            c._packed = {}
+
+    def mark_weights_updated(self):
+        """Call after writing the flat bucket through a raw pointer (optimizer kernel): packed
+        MFMA fragments are re-derived on next use."""
+        self._epoch[0] += 1
 
     def load_weights(self, weights):
         """weights = {'query': [[(kernel, bias), ...] per layer], 'obs': [...]} in Keras layouts
@@ -83,15 +161,11 @@ class Model(BaseModel):
         return self
 
     # ---------------------------------------------------------------- forward
-    def call(self, batch, mode, obs_override=None, obs_weights=None, want_indices=False):
-        self._validate_mode(mode)
-        id_, base, cvis, lvis, warp, rgb, rgb_camspc, nn_id, nn_base, nn_rgb, nn_rgb_camspc = batch
-        if nn_rgb.dim() == 4:           # the reference's single neighbour
-            nn_rgb, nn_base = nn_rgb.unsqueeze(1), nn_base.unsqueeze(1)
+    def _render(self, base, cvis, lvis, warp, nn_rgb, nn_base, obs_weights, obs_override, want_indices):
         n, hc, wc, _ = warp.shape
-        pred, _ = self.plan.forward(base, cvis, lvis, nn_rgb.contiguous(), nn_base.contiguous(),
-                                    obs_weights=obs_weights, obs_override=obs_override,
-                                    skip_connect_base=self.skip_connect_base, algo=self.conv_algo)
+        pred, _ = self.plan.forward(base, cvis, lvis, nn_rgb, nn_base, obs_weights=obs_weights,
+                                    obs_override=obs_override, skip_connect_base=self.skip_connect_base,
+                                    algo=self.conv_algo)
         E = lambda: torch.empty((n, hc, wc, 3), device=base.device, dtype=torch.float32)
         pred_camspc, base_camspc, fg_camspc = E(), E(), E()
         idx = torch.empty((n, hc, wc, 4), device=base.device, dtype=torch.int32) if want_indices else None
@@ -100,7 +174,24 @@ class Model(BaseModel):
             fg_camspc = C.resize_bilinear_forward(fg_camspc, self.imh, self.imw)
             base_camspc = C.resize_bilinear_forward(base_camspc, self.imh, self.imw)
             pred_camspc = C.resize_bilinear_forward(pred_camspc, self.imh, self.imw)
-        to_vis = {'id': id_, 'nn_id': nn_id, 'base_camspc': base_camspc, 'pred': pred,
+        return pred, pred_camspc, base_camspc, fg_camspc, idx
+
+    def call(self, batch, mode, obs_override=None, obs_weights=None, want_indices=False):
+        self._validate_mode(mode)
+        id_, base, cvis, lvis, warp, rgb, rgb_camspc, nn_id, nn_base, nn_rgb, nn_rgb_camspc = batch
+        if nn_rgb.dim() == 4:           # the reference's single neighbour
+            nn_rgb, nn_base = nn_rgb.unsqueeze(1), nn_base.unsqueeze(1)
+        nn_rgb, nn_base = nn_rgb.contiguous(), nn_base.contiguous()
+        differentiable = (mode == 'train' and torch.is_grad_enabled() and obs_override is None
+                          and getattr(self, 'flat_params', None) is not None)
+        if differentiable:
+            pred_camspc, pred, base_camspc, fg_camspc, idx = _RenderFn.apply(
+                self.flat_params, self, (base, cvis, lvis, warp, nn_rgb, nn_base, obs_weights), want_indices)
+        else:
+            pred, pred_camspc, base_camspc, fg_camspc, idx = self._render(
+                base, cvis, lvis, warp, nn_rgb, nn_base, obs_weights, obs_override, want_indices)
+        # `pred` lives in the plan's reusable buffer: hand out a copy
+        to_vis = {'id': id_, 'nn_id': nn_id, 'base_camspc': base_camspc, 'pred': pred.clone(),
                   'pred_camspc': pred_camspc, 'nn_camspc': nn_rgb_camspc}
         if want_indices:
             to_vis['uv_indices'] = idx

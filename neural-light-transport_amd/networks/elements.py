@@ -48,9 +48,11 @@ class Conv2D(Layer):
         else:
             self.mode = C.CONV_K2S2 if stride == 2 else C.CONV_K2S1
         self.built = False
-        self.kernel = self.bias = None
+        self.kernel = self.bias = None          # Keras-layout weights (views into the model's flat bucket once bound)
+        self.dkernel = self.dbias = None        # matching views into the flat gradient bucket
         self.cin = None
         self._packed = {}
+        self._epoch = [0]                       # shared "weights were rewritten" counter (optimizer bumps it)
 
     def build(self, cin, device='cuda', seed=None):
         if not self.built:
@@ -59,8 +61,8 @@ class Conv2D(Layer):
                 seed = _seed_counter[0]
             k, n = self.kernel_size, self.n_ch_out
             shape = (k, k, n, cin) if self.transpose else (k, k, cin, n)
-            self.kernel = _glorot_uniform(shape, device, seed).requires_grad_(True)
-            self.bias = torch.zeros(n, device=device, requires_grad=True)   # Keras: zeros
+            self.kernel = _glorot_uniform(shape, device, seed)
+            self.bias = torch.zeros(n, device=device)                        # Keras: zeros
             self.cin = cin
             self.built = True
         return self.n_ch_out
@@ -69,9 +71,14 @@ class Conv2D(Layer):
         kernel = torch.as_tensor(kernel, dtype=torch.float32)
         bias = torch.as_tensor(bias, dtype=torch.float32)
         cin = kernel.shape[3] if self.transpose else kernel.shape[2]
-        dev = self.kernel.device if self.built else 'cuda'
-        self.kernel = kernel.to(dev).contiguous().requires_grad_(True)
-        self.bias = bias.to(dev).contiguous().requires_grad_(True)
+        if self.built and tuple(kernel.shape) == tuple(self.kernel.shape):
+            with torch.no_grad():               # in place: keeps views into a flat bucket valid
+                self.kernel.copy_(kernel)
+                self.bias.copy_(bias)
+        else:
+            dev = self.kernel.device if self.built else 'cuda'
+            self.kernel = kernel.to(dev).contiguous()
+            self.bias = bias.to(dev).contiguous()
         self.cin, self.built = cin, True
         self._packed = {}
 
@@ -83,11 +90,29 @@ class Conv2D(Layer):
         kernel tensor has been written (optimizer step / set_weights)."""
         key = (c0, c1)
         ent = self._packed.get(key)
-        ver = (self.kernel.data_ptr(), self.kernel._version)
+        ver = (self.kernel.data_ptr(), self.kernel._version, self._epoch[0])
         if ent is None or ent[0] != ver:
             ent = (ver, C.pack_conv_weights(self.mode, self.kernel.detach(), c0, c1, self.n_ch_out))
             self._packed[key] = ent
         return ent[1]
+
+    ADJOINT = {C.CONV_K2S2: C.DECONV_K2S2, C.CONV_K2S1: C.DECONV_K2S1,
+               C.DECONV_K2S2: C.CONV_K2S2, C.DECONV_K2S1: C.CONV_K2S1}
+
+    def packed_adjoint(self, lo, hi):
+        """Fragments for backward-DATA w.r.t. forward input channels [lo, hi): the adjoint conv
+        family reads the SAME Keras array (a conv kernel (kh,kw,Cin,Cout) is the transposed
+        conv's (kh,kw,Cout',Cin') and vice versa), sliced along the forward-input axis."""
+        key = ('adj', lo, hi)
+        ent = self._packed.get(key)
+        ver = (self.kernel.data_ptr(), self.kernel._version, self._epoch[0])
+        if ent is None or ent[0] != ver:
+            k = self.kernel.detach()
+            ks = k[..., lo:hi] if self.transpose else k[:, :, lo:hi, :]
+            ks = ks.contiguous()
+            ent = (ver, C.pack_conv_weights(self.ADJOINT[self.mode], ks, self.n_ch_out, 0, hi - lo), ks)
+            self._packed[key] = ent
+        return ent[1], ent[2]
 
     def out_hw(self, h, w):
         if self.mode == C.CONV_K2S2:

@@ -1,0 +1,35 @@
+"""Keras Adam(amsgrad=True) as TF 2.2 executes it, fused over the model's flat parameter bucket
+(replaces tf.keras.optimizers.Adam + apply_gradients, nlt/trainvali.py:122-127,280)."""
+import math
+
+import torch
+
+from . import _capi as C
+
+
+class AdamAMSGrad:
+    def __init__(self, model, lr, beta1=0.9, beta2=0.999, eps=1e-7, clipnorm=None):
+        if clipnorm is not None and clipnorm > 0:
+            raise NotImplementedError("clipnorm (mgm > 0); the released configs use mgm = -1")
+        self.model, self.lr, self.b1, self.b2, self.eps = model, lr, beta1, beta2, eps
+        self.t = 0
+        z = lambda: torch.zeros_like(model.flat_params, requires_grad=False)
+        self.m, self.v, self.vhat = z(), z(), z()
+
+    def step(self, grad=None):
+        """grad: flat gradient bucket (defaults to model.flat_params.grad, i.e. what backward() left)."""
+        if grad is None:
+            grad = self.model.flat_params.grad
+        self.t += 1
+        lr_t = self.lr * math.sqrt(1.0 - self.b2 ** self.t) / (1.0 - self.b1 ** self.t)
+        C.adam_amsgrad_step(self.model.flat_params.detach(), grad, self.m, self.v, self.vhat, lr_t, self.b1, self.b2,
+                            self.eps)
+        self.model.mark_weights_updated()
+
+    def state_dict(self):
+        return {'t': self.t, 'm': self.m, 'v': self.v, 'vhat': self.vhat}
+
+    def load_state_dict(self, sd):
+        self.t = sd['t']
+        for k in ('m', 'v', 'vhat'):
+            getattr(self, k).copy_(sd[k])

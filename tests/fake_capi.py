@@ -22,7 +22,7 @@ def conv_forward(mode, src0, c0, ld0, src1, c1, ld1, n, h, w, w_keras, w_packed,
         x = torch.cat((x, _view(src1, n, h, w, c1, ld1)), -1)
     s, tr = _MODES[mode]
     f = T.conv2d_transpose_same if tr else T.conv2d_same
-    y = f(x, w_keras, bias, s)
+    y = f(x, w_keras, bias[:cout], s)
     oh, ow = y.shape[1:3]
     o = _view(out, n, oh, ow, cout, ldo)
     if accumulate:
@@ -91,4 +91,125 @@ def mul_forward(a, b):
 def install(monkeypatch):
     for name in ('conv_forward', 'pack_conv_weights', 'stem_forward', 'obs_mean_forward', 'head_forward',
                  'warp_forward', 'resize_bilinear_forward', 'mul_forward'):
+        monkeypatch.setattr(C, name, globals()[name])
+
+
+# ------------------------------------------------------------------ train-step ops (TEST-ONLY emulation)
+from oracle import barron as _B
+
+
+def conv_backward_weights(mode, src0, c0, ld0, src1, c1, ld1, n, h, w, dpre, ldp, cout, dw, db, algo=0):
+    x = _view(src0, n, h, w, c0, ld0)
+    if c1:
+        x = torch.cat((x, _view(src1, n, h, w, c1, ld1)), -1)
+    s, tr = _MODES[mode]
+    f = T.conv2d_transpose_same if tr else T.conv2d_same
+    with torch.enable_grad():
+        wz = torch.zeros_like(dw, requires_grad=True)
+        bz = torch.zeros(cout, requires_grad=True)
+        y = f(x.detach(), wz, bz, s)
+        g = _view(dpre, n, y.shape[1], y.shape[2], cout, ldp)
+        gw, gb = torch.autograd.grad(y, (wz, bz), g)
+    dw += gw
+    if db is not None:
+        db += gb
+
+
+def lrelu_backward(g, ldg, y, ldy, c, texels, alpha, out, ldo):
+    gv = torch.as_strided(g, (texels, c), (ldg, 1))
+    yv = torch.as_strided(y, (texels, c), (ldy, 1))
+    torch.as_strided(out, (texels, c), (ldo, 1)).copy_(gv * torch.where(yv > 0, 1.0, alpha))
+
+
+def obs_mean_backward(dmean, ldm, obs_y, obs_weights, dobs_partial, n, k, hw, c, alpha, dpre_obs):
+    dm = torch.as_strided(dmean, (n, hw, c), (hw * ldm, ldm, 1)).unsqueeze(1) / k
+    g = dm.expand(n, k, hw, c)
+    if obs_weights is not None:
+        g = g * obs_weights[:, :, None, None]
+    if dobs_partial is not None:
+        g = g + dobs_partial.reshape(n, k, hw, c)
+    if obs_y is not None:
+        g = g * torch.where(obs_y.reshape(n, k, hw, c) > 0, 1.0, alpha)
+    dpre_obs.copy_(g.reshape(dpre_obs.shape))
+
+
+def stem_backward(base, cvis, lvis, nn_rgb, nn_base, obs_weights, n, k, h, w, c, dfm0, dobs0, dwq, dbq, dwo, dbo):
+    x = torch.cat((base, cvis, lvis), -1).reshape(-1, 5)
+    gq = dfm0[..., :c].reshape(-1, c)
+    dwq += (x.t() @ gq).reshape(dwq.shape)
+    dbq += gq.sum(0)
+    gm = (dfm0[..., c:] / k).unsqueeze(1).expand(n, k, h, w, c)
+    if obs_weights is not None:
+        gm = gm * obs_weights[:, :, None, None, None]
+    g = gm + (dobs0 if dobs0 is not None else 0)
+    d = (nn_rgb - nn_base).reshape(-1, 3)
+    dwo += (d.t() @ g.reshape(-1, c)).reshape(dwo.shape)
+    dbo += g.reshape(-1, c).sum(0)
+
+
+def head_backward(dec, ldd, cd, skip, lds, cs, w_keras, dpred, n, h, w, d_dec, ldgd, d_skip, ldgs, dw, db):
+    x = torch.cat((_view(dec, n, h, w, cd, ldd), _view(skip, n, h, w, cs, lds)), -1)
+    g = dpred.clone()
+    g[:, 0, 0, :] = 0
+    dx = g @ w_keras[0, 0].t()
+    _view(d_dec, n, h, w, cd, ldgd).copy_(dx[..., :cd])
+    _view(d_skip, n, h, w, cs, ldgs).copy_(dx[..., cd:])
+    dw += (x.reshape(-1, cd + cs).t() @ g.reshape(-1, 3)).reshape(dw.shape)
+    db += g.reshape(-1, 3).sum(0)
+
+
+def warp_backward(dpred_cam, warp, n, uvh, uvw, hc, wc, dpred):
+    wpx = warp * torch.tensor([uvw, uvh], dtype=torch.float32)
+    with torch.enable_grad():
+        data = torch.zeros((n, uvh, uvw, 3), requires_grad=True)
+        out = T.resampler(T.set_left_top_corner(data, 0), wpx)
+        (g,) = torch.autograd.grad(out, data, dpred_cam)
+    dpred.copy_(g)
+
+
+def resize_bilinear_backward(dout, h, w):
+    n, oh, ow, c = dout.shape
+    with torch.enable_grad():
+        x = torch.zeros((n, h, w, c), requires_grad=True)
+        (g,) = torch.autograd.grad(T.resize_bilinear(x, oh, ow), x, dout)
+    return g
+
+
+def l2_loss_forward(pred, gt):
+    return ((gt - pred) ** 2).mean(dim=(1, 2, 3))
+
+
+def l2_loss_backward(pred, gt, gloss):
+    return gloss.view(-1, 1, 1, 1) * 2 * (pred - gt) / pred[0].numel()
+
+
+def barron_loss(pred, gt, want_grad):
+    p = pred.detach().clone().requires_grad_(True)
+    with torch.enable_grad():
+        loss = _B.barron_loss(gt, p, keep_batch=True)
+        dunit = torch.autograd.grad(loss.sum(), p)[0] if want_grad else None
+    return loss.detach(), dunit
+
+
+def scale_rows(x, scale):
+    return x * scale.view(-1, *([1] * (x.dim() - 1)))
+
+
+def adam_amsgrad_step(param, grad, m, v, vhat, lr_t, beta1, beta2, eps):
+    with torch.no_grad():
+        m.mul_(beta1).add_(grad, alpha=1 - beta1)
+        v.mul_(beta2).addcmul_(grad, grad, value=1 - beta2)
+        torch.maximum(vhat, v, out=vhat)
+        param.sub_(lr_t * m / (vhat.sqrt() + eps))
+
+
+_TRAIN = ('conv_backward_weights', 'lrelu_backward', 'obs_mean_backward', 'stem_backward', 'head_backward',
+          'warp_backward', 'resize_bilinear_backward', 'l2_loss_forward', 'l2_loss_backward', 'barron_loss',
+          'scale_rows', 'adam_amsgrad_step')
+_install_fwd = install
+
+
+def install(monkeypatch):
+    _install_fwd(monkeypatch)
+    for name in _TRAIN:
         monkeypatch.setattr(C, name, globals()[name])

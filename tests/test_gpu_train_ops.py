@@ -1,0 +1,235 @@
+"""-m gpu: backward / loss / optimizer kernels against torch-CPU autograd over the oracle's primitives."""
+import os
+import numpy as np
+import pytest
+import torch
+
+from nlt_amd import capi as C
+from oracle import tf_ops as T
+from oracle import barron as B
+from oracle import nlt_oracle as O
+
+pytestmark = pytest.mark.gpu
+d = lambda a: None if a is None else torch.tensor(a).cuda()
+MODES = {C.CONV1X1: (1, 1, False), C.CONV_K2S2: (2, 2, False), C.CONV_K2S1: (2, 1, False),
+         C.DECONV_K2S2: (2, 2, True), C.DECONV_K2S1: (2, 1, True)}
+
+
+def wgrad_case(mode, n, h, w, c0, c1, cout, algo, pad0=0, pad1=0, padp=0, seed=0):
+    rng = np.random.default_rng(seed)
+    k, s, tr = MODES[mode]
+    cin = c0 + c1
+    x0 = rng.standard_normal((n, h, w, c0 + pad0)).astype(np.float32)
+    x1 = rng.standard_normal((n, h, w, c1 + pad1)).astype(np.float32) if c1 else None
+    x = x0[..., :c0] if not c1 else np.concatenate((x0[..., :c0], x1[..., :c1]), -1)
+    wshape = (k, k, cout, cin) if tr else (k, k, cin, cout)
+    wz = torch.zeros(wshape, requires_grad=True); bz = torch.zeros(cout, requires_grad=True)
+    f = T.conv2d_transpose_same if tr else T.conv2d_same
+    y = f(torch.tensor(x), wz, bz, s)
+    oh, ow = y.shape[1:3]
+    dp = rng.standard_normal((n, oh, ow, cout + padp)).astype(np.float32)
+    gw, gb = torch.autograd.grad(y, (wz, bz), torch.tensor(dp[..., :cout]))
+    dw = torch.zeros(wshape, device='cuda'); db = torch.zeros(cout, device='cuda')
+    C.conv_backward_weights(mode, d(x0), c0, c0 + pad0, d(x1), c1, c1 + pad1, n, h, w, d(dp), cout + padp, cout, dw, db,
+                            algo=algo)
+    torch.cuda.synchronize()
+    sw, sb = max(gw.abs().max().item(), 1.0), max(gb.abs().max().item(), 1.0)
+    np.testing.assert_allclose(dw.cpu().numpy(), gw.numpy(), atol=3e-5 * sw)
+    np.testing.assert_allclose(db.cpu().numpy(), gb.numpy(), atol=3e-5 * sb)
+
+
+@pytest.mark.parametrize('mode', list(MODES))
+@pytest.mark.parametrize('algo', [C.ALGO_DIRECT, C.ALGO_MFMA])
+def test_wgrad_modes(mode, algo):
+    wgrad_case(mode, 2, 6, 10, 16, 0, 16, algo, seed=mode)
+
+
+@pytest.mark.parametrize('mode', list(MODES))
+def test_wgrad_mfma_dual_source_slices_ragged(mode):
+    wgrad_case(mode, 3, 6, 10, 24, 40, 48, C.ALGO_MFMA, pad0=8, pad1=4, padp=16, seed=10 + mode)
+
+
+@pytest.mark.parametrize('mode,c0,c1,cout', [(C.DECONV_K2S2, 8, 32, 4), (C.DECONV_K2S1, 4, 0, 4), (C.CONV_K2S2, 512, 0, 256),
+                                             (C.DECONV_K2S2, 512, 512, 128), (C.CONV1X1, 4, 32, 12)])
+def test_wgrad_mfma_shapes(mode, c0, c1, cout):
+    wgrad_case(mode, 2, 4, 4, c0, c1, cout, C.ALGO_MFMA, seed=20)
+
+
+def test_wgrad_direct_odd_channels_and_accumulation():
+    wgrad_case(C.CONV1X1, 2, 5, 7, 5, 0, 16, C.ALGO_DIRECT, seed=30)
+    wgrad_case(C.CONV_K2S1, 1, 4, 4, 3, 2, 7, C.ALGO_DIRECT, seed=31)
+    # accumulation into a non-zero buffer
+    x = torch.randn(1, 4, 4, 16, device='cuda'); dp = torch.randn(1, 4, 4, 16, device='cuda')
+    dw = torch.ones(2, 2, 16, 16, device='cuda'); db = torch.ones(16, device='cuda')
+    C.conv_backward_weights(C.CONV_K2S1, x, 16, 16, None, 0, 0, 1, 4, 4, dp, 16, 16, dw, db)
+    dw2 = torch.zeros_like(dw); db2 = torch.zeros_like(db)
+    C.conv_backward_weights(C.CONV_K2S1, x, 16, 16, None, 0, 0, 1, 4, 4, dp, 16, 16, dw2, db2)
+    np.testing.assert_allclose((dw - 1).cpu().numpy(), dw2.cpu().numpy(), atol=1e-5)
+    np.testing.assert_allclose((db - 1).cpu().numpy(), db2.cpu().numpy(), atol=1e-5)
+
+
+@pytest.mark.parametrize('mode', [C.CONV_K2S2, C.CONV_K2S1, C.DECONV_K2S2, C.DECONV_K2S1])
+def test_dgrad_is_adjoint_mode_on_same_kernel(mode):
+    """backward-data = nlt_conv_forward in the adjoint family on the SAME Keras array."""
+    from nlt_amd.networks.elements import Conv2D
+    rng = np.random.default_rng(mode)
+    k, s, tr = MODES[mode]
+    cin, cout, n, h, w = 24, 16, 2, 4, 6
+    wk = rng.standard_normal((2, 2, cout, cin) if tr else (2, 2, cin, cout)).astype(np.float32)
+    x = torch.tensor(rng.standard_normal((n, h, w, cin)).astype(np.float32), requires_grad=True)
+    f = T.conv2d_transpose_same if tr else T.conv2d_same
+    y = f(x, torch.tensor(wk), torch.zeros(cout), s)
+    dp = rng.standard_normal(tuple(y.shape)).astype(np.float32)
+    (gx,) = torch.autograd.grad(y, x, torch.tensor(dp))
+    layer = Conv2D(cout, 2, s, transpose=tr)
+    layer.set_weights(wk, np.zeros(cout, np.float32))
+    oh, ow = y.shape[1:3]
+    zb = torch.zeros(64, device='cuda')
+    for lo, hi in ((0, cin), (0, 8), (8, 24)):
+        packed, ks = layer.packed_adjoint(lo, hi)
+        out = torch.empty(n, h, w, hi - lo, device='cuda')
+        C.conv_forward(layer.ADJOINT[mode], d(dp), cout, cout, None, 0, 0, n, oh, ow, ks, packed, zb, hi - lo, out,
+                       hi - lo, act=False, algo=C.ALGO_MFMA)
+        np.testing.assert_allclose(out.cpu().numpy(), gx.numpy()[..., lo:hi], atol=3e-5 * gx.abs().max().item())
+
+
+def test_lrelu_and_obs_mean_backward():
+    rng = np.random.default_rng(0)
+    n, k, hw, c = 2, 3, 35, 16
+    g = rng.standard_normal((n * hw, 2 * c)).astype(np.float32)
+    y = rng.standard_normal((n * hw, 2 * c)).astype(np.float32)
+    gd = d(g)
+    C.lrelu_backward(gd, 2 * c, d(y), 2 * c, c, n * hw, 0.3, gd, 2 * c)           # in place on the first half
+    ref = g.copy(); ref[:, :c] = g[:, :c] * np.where(y[:, :c] > 0, 1.0, 0.3)
+    np.testing.assert_allclose(gd.cpu().numpy(), ref, atol=1e-6)
+    dmean = rng.standard_normal((n, hw, 2 * c)).astype(np.float32)
+    obs_y = rng.standard_normal((n, k, hw, c)).astype(np.float32)
+    part = rng.standard_normal((n, k, hw, c)).astype(np.float32)
+    ow = rng.random((n, k), dtype=np.float32)
+    for use_w, use_p, use_y in ((True, True, True), (False, False, True), (False, True, False)):
+        pd = d(part)
+        C.obs_mean_backward(d(dmean).view(-1)[c:], 2 * c, d(obs_y) if use_y else None, d(ow) if use_w else None,
+                            pd if use_p else None, n, k, hw, c, 0.3, pd)
+        ref = np.broadcast_to(dmean[:, None, :, c:] / k, (n, k, hw, c)).copy()
+        if use_w: ref = ref * ow[:, :, None, None]
+        if use_p: ref = ref + part
+        if use_y: ref = ref * np.where(obs_y > 0, 1.0, 0.3)
+        np.testing.assert_allclose(pd.cpu().numpy(), ref, atol=1e-6)
+
+
+@pytest.mark.parametrize('k,weights,partial', [(1, False, True), (3, True, True), (2, False, False)])
+def test_stem_backward(k, weights, partial):
+    rng = np.random.default_rng(k)
+    n, h, w, c = 2, 9, 7, 16
+    U = lambda *s: rng.random(s, dtype=np.float32)
+    base, cvis, lvis, nn_rgb, nn_base = U(n, h, w, 3), U(n, h, w, 1), U(n, h, w, 1), U(n, k, h, w, 3), U(n, k, h, w, 3)
+    ow = U(n, k) if weights else None
+    dfm0 = rng.standard_normal((n, h, w, 2 * c)).astype(np.float32)
+    dobs0 = rng.standard_normal((n, k, h, w, c)).astype(np.float32) if partial else None
+    Z = lambda *s: torch.zeros(s, device='cuda')
+    dwq, dbq, dwo, dbo = Z(1, 1, 5, c), Z(c), Z(1, 1, 3, c), Z(c)
+    C.stem_backward(d(base), d(cvis), d(lvis), d(nn_rgb), d(nn_base), d(ow), n, k, h, w, c, d(dfm0), d(dobs0), dwq, dbq, dwo, dbo)
+    x = np.concatenate((base, cvis, lvis), -1).reshape(-1, 5).astype(np.float64)
+    gq = dfm0[..., :c].reshape(-1, c).astype(np.float64)
+    gm = np.broadcast_to(dfm0[:, None, ..., c:] / k, (n, k, h, w, c)).astype(np.float64)
+    if weights: gm = gm * ow[:, :, None, None, None]
+    g = gm + (dobs0 if partial else 0)
+    dd = (nn_rgb - nn_base).reshape(-1, 3).astype(np.float64)
+    np.testing.assert_allclose(dwq.cpu().numpy()[0, 0], x.T @ gq, atol=2e-4)
+    np.testing.assert_allclose(dbq.cpu().numpy(), gq.sum(0), atol=2e-4)
+    np.testing.assert_allclose(dwo.cpu().numpy()[0, 0], dd.T @ g.reshape(-1, c), atol=2e-4)
+    np.testing.assert_allclose(dbo.cpu().numpy(), g.reshape(-1, c).sum(0), atol=2e-4)
+
+
+def test_head_backward():
+    rng = np.random.default_rng(1)
+    n, h, w, cd, cs = 2, 7, 9, 4, 32
+    dec = rng.standard_normal((n, h, w, cd)).astype(np.float32); skip = rng.standard_normal((n, h, w, cs)).astype(np.float32)
+    wk = rng.standard_normal((1, 1, cd + cs, 3)).astype(np.float32)
+    dpred = rng.standard_normal((n, h, w, 3)).astype(np.float32)
+    d_dec = torch.empty(n, h, w, cd, device='cuda'); d_skip = torch.empty(n, h, w, cs, device='cuda')
+    dw = torch.zeros(1, 1, cd + cs, 3, device='cuda'); db = torch.zeros(3, device='cuda')
+    C.head_backward(d(dec), cd, cd, d(skip), cs, cs, d(wk), d(dpred), n, h, w, d_dec, cd, d_skip, cs, dw, db)
+    g = dpred.copy(); g[:, 0, 0, :] = 0
+    dx = g @ wk[0, 0].T
+    np.testing.assert_allclose(d_dec.cpu().numpy(), dx[..., :cd], atol=1e-5)
+    np.testing.assert_allclose(d_skip.cpu().numpy(), dx[..., cd:], atol=1e-5)
+    x = np.concatenate((dec, skip), -1).reshape(-1, cd + cs).astype(np.float64)
+    np.testing.assert_allclose(dw.cpu().numpy()[0, 0], x.T @ g.reshape(-1, 3), atol=2e-4)
+    np.testing.assert_allclose(db.cpu().numpy(), g.reshape(-1, 3).sum(0), atol=2e-4)
+
+
+def test_warp_and_resize_backward():
+    rng = np.random.default_rng(2)
+    n, uvh, uvw, hc, wc = 2, 16, 24, 12, 10
+    warp = rng.random((n, hc, wc, 2), dtype=np.float32).astype(np.float16).astype(np.float32)
+    warp[rng.random((n, hc, wc)) > 0.7] = 0
+    warp[0, 0, 0] = (1.0, 0.2); warp[0, 0, 1] = ((uvw - 1) / uvw, (uvh - 1) / uvh)
+    dcam = rng.standard_normal((n, hc, wc, 3)).astype(np.float32)
+    dpred = torch.empty(n, uvh, uvw, 3, device='cuda')
+    C.warp_backward(d(dcam), d(warp), n, uvh, uvw, hc, wc, dpred)
+    data = torch.zeros(n, uvh, uvw, 3, requires_grad=True)
+    out = T.resampler(T.set_left_top_corner(data, 0), torch.tensor(warp) * torch.tensor([uvw, uvh], dtype=torch.float32))
+    (ref,) = torch.autograd.grad(out, data, torch.tensor(dcam))
+    np.testing.assert_allclose(dpred.cpu().numpy(), ref.numpy(), atol=1e-5)
+    assert np.all(dpred.cpu().numpy()[:, 0, 0, :] == 0)
+    dout = rng.standard_normal((2, 20, 14, 3)).astype(np.float32)
+    x = torch.zeros(2, 12, 10, 3, requires_grad=True)
+    (ref,) = torch.autograd.grad(T.resize_bilinear(x, 20, 14), x, torch.tensor(dout))
+    np.testing.assert_allclose(C.resize_bilinear_backward(d(dout), 12, 10).cpu().numpy(), ref.numpy(), atol=1e-5)
+
+
+def test_l2_loss_and_scale_rows():
+    rng = np.random.default_rng(3)
+    pred, gt = rng.random((3, 17, 19, 3), dtype=np.float32), rng.random((3, 17, 19, 3), dtype=np.float32)
+    ref = O.l2_loss(torch.tensor(gt), torch.tensor(pred), keep_batch=True).numpy()
+    np.testing.assert_allclose(C.l2_loss_forward(d(pred), d(gt)).cpu().numpy(), ref, rtol=2e-6)
+    gl = rng.random(3, dtype=np.float32)
+    got = C.l2_loss_backward(d(pred), d(gt), d(gl)).cpu().numpy()
+    np.testing.assert_allclose(got, gl[:, None, None, None] * 2 * (pred - gt) / (17 * 19 * 3), atol=1e-7)
+    np.testing.assert_allclose(C.scale_rows(d(pred), d(gl)).cpu().numpy(), pred * gl[:, None, None, None], atol=1e-7)
+
+
+@pytest.mark.parametrize('h,w', [(64, 64), (32, 48), (83, 71), (17, 17)])
+def test_barron_loss_and_grad(h, w):
+    rng = np.random.default_rng(h)
+    pred = torch.tensor(rng.random((2, h, w, 3), dtype=np.float32), requires_grad=True)
+    gt = torch.tensor(rng.random((2, h, w, 3), dtype=np.float32))
+    ref = B.barron_loss(gt.double(), pred.double(), keep_batch=True)
+    (gref,) = torch.autograd.grad(ref.sum(), pred)
+    loss, dunit = C.barron_loss(pred.detach().cuda(), gt.cuda(), True)
+    np.testing.assert_allclose(loss.cpu().numpy(), ref.detach().numpy(), rtol=2e-5)
+    assert float((dunit.cpu() - gref).norm() / gref.norm()) < 1e-4
+    loss2, none = C.barron_loss(pred.detach().cuda(), gt.cuda(), False)
+    assert none is None
+    np.testing.assert_allclose(loss2.cpu().numpy(), loss.cpu().numpy(), rtol=1e-6)
+
+
+def test_barron_wavelet_matches_reference_golden():
+    """The kernel's CDF9/7 pyramid reproduces the reference's wavelet_golden.mat through the loss:
+    loss(x) for x = golden image equals the Charbonnier NLL of the GOLDEN coefficients."""
+    g = np.load(os.path.join(os.path.dirname(__file__), 'golden', 'wavelet_golden.npz'))
+    im = g['I_color'].astype(np.float64)                       # (3, 83, 71): already "sYUV planes"
+    coefs = np.concatenate([g[k].reshape(-1) for k in g.files if k.startswith('band_') or k == 'resid'])
+    nll = np.sqrt((coefs / 0.01) ** 2 + 1) - 1 + np.log(0.01) + B.LOG_Z_ALPHA1
+    # feed residual r with syuv(r) == im:  r = im^T @ inv(M)
+    M = B.RGB_TO_YUV * B.VOLUME_PRESERVING_YUV_SCALE
+    r = np.transpose(im, (1, 2, 0)) @ np.linalg.inv(M)
+    gt = torch.tensor(r[None].astype(np.float32)); pred = torch.zeros_like(gt)
+    loss, _ = C.barron_loss(pred.cuda(), gt.cuda(), False)
+    assert abs(loss.item() - nll.mean()) < 2e-3 * abs(nll.mean())   # fp32 input rounding through /0.01
+
+
+def test_adam_amsgrad_matches_keras_form():
+    rng = np.random.default_rng(4)
+    p0 = rng.standard_normal(1001).astype(np.float32)
+    p = torch.tensor(p0.copy(), requires_grad=True)
+    opt = O.KerasAdamAMSGrad([p], 1e-2)
+    pd = d(p0.copy()); m = torch.zeros_like(pd); v = torch.zeros_like(pd); vh = torch.zeros_like(pd)
+    import math
+    for t in range(1, 4):
+        g = rng.standard_normal(1001).astype(np.float32) * (1.0 if t != 2 else 0.1)   # t=2: vhat keeps the max
+        opt.step([torch.tensor(g)])
+        lr_t = 1e-2 * math.sqrt(1 - 0.999 ** t) / (1 - 0.9 ** t)
+        C.adam_amsgrad_step(pd, d(g), m, v, vh, lr_t, 0.9, 0.999, 1e-7)
+        np.testing.assert_allclose(pd.cpu().numpy(), p.detach().numpy(), atol=2e-6)

@@ -1,0 +1,57 @@
+"""-m gpu: full train step on HIP kernels (forward plan, losses, backward plan, flat gradient
+bucket, fused Adam-AMSGrad) vs the oracle's torch-CPU autograd train step (nlt/trainvali.py:272-281)."""
+import numpy as np
+import pytest
+import torch
+
+import nlt_amd
+from nlt_amd import trainvali
+from oracle import nlt_oracle as O
+from gpu_util import make_pair, to_device_batch
+
+pytestmark = pytest.mark.gpu
+
+
+def flat_oracle_grads(pm, grads):
+    out = torch.zeros_like(pm.flat_grads)
+    it = iter(grads)
+    for c in pm._conv_layers():
+        for name in ('dkernel', 'dbias'):
+            g = next(it)
+            off = (getattr(c, name).data_ptr() - pm.flat_grads.data_ptr()) // 4
+            out[off: off + g.numel()] = g.reshape(-1).to(out.device)
+    return out
+
+
+@pytest.mark.parametrize('loss,k,uv,cam,im', [('l2', 1, 64, 64, 64), ('l2', 4, 128, 64, 64), ('barron', 2, 64, 32, 32),
+                                              ('barron,5e-1l2', 1, 64, 32, 48)])
+def test_train_step_matches_oracle(loss, k, uv, cam, im):
+    om, pm = make_pair(depth=256, uv=uv, im=im, loss=loss, seed=k)
+    pm.build('cuda')
+    batch, nn = O.synth_batch(2, uv, uv, cam, cam, im, im, k=k, seed=20 + k)
+    db = to_device_batch(batch, nn)
+    opt_o = O.KerasAdamAMSGrad(om.parameters(), 1e-3)
+    opt_p = nlt_amd.optim.AdamAMSGrad(pm, 1e-3)
+    for step in range(3):
+        lo, go = O.train_step(om, opt_o, batch, global_bs=2, nn_list=nn)
+        lp, _ = trainvali.distributed_train_step(pm, db, opt_p, global_bs=2)
+        torch.cuda.synchronize()
+        assert abs(float(lp) - float(lo)) <= 2e-5 * max(1.0, abs(float(lo))), (step, float(lp), float(lo))
+        ref = flat_oracle_grads(pm, go)
+        rel = float((pm.flat_params.grad - ref).norm() / ref.norm())
+        assert rel < 1e-3, (step, rel)
+    # three Adam steps later the weights still track the oracle (lr 1e-3: each step moves ~1e-3)
+    worst = max(float((po.detach() - c.kernel.cpu()).abs().max()) for po, c in zip(om.parameters()[::2], pm._conv_layers()))
+    assert worst < 2e-4, worst
+
+
+def test_loss_decreases_and_vali_step():
+    om, pm = make_pair(depth=256, uv=64, im=64, loss='l2', seed=3)
+    pm.build('cuda')
+    batch, nn = O.synth_batch(4, 64, 64, 64, 64, 64, 64, k=1, seed=31)
+    db = to_device_batch(batch, nn)
+    opt = nlt_amd.optim.AdamAMSGrad(pm, 1e-3)
+    losses = [float(trainvali.distributed_train_step(pm, db, opt, 4)[0]) for _ in range(8)]
+    assert losses[-1] < losses[0]
+    lv, vis = trainvali.distributed_vali_step(pm, db, 4)
+    assert np.isfinite(float(lv)) and not vis['pred_camspc'].requires_grad

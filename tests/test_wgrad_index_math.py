@@ -1,0 +1,118 @@
+"""CPU: lane-level NumPy mirror of csrc/wgrad.hip's MFMA kernel (K tiles over tap x source
+segments, N tiles incl. the DECONV_K2S2 (a,b,o) columns, row slices, Keras-layout write-back,
+bias column sums) under the documented v_mfma_f32_16x16x4_f32 fragment layout."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import tf_ops as T
+from test_mfma_index_math import TAPS, keras_widx, chunks16, tap_texel, mfma, CONV1X1, CONV_K2S2, CONV_K2S1, DECONV_K2S2, DECONV_K2S1
+
+
+def emulate_wgrad(mode, src0, ld0, c0, src1, ld1, c1, n, h, w, dp, ldp, cout, KT, NT, rows_per_split):
+    gh, gw, oh, ow, N = h, w, h, w, cout
+    if mode == CONV_K2S2:
+        gh = oh = h // 2; gw = ow = w // 2
+    if mode == DECONV_K2S2:
+        oh, ow, N = 2 * h, 2 * w, 4 * cout
+    M = n * gh * gw
+    cin = c0 + c1
+    ch0, ch1 = chunks16(c0), chunks16(c1)
+    cps = ch0 + ch1
+    ktiles, ntiles = TAPS[mode] * cps, (N + 15) >> 4
+    kgroups, ngroups = -(-ktiles // KT), -(-ntiles // NT)
+    msplits = -(-M // rows_per_split)
+    dw = np.zeros(TAPS[mode] * cin * N, np.float64)
+    db = np.zeros(cout, np.float64)
+    for wave in range(kgroups * ngroups * msplits):
+        ms = wave % msplits; rest = wave // msplits
+        ng, kg = rest % ngroups, rest // ngroups
+        acc = np.zeros((KT, NT, 64, 4), np.float32)
+        bsum = np.zeros((NT, 64), np.float32)
+        m_begin = ms * rows_per_split
+        m_end = min(m_begin + rows_per_split, M)
+        for m0 in range(m_begin, m_end, 4):
+            a = np.zeros((KT, 64), np.float32); b = np.zeros((NT, 64), np.float32)
+            for lane in range(64):
+                li, mm = lane & 15, lane >> 4
+                m = m0 + mm
+                rv = m < m_end
+                mc = m if rv else m_begin
+                x, y, f = mc % gw, (mc // gw) % gh, mc // (gw * gh)
+                for kt in range(KT):
+                    tile = kg * KT + kt
+                    if tile >= ktiles:
+                        continue
+                    t, r = tile // cps, tile % cps
+                    s1 = r >= ch0
+                    c = ((r - ch0) if s1 else r) * 16 + li
+                    cs = c1 if s1 else c0
+                    tex = tap_texel(mode, h, w, f, y, x, t)
+                    if rv and c < cs and tex >= 0:
+                        a[kt, lane] = (src1[tex * ld1 + c] if s1 else src0[tex * ld0 + c])
+                for nt in range(NT):
+                    col = (ng * NT + nt) * 16 + li
+                    if col >= N or not rv:
+                        continue
+                    ab, oc = (col // cout, col % cout) if mode == DECONV_K2S2 else (0, col)
+                    otex = mc if mode != DECONV_K2S2 else (f * oh + 2 * y + (ab >> 1)) * ow + 2 * x + (ab & 1)
+                    b[nt, lane] = dp[otex * ldp + oc]
+                    bsum[nt, lane] += b[nt, lane]
+            for kt in range(KT):
+                for nt in range(NT):
+                    mfma(a[kt], b[nt], acc[kt, nt])
+        for kt in range(KT):
+            tile = kg * KT + kt
+            if tile >= ktiles:
+                continue
+            t, r0 = tile // cps, tile % cps
+            s1 = r0 >= ch0
+            cs = c1 if s1 else c0
+            for nt in range(NT):
+                for lane in range(64):
+                    li, mm = lane & 15, lane >> 4
+                    col = (ng * NT + nt) * 16 + li
+                    if col >= N:
+                        continue
+                    for r in range(4):
+                        cl = ((r0 - ch0) if s1 else r0) * 16 + mm * 4 + r
+                        if cl < cs:
+                            dw[keras_widx(mode, t, (c0 if s1 else 0) + cl, col, cin, cout)] += acc[kt, nt, lane, r]
+        if kg == 0:
+            for nt in range(NT):
+                for li in range(16):
+                    col = (ng * NT + nt) * 16 + li
+                    if col < N:
+                        oc = col % cout if mode == DECONV_K2S2 else col
+                        db[oc] += bsum[nt, li] + bsum[nt, li + 16] + bsum[nt, li + 32] + bsum[nt, li + 48]
+    return dw, db
+
+
+@pytest.mark.parametrize('mode,n,h,w,c0,c1,cout,KT,NT,rows', [
+    (CONV1X1, 1, 3, 5, 16, 0, 16, 1, 1, 8),
+    (CONV_K2S2, 1, 4, 6, 8, 4, 32, 4, 2, 4),
+    (CONV_K2S1, 2, 3, 3, 16, 0, 16, 4, 1, 12),
+    (DECONV_K2S2, 1, 2, 3, 8, 32, 4, 2, 1, 4),
+    (DECONV_K2S2, 1, 3, 2, 16, 0, 16, 1, 4, 8),
+    (DECONV_K2S1, 1, 3, 4, 4, 0, 4, 4, 1, 64),
+])
+def test_wgrad_kernel_index_math(mode, n, h, w, c0, c1, cout, KT, NT, rows):
+    rng = np.random.default_rng(mode * 5 + cout)
+    tr = mode in (DECONV_K2S2, DECONV_K2S1)
+    k = 1 if mode == CONV1X1 else 2
+    s = 2 if mode in (CONV_K2S2, DECONV_K2S2) else 1
+    cin = c0 + c1
+    pad0, pad1, padp = 4, 8, 4
+    x0 = rng.standard_normal((n, h, w, c0 + pad0)).astype(np.float32)
+    x1 = rng.standard_normal((n, h, w, c1 + pad1)).astype(np.float32)
+    x = np.concatenate((x0[..., :c0], x1[..., :c1]), -1) if c1 else x0[..., :c0]
+    wshape = (k, k, cout, cin) if tr else (k, k, cin, cout)
+    wz = torch.zeros(wshape, requires_grad=True); bz = torch.zeros(cout, requires_grad=True)
+    f = T.conv2d_transpose_same if tr else T.conv2d_same
+    y = f(torch.tensor(x), wz, bz, s)
+    dp = rng.standard_normal(tuple(y.shape[:3]) + (cout + padp,)).astype(np.float32)
+    gw, gb = torch.autograd.grad(y, (wz, bz), torch.tensor(dp[..., :cout]))
+    dw, db = emulate_wgrad(mode, x0.reshape(-1), c0 + pad0, c0, x1.reshape(-1), c1 + pad1, c1, n, h, w,
+                           dp.reshape(-1), cout + padp, cout, KT, NT, rows)
+    np.testing.assert_allclose(dw.reshape(wshape), gw.numpy(), atol=1e-4)
+    np.testing.assert_allclose(db, gb.numpy(), atol=1e-4)
