@@ -219,6 +219,92 @@ int nlt_scale_rows(const float* x, const float* scale, int n, long per_row, floa
 int nlt_adam_amsgrad_step(float* param, const float* grad, float* m, float* v, float* vhat, long count,
                           float lr_t, float beta1, float beta2, float eps, void* stream);
 
+/* ============ texel-buffer assembly (data_gen/ + nlt/datasets/nlt.py; SURVEY.md 8a a-B1..a-B6) ============
+ * Byte / integer work on float64 geometry: every result below is bit-exact against oracle/buffers.py
+ * (the float64 stages follow the reference's NumPy operation order; no fused multiply-add). */
+
+/* dtype of a [0,1] coordinate map handed to the remap entry points */
+typedef enum { NLT_MAP_F64 = 0, NLT_MAP_F32 = 1, NLT_MAP_F16 = 2 } nlt_map_dtype;
+
+/*
+ * View / light cosine map of one camera: cos = <normalize(src - p), normalize(n)> at pixels with valid != 0
+ * and (occluded == NULL or occluded == 0), 0 elsewhere.
+ *   replaces: data_gen/render.py:209-228 calc_view_cosines (src = camera location, occluded = NULL) and
+ *             :231-276 calc_light_cosines (src = light location; `occluded` is the result of the reference's
+ *             BVH shadow rays, which stay in Blender), plus :164,170 np.clip + xm.img.denormalize_float.
+ * locs, normals [pixels,3] float64; valid / occluded [pixels] uint8.  cos_out float64 and/or u8_out (clipped to
+ * [0,1], TRUNCATED x255) -- either may be NULL.
+ */
+int nlt_cosine_map(const double* locs, const double* normals, const unsigned char* valid,
+                   const unsigned char* occluded, double sx, double sy, double sz, long pixels,
+                   double* cos_out, unsigned char* u8_out, void* stream);
+
+/*
+ * UV albedo = (sum over frames of rgb/255, in frame order) / max of that sum.
+ *   replaces: data_gen/postproc.py:53-64.   rgb_frames [frames, elems] uint8 (elems = H*W*3); albedo [elems]
+ *   float64; workspace8: 8 bytes of device scratch.
+ */
+int nlt_albedo(const unsigned char* rgb_frames, int frames, long elems, double* albedo, void* workspace8, void* stream);
+
+/* diffuse base = clip(albedo * lvis/255, 0, 1) truncated to uint8, for `frames` light-visibility maps at once.
+ *   replaces: data_gen/postproc.py:66-76.   lvis [frames,texels] uint8 -> diffuse [frames,texels,3] uint8. */
+int nlt_diffuse_base(const double* albedo, const unsigned char* lvis, int frames, long texels,
+                     unsigned char* diffuse, void* stream);
+
+/*
+ * Bilinear gather of src at mapping * (w, h) with cv2.remap(INTER_LINEAR, BORDER_CONSTANT 0) semantics --
+ * coordinates quantised to 1/32 texel (round half to even), 15-bit fixed-point weights for 8-bit sources --
+ * and source texel (0,0) read as 0 when force_kbg.
+ *   replaces: data_gen/util.py:45-58 remap (camera->UV: data_gen/render.py:174-176; UV->camera:
+ *             data_gen/postproc.py:78-82).
+ * src [h,w,c]; mapping [oh,ow,ldm] of map_dtype, channel 0 = x, 1 = y, in [0,1]; out [oh,ow,c].
+ */
+int nlt_remap_bilinear_u8(const unsigned char* src, int h, int w, int c, const void* mapping, int map_dtype,
+                          int ldm, int oh, int ow, int force_kbg, unsigned char* out, void* stream);
+int nlt_remap_bilinear_f32(const float* src, int h, int w, int c, const void* mapping, int map_dtype,
+                           int ldm, int oh, int ow, int force_kbg, float* out, void* stream);
+
+/*
+ * UV-index map: paints `samples` scattered (u,v) -> value samples onto an h x w grid.  A texel is TRUSTED when
+ * an occupied texel -- integer indices ri = int((1-v)(h-1)), ci = int(u(w-1)) of some sample -- lies within L1
+ * distance max_l1; trusted texels take the value of the nearest sample (Euclidean in uv; ties -> lowest sample
+ * index), the others `fill`.
+ *   replaces: xiuminglib/img.py:289-431 grid_query_unstruct(method griddata/nearest, max_l1_interp) as called by
+ *             data_gen/render.py:279-351 calc_bidir_mapping (scipy KD-tree + cv2.distanceTransform(DIST_L1)).
+ * uvs [samples,2], values [samples,m] float64 -> out [h,w,m] float64; index_out [h,w] int32 (chosen sample, -1 =
+ * filled) or NULL.  workspace: nlt_uv_index_map_workspace_bytes() bytes.  h, w >= 2; max_l1 <= 64.
+ */
+long nlt_uv_index_map_workspace_bytes(int h, int w, long samples);
+int nlt_uv_index_map(const double* uvs, const double* values, long samples, int m, int h, int w,
+                     int max_l1, double fill, void* workspace, double* out, int* index_out, void* stream);
+
+/*
+ * k nearest candidates (non-zero distance, nearest first, equal distances in candidate order) of every reference
+ * position; -1 where fewer than k qualify.
+ *   replaces: data_gen/get_neighbors.py:52-71 get_neighbors (k = 1), whose result picks the observation maps
+ *             (data_gen/render.py:200-206, nlt/datasets/nlt.py:88-100,150-171).
+ * ref_pos [np,3], cand_pos [nq,3] float64 -> out [np,k] int32.
+ */
+int nlt_knn_indices(const double* ref_pos, int np, const double* cand_pos, int nq, int k, int* out, void* stream);
+
+/* out[i] = float32(float64(store[ids[i]]) / 255) for whole frames of per_frame bytes (per_frame % 4 == 0);
+ * ids == NULL means frames 0..n-1, id -1 a frame of zeros.  The primitive behind nlt_assemble_batch; also serves
+ * the camera-space images (rgb_camspc, nn_rgb_camspc; nlt/datasets/nlt.py:129-136,162-171). */
+int nlt_gather_frames_u8(const unsigned char* store, const int* ids, int n, long per_frame, float* out, void* stream);
+
+/*
+ * Batch assembly from a uint8 frame store resident in HBM: gathers frames `ids` [n] and their neighbours
+ * `nn_ids` [n,k] (-1 = missing neighbour -> zeros) and converts uint8 -> float64/255 -> float32.
+ *   replaces: nlt/datasets/nlt.py:115-184 _load_data (PNG decode itself stays on the host).
+ * stores: diffuse/rgb [F,texels,3], cvis/lvis [F,texels] uint8.  Outputs float32: base, rgb [n,texels,3];
+ * cvis, lvis [n,texels]; nn_base, nn_rgb [n,k,texels,3].  test_mode != 0: rgb = 0 (nlt.py:126-128).
+ */
+int nlt_assemble_batch(const unsigned char* diffuse_store, const unsigned char* rgb_store,
+                       const unsigned char* cvis_store, const unsigned char* lvis_store,
+                       const int* ids, const int* nn_ids, int n, int k, long texels, int test_mode,
+                       float* base, float* cvis, float* lvis, float* rgb, float* nn_base, float* nn_rgb,
+                       void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -17,6 +17,8 @@ CONV1X1, CONV_K2S2, CONV_K2S1, DECONV_K2S2, DECONV_K2S1 = range(5)
 ALGO_AUTO, ALGO_DIRECT, ALGO_MFMA = range(3)
 
 _c_int, _c_long, _c_float, _vp = ctypes.c_int, ctypes.c_long, ctypes.c_float, ctypes.c_void_p
+_c_double = ctypes.c_double
+MAP_F64, MAP_F32, MAP_F16 = range(3)
 
 # name -> (restype, argtypes); must list every symbol include/nlt_hip.h declares
 SIGNATURES = {
@@ -49,6 +51,16 @@ SIGNATURES = {
     'nlt_barron_loss': (_c_int, [_vp, _vp, _c_int, _c_int, _c_int, _vp, _vp, _vp, _vp]),
     'nlt_scale_rows': (_c_int, [_vp, _vp, _c_int, _c_long, _vp, _vp]),
     'nlt_adam_amsgrad_step': (_c_int, [_vp] * 5 + [_c_long] + [_c_float] * 4 + [_vp]),
+    'nlt_cosine_map': (_c_int, [_vp] * 4 + [_c_double] * 3 + [_c_long, _vp, _vp, _vp]),
+    'nlt_albedo': (_c_int, [_vp, _c_int, _c_long, _vp, _vp, _vp]),
+    'nlt_diffuse_base': (_c_int, [_vp, _vp, _c_int, _c_long, _vp, _vp]),
+    'nlt_remap_bilinear_u8': (_c_int, [_vp, _c_int, _c_int, _c_int, _vp, _c_int, _c_int, _c_int, _c_int, _c_int, _vp, _vp]),
+    'nlt_remap_bilinear_f32': (_c_int, [_vp, _c_int, _c_int, _c_int, _vp, _c_int, _c_int, _c_int, _c_int, _c_int, _vp, _vp]),
+    'nlt_uv_index_map_workspace_bytes': (_c_long, [_c_int, _c_int, _c_long]),
+    'nlt_uv_index_map': (_c_int, [_vp, _vp, _c_long, _c_int, _c_int, _c_int, _c_int, _c_double, _vp, _vp, _vp, _vp]),
+    'nlt_knn_indices': (_c_int, [_vp, _c_int, _vp, _c_int, _c_int, _vp, _vp]),
+    'nlt_gather_frames_u8': (_c_int, [_vp, _vp, _c_int, _c_long, _vp, _vp]),
+    'nlt_assemble_batch': (_c_int, [_vp] * 6 + [_c_int, _c_int, _c_long, _c_int] + [_vp] * 6 + [_vp]),
 }
 
 _lib = None
@@ -84,6 +96,15 @@ def _ptr(t):
         return None
     if not (t.is_cuda and t.dtype in (torch.float32, torch.int32)):
         raise NLTError("expected a float32/int32 CUDA tensor, got %s on %s" % (t.dtype, t.device))
+    return t.data_ptr()
+
+
+def _tptr(t, dtype, what):
+    """Device pointer of a contiguous CUDA tensor of exactly `dtype` (None passes through)."""
+    if t is None:
+        return None
+    if not (t.is_cuda and t.dtype == dtype and t.is_contiguous()):
+        raise NLTError("%s: expected a contiguous %s CUDA tensor, got %s on %s" % (what, dtype, t.dtype, t.device))
     return t.data_ptr()
 
 
@@ -240,3 +261,113 @@ def adam_amsgrad_step(param, grad, m, v, vhat, lr_t, beta1, beta2, eps):
     _check(lib().nlt_adam_amsgrad_step(_ptr(param), _ptr(grad), _ptr(m), _ptr(v), _ptr(vhat), param.numel(),
                                        float(lr_t), float(beta1), float(beta2), float(eps), _stream()),
            'nlt_adam_amsgrad_step')
+
+
+# ---------------------------------------------------------------- texel-buffer assembly
+_MAP_DTYPES = {torch.float64: MAP_F64, torch.float32: MAP_F32, torch.float16: MAP_F16}
+
+
+def cosine_map(locs, normals, valid, occluded, src_loc, want_float=True, want_u8=True):
+    """locs/normals [...,3] float64, valid/occluded [...] uint8 -> (cos float64, quantised uint8)."""
+    shape = valid.shape
+    pixels = valid.numel()
+    cos = torch.empty(shape, device=valid.device, dtype=torch.float64) if want_float else None
+    q = torch.empty(shape, device=valid.device, dtype=torch.uint8) if want_u8 else None
+    sx, sy, sz = (float(x) for x in src_loc)
+    _check(lib().nlt_cosine_map(_tptr(locs, torch.float64, 'locs'), _tptr(normals, torch.float64, 'normals'),
+                                _tptr(valid, torch.uint8, 'valid'), _tptr(occluded, torch.uint8, 'occluded'),
+                                sx, sy, sz, pixels, _tptr(cos, torch.float64, 'cos'), _tptr(q, torch.uint8, 'q'),
+                                _stream()), 'nlt_cosine_map')
+    return cos, q
+
+
+def albedo(rgb_frames):
+    """rgb_frames [F,H,W,3] uint8 -> albedo [H,W,3] float64."""
+    f = rgb_frames.shape[0]
+    elems = rgb_frames[0].numel()
+    out = torch.empty(rgb_frames.shape[1:], device=rgb_frames.device, dtype=torch.float64)
+    ws = torch.empty(1, device=rgb_frames.device, dtype=torch.int64)
+    _check(lib().nlt_albedo(_tptr(rgb_frames, torch.uint8, 'rgb_frames'), f, elems, out.data_ptr(), ws.data_ptr(),
+                            _stream()), 'nlt_albedo')
+    return out
+
+
+def diffuse_base(albedo_, lvis):
+    """albedo [H,W,3] float64, lvis [F,H,W] uint8 -> diffuse [F,H,W,3] uint8."""
+    f = lvis.shape[0]
+    texels = lvis[0].numel()
+    out = torch.empty(tuple(lvis.shape) + (3,), device=lvis.device, dtype=torch.uint8)
+    _check(lib().nlt_diffuse_base(_tptr(albedo_, torch.float64, 'albedo'), _tptr(lvis, torch.uint8, 'lvis'), f, texels,
+                                  out.data_ptr(), _stream()), 'nlt_diffuse_base')
+    return out
+
+
+def remap_bilinear(src, mapping, force_kbg=True):
+    """src [h,w] or [h,w,c] uint8 / float32; mapping [oh,ow,>=2] float64/32/16 in [0,1] -> [oh,ow(,c)]."""
+    if mapping.dtype not in _MAP_DTYPES:
+        raise NLTError("mapping dtype %s" % mapping.dtype)
+    squeeze = src.dim() == 2
+    h, w = src.shape[:2]
+    c = 1 if squeeze else src.shape[2]
+    oh, ow, ldm = mapping.shape
+    out = torch.empty((oh, ow) if squeeze else (oh, ow, c), device=src.device, dtype=src.dtype)
+    if src.dtype == torch.uint8:
+        fn, what = lib().nlt_remap_bilinear_u8, 'nlt_remap_bilinear_u8'
+    elif src.dtype == torch.float32:
+        fn, what = lib().nlt_remap_bilinear_f32, 'nlt_remap_bilinear_f32'
+    else:
+        raise NLTError("remap source dtype %s" % src.dtype)
+    _check(fn(_tptr(src, src.dtype, 'src'), h, w, c, _tptr(mapping, mapping.dtype, 'mapping'), _MAP_DTYPES[mapping.dtype],
+              ldm, oh, ow, 1 if force_kbg else 0, out.data_ptr(), _stream()), what)
+    return out
+
+
+def uv_index_map(uvs, values, h, w, max_l1=4, fill=0.0, want_index=False):
+    """uvs [P,2], values [P,M] float64 -> grid [h,w,M] float64 (+ int32 sample-index map)."""
+    p, m = values.shape
+    nbytes = lib().nlt_uv_index_map_workspace_bytes(h, w, p)
+    if nbytes <= 0:
+        raise NLTError("nlt_uv_index_map_workspace_bytes(%d,%d,%d) failed" % (h, w, p))
+    ws = torch.empty((nbytes + 3) // 4, device=uvs.device, dtype=torch.int32)
+    out = torch.empty((h, w, m), device=uvs.device, dtype=torch.float64)
+    idx = torch.empty((h, w), device=uvs.device, dtype=torch.int32) if want_index else None
+    _check(lib().nlt_uv_index_map(_tptr(uvs, torch.float64, 'uvs'), _tptr(values, torch.float64, 'values'), p, m, h, w,
+                                  int(max_l1), float(fill), ws.data_ptr(), out.data_ptr(),
+                                  _tptr(idx, torch.int32, 'index_out'), _stream()), 'nlt_uv_index_map')
+    return (out, idx) if want_index else out
+
+
+def knn_indices(ref_pos, cand_pos, k=1):
+    """ref_pos [P,3], cand_pos [Q,3] float64 -> int32 [P,k]."""
+    p, q = ref_pos.shape[0], cand_pos.shape[0]
+    out = torch.empty((p, k), device=ref_pos.device, dtype=torch.int32)
+    _check(lib().nlt_knn_indices(_tptr(ref_pos, torch.float64, 'ref_pos'), p, _tptr(cand_pos, torch.float64, 'cand_pos'),
+                                 q, k, out.data_ptr(), _stream()), 'nlt_knn_indices')
+    return out
+
+
+def gather_frames_u8(store, ids):
+    """store [F,...] uint8, ids [n] int32 (-1 -> zeros) -> float32 [n,...] = float32(float64(u8) / 255)."""
+    n = ids.numel()
+    out = torch.empty((n,) + tuple(store.shape[1:]), device=store.device, dtype=torch.float32)
+    _check(lib().nlt_gather_frames_u8(_tptr(store, torch.uint8, 'store'), _tptr(ids, torch.int32, 'ids'), n,
+                                      store[0].numel(), _ptr(out), _stream()), 'nlt_gather_frames_u8')
+    return out
+
+
+def assemble_batch(diffuse_store, rgb_store, cvis_store, lvis_store, ids, nn_ids, test_mode=False):
+    """uint8 stores [F,H,W,3] / [F,H,W]; ids [N] int32; nn_ids [N,k] int32 -> dict of float32 buffers."""
+    n = ids.numel()
+    k = 0 if nn_ids is None else nn_ids.shape[1]
+    _, h, w = cvis_store.shape
+    dev = cvis_store.device
+    E = lambda *s: torch.empty(s, device=dev, dtype=torch.float32)
+    out = {'base': E(n, h, w, 3), 'cvis': E(n, h, w, 1), 'lvis': E(n, h, w, 1), 'rgb': E(n, h, w, 3),
+           'nn_base': E(n, k, h, w, 3) if k else None, 'nn_rgb': E(n, k, h, w, 3) if k else None}
+    u8 = torch.uint8
+    _check(lib().nlt_assemble_batch(_tptr(diffuse_store, u8, 'diffuse_store'), _tptr(rgb_store, u8, 'rgb_store'),
+                                    _tptr(cvis_store, u8, 'cvis_store'), _tptr(lvis_store, u8, 'lvis_store'),
+                                    _tptr(ids, torch.int32, 'ids'), _tptr(nn_ids, torch.int32, 'nn_ids'), n, k, h * w,
+                                    1 if test_mode else 0, *[_ptr(out[x]) for x in ('base', 'cvis', 'lvis', 'rgb', 'nn_base', 'nn_rgb')],
+                                    _stream()), 'nlt_assemble_batch')
+    return out

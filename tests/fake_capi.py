@@ -213,3 +213,66 @@ def install(monkeypatch):
     _install_fwd(monkeypatch)
     for name in _TRAIN:
         monkeypatch.setattr(C, name, globals()[name])
+
+
+# ------------------------------------------------------------------ texel-buffer assembly (TEST-ONLY emulation)
+from oracle import buffers as _BU
+import numpy as _np
+
+
+def _t(a):
+    return torch.from_numpy(_np.ascontiguousarray(a))
+
+
+def cosine_map(locs, normals, valid, occluded, src_loc, want_float=True, want_u8=True):
+    shp = tuple(valid.shape)
+    ref = _BU.cosine_map(src_loc, locs.numpy().reshape(shp + (3,)), normals.numpy().reshape(shp + (3,)), valid.numpy(),
+                         None if occluded is None else occluded.numpy())
+    return (_t(ref) if want_float else None), (_t(_BU.quantize_unit(ref)) if want_u8 else None)
+
+
+def albedo(rgb_frames):
+    return _t(_BU.albedo_from_frames(rgb_frames.numpy()))
+
+
+def diffuse_base(albedo_, lvis):
+    return _t(_np.stack([_BU.diffuse_base(albedo_.numpy(), l) for l in lvis.numpy()]))
+
+
+def remap_bilinear(src, mapping, force_kbg=True):
+    f = _BU.remap_u8 if src.dtype == torch.uint8 else _BU.remap_f32
+    return _t(f(src.numpy(), mapping.numpy(), force_kbg))
+
+
+def uv_index_map(uvs, values, h, w, max_l1=4, fill=0.0, want_index=False):
+    out, idx = _BU.uv_index_map(uvs.numpy(), values.numpy(), (h, w), max_l1, fill, return_index=True)
+    return (_t(out), _t(idx)) if want_index else _t(out)
+
+
+def knn_indices(ref_pos, cand_pos, k=1):
+    return _t(_BU.knn_indices(ref_pos.numpy(), cand_pos.numpy(), k))
+
+
+def gather_frames_u8(store, ids):
+    i = ids.numpy()
+    out = (store.numpy()[_np.maximum(i, 0)] / 255.0).astype(_np.float32)
+    out[i < 0] = 0
+    return _t(out)
+
+
+def assemble_batch(diffuse_store, rgb_store, cvis_store, lvis_store, ids, nn_ids, test_mode=False):
+    st = {'diffuse': diffuse_store.numpy(), 'rgb': rgb_store.numpy(), 'cvis': cvis_store.numpy(), 'lvis': lvis_store.numpy()}
+    nn = _np.zeros((ids.numel(), 0), _np.int32) if nn_ids is None else nn_ids.numpy()
+    b = _BU.assemble_batch(st, ids.numpy(), nn, 'test' if test_mode else 'train')
+    return {k: _t(v) for k, v in b.items()}
+
+
+_BUFFERS = ('cosine_map', 'albedo', 'diffuse_base', 'remap_bilinear', 'uv_index_map', 'knn_indices', 'gather_frames_u8',
+            'assemble_batch')
+_install_train = install
+
+
+def install(monkeypatch):
+    _install_train(monkeypatch)
+    for name in _BUFFERS:
+        monkeypatch.setattr(C, name, globals()[name])
