@@ -25,6 +25,27 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E peak (MI355X_MICROARCH.md)
+# launch label -> kernel-name fragment in the rocprofv3 output (profiles/*_pmc_traffic.json)
+KERNEL_OF_LABEL = {'F.front': 'front_kernel', 'F.back': 'back_kernel', 'L0.stem': 'stem_kernel', 'L13.head': 'head_kernel'}
+
+
+def pmc_traffic(label):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC summary
+    (FETCH_SIZE / WRITE_SIZE collected in separate --pmc passes, tools/pmc_summary.py applies the
+    gfx950 corrections of MI355X_MICROARCH.md).  None when no summary covers this kernel."""
+    import glob
+    frag = KERNEL_OF_LABEL.get(label)
+    for path in sorted(glob.glob(os.path.join(ROOT, 'profiles', '*_pmc_traffic.json')), reverse=True):
+        try:
+            with open(path) as f:
+                d = json.load(f)
+        except (OSError, ValueError):
+            continue
+        for name, rec in d.get('kernels', {}).items():
+            if frag and frag in name and rec.get('hbm_bytes') is not None:
+                return int(rec['hbm_bytes'])
+    return None
+
 BYTES_PER_TEXEL = {1: 961.5, 4: 1755.75}   # SURVEY.md 8d, fp32 layer-wise algorithmic bytes
 
 
@@ -44,6 +65,8 @@ def parse():
     ap.add_argument('--depth', type=int, default=256)
     ap.add_argument('--algo', type=str, default='auto', choices=['auto', 'direct'])
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-fused', action='store_true', help='layer-by-layer plan (disable csrc/fused.hip) for A/B runs')
+    ap.add_argument('--tune-cache', type=str, default=None, help='JSON of tile choices: loaded if present, else written')
     ap.add_argument('--cpu-baseline-worker', action='store_true', help=argparse.SUPPRESS)
     ap.add_argument('--cpu-threads', type=int, default=32, help='host threads for the CPU oracle leg (0 = all)')
     ap.add_argument('--per-op', action='store_true', help='print a per-launch timing table to stderr')
@@ -188,6 +211,10 @@ def main():
             v.data.uniform_(-0.1, 0.1, generator=g)
     if args.algo == 'direct':
         model.conv_algo = capi.ALGO_DIRECT
+    if args.no_fused:
+        model.plan.fuse_ends = False
+    if args.tune_cache and os.path.exists(args.tune_cache):
+        model.plan.load_tuning(args.tune_cache)
     batch = synth_device_batch(args.frames, args.uv, args.cam, args.k, device, seed=100 + rank)
 
     def step():
@@ -196,6 +223,8 @@ def main():
     # per-launch survey (outside the timed region) -> dominant kernel
     for _ in range(2):
         step()
+    if args.tune_cache and not os.path.exists(args.tune_cache) and rank == 0:
+        model.plan.save_tuning(args.tune_cache)
     timer = OpTimer()
     model.plan.timer = timer
     for _ in range(3):
@@ -254,9 +283,9 @@ def main():
                                    "%d frames/GPU, %d^2 UV, k=%d obs maps, %d^2 camera warp"
                                    % (args.depth, args.frames, args.uv, args.k, args.cam),
                        "frames_per_gpu": args.frames, "uv": args.uv, "k": args.k, "cam": args.cam,
-                       "conv_algo": args.algo, "parallelism": "dp%d (frames sharded, no forward collective)" % world},
+                       "conv_algo": args.algo, "plan": "layer-by-layer" if args.no_fused else "fused ends", "parallelism": "dp%d (frames sharded, no forward collective)" % world},
             "roofline": {"bound": "hbm", "kernel": dominant, "achieved": round(ach, 1), "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None,
+                         "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": pmc_traffic(dominant),
                          "launch_ms": round(dom_ms, 4), "algorithmic_bytes_per_launch": int(dom_bytes)},
             "roofline_whole_pass": {"algorithmic_bytes_per_texel": bpt,
                                     "achieved": round(value / world * 1e6 * bpt / 1e9, 1), "unit": "GB/s per GPU",

@@ -305,6 +305,50 @@ int nlt_assemble_batch(const unsigned char* diffuse_store, const unsigned char* 
                        float* base, float* cvis, float* lvis, float* rgb, float* nn_base, float* nn_rgb,
                        void* stream);
 
+/* ======================= fused inference ends (csrc/fused.hip) =======================
+ * Forward-only fusions of everything that touches full-resolution texels; algebraically identical to the
+ * layer-by-layer entry points above (L0 is linear, so it folds into its consumers), fp32 re-association only. */
+
+/* Floats nlt_front_pack_weights() writes. */
+long nlt_front_packed_floats(void);
+
+/* Folds L0 of both nets into L1's stride-2 convs and into the head, and lays L1's four kernels out as MFMA
+ * fragments.  All inputs Keras layout: wq0 (1,1,5,16) wo0 (1,1,3,16) [convnet.py:44]; query L1 wqa (2,2,32,16),
+ * wqb (2,2,16,16); obs L1 woa, wob (2,2,16,16) [convnet.py:50-59]; head wh (1,1,36,3) [convnet.py:85].
+ * Call again whenever any of them changes. */
+int nlt_front_pack_weights(const float* wq0, const float* bq0, const float* wo0, const float* bo0,
+                           const float* wqa, const float* bqa, const float* wqb, const float* bqb,
+                           const float* woa, const float* boa, const float* wob, const float* bob,
+                           const float* wh, const float* bh, float* packed, void* stream);
+
+/*
+ * Layers 0 and 1 of both paths + both observation means, from the raw texel buffers, in one pass.
+ *   replaces: nlt/models/nlt.py:95-96 (input assembly) and the i = 0, 1 iterations of Model._call's layer loop
+ *             (nlt.py:153-180: obs layers, reduce_mean, query layers, concat), i.e. nlt_stem_forward +
+ *             4x nlt_conv_forward + nlt_obs_mean_forward of the unfused plan.
+ * base [n,h,w,3], cvis/lvis [n,h,w,1], nn_rgb/nn_base [n,k,h,w,3] (h, w even).  Writes
+ *   fm1   [n,h/2,w/2,32]    = [query L1 | mean_k obs L1]
+ *   obs1  [n,k,h/2,w/2,16]  per-observation L1 maps
+ *   skip3 [n,h,w,3]         = head weights applied to the (never materialised) L0 features + head bias
+ *                             (+ base when add_base): what nlt_back_forward adds to finish pred.
+ */
+int nlt_front_forward(const float* base, const float* cvis, const float* lvis, const float* nn_rgb,
+                      const float* nn_base, int n, int k, int h, int w, const float* packed,
+                      int add_base, float alpha, float* fm1, float* obs1, float* skip3, void* stream);
+
+/*
+ * Last expanding block + output head: Conv2DTranspose k2s2 (8 + 32 -> 4) + LeakyReLU, Conv2DTranspose k2s1
+ * (4 -> 4) + LeakyReLU, 1x1 head on those 4 channels + skip3, texel (0,0) of every frame forced to 0.
+ *   replaces: the last two entries of net['query'].layers (convnet.py:67-76,85) as Model._call runs them
+ *             (nlt.py:182-195) and nlt.py:99-102,110, i.e. 2x nlt_conv_forward + nlt_head_forward.
+ * x [n,h2,w2,8] (previous decoder output), fm1 [n,h2,w2,32] (the popped skip), skip3 [n,2h2,2w2,3];
+ * Keras weights w_s2 (2,2,4,40), w_s1 (2,2,4,4); w_head = first 4 input rows of the (1,1,36,3) head kernel.
+ * pred [n,2h2,2w2,3].
+ */
+int nlt_back_forward(const float* x, const float* fm1, const float* skip3, int n, int h2, int w2,
+                     const float* w_s2, const float* b_s2, const float* w_s1, const float* b_s1,
+                     const float* w_head, float alpha, float* pred, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -51,6 +51,10 @@ SIGNATURES = {
     'nlt_barron_loss': (_c_int, [_vp, _vp, _c_int, _c_int, _c_int, _vp, _vp, _vp, _vp]),
     'nlt_scale_rows': (_c_int, [_vp, _vp, _c_int, _c_long, _vp, _vp]),
     'nlt_adam_amsgrad_step': (_c_int, [_vp] * 5 + [_c_long] + [_c_float] * 4 + [_vp]),
+    'nlt_front_packed_floats': (_c_long, []),
+    'nlt_front_pack_weights': (_c_int, [_vp] * 15 + [_vp]),
+    'nlt_front_forward': (_c_int, [_vp] * 5 + [_c_int] * 4 + [_vp, _c_int, _c_float, _vp, _vp, _vp, _vp]),
+    'nlt_back_forward': (_c_int, [_vp] * 3 + [_c_int] * 3 + [_vp] * 5 + [_c_float, _vp, _vp]),
     'nlt_cosine_map': (_c_int, [_vp] * 4 + [_c_double] * 3 + [_c_long, _vp, _vp, _vp]),
     'nlt_albedo': (_c_int, [_vp, _c_int, _c_long, _vp, _vp, _vp]),
     'nlt_diffuse_base': (_c_int, [_vp, _vp, _c_int, _c_long, _vp, _vp]),
@@ -261,6 +265,28 @@ def adam_amsgrad_step(param, grad, m, v, vhat, lr_t, beta1, beta2, eps):
     _check(lib().nlt_adam_amsgrad_step(_ptr(param), _ptr(grad), _ptr(m), _ptr(v), _ptr(vhat), param.numel(),
                                        float(lr_t), float(beta1), float(beta2), float(eps), _stream()),
            'nlt_adam_amsgrad_step')
+
+
+# ---------------------------------------------------------------- fused inference ends
+def front_pack_weights(wq0, bq0, wo0, bo0, wqa, bqa, wqb, bqb, woa, boa, wob, bob, wh, bh):
+    out = torch.empty(lib().nlt_front_packed_floats(), device=wq0.device, dtype=torch.float32)
+    args = [_ptr(_dense(t, 'weight')) for t in (wq0, bq0, wo0, bo0, wqa, bqa, wqb, bqb, woa, boa, wob, bob, wh, bh)]
+    _check(lib().nlt_front_pack_weights(*args, _ptr(out), _stream()), 'nlt_front_pack_weights')
+    return out
+
+
+def front_forward(base, cvis, lvis, nn_rgb, nn_base, n, k, h, w, packed, add_base, alpha, fm1, obs1, skip3):
+    for t, nm in ((base, 'base'), (cvis, 'cvis'), (lvis, 'lvis'), (nn_rgb, 'nn_rgb'), (nn_base, 'nn_base')):
+        _dense(t, nm)
+    _check(lib().nlt_front_forward(_ptr(base), _ptr(cvis), _ptr(lvis), _ptr(nn_rgb), _ptr(nn_base), n, k, h, w,
+                                   _ptr(packed), 1 if add_base else 0, float(alpha), _ptr(fm1), _ptr(obs1), _ptr(skip3),
+                                   _stream()), 'nlt_front_forward')
+
+
+def back_forward(x, fm1, skip3, n, h2, w2, w_s2, b_s2, w_s1, b_s1, w_head, alpha, pred):
+    _check(lib().nlt_back_forward(_ptr(_dense(x, 'x')), _ptr(_dense(fm1, 'fm1')), _ptr(_dense(skip3, 'skip3')), n, h2, w2,
+                                  _ptr(w_s2), _ptr(b_s2), _ptr(w_s1), _ptr(b_s1), _ptr(w_head), float(alpha), _ptr(pred),
+                                  _stream()), 'nlt_back_forward')
 
 
 # ---------------------------------------------------------------- texel-buffer assembly

@@ -52,6 +52,8 @@ class RenderPlan:
         self.tile_hints = {}            # label -> 16*RT+CT wave tile ('*' = every launch)
         self.algo_hints = {}            # label -> C.ALGO_DIRECT for the few tiny-channel layers where it wins
         self.autotune = os.environ.get('NLT_AUTOTUNE', '1') != '0'
+        self.fuse_ends = os.environ.get('NLT_FUSED', '1') != '0'   # inference: csrc/fused.hip for layers 0-1 and the last block + head
+        self._front_blob = None
         self._trial_direct = False
         self._ran_direct = set()
         is_c = net_query.is_contracting
@@ -87,6 +89,7 @@ class RenderPlan:
             b['dtmp'].append(E(n, hh, ww, nl))
             b['dec'].append(E(n, hh, ww, nl))
         b['pred'] = E(n, h, w, 3)
+        b['skip3'] = None               # allocated by the fused inference path on first use
         self._bufs = {key: b}           # keep one shape resident
         return b
 
@@ -125,7 +128,9 @@ class RenderPlan:
         with HIP events on this shape and keeps the fastest."""
         saved = (self.timer, dict(self.tile_hints), dict(self.algo_hints))
         results = {}
-        trials = [('tile', 16 * r + c) for r in (1, 2, 4) for c in (1, 2, 4)] + [('direct', 0)]
+        trials = [('tile', 16 * r + c) for r in (1, 2, 4) for c in (1, 2, 4)]
+        if not self.fuse_ends:
+            trials.append(('direct', 0))    # only the 4/8-channel full-resolution layers ever preferred it
         for kind, hint in trials:
             self.tile_hints = {'*': hint} if kind == 'tile' else {}
             self.algo_hints = {}
@@ -150,22 +155,70 @@ class RenderPlan:
                 self.tile_hints.setdefault(label, hint)
         self.tuned = results
 
+    def save_tuning(self, path):
+        import json
+        with open(path, 'w') as f:
+            json.dump({'tile_hints': self.tile_hints, 'algo_hints': self.algo_hints}, f)
+
+    def load_tuning(self, path):
+        """Re-uses tile choices measured by an earlier run (skips the plan-time trials)."""
+        import json
+        with open(path) as f:
+            d = json.load(f)
+        self.tile_hints.update(d['tile_hints']); self.algo_hints.update(d['algo_hints'])
+        self.autotune = False
+
     # ------------------------------------------------------------------ forward
+    def can_fuse(self, b, obs_weights, obs_override):
+        """The fused ends cover the released first/last levels (depth0 = 16 fixes them: L0 -> 16, first
+        contracting block 16, last expanding block 8 -> 4, head 36 -> 3) with plain observation means."""
+        q, D, U, cl = self.q, self.n_down, self.n_up, b['C']
+        if not (self.fuse_ends and self.use_obs and obs_weights is None and obs_override is None and D >= 2 and U >= 2):
+            return False
+        last = q.layers[D + U].convs()
+        prev = q.layers[D + U - 1].convs()
+        acts = [a for blk in (q.layers[1], self.o.layers[1], q.layers[D + U]) for _, a in blk.convs()]
+        return (cl[0] == 16 and cl[1] == 16 and last[0][0].n_ch_out == 4 and last[1][0].n_ch_out == 4
+                and prev[1][0].n_ch_out == 8 and q.layers[-1].n_ch_out == 3
+                and all(a is not None for a in acts) and len({a.alpha for a in acts}) == 1)
+
+    def _front_weights(self, dev):
+        """Folded + fragment-packed weights of the front kernel, re-derived when any source kernel changed."""
+        q, o, D, U = self.q, self.o, self.n_down, self.n_up
+        q0, o0, head = q.layers[0], o.layers[0], q.layers[-1]
+        (qa, _), (qb, _) = q.layers[1].convs()
+        (oa, _), (ob, _) = o.layers[1].convs()
+        q0.build(5, dev); o0.build(3, dev); qa.build(32, dev); qb.build(16, dev); oa.build(16, dev); ob.build(16, dev)
+        head.build(36, dev)
+        convs = (q0, o0, qa, qb, oa, ob, head)
+        ver = tuple((c.kernel.data_ptr(), c.kernel._version, c.bias._version, c._epoch[0]) for c in convs)
+        if self._front_blob is None or self._front_blob[0] != ver:
+            w = lambda c: (c.kernel.detach(), c.bias.detach())
+            blob = C.front_pack_weights(*w(q0), *w(o0), *w(qa), *w(qb), *w(oa), *w(ob), *w(head))
+            self._front_blob = (ver, blob)
+        return self._front_blob[1]
+
     def forward(self, base, cvis, lvis, nn_rgb, nn_base, obs_weights=None, obs_override=None,
-                skip_connect_base=True, algo=C.ALGO_AUTO):
+                skip_connect_base=True, algo=C.ALGO_AUTO, inference=False):
         """base [N,H,W,3], cvis/lvis [N,H,W,1], nn_rgb/nn_base [N,k,H,W,3] -> pred [N,H,W,3]
-        (texel (0,0) zeroed, base added).  Returns (pred, buffers)."""
+        (texel (0,0) zeroed, base added).  Returns (pred, buffers).
+        inference=True lets the plan use the fused ends (csrc/fused.hip), which do not keep the
+        activations a backward pass would need (fm0, obs0, the L1 / last-block intermediates)."""
         n, h, w, _ = base.shape
         k = nn_rgb.shape[1]
         dev = base.device
         b = self._buffers(n, k, h, w, dev)
-        if self.autotune and not b.get('tuned') and base.is_cuda:
-            b['tuned'] = True
+        fused = inference and self.can_fuse(b, obs_weights, obs_override)
+        tuned_key = 'tuned_fused' if fused else 'tuned'
+        if self.autotune and not b.get(tuned_key) and base.is_cuda:
+            b[tuned_key] = True
             self._autotune(lambda: self.forward(base, cvis, lvis, nn_rgb, nn_base, obs_weights, obs_override,
-                                                skip_connect_base, algo))
+                                                skip_connect_base, algo, inference))
         q, o, D, cl = self.q, self.o, self.n_down, b['C']
         mult = 2 if self.use_obs else 1
         run_obs = self.use_obs and obs_override is None
+        if fused:
+            return self._forward_fused(b, base, cvis, lvis, nn_rgb, nn_base, skip_connect_base, algo)
 
         # L0 (both paths) + first observation mean
         q0, o0 = q.layers[0], o.layers[0]
@@ -223,6 +276,52 @@ class RenderPlan:
         self._launch('L%d.head' % (2 * D + 1), 4 * n * h * w * (cx + cs + 3 + 3), C.head_forward,
                      x, cx, cx, b['fm'][0], cs, cs, head.kernel.detach(), head.bias.detach(),
                      base if skip_connect_base else None, n, h, w, b['pred'])
+        return b['pred'], b
+
+    def _forward_fused(self, b, base, cvis, lvis, nn_rgb, nn_base, skip_connect_base, algo):
+        """front kernel (layers 0-1) -> unfused levels 2..D and decoder blocks -> back kernel."""
+        n, h, w, _ = base.shape
+        k = nn_rgb.shape[1]
+        q, o, D, U, cl = self.q, self.o, self.n_down, self.n_up, b['C']
+        alpha = q.layers[1].convs()[0][1].alpha
+        if b['skip3'] is None:
+            b['skip3'] = torch.empty((n, h, w, 3), device=base.device, dtype=torch.float32)
+        blob = self._front_weights(base.device)
+        # SURVEY 8d accounting of what this launch replaces: L0 + L1 of both paths (+ the two means)
+        nbytes = 4 * n * h * w * ((5 + 3 * k + 16 + 16 * k) + (36 + 20 * k + 8 + 8 * k))
+        self._launch('F.front', nbytes, C.front_forward, base, cvis, lvis, nn_rgb, nn_base, n, k, h, w, blob,
+                     skip_connect_base, alpha, b['fm'][1], b['obs'][1], b['skip3'])
+        hh, ww = h // 2, w // 2
+        for l in range(2, D + 1):
+            (qa, qact_a), (qb, qact_b) = q.layers[l].convs()
+            (oa, oact_a), (ob, oact_b) = o.layers[l].convs()
+            cin = 2 * cl[l - 1]
+            self._conv('L%d.q.s2' % l, qa, qact_a, b['fm'][l - 1], cin, cin, None, 0, 0, n, hh, ww, b['qtmp'][l], cl[l], algo)
+            self._conv('L%d.o.s2' % l, oa, oact_a, b['obs'][l - 1], cl[l - 1], cl[l - 1], None, 0, 0,
+                       n * k, hh, ww, b['otmp'][l], cl[l], algo)
+            hh, ww = hh // 2, ww // 2
+            self._conv('L%d.q.s1' % l, qb, qact_b, b['qtmp'][l], cl[l], cl[l], None, 0, 0, n, hh, ww, b['fm'][l], 2 * cl[l], algo)
+            self._conv('L%d.o.s1' % l, ob, oact_b, b['otmp'][l], cl[l], cl[l], None, 0, 0, n * k, hh, ww, b['obs'][l], cl[l], algo)
+            self._launch('L%d.o.mean' % l, 4 * n * hh * ww * cl[l] * (k + 1), C.obs_mean_forward,
+                         b['obs'][l], None, n, k, hh * ww, cl[l], b['fm'][l].view(-1)[cl[l]:], 2 * cl[l])
+        x, cx = b['fm'][D], 2 * cl[D]
+        for j in range(U - 1):
+            (da, dact_a), (db, dact_b) = q.layers[D + 1 + j].convs()
+            skip, cs = b['fm'][D - j], 2 * cl[D - j]
+            lab = 'L%d.q' % (D + 1 + j)
+            self._conv(lab + '.s2', da, dact_a, x, cx, cx, skip, cs, cs, n, hh, ww, b['dtmp'][j], da.n_ch_out, algo)
+            hh, ww = hh * 2, ww * 2
+            self._conv(lab + '.s1', db, dact_b, b['dtmp'][j], da.n_ch_out, da.n_ch_out, None, 0, 0, n, hh, ww,
+                       b['dec'][j], db.n_ch_out, algo)
+            x, cx = b['dec'][j], db.n_ch_out
+        (da, _), (db, _) = q.layers[D + U].convs()
+        head = q.layers[-1]
+        da.build(cx + 2 * cl[1], base.device); db.build(4, base.device)
+        assert (hh, ww) == (h // 2, w // 2) and cx == 8 and da.cin == 40
+        # last block (40 -> 4 -> 4 at full resolution) + head (36 -> 3) in SURVEY 8d accounting
+        nbytes = 4 * n * h * w * ((10 + 4) + (4 + 4) + (36 + 3))
+        self._launch('F.back', nbytes, C.back_forward, x, b['fm'][1], b['skip3'], n, hh, ww, da.kernel.detach(),
+                     da.bias.detach(), db.kernel.detach(), db.bias.detach(), head.kernel.detach(), alpha, b['pred'])
         return b['pred'], b
 
     # ------------------------------------------------------------------ backward

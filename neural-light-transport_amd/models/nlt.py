@@ -19,7 +19,7 @@ class _RenderFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, flat_params, model, inputs, want_indices):
         base, cvis, lvis, warp, nn_rgb, nn_base, obs_weights = inputs
-        out = model._render(base, cvis, lvis, warp, nn_rgb, nn_base, obs_weights, None, want_indices)
+        out = model._render(base, cvis, lvis, warp, nn_rgb, nn_base, obs_weights, None, want_indices, inference=False)
         ctx.model, ctx.inputs = model, inputs
         pred, pred_c, base_c, fg_c, idx = out
         nd = [t for t in (pred, base_c, fg_c) if t is not None]
@@ -161,11 +161,11 @@ class Model(BaseModel):
         return self
 
     # ---------------------------------------------------------------- forward
-    def _render(self, base, cvis, lvis, warp, nn_rgb, nn_base, obs_weights, obs_override, want_indices):
+    def _render(self, base, cvis, lvis, warp, nn_rgb, nn_base, obs_weights, obs_override, want_indices, inference=True):
         n, hc, wc, _ = warp.shape
         pred, _ = self.plan.forward(base, cvis, lvis, nn_rgb, nn_base, obs_weights=obs_weights,
                                     obs_override=obs_override, skip_connect_base=self.skip_connect_base,
-                                    algo=self.conv_algo)
+                                    algo=self.conv_algo, inference=inference)
         E = lambda: torch.empty((n, hc, wc, 3), device=base.device, dtype=torch.float32)
         pred_camspc, base_camspc, fg_camspc = E(), E(), E()
         idx = torch.empty((n, hc, wc, 4), device=base.device, dtype=torch.int32) if want_indices else None

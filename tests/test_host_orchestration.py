@@ -92,14 +92,38 @@ def test_op_labels_and_algorithmic_bytes(monkeypatch):
             self.records[label] = [1, 0.0, nbytes]
             fn(*a, **kw)
     for k, per_texel in ((1, 961.5), (4, 1755.75)):
-        om, pm = make(256, 64, 64)
-        pm.plan.timer = Rec()
-        batch, nn = O.synth_batch(1, 64, 64, 64, 64, 64, 64, k=k, seed=5)
-        pm.call(cpu_batch(batch, nn), 'test')
-        total = sum(r[2] for r in pm.plan.timer.records.values())
-        # the fused plan adds the explicit obs-mean launches and the stem's raw-input reads /
-        # mean write on top of the layer-wise accounting; everything else must match exactly
-        extra = sum(r[2] for l, r in pm.plan.timer.records.items() if l.endswith('.o.mean'))
-        extra += 4 * 64 * 64 * (3 * k + 16) + 4 * 64 * 64 * 3        # stem: second raw obs input + mean write; head: base read
-        assert abs((total - extra) / (64 * 64) - per_texel) < 1e-6, (k, (total - extra) / 4096)
-        assert len(pm.plan.timer.records) == 1 + 6 * 5 + 6 * 2 + 1
+        for fused in (False, True):
+            om, pm = make(256, 64, 64)
+            pm.plan.fuse_ends = fused
+            pm.plan.timer = Rec()
+            batch, nn = O.synth_batch(1, 64, 64, 64, 64, 64, 64, k=k, seed=5)
+            pm.call(cpu_batch(batch, nn), 'test')
+            total = sum(r[2] for r in pm.plan.timer.records.values())
+            # the explicit obs-mean launches come on top of the layer-wise accounting; unfused, so do the stem's
+            # second raw obs input + mean write and the head's base read.  Everything else must match exactly.
+            extra = sum(r[2] for l, r in pm.plan.timer.records.items() if l.endswith('.o.mean'))
+            if not fused:
+                extra += 4 * 64 * 64 * (3 * k + 16) + 4 * 64 * 64 * 3
+            assert abs((total - extra) / (64 * 64) - per_texel) < 1e-6, (k, fused, (total - extra) / 4096)
+            assert len(pm.plan.timer.records) == (1 + 5 * 5 + 5 * 2 + 1 if fused else 1 + 6 * 5 + 6 * 2 + 1)
+            assert ('F.front' in pm.plan.timer.records) == fused and ('L0.stem' in pm.plan.timer.records) != fused
+
+
+def test_fused_ends_match_unfused_and_are_skipped_when_they_must_be(monkeypatch):
+    fake_capi.install(monkeypatch)
+    om, pm = make(256, 64, 32)
+    batch, nn = O.synth_batch(2, 64, 64, 32, 32, 32, 32, k=2, seed=8)
+    cb = cpu_batch(batch, nn)
+    with torch.no_grad():
+        ref = om.call(batch, 'test', nn_list=nn)[3]['pred']
+    a = pm.call(cb, 'test')[3]['pred']
+    pm.plan.fuse_ends = False
+    b = pm.call(cb, 'test')[3]['pred']
+    assert rel_l2(a, ref) < 1e-5 and rel_l2(b, ref) < 1e-5
+    pm.plan.fuse_ends = True
+    bufs = pm.plan._buffers(2, 2, 64, 64, cb[1].device)
+    assert pm.plan.can_fuse(bufs, None, None)
+    assert not pm.plan.can_fuse(bufs, torch.ones(2, 2), None)       # obs_weights -> layer-by-layer kernels
+    assert not pm.plan.can_fuse(bufs, None, [None])                  # obs_override (nlt_test.py) -> layer-by-layer
+    pm.plan.fuse_ends = False
+    assert not pm.plan.can_fuse(bufs, None, None)

@@ -1,21 +1,34 @@
 #!/bin/bash
-# One GPU-box session: parity tests, smoke, bench (+per-op table), rocprofv3 kernel trace.
-# TUNE=1 adds the tile sweep.
+# One GPU-box session: parity tests, smoke, bench (+per-op table, fused vs layer-by-layer), rocprofv3 kernel
+# trace of the forward, and two PMC passes (FETCH_SIZE / WRITE_SIZE separately, no tracing domains beside
+# --kernel-trace).   TESTS="..." restricts pytest; TUNE=1 adds the tile sweep; PMC=0 skips the counter passes.
 set -u
 cd "$GRAFT_REPO_ROOT"
 mkdir -p gpurun_out
 export TMPDIR=/tmp
-(timeout 1200 python -m pytest tests -m gpu -q --maxfail=40 --tb=short -p no:cacheprovider 2>&1 | tail -150) > gpurun_out/pytest_gpu.log
-tail -5 gpurun_out/pytest_gpu.log
+R="$GRAFT_REPO_ROOT"
+(timeout 1500 python -m pytest ${TESTS:-tests} -m gpu -q --maxfail=30 --tb=short --timeout=600 -p no:cacheprovider 2>&1 | tail -200) > gpurun_out/pytest_gpu.log
+tail -40 gpurun_out/pytest_gpu.log
 (timeout 300 python __graft_entry__.py smoke 2>&1 | tail -5) > gpurun_out/smoke.log; cat gpurun_out/smoke.log
-timeout 600 python bench.py --steps 20 --warmup 5 --per-op > gpurun_out/bench.json 2> gpurun_out/bench_perop.txt
-cat gpurun_out/bench.json; tail -70 gpurun_out/bench_perop.txt
+timeout 900 python bench.py --steps 20 --warmup 5 --per-op --tune-cache gpurun_out/tune_fused.json > gpurun_out/bench.json 2> gpurun_out/bench_perop.txt
+cat gpurun_out/bench.json; tail -45 gpurun_out/bench_perop.txt
+timeout 600 python bench.py --steps 20 --warmup 5 --per-op --no-fused --no-cpu-baseline --train-steps 0 --tune-cache gpurun_out/tune_unfused.json > gpurun_out/bench_unfused.json 2> gpurun_out/bench_unfused_perop.txt
+cat gpurun_out/bench_unfused.json; head -8 gpurun_out/bench_unfused_perop.txt
 if [ "${TUNE:-0}" = "1" ]; then
   timeout 600 python tools/tune_tiles.py > gpurun_out/tune.txt 2> gpurun_out/tune.err; tail -70 gpurun_out/tune.txt; tail -5 gpurun_out/tune.err
 fi
-cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats -d "$GRAFT_REPO_ROOT/gpurun_out/prof" -o bench -- python "$GRAFT_REPO_ROOT/bench.py" --steps 10 --warmup 3 --no-cpu-baseline > "$GRAFT_REPO_ROOT/gpurun_out/prof_bench.json" 2> "$GRAFT_REPO_ROOT/gpurun_out/prof.err"
-cd "$GRAFT_REPO_ROOT"; cat gpurun_out/prof_bench.json; tail -3 gpurun_out/prof.err
+B="python $R/bench.py --steps 10 --warmup 3 --no-cpu-baseline --train-steps 0 --tune-cache $R/gpurun_out/tune_fused.json"
+cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats -d "$R/gpurun_out/prof" -o bench -- $B > "$R/gpurun_out/prof_bench.json" 2> "$R/gpurun_out/prof.err"
+cd "$R"; cat gpurun_out/prof_bench.json; tail -2 gpurun_out/prof.err
 db=$(find gpurun_out/prof -name "*.db" | head -1)
-[ -n "$db" ] && python tools/rocpd_summary.py "$db" gpurun_out/kernel_stats.csv && cut -c1-160 gpurun_out/kernel_stats.csv | head -50
-f=$(find gpurun_out/prof -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp "$f" gpurun_out/kernel_stats_rocprof.csv
-rm -rf gpurun_out/prof/*/*.db 2>/dev/null; du -sh gpurun_out
+[ -n "$db" ] && python tools/rocpd_summary.py "$db" gpurun_out/kernel_stats.csv && cut -c1-150 gpurun_out/kernel_stats.csv | head -40
+rm -f gpurun_out/prof/*.db gpurun_out/prof/*/*.db 2>/dev/null
+if [ "${PMC:-1}" = "1" ]; then
+  cd /tmp
+  timeout 600 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d "$R/gpurun_out/pmc_fetch" -- $B > /dev/null 2> "$R/gpurun_out/pmc_fetch.err"
+  timeout 600 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d "$R/gpurun_out/pmc_write" -- $B > /dev/null 2> "$R/gpurun_out/pmc_write.err"
+  cd "$R"; tail -2 gpurun_out/pmc_fetch.err
+  python tools/pmc_summary.py gpurun_out/pmc_traffic.json gpurun_out/pmc_fetch gpurun_out/pmc_write
+  find gpurun_out/pmc_fetch gpurun_out/pmc_write -name "*.csv" -size +8M -delete
+fi
+du -sh gpurun_out
