@@ -25,6 +25,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E peak (MI355X_MICROARCH.md)
+MFMA_F32_PEAK_TFLOPS = 157.3   # dense fp32-input MFMA peak = the fp32 vector peak (MI355X_MICROARCH.md)
 # launch label -> kernel-name fragment in the rocprofv3 output (profiles/*_pmc_traffic.json)
 KERNEL_OF_LABEL = {'F.front': 'front_kernel', 'F.back': 'back_kernel', 'L0.stem': 'stem_kernel', 'L13.head': 'head_kernel'}
 
@@ -234,9 +235,10 @@ def main():
     table = sorted(((r[1] / r[0], l, r[2]) for l, r in rec.items()), reverse=True)
     if args.per_op and rank == 0:
         tot = sum(t for t, _, _ in table)
-        sys.stderr.write("%-12s %10s %7s %10s\n" % ("launch", "ms", "%", "algGB/s"))
+        sys.stderr.write("%-12s %10s %7s %10s %8s\n" % ("launch", "ms", "%", "GB/s", "TFLOP/s"))
         for t, l, nb in table:
-            sys.stderr.write("%-12s %10.4f %6.1f%% %10.1f\n" % (l, t, 100 * t / tot, nb / t / 1e6))
+            sys.stderr.write("%-12s %10.4f %6.1f%% %10.1f %8.1f\n" % (l, t, 100 * t / tot, timer.moved.get(l, nb) / t / 1e6,
+                                                                     timer.flops.get(l, 0) / t / 1e9))
         sys.stderr.write("sum of launches %.3f ms\n" % tot)
     dominant = args.dominant or table[0][1]
 
@@ -261,7 +263,9 @@ def main():
         elapsed = float(te.item())
     drec = dom.collect()[dominant]
     dom_ms = drec[1] / drec[0]
-    dom_bytes = drec[2]
+    dom_layerwise = drec[2]                                   # SURVEY 8d layer-wise bytes of what the launch computes
+    dom_bytes = timer.moved.get(dominant, dom_layerwise)      # a fused launch: the bytes it must itself move
+    dom_flops = timer.flops.get(dominant, 0)
 
     train = None
     n_train = args.steps // 2 if args.train_steps < 0 else args.train_steps
@@ -273,6 +277,18 @@ def main():
         value = texels / elapsed / 1e6
         ach = dom_bytes / (dom_ms * 1e-3) / 1e9
         bpt = algorithmic_bytes_per_texel(args.k)
+        if dom_flops / max(dom_bytes, 1) > MFMA_F32_PEAK_TFLOPS * 1e12 / (HBM_PEAK_GBS * 1e9):   # above the fp32 ridge
+            tf = dom_flops / (dom_ms * 1e-3) / 1e12
+            roof = {"bound": "mfma", "kernel": dominant, "achieved": round(tf, 2), "peak": MFMA_F32_PEAK_TFLOPS,
+                    "unit": "TFLOP/s", "frac": round(tf / MFMA_F32_PEAK_TFLOPS, 4), "traffic": pmc_traffic(dominant),
+                    "launch_ms": round(dom_ms, 4), "flops_per_launch": int(dom_flops),
+                    "algorithmic_bytes_per_launch": int(dom_bytes)}
+        else:
+            roof = {"bound": "hbm", "kernel": dominant, "achieved": round(ach, 1), "peak": HBM_PEAK_GBS,
+                    "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": pmc_traffic(dominant),
+                    "launch_ms": round(dom_ms, 4), "algorithmic_bytes_per_launch": int(dom_bytes)}
+        if dom_layerwise != dom_bytes:                          # fused launch: also what it replaces, layer by layer
+            roof["layerwise_bytes_replaced"] = int(dom_layerwise)
         out = {
             "metric": "rendered Mtexels/s at %d^2 UV (full Model.call forward: U-Net + UV->camera warp)" % args.uv,
             "value": round(value, 2), "unit": "Mtexels/s", "n_gpus": world, "steps": args.steps,
@@ -284,9 +300,7 @@ def main():
                                    % (args.depth, args.frames, args.uv, args.k, args.cam),
                        "frames_per_gpu": args.frames, "uv": args.uv, "k": args.k, "cam": args.cam,
                        "conv_algo": args.algo, "plan": "layer-by-layer" if args.no_fused else "fused ends", "parallelism": "dp%d (frames sharded, no forward collective)" % world},
-            "roofline": {"bound": "hbm", "kernel": dominant, "achieved": round(ach, 1), "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": pmc_traffic(dominant),
-                         "launch_ms": round(dom_ms, 4), "algorithmic_bytes_per_launch": int(dom_bytes)},
+            "roofline": roof,
             "roofline_whole_pass": {"algorithmic_bytes_per_texel": bpt,
                                     "achieved": round(value / world * 1e6 * bpt / 1e9, 1), "unit": "GB/s per GPU",
                                     "frac": round(value / world * 1e6 * bpt / 1e9 / HBM_PEAK_GBS, 4)},

@@ -27,6 +27,8 @@ class OpTimer:
 
     def __init__(self):
         self.pending, self.records = [], {}
+        self.flops = {}                 # label -> fp32 FLOPs of one launch (2 x MACs), filled by the plan
+        self.moved = {}                 # label -> bytes a FUSED launch itself has to move (its inputs + outputs)
 
     def launch(self, label, nbytes, fn, *args, **kw):
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -93,8 +95,12 @@ class RenderPlan:
         self._bufs = {key: b}           # keep one shape resident
         return b
 
-    def _launch(self, label, nbytes, fn, *args, **kw):
+    def _launch(self, label, nbytes, fn, *args, flops=0, moved=None, **kw):
         t = self.timer
+        if t is not None:
+            t.flops[label] = flops
+            if moved is not None:
+                t.moved[label] = moved
         if t is not None and (getattr(t, 'only', None) is None or label in t.only):
             t.launch(label, nbytes, fn, *args, **kw)
         else:
@@ -113,12 +119,15 @@ class RenderPlan:
         nbytes = 4 * (n * h * w * (c0 + c1) + n * oh * ow * layer.n_ch_out)
         tile_hint = self.tile_hints.get(label, self.tile_hints.get('*', 0))
         ncols = layer.n_ch_out * (4 if layer.mode == C.DECONV_K2S2 else 1)
+        taps = 4 if layer.mode in (C.CONV_K2S2, C.CONV_K2S1, C.DECONV_K2S1) else 1
+        rows = n * h * w // (4 if layer.mode == C.CONV_K2S2 else 1)
+        flops = 2 * rows * taps * (c0 + c1) * ncols
         if tile_hint and ((ncols + 15) // 16) % (tile_hint & 15):
             tile_hint = 0                # CT must divide the number of 16-column tiles
         self._launch(label, nbytes, C.conv_forward, layer.mode, src0, c0, ld0, src1, c1, ld1, n, h, w, layer.kernel.detach(),
                        layer.packed(c0, c1) if ok else None, layer.bias.detach(), layer.n_ch_out, out, ldo,
                        act=act is not None, alpha=act.alpha if act is not None else 0.0,
-                       algo=algo if ok else C.ALGO_DIRECT, tile_hint=tile_hint if ok else 0)
+                       algo=algo if ok else C.ALGO_DIRECT, tile_hint=tile_hint if ok else 0, flops=flops)
 
     # ------------------------------------------------------------------ autotune
     def _autotune(self, run):
@@ -289,8 +298,11 @@ class RenderPlan:
         blob = self._front_weights(base.device)
         # SURVEY 8d accounting of what this launch replaces: L0 + L1 of both paths (+ the two means)
         nbytes = 4 * n * h * w * ((5 + 3 * k + 16 + 16 * k) + (36 + 20 * k + 8 + 8 * k))
+        # what the fused launch itself must move: raw inputs + skip3 out, fm1 + obs1 out (per texel: 5+6k+3 | (32+16k)/4)
+        moved = 4 * n * h * w * (5 + 6 * k + 3 + 8 + 4 * k)
+        flops = 2 * n * (h // 2) * (w // 2) * ((32 + 64) * 16 + k * (12 + 64) * 16) + 2 * n * h * w * 24
         self._launch('F.front', nbytes, C.front_forward, base, cvis, lvis, nn_rgb, nn_base, n, k, h, w, blob,
-                     skip_connect_base, alpha, b['fm'][1], b['obs'][1], b['skip3'])
+                     skip_connect_base, alpha, b['fm'][1], b['obs'][1], b['skip3'], flops=flops, moved=moved)
         hh, ww = h // 2, w // 2
         for l in range(2, D + 1):
             (qa, qact_a), (qb, qact_b) = q.layers[l].convs()
@@ -321,7 +333,8 @@ class RenderPlan:
         # last block (40 -> 4 -> 4 at full resolution) + head (36 -> 3) in SURVEY 8d accounting
         nbytes = 4 * n * h * w * ((10 + 4) + (4 + 4) + (36 + 3))
         self._launch('F.back', nbytes, C.back_forward, x, b['fm'][1], b['skip3'], n, hh, ww, da.kernel.detach(),
-                     da.bias.detach(), db.kernel.detach(), db.bias.detach(), head.kernel.detach(), alpha, b['pred'])
+                     da.bias.detach(), db.kernel.detach(), db.bias.detach(), head.kernel.detach(), alpha, b['pred'],
+                     flops=2 * n * hh * ww * 40 * 16 + 2 * n * h * w * (64 + 12), moved=4 * n * h * w * (10 + 3 + 3))
         return b['pred'], b
 
     # ------------------------------------------------------------------ backward
