@@ -349,6 +349,21 @@ int nlt_back_forward(const float* x, const float* fm1, const float* skip3, int n
                      const float* w_s2, const float* b_s2, const float* w_s1, const float* b_s1,
                      const float* w_head, float alpha, float* pred, void* stream);
 
+/* ======================= LDS-tiled encoder convs (csrc/conv_tile.hip) =======================
+ * Same arithmetic as nlt_conv_forward for mode NLT_CONV_K2S2 / NLT_CONV_K2S1 with a single source (bias +
+ * optional LeakyReLU), laid out for the MFMA-bound levels: 8 x 16 output tile x tn output channels per
+ * workgroup, input slab + weight fragments staged through double-buffered LDS.
+ *   replaces: the Conv2D + LeakyReLU pairs of the contracting blocks (nlt/networks/convnet.py:50-59) and,
+ *             with kobs > 1 and mean_out, the observation mean of nlt/models/nlt.py:161-164.
+ * cin % 16 == 0, tn in {32, 64}, cout % tn == 0.  src holds frames*kobs frames [h,w,ld]; out (may be NULL)
+ * gets frames*kobs frames [oh,ow,ldo]; mean_out (may be NULL) gets, per frame, the mean over its kobs
+ * consecutive source frames at stride ldm. */
+long nlt_conv_tile_packed_floats(int mode, int cin, int cout, int tn);
+int nlt_pack_conv_tile_weights(int mode, const float* w_keras, int cin, int cout, int tn, float* packed, void* stream);
+int nlt_conv_tile_forward(int mode, const float* src, int ld, int cin, int frames, int kobs, int h, int w,
+                          const float* packed, const float* bias, int cout, int tn,
+                          float* out, int ldo, float* mean_out, int ldm, int act, float alpha, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -55,6 +55,10 @@ SIGNATURES = {
     'nlt_front_pack_weights': (_c_int, [_vp] * 15 + [_vp]),
     'nlt_front_forward': (_c_int, [_vp] * 5 + [_c_int] * 4 + [_vp, _c_int, _c_float, _vp, _vp, _vp, _vp]),
     'nlt_back_forward': (_c_int, [_vp] * 3 + [_c_int] * 3 + [_vp] * 5 + [_c_float, _vp, _vp]),
+    'nlt_conv_tile_packed_floats': (_c_long, [_c_int] * 4),
+    'nlt_pack_conv_tile_weights': (_c_int, [_c_int, _vp, _c_int, _c_int, _c_int, _vp, _vp]),
+    'nlt_conv_tile_forward': (_c_int, [_c_int, _vp, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _vp, _vp, _c_int, _c_int,
+                                       _vp, _c_int, _vp, _c_int, _c_int, _c_float, _vp]),
     'nlt_cosine_map': (_c_int, [_vp] * 4 + [_c_double] * 3 + [_c_long, _vp, _vp, _vp]),
     'nlt_albedo': (_c_int, [_vp, _c_int, _c_long, _vp, _vp, _vp]),
     'nlt_diffuse_base': (_c_int, [_vp, _vp, _c_int, _c_long, _vp, _vp]),
@@ -265,6 +269,28 @@ def adam_amsgrad_step(param, grad, m, v, vhat, lr_t, beta1, beta2, eps):
     _check(lib().nlt_adam_amsgrad_step(_ptr(param), _ptr(grad), _ptr(m), _ptr(v), _ptr(vhat), param.numel(),
                                        float(lr_t), float(beta1), float(beta2), float(eps), _stream()),
            'nlt_adam_amsgrad_step')
+
+
+# ---------------------------------------------------------------- LDS-tiled encoder convs
+def conv_tile_supported(mode, cin, cout, tn):
+    return lib().nlt_conv_tile_packed_floats(mode, cin, cout, tn) > 0
+
+
+def pack_conv_tile_weights(mode, w_keras, cin, cout, tn):
+    n = lib().nlt_conv_tile_packed_floats(mode, cin, cout, tn)
+    if n <= 0:
+        raise NLTError("conv_tile: unsupported (mode %d, cin %d, cout %d, tn %d)" % (mode, cin, cout, tn))
+    out = torch.empty(n, device=w_keras.device, dtype=torch.float32)
+    _check(lib().nlt_pack_conv_tile_weights(mode, _ptr(_dense(w_keras, 'w_keras')), cin, cout, tn, _ptr(out), _stream()),
+           'nlt_pack_conv_tile_weights')
+    return out
+
+
+def conv_tile_forward(mode, src, ld, cin, frames, kobs, h, w, packed, bias, cout, tn, out, ldo, mean_out, ldm,
+                      act=True, alpha=0.3):
+    _check(lib().nlt_conv_tile_forward(mode, _ptr(src), ld, cin, frames, kobs, h, w, _ptr(packed), _ptr(bias), cout, tn,
+                                       _ptr(out), ldo, _ptr(mean_out), ldm, 1 if act else 0, float(alpha), _stream()),
+           'nlt_conv_tile_forward')
 
 
 # ---------------------------------------------------------------- fused inference ends

@@ -1,0 +1,242 @@
+// LDS-tiled implicit-GEMM conv for the encoder's k2 convs (Conv2D k2s2 / k2s1, 'same') on the fp32 matrix
+// cores (v_mfma_f32_16x16x4_f32, exact fp32) -- the path for the MFMA-bound middle of the network.
+//
+// One 256-thread workgroup owns an 8 x 16 tile of OUTPUT texels x TN output channels.  The K loop runs
+// over 16-channel slabs of the input; per stage the workgroup copies, with 16-byte coalesced loads,
+//   B: the slab of the (haloed) input tile   -- k2s1: 9 x 17 texels, shared by all 4 taps;
+//                                               k2s2: one tap row, 8 x 32 texels, split by x parity
+//   A: the slab's weight fragments for the stage's taps (pre-packed in fragment order)
+// into a double-buffered LDS stage (registers -> LDS after the current stage's MFMAs, one barrier per stage)
+// and every wave then feeds its RT x 2 MFMA tiles from LDS with ds_read_b128.  Layouts are planar by
+// channel quad ([kk][texel][4]) so that the 16 lanes a ds_read_b128 services together hit 16 different
+// 16-byte slots (no bank conflicts); weights = MFMA A operand, texels = B operand, so a lane ends up with 4
+// consecutive output channels of one texel and stores them with one 16-byte NHWC store.
+//
+// Observation path: with kobs > 1 the workgroup runs the kobs observation frames of its tile back to back
+// and keeps their mean in registers -> the interleaved [query | mean] slice of fm[l] is written here and
+// the separate reduce_mean pass (nlt/models/nlt.py:161-164) disappears.
+#include "nlt_common.h"
+
+namespace {
+
+constexpr int TH = 8, TW = 16;
+constexpr int PL = 160;                      // k2s1 haloed tile: 9 x 17 = 153 texels, plane padded to 160 slots
+
+template <int MODE> struct TileTraits;
+template <> struct TileTraits<NLT_CONV_K2S1> { static constexpr int STAGE_TAPS = 4, B_UNITS = 153 * 4, B_FLOATS = 4 * PL * 4; };
+template <> struct TileTraits<NLT_CONV_K2S2> { static constexpr int STAGE_TAPS = 2, B_UNITS = 256 * 4, B_FLOATS = 4 * 2 * 128 * 4; };
+
+struct TileP {
+  const float* src; const float* packed; const float* bias;
+  float* out; float* mean_out;
+  int ld, cin, frames, kobs, h, w;           // input dims
+  int oh, ow, cout, ldo, ldm;
+  int tiles_y, tiles_x, ncc;                 // ncc = cin / 16
+  int act; float alpha;
+};
+
+__device__ __forceinline__ int xcd_tile(int b, int nblocks) {
+  return (nblocks & 7) ? b : (b & 7) * (nblocks >> 3) + (b >> 3);
+}
+
+// packed weights: [g = cout / TN][cc = cin / 16][tap 4][ct TNT][lane 64][s4 4]
+template <int MODE>
+__global__ void pack_tile_kernel(const float* __restrict__ wk, int cin, int cout, int tnt, long total, float* __restrict__ wp) {
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= total) return;
+  const int s4 = idx & 3, lane = (idx >> 2) & 63;
+  long r = idx >> 8;
+  const int ct = r % tnt; r /= tnt;
+  const int t = r & 3; r >>= 2;
+  const int ncc = cin >> 4;
+  const int cc = r % ncc;
+  const int g = r / ncc;
+  const int c = cc * 16 + 4 * (lane >> 4) + s4;
+  const int o = (g * tnt + ct) * 16 + (lane & 15);
+  wp[idx] = wk[((long)t * cin + c) * cout + o];                       // Keras (kh,kw,Cin,Cout), t = a*2+b
+}
+
+template <int MODE, int TNT>
+__global__ __launch_bounds__(256) void conv_tile_kernel(TileP p) {
+  using TT = TileTraits<MODE>;
+  constexpr int WN = TNT == 4 ? 2 : 1, WM = 4 / WN, RT = TH / WM, CT = 2;
+  constexpr int A_FLOATS = TT::STAGE_TAPS * TNT * 256;
+  constexpr int A_UNITS = A_FLOATS / 4, NA = A_UNITS / 256, NB = (TT::B_UNITS + 255) / 256;
+  constexpr int STAGE = A_FLOATS + TT::B_FLOATS;
+  __shared__ __attribute__((aligned(16))) float lds[2 * STAGE];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int kk = lane >> 4, j = lane & 15;
+  const int wn = wave % WN, wm = wave / WN;
+  int tile = xcd_tile(blockIdx.x, gridDim.x);
+  const int tx0 = (tile % p.tiles_x) * TW; tile /= p.tiles_x;
+  const int ty0 = (tile % p.tiles_y) * TH;
+  const int f = tile / p.tiles_y;
+  const int g = blockIdx.y;
+  const int stages_per_frame = (MODE == NLT_CONV_K2S1 ? 1 : 2) * p.ncc;
+  const int total_stages = stages_per_frame * p.kobs;
+  const long in_frame = (long)p.h * p.w;
+
+  // B-slab addressing of this thread's copy units (fixed across stages except for the channel slab / tap row)
+  int b_lds[NB]; long b_tex[NB]; bool b_ok[NB];
+#pragma unroll
+  for (int i = 0; i < NB; ++i) {
+    const int u = tid + 256 * i;
+    const int q = u & 3, tx = u >> 2;
+    if (MODE == NLT_CONV_K2S1) {
+      const int hy = tx / 17, hx = tx % 17;
+      const int gy = ty0 + hy, gx = tx0 + hx;
+      b_ok[i] = u < TT::B_UNITS && gy < p.h && gx < p.w;             // beyond the image: TF's bottom/right zero padding
+      b_tex[i] = (long)gy * p.w + gx;
+      b_lds[i] = (q * PL + tx) * 4;
+    } else {
+      const int y = tx >> 5, xx = tx & 31;
+      const int gy = 2 * (ty0 + y), gx = 2 * tx0 + xx;               // + a (tap row) per stage
+      b_ok[i] = (ty0 + y) < p.oh && gx < p.w;                      // h, w even: both tap rows / parities exist
+      b_tex[i] = (long)gy * p.w + gx;
+      b_lds[i] = ((q * 2 + (xx & 1)) * 128 + y * 16 + (xx >> 1)) * 4;
+    }
+  }
+
+  f32x4 ra[NA], rb[NB];
+  auto load_stage = [&](int q) {
+    const int i = q / stages_per_frame, s = q - i * stages_per_frame;
+    const int cc = MODE == NLT_CONV_K2S1 ? s : (s >> 1);
+    const int a = MODE == NLT_CONV_K2S1 ? 0 : (s & 1);
+    const float* ap = p.packed + ((((long)g * p.ncc + cc) * 4 + 2 * a) * TNT) * 256;
+#pragma unroll
+    for (int n = 0; n < NA; ++n) ra[n] = *reinterpret_cast<const f32x4*>(ap + (tid + 256 * n) * 4);
+    const float* sp = p.src + ((long)(f * p.kobs + i) * in_frame + (long)a * p.w) * p.ld + cc * 16;
+#pragma unroll
+    for (int n = 0; n < NB; ++n) {
+      const int u = tid + 256 * n;
+      const f32x4 v = *reinterpret_cast<const f32x4*>(sp + (b_ok[n] ? b_tex[n] : 0) * p.ld + 4 * (u & 3));
+      rb[n] = b_ok[n] ? v : (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+  };
+  auto store_stage = [&](int buf) {
+    float* base = lds + buf * STAGE;
+#pragma unroll
+    for (int n = 0; n < NA; ++n) *reinterpret_cast<f32x4*>(base + (tid + 256 * n) * 4) = ra[n];
+#pragma unroll
+    for (int n = 0; n < NB; ++n)
+      if (tid + 256 * n < TT::B_UNITS) *reinterpret_cast<f32x4*>(base + A_FLOATS + b_lds[n]) = rb[n];
+  };
+
+  f32x4 acc[RT][CT], mean[RT][CT];
+#pragma unroll
+  for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct) { acc[rt][ct] = (f32x4){0.f, 0.f, 0.f, 0.f}; mean[rt][ct] = acc[rt][ct]; }
+
+  load_stage(0);
+  store_stage(0);
+  __syncthreads();
+  for (int q = 0; q < total_stages; ++q) {
+    if (q + 1 < total_stages) load_stage(q + 1);
+    const float* A = lds + (q & 1) * STAGE;
+    const float* B = A + A_FLOATS;
+    const int s = q % stages_per_frame;
+#pragma unroll
+    for (int tl = 0; tl < TT::STAGE_TAPS; ++tl) {
+      f32x4 bf[RT], af[CT];
+#pragma unroll
+      for (int rt = 0; rt < RT; ++rt) {
+        const int y = wm * RT + rt;
+        const int off = MODE == NLT_CONV_K2S1 ? (kk * PL + (y + (tl >> 1)) * 17 + j + (tl & 1)) * 4
+                                              : ((kk * 2 + tl) * 128 + y * 16 + j) * 4;
+        bf[rt] = *reinterpret_cast<const f32x4*>(B + off);
+      }
+#pragma unroll
+      for (int ct = 0; ct < CT; ++ct)
+        af[ct] = *reinterpret_cast<const f32x4*>(A + ((tl * TNT + wn * CT + ct) * 64 + lane) * 4);
+#pragma unroll
+      for (int s4 = 0; s4 < 4; ++s4)
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+          for (int ct = 0; ct < CT; ++ct)
+            acc[rt][ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[ct][s4], bf[rt][s4], acc[rt][ct], 0, 0, 0);
+    }
+    if (s == stages_per_frame - 1) {                                  // this observation frame is complete
+      const int i = q / stages_per_frame;
+#pragma unroll
+      for (int ct = 0; ct < CT; ++ct) {
+        const int oc = (g * TNT + wn * CT + ct) * 16 + 4 * kk;
+        const f32x4 bv = *reinterpret_cast<const f32x4*>(p.bias + oc);
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) {
+          const int gy = ty0 + wm * RT + rt, gx = tx0 + j;
+          f32x4 v = acc[rt][ct] + bv;
+          if (p.act) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : p.alpha * v[e];
+          }
+          acc[rt][ct] = (f32x4){0.f, 0.f, 0.f, 0.f};
+          mean[rt][ct] += v;
+          if (gy < p.oh && gx < p.ow) {
+            const long ot = ((long)(f * p.kobs + i) * p.oh + gy) * p.ow + gx;
+            if (p.out) *reinterpret_cast<f32x4*>(p.out + ot * p.ldo + oc) = v;
+            if (p.mean_out && i == p.kobs - 1) {
+              const long mt = ((long)f * p.oh + gy) * p.ow + gx;
+              *reinterpret_cast<f32x4*>(p.mean_out + mt * p.ldm + oc) = mean[rt][ct] * (1.f / (float)p.kobs);
+            }
+          }
+        }
+      }
+    }
+    if (q + 1 < total_stages) store_stage((q + 1) & 1);
+    __syncthreads();
+  }
+}
+
+template <int MODE, int TNT>
+int launch(const TileP& p, hipStream_t s) {
+  const long tiles = (long)p.frames * p.tiles_y * p.tiles_x;
+  hipLaunchKernelGGL((conv_tile_kernel<MODE, TNT>), dim3((unsigned)tiles, (unsigned)(p.cout / (16 * TNT))), dim3(256), 0, s, p);
+  NLT_CHECK_LAUNCH();
+  return NLT_OK;
+}
+
+}  // namespace
+
+extern "C" long nlt_conv_tile_packed_floats(int mode, int cin, int cout, int tn) {
+  if ((mode != NLT_CONV_K2S1 && mode != NLT_CONV_K2S2) || cin <= 0 || cout <= 0) return -1;
+  if ((cin & 15) || (tn != 32 && tn != 64) || cout % tn) return -1;
+  return (long)4 * cin * cout;
+}
+
+extern "C" int nlt_pack_conv_tile_weights(int mode, const float* w_keras, int cin, int cout, int tn, float* packed,
+                                          void* stream) {
+  const long total = nlt_conv_tile_packed_floats(mode, cin, cout, tn);
+  if (total <= 0) return NLT_ERR_UNSUPPORTED;
+  if (!w_keras || !packed || !nlt_aligned16(packed)) return NLT_ERR_BAD_ARG;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const unsigned blocks = (unsigned)((total + 255) / 256);
+  if (mode == NLT_CONV_K2S1) hipLaunchKernelGGL(pack_tile_kernel<NLT_CONV_K2S1>, dim3(blocks), dim3(256), 0, s, w_keras, cin, cout, tn / 16, total, packed);
+  else hipLaunchKernelGGL(pack_tile_kernel<NLT_CONV_K2S2>, dim3(blocks), dim3(256), 0, s, w_keras, cin, cout, tn / 16, total, packed);
+  NLT_CHECK_LAUNCH();
+  return NLT_OK;
+}
+
+extern "C" int nlt_conv_tile_forward(int mode, const float* src, int ld, int cin, int frames, int kobs, int h, int w,
+                                     const float* packed, const float* bias, int cout, int tn,
+                                     float* out, int ldo, float* mean_out, int ldm, int act, float alpha, void* stream) {
+  if (!src || !packed || !bias || (!out && !mean_out)) return NLT_ERR_BAD_ARG;
+  if (frames <= 0 || kobs <= 0 || h <= 0 || w <= 0 || cin <= 0 || cout <= 0) return NLT_ERR_BAD_ARG;
+  if (nlt_conv_tile_packed_floats(mode, cin, cout, tn) <= 0) return NLT_ERR_UNSUPPORTED;
+  if (mode == NLT_CONV_K2S2 && ((h | w) & 1)) return NLT_ERR_UNSUPPORTED;
+  if (ld < cin || (ld & 3) || (out && (ldo < cout || (ldo & 3))) || (mean_out && (ldm < cout || (ldm & 3)))) return NLT_ERR_BAD_ARG;
+  if (!nlt_aligned16(src) || !nlt_aligned16(packed) || !nlt_aligned16(bias) || (out && !nlt_aligned16(out)) ||
+      (mean_out && !nlt_aligned16(mean_out))) return NLT_ERR_BAD_ARG;
+  if ((long long)frames * kobs * h * w * (long long)(ld > ldo ? ld : ldo) >= (1ll << 31)) return NLT_ERR_UNSUPPORTED;
+  TileP p;
+  p.src = src; p.packed = packed; p.bias = bias; p.out = out; p.mean_out = mean_out;
+  p.ld = ld; p.cin = cin; p.frames = frames; p.kobs = kobs; p.h = h; p.w = w;
+  p.oh = mode == NLT_CONV_K2S2 ? h / 2 : h; p.ow = mode == NLT_CONV_K2S2 ? w / 2 : w;
+  p.cout = cout; p.ldo = ldo; p.ldm = ldm; p.ncc = cin / 16; p.act = act; p.alpha = alpha;
+  p.tiles_y = (p.oh + TH - 1) / TH; p.tiles_x = (p.ow + TW - 1) / TW;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  if (mode == NLT_CONV_K2S1) return tn == 64 ? launch<NLT_CONV_K2S1, 4>(p, s) : launch<NLT_CONV_K2S1, 2>(p, s);
+  return tn == 64 ? launch<NLT_CONV_K2S2, 4>(p, s) : launch<NLT_CONV_K2S2, 2>(p, s);
+}

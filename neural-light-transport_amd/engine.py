@@ -58,6 +58,9 @@ class RenderPlan:
         self._front_blob = None
         self._trial_direct = False
         self._ran_direct = set()
+        self._trial_lds = 0             # autotune: try the LDS-tiled kernel with this many output channels per workgroup
+        self._ran_lds = set()
+        self.lds_hints = {}             # label -> tn (32 / 64): launches that go to csrc/conv_tile.hip
         is_c = net_query.is_contracting
         self.n_down = sum(is_c) - 1                      # contracting Sequential blocks
         self.n_up = len(is_c) - sum(is_c) - 1            # expanding Sequential blocks
@@ -129,6 +132,36 @@ class RenderPlan:
                        act=act is not None, alpha=act.alpha if act is not None else 0.0,
                        algo=algo if ok else C.ALGO_DIRECT, tile_hint=tile_hint if ok else 0, flops=flops)
 
+    def _conv_enc(self, label, layer, act, src, cin, ld, frames, kobs, h, w, out, ldo, algo, mean_out=None, ldm=0,
+                  obs_weights=None):
+        """One encoder conv (single source) over frames*kobs frames; with mean_out also the mean over the kobs
+        observations (label + '.mean' when it needs its own launch).  Goes to the LDS-tiled kernel when the plan
+        chose it for this launch, else to the register-tiled MFMA / direct kernels."""
+        layer.build(cin, src.device)
+        tn = self.lds_hints.get(label, 0)
+        if self._trial_lds:
+            tn = self._trial_lds
+        ok = (tn and obs_weights is None and algo == C.ALGO_AUTO and layer.mode in (C.CONV_K2S2, C.CONV_K2S1)
+              and layer.cin == cin and cin % 16 == 0 and layer.n_ch_out % tn == 0)
+        if ok:
+            oh, ow = layer.out_hw(h, w)
+            nf = frames * kobs
+            nbytes = 4 * (nf * h * w * cin + nf * oh * ow * layer.n_ch_out)
+            if mean_out is not None:
+                nbytes += 4 * frames * oh * ow * layer.n_ch_out * (kobs + 1)       # what the separate mean launch would move
+            flops = 2 * nf * oh * ow * 4 * cin * layer.n_ch_out
+            self._ran_lds.add(label)
+            self._launch(label, nbytes, C.conv_tile_forward, layer.mode, src, ld, cin, frames, kobs, h, w,
+                         layer.packed_tile(tn), layer.bias.detach(), layer.n_ch_out, tn, out, ldo, mean_out, ldm,
+                         act=act is not None, alpha=act.alpha if act is not None else 0.0, flops=flops)
+            return
+        self._conv(label, layer, act, src, cin, ld, None, 0, 0, frames * kobs, h, w, out, ldo, algo)
+        if mean_out is not None:
+            oh, ow = layer.out_hw(h, w)
+            c = layer.n_ch_out
+            self._launch(label.replace('.s1', '.mean'), 4 * frames * oh * ow * c * (kobs + 1), C.obs_mean_forward,
+                         out, obs_weights, frames, kobs, oh * ow, c, mean_out, ldm)
+
     # ------------------------------------------------------------------ autotune
     def _autotune(self, run):
         """Plan-creation-time choice of the MFMA wave tile (RT x CT) per launch: streaming layers
@@ -140,26 +173,38 @@ class RenderPlan:
         trials = [('tile', 16 * r + c) for r in (1, 2, 4) for c in (1, 2, 4)]
         if not self.fuse_ends:
             trials.append(('direct', 0))    # only the 4/8-channel full-resolution layers ever preferred it
+        trials += [('lds', 32), ('lds', 64)]
+        saved_lds = dict(self.lds_hints)
         for kind, hint in trials:
             self.tile_hints = {'*': hint} if kind == 'tile' else {}
             self.algo_hints = {}
+            self.lds_hints = {}
             self._trial_direct = kind == 'direct'
-            self._ran_direct = set()
+            self._trial_lds = hint if kind == 'lds' else 0
+            self._ran_direct, self._ran_lds = set(), set()
             self.timer = None
             run()
             self.timer = OpTimer()
             run(); run()
-            for label, r in self.timer.collect().items():
-                if kind == 'tile' or label in self._ran_direct:
-                    results.setdefault(label, []).append((r[1] / r[0], kind, hint))
-        self._trial_direct = False
+            rec = self.timer.collect()
+            for label, r in rec.items():
+                t = r[1] / r[0]
+                if kind == 'tile' and label.endswith('.o.s1') and label.replace('.s1', '.mean') in rec:
+                    m = rec[label.replace('.s1', '.mean')]
+                    t += m[1] / m[0]        # the LDS kernel folds the mean in: compare like with like
+                if kind == 'tile' or label in self._ran_direct or label in self._ran_lds:
+                    results.setdefault(label, []).append((t, kind, hint))
+        self._trial_direct, self._trial_lds = False, 0
         self.timer, self.tile_hints, self.algo_hints = saved
+        self.lds_hints = saved_lds
         for label, res in results.items():
             if '.s1' not in label and '.s2' not in label and label != 'L0.q':
                 continue
             t, kind, hint = min(res)
             if kind == 'direct':
                 self.algo_hints.setdefault(label, C.ALGO_DIRECT)
+            elif kind == 'lds':
+                self.lds_hints.setdefault(label, hint)
             else:
                 self.tile_hints.setdefault(label, hint)
         self.tuned = results
@@ -167,7 +212,7 @@ class RenderPlan:
     def save_tuning(self, path):
         import json
         with open(path, 'w') as f:
-            json.dump({'tile_hints': self.tile_hints, 'algo_hints': self.algo_hints}, f)
+            json.dump({'tile_hints': self.tile_hints, 'algo_hints': self.algo_hints, 'lds_hints': self.lds_hints}, f)
 
     def load_tuning(self, path):
         """Re-uses tile choices measured by an earlier run (skips the plan-time trials)."""
@@ -175,6 +220,7 @@ class RenderPlan:
         with open(path) as f:
             d = json.load(f)
         self.tile_hints.update(d['tile_hints']); self.algo_hints.update(d['algo_hints'])
+        self.lds_hints.update(d.get('lds_hints', {}))
         self.autotune = False
 
     # ------------------------------------------------------------------ forward
@@ -247,20 +293,16 @@ class RenderPlan:
         for l in range(1, D + 1):
             (qa, qact_a), (qb, qact_b) = q.layers[l].convs()
             cin = mult * cl[l - 1]
-            self._conv('L%d.q.s2' % l, qa, qact_a, b['fm'][l - 1], cin, cin, None, 0, 0, n, hh, ww,
-                       b['qtmp'][l], cl[l], algo)
+            self._conv_enc('L%d.q.s2' % l, qa, qact_a, b['fm'][l - 1], cin, cin, n, 1, hh, ww, b['qtmp'][l], cl[l], algo)
             if run_obs:
                 (oa, oact_a), (ob, oact_b) = o.layers[l].convs()
-                self._conv('L%d.o.s2' % l, oa, oact_a, b['obs'][l - 1], cl[l - 1], cl[l - 1], None, 0, 0,
-                           n * k, hh, ww, b['otmp'][l], cl[l], algo)
+                self._conv_enc('L%d.o.s2' % l, oa, oact_a, b['obs'][l - 1], cl[l - 1], cl[l - 1], n, k, hh, ww,
+                               b['otmp'][l], cl[l], algo)
             hh, ww = hh // 2, ww // 2
-            self._conv('L%d.q.s1' % l, qb, qact_b, b['qtmp'][l], cl[l], cl[l], None, 0, 0, n, hh, ww,
-                       b['fm'][l], mult * cl[l], algo)
+            self._conv_enc('L%d.q.s1' % l, qb, qact_b, b['qtmp'][l], cl[l], cl[l], n, 1, hh, ww, b['fm'][l], mult * cl[l], algo)
             if run_obs:
-                self._conv('L%d.o.s1' % l, ob, oact_b, b['otmp'][l], cl[l], cl[l], None, 0, 0, n * k, hh, ww,
-                           b['obs'][l], cl[l], algo)
-                self._launch('L%d.o.mean' % l, 4 * n * hh * ww * cl[l] * (k + 1), C.obs_mean_forward,
-                             b['obs'][l], obs_weights, n, k, hh * ww, cl[l], b['fm'][l].view(-1)[cl[l]:], 2 * cl[l])
+                self._conv_enc('L%d.o.s1' % l, ob, oact_b, b['otmp'][l], cl[l], cl[l], n, k, hh, ww, b['obs'][l], cl[l],
+                               algo, mean_out=b['fm'][l].view(-1)[cl[l]:], ldm=2 * cl[l], obs_weights=obs_weights)
             elif self.use_obs:
                 b['fm'][l][..., cl[l]:].copy_(obs_override[l].expand(n, -1, -1, -1))
 
@@ -308,14 +350,12 @@ class RenderPlan:
             (qa, qact_a), (qb, qact_b) = q.layers[l].convs()
             (oa, oact_a), (ob, oact_b) = o.layers[l].convs()
             cin = 2 * cl[l - 1]
-            self._conv('L%d.q.s2' % l, qa, qact_a, b['fm'][l - 1], cin, cin, None, 0, 0, n, hh, ww, b['qtmp'][l], cl[l], algo)
-            self._conv('L%d.o.s2' % l, oa, oact_a, b['obs'][l - 1], cl[l - 1], cl[l - 1], None, 0, 0,
-                       n * k, hh, ww, b['otmp'][l], cl[l], algo)
+            self._conv_enc('L%d.q.s2' % l, qa, qact_a, b['fm'][l - 1], cin, cin, n, 1, hh, ww, b['qtmp'][l], cl[l], algo)
+            self._conv_enc('L%d.o.s2' % l, oa, oact_a, b['obs'][l - 1], cl[l - 1], cl[l - 1], n, k, hh, ww, b['otmp'][l], cl[l], algo)
             hh, ww = hh // 2, ww // 2
-            self._conv('L%d.q.s1' % l, qb, qact_b, b['qtmp'][l], cl[l], cl[l], None, 0, 0, n, hh, ww, b['fm'][l], 2 * cl[l], algo)
-            self._conv('L%d.o.s1' % l, ob, oact_b, b['otmp'][l], cl[l], cl[l], None, 0, 0, n * k, hh, ww, b['obs'][l], cl[l], algo)
-            self._launch('L%d.o.mean' % l, 4 * n * hh * ww * cl[l] * (k + 1), C.obs_mean_forward,
-                         b['obs'][l], None, n, k, hh * ww, cl[l], b['fm'][l].view(-1)[cl[l]:], 2 * cl[l])
+            self._conv_enc('L%d.q.s1' % l, qb, qact_b, b['qtmp'][l], cl[l], cl[l], n, 1, hh, ww, b['fm'][l], 2 * cl[l], algo)
+            self._conv_enc('L%d.o.s1' % l, ob, oact_b, b['otmp'][l], cl[l], cl[l], n, k, hh, ww, b['obs'][l], cl[l], algo,
+                           mean_out=b['fm'][l].view(-1)[cl[l]:], ldm=2 * cl[l])
         x, cx = b['fm'][D], 2 * cl[D]
         for j in range(U - 1):
             (da, dact_a), (db, dact_b) = q.layers[D + 1 + j].convs()

@@ -96,6 +96,16 @@ class Conv2D(Layer):
             self._packed[key] = ent
         return ent[1]
 
+    def packed_tile(self, tn):
+        """Fragment layout of the kernel for the LDS-tiled conv (csrc/conv_tile.hip), re-made on weight change."""
+        key = ('tile', tn)
+        ent = self._packed.get(key)
+        ver = (self.kernel.data_ptr(), self.kernel._version, self._epoch[0])
+        if ent is None or ent[0] != ver:
+            ent = (ver, C.pack_conv_tile_weights(self.mode, self.kernel.detach(), self.cin, self.n_ch_out, tn))
+            self._packed[key] = ent
+        return ent[1]
+
     ADJOINT = {C.CONV_K2S2: C.DECONV_K2S2, C.CONV_K2S1: C.DECONV_K2S1,
                C.DECONV_K2S2: C.CONV_K2S2, C.DECONV_K2S1: C.CONV_K2S1}
 

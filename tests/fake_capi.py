@@ -315,3 +315,33 @@ def install(monkeypatch):
     _install_buffers(monkeypatch)
     for name in _FUSED:
         monkeypatch.setattr(C, name, globals()[name])
+
+
+# ------------------------------------------------------------------ LDS-tiled encoder convs (TEST-ONLY emulation)
+def pack_conv_tile_weights(mode, w_keras, cin, cout, tn):
+    assert cin % 16 == 0 and cout % tn == 0 and tn in (32, 64)
+    return w_keras
+
+
+def conv_tile_forward(mode, src, ld, cin, frames, kobs, h, w, packed, bias, cout, tn, out, ldo, mean_out, ldm,
+                      act=True, alpha=0.3):
+    nf = frames * kobs
+    x = _view(src, nf, h, w, cin, ld)
+    y = T.conv2d_same(x, packed, bias[:cout], 2 if mode == C.CONV_K2S2 else 1)
+    if act:
+        y = T.leaky_relu(y, alpha)
+    oh, ow = y.shape[1:3]
+    if out is not None:
+        _view(out, nf, oh, ow, cout, ldo).copy_(y)
+    if mean_out is not None:
+        _view(mean_out, frames, oh, ow, cout, ldm).copy_(y.reshape(frames, kobs, oh, ow, cout).mean(1))
+
+
+_TILE = ('pack_conv_tile_weights', 'conv_tile_forward')
+_install_fused = install
+
+
+def install(monkeypatch):
+    _install_fused(monkeypatch)
+    for name in _TILE:
+        monkeypatch.setattr(C, name, globals()[name])

@@ -1,0 +1,76 @@
+"""-m gpu: the LDS-tiled encoder conv (csrc/conv_tile.hip) against the oracle's Conv2D 'same' + LeakyReLU, alone
+(channel-slice strides, partial tiles, observation mean) and with every eligible launch of Model.call routed to it."""
+import numpy as np
+import pytest
+import torch
+
+from nlt_amd import capi as C
+from oracle import nlt_oracle as O
+from oracle import tf_ops as T
+from gpu_util import rel_l2, make_pair, to_device_batch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize('mode,cin,cout,tn,h,w,frames,kobs', [
+    (C.CONV_K2S1, 16, 32, 32, 10, 20, 2, 2), (C.CONV_K2S1, 32, 64, 64, 8, 16, 1, 1), (C.CONV_K2S1, 64, 64, 32, 33, 47, 1, 3),
+    (C.CONV_K2S1, 256, 256, 64, 16, 16, 2, 2), (C.CONV_K2S1, 128, 128, 64, 64, 64, 1, 4),
+    (C.CONV_K2S2, 16, 32, 32, 20, 36, 2, 2), (C.CONV_K2S2, 32, 128, 64, 16, 32, 1, 1), (C.CONV_K2S2, 64, 64, 64, 66, 94, 1, 2),
+    (C.CONV_K2S2, 512, 256, 64, 32, 32, 1, 1), (C.CONV_K2S2, 32, 32, 32, 256, 256, 2, 1)])
+def test_conv_tile_vs_oracle(mode, cin, cout, tn, h, w, frames, kobs):
+    rng = np.random.default_rng(cin + cout + h + kobs)
+    ld = cin + 8
+    src = torch.from_numpy(rng.standard_normal((frames * kobs, h, w, ld)).astype(np.float32))
+    wk = torch.from_numpy((rng.standard_normal((2, 2, cin, cout)) * (1.0 / np.sqrt(4 * cin))).astype(np.float32))
+    bias = torch.from_numpy(rng.standard_normal(cout).astype(np.float32) * 0.1)
+    stride = 2 if mode == C.CONV_K2S2 else 1
+    with torch.no_grad():
+        ref = T.leaky_relu(T.conv2d_same(src[..., :cin].contiguous(), wk, bias, stride), 0.3)
+    oh, ow = ref.shape[1:3]
+    packed = C.pack_conv_tile_weights(mode, wk.cuda(), cin, cout, tn)
+    out = torch.full((frames * kobs, oh, ow, cout + 4), float('nan'), device='cuda')      # ldo = cout + 4
+    mean = torch.full((frames, oh, ow, 2 * cout), float('nan'), device='cuda')            # slice [cout, 2cout) of fm
+    C.conv_tile_forward(mode, src.cuda(), ld, cin, frames, kobs, h, w, packed, bias.cuda(), cout, tn, out, cout + 4,
+                        mean.view(-1)[cout:], 2 * cout, act=True, alpha=0.3)
+    torch.cuda.synchronize()
+    got = out[..., :cout].cpu()
+    assert not torch.isnan(got).any() and torch.isnan(out[..., cout:]).all()            # nothing written outside the slice
+    assert rel_l2(got, ref) <= 1e-5
+    m = mean[..., cout:].cpu()
+    assert torch.isnan(mean[..., :cout]).all() and not torch.isnan(m).any()
+    assert rel_l2(m, ref.reshape(frames, kobs, oh, ow, cout).mean(1)) <= 1e-5
+    # mean only (no per-frame output) and no activation
+    mean2 = torch.empty((frames, oh, ow, cout), device='cuda')
+    C.conv_tile_forward(mode, src.cuda(), ld, cin, frames, kobs, h, w, packed, bias.cuda(), cout, tn, None, 0, mean2, cout,
+                        act=False)
+    with torch.no_grad():
+        ref2 = T.conv2d_same(src[..., :cin].contiguous(), wk, bias, stride).reshape(frames, kobs, oh, ow, cout).mean(1)
+    assert rel_l2(mean2.cpu(), ref2) <= 1e-5
+
+
+def test_conv_tile_rejects_what_it_cannot_do():
+    x = torch.zeros(1, 8, 8, 24, device='cuda')
+    assert not C.conv_tile_supported(C.CONV_K2S1, 24, 32, 32) and not C.conv_tile_supported(C.CONV_K2S1, 32, 48, 32)
+    assert not C.conv_tile_supported(C.CONV1X1, 32, 32, 32) and not C.conv_tile_supported(C.CONV_K2S2, 32, 32, 16)
+    with pytest.raises(C.NLTError):
+        C.pack_conv_tile_weights(C.CONV_K2S1, torch.zeros(2, 2, 24, 32, device='cuda'), 24, 32, 32)
+    packed = C.pack_conv_tile_weights(C.CONV_K2S2, torch.zeros(2, 2, 16, 32, device='cuda'), 16, 32, 32)
+    with pytest.raises(C.NLTError):                      # odd input size for the stride-2 conv
+        C.conv_tile_forward(C.CONV_K2S2, torch.zeros(1, 7, 8, 16, device='cuda'), 16, 16, 1, 1, 7, 8, packed,
+                            torch.zeros(32, device='cuda'), 32, 32, torch.zeros(1, 3, 4, 32, device='cuda'), 32, None, 0)
+
+
+@pytest.mark.parametrize('depth,uv,k,tn,mode', [(256, 64, 2, 32, 'test'), (256, 128, 3, 64, 'test'), (1024, 256, 1, 64, 'test'),
+                                                 (256, 64, 2, 32, 'train')])
+def test_model_with_lds_tiled_encoder_vs_oracle(depth, uv, k, tn, mode):
+    om, pm = make_pair(depth=depth, uv=uv, im=uv // 2, seed=depth + k + tn)
+    batch, nn = O.synth_batch(1, uv, uv, uv // 2, uv // 2, uv // 2, uv // 2, k=k, seed=30 + k)
+    with torch.no_grad():
+        o_vis = om.call(batch, mode, nn_list=nn)[3]
+    pm.plan.autotune = False
+    nlev = sum(pm.net['query'].is_contracting) - 1
+    pm.plan.lds_hints = {'L%d.%s.%s' % (l, p, s): tn for l in range(1, nlev + 1) for p in 'qo' for s in ('s1', 's2')}
+    p_vis = pm.call(to_device_batch(batch, nn), mode)[3]
+    torch.cuda.synchronize()
+    assert 'L2.o.s1' in pm.plan._ran_lds and 'L%d.q.s2' % nlev in pm.plan._ran_lds
+    assert rel_l2(p_vis['pred'].cpu(), o_vis['pred']) <= 1e-4

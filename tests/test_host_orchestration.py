@@ -127,3 +127,31 @@ def test_fused_ends_match_unfused_and_are_skipped_when_they_must_be(monkeypatch)
     assert not pm.plan.can_fuse(bufs, None, [None])                  # obs_override (nlt_test.py) -> layer-by-layer
     pm.plan.fuse_ends = False
     assert not pm.plan.can_fuse(bufs, None, None)
+
+
+@pytest.mark.parametrize('fused', [False, True])
+def test_lds_tiled_encoder_launches_fold_the_observation_mean(monkeypatch, fused):
+    """Plan with every eligible encoder conv routed to csrc/conv_tile.hip: same result, no '.o.mean' launch
+    where the tiled kernel produced the mean itself."""
+    fake_capi.install(monkeypatch)
+    from nlt_amd.engine import OpTimer
+
+    class Rec(OpTimer):
+        def launch(self, label, nbytes, fn, *a, **kw):
+            self.records[label] = [1, 0.0, nbytes]
+            fn(*a, **kw)
+    om, pm = make(256, 64, 32)
+    pm.plan.fuse_ends = fused
+    batch, nn = O.synth_batch(2, 64, 64, 32, 32, 32, 32, k=3, seed=9)
+    with torch.no_grad():
+        ref = om.call(batch, 'test', nn_list=nn)[3]['pred']
+    labels = ['L%d.%s.%s' % (l, p, s) for l in range(1, 7) for p in 'qo' for s in ('s1', 's2')]
+    pm.plan.lds_hints = {lab: 32 for lab in labels}
+    pm.plan.timer = Rec()
+    got = pm.call(cpu_batch(batch, nn), 'test')[3]['pred']
+    assert rel_l2(got, ref) < 1e-5
+    rec = pm.plan.timer.records
+    means = sorted(l for l in rec if l.endswith('.o.mean'))
+    assert means == ([] if fused else ['L1.o.mean'])            # level 1 has 16 output channels: not eligible
+    assert pm.plan._ran_lds >= {'L2.q.s2', 'L2.o.s2', 'L2.q.s1', 'L2.o.s1', 'L6.o.s1'}
+    assert 'L1.q.s2' not in pm.plan._ran_lds
