@@ -349,6 +349,18 @@ int nlt_back_forward(const float* x, const float* fm1, const float* skip3, int n
                      const float* w_s2, const float* b_s2, const float* w_s1, const float* b_s1,
                      const float* w_head, float alpha, float* pred, void* stream);
 
+/* nlt_conv_forward on the MFMA path with the K loop split into `ksplit` slices run by different waves (for
+ * the deep levels: a few hundred texels x thousands of input channels would otherwise occupy a fraction of the
+ * chip).  Slices write raw partial sums to `workspace` (nlt_conv_splitk_workspace_floats() floats); a second
+ * launch adds them in slice order -- deterministic -- and applies the usual epilogue.  ksplit = 1 is
+ * nlt_conv_forward(algo = MFMA). */
+long nlt_conv_splitk_workspace_floats(int mode, int n, int h, int w, int cout, int ksplit);
+int nlt_conv_forward_splitk(int mode, int tile_hint, int ksplit, float* workspace,
+                            const float* src0, int ld0, int c0, const float* src1, int ld1, int c1,
+                            int n, int h, int w, const float* w_packed, const float* bias,
+                            int cout, float* out, int ldo, int act, float alpha,
+                            const float* mask_src, int ldm, int accumulate, void* stream);
+
 /* ======================= LDS-tiled encoder convs (csrc/conv_tile.hip) =======================
  * Same arithmetic as nlt_conv_forward for mode NLT_CONV_K2S2 / NLT_CONV_K2S1 with a single source (bias +
  * optional LeakyReLU), laid out for the MFMA-bound levels: 8 x 16 output tile x tn output channels per

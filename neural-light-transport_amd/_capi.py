@@ -55,6 +55,10 @@ SIGNATURES = {
     'nlt_front_pack_weights': (_c_int, [_vp] * 15 + [_vp]),
     'nlt_front_forward': (_c_int, [_vp] * 5 + [_c_int] * 4 + [_vp, _c_int, _c_float, _vp, _vp, _vp, _vp]),
     'nlt_back_forward': (_c_int, [_vp] * 3 + [_c_int] * 3 + [_vp] * 5 + [_c_float, _vp, _vp]),
+    'nlt_conv_splitk_workspace_floats': (_c_long, [_c_int] * 6),
+    'nlt_conv_forward_splitk': (_c_int, [_c_int, _c_int, _c_int, _vp, _vp, _c_int, _c_int, _vp, _c_int, _c_int,
+                                         _c_int, _c_int, _c_int, _vp, _vp, _c_int, _vp, _c_int, _c_int, _c_float,
+                                         _vp, _c_int, _c_int, _vp]),
     'nlt_conv_tile_packed_floats': (_c_long, [_c_int] * 4),
     'nlt_pack_conv_tile_weights': (_c_int, [_c_int, _vp, _c_int, _c_int, _c_int, _vp, _vp]),
     'nlt_conv_tile_forward': (_c_int, [_c_int, _vp, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _vp, _vp, _c_int, _c_int,
@@ -269,6 +273,26 @@ def adam_amsgrad_step(param, grad, m, v, vhat, lr_t, beta1, beta2, eps):
     _check(lib().nlt_adam_amsgrad_step(_ptr(param), _ptr(grad), _ptr(m), _ptr(v), _ptr(vhat), param.numel(),
                                        float(lr_t), float(beta1), float(beta2), float(eps), _stream()),
            'nlt_adam_amsgrad_step')
+
+
+_splitk_ws = {}
+
+
+def conv_forward_splitk(mode, ksplit, src0, c0, ld0, src1, c1, ld1, n, h, w, w_packed, bias, cout, out, ldo,
+                        act=True, alpha=0.3, tile_hint=0, mask_src=None, ldm=0, accumulate=False):
+    """nlt_conv_forward (MFMA path) with the K loop split over `ksplit` wave slices; the partial-sum
+    workspace is cached per device and grown on demand."""
+    need = lib().nlt_conv_splitk_workspace_floats(mode, n, h, w, cout, ksplit)
+    if need <= 0:
+        raise NLTError("nlt_conv_splitk_workspace_floats failed")
+    key = str(src0.device)
+    ws = _splitk_ws.get(key)
+    if ws is None or ws.numel() < need:
+        ws = torch.empty(need, device=src0.device, dtype=torch.float32)
+        _splitk_ws[key] = ws
+    _check(lib().nlt_conv_forward_splitk(mode, tile_hint, ksplit, _ptr(ws), _ptr(src0), ld0, c0, _ptr(src1), ld1, c1, n, h, w,
+                                         _ptr(w_packed), _ptr(bias), cout, _ptr(out), ldo, 1 if act else 0, float(alpha),
+                                         _ptr(mask_src), ldm, 1 if accumulate else 0, _stream()), 'nlt_conv_forward_splitk')
 
 
 # ---------------------------------------------------------------- LDS-tiled encoder convs

@@ -41,3 +41,24 @@ extern "C" int nlt_conv_forward(int mode, int algo, int tile_hint,
   if (algo == NLT_ALGO_MFMA) return nlt_conv_mfma_launch(mode, p, tile_hint, s);
   return nlt_conv_direct_launch(mode, p, s);
 }
+
+extern "C" long nlt_conv_splitk_workspace_floats(int mode, int n, int h, int w, int cout, int ksplit) {
+  if (n <= 0 || h <= 0 || w <= 0 || cout <= 0 || ksplit < 1) return -1;
+  long rows = (long)n * h * w;
+  if (mode == NLT_CONV_K2S2) rows /= 4;
+  const long ncols = mode == NLT_DECONV_K2S2 ? 4l * cout : cout;
+  return ksplit * rows * ((ncols + 15) / 16 * 16);
+}
+
+extern "C" int nlt_conv_forward_splitk(int mode, int tile_hint, int ksplit, float* workspace,
+                                       const float* src0, int ld0, int c0, const float* src1, int ld1, int c1,
+                                       int n, int h, int w, const float* w_packed, const float* bias,
+                                       int cout, float* out, int ldo, int act, float alpha,
+                                       const float* mask_src, int ldm, int accumulate, void* stream) {
+  if (ksplit < 1 || (ksplit > 1 && (!workspace || !nlt_aligned16(workspace)))) return NLT_ERR_BAD_ARG;
+  ConvP p;
+  const int st = nlt_fill_conv_params(p, mode, src0, ld0, c0, src1, ld1, c1, n, h, w, w_packed, bias, cout, out, ldo,
+                                      act, alpha, mask_src, ldm, accumulate);
+  if (st != NLT_OK) return st;
+  return nlt_conv_mfma_launch(mode, p, tile_hint, static_cast<hipStream_t>(stream), ksplit, workspace);
+}

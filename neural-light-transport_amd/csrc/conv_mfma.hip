@@ -45,13 +45,15 @@ __global__ void pack_weights_kernel(const float* __restrict__ wk, int c0, int c1
 }
 
 template <int MODE, int RT, int CT>
-__global__ __launch_bounds__(256) void conv_mfma_kernel(ConvP p, int mtiles, int ngroups, int ntiles) {
+__global__ __launch_bounds__(256) void conv_mfma_kernel(ConvP p, int mtiles, int ngroups, int ntiles, int ksplit,
+                                                        float* __restrict__ ws) {
   constexpr int TAPS = ConvTraits<MODE>::TAPS;
   const int lane = threadIdx.x & 63;
-  const int wave = blockIdx.x * 4 + (threadIdx.x >> 6);
-  const int ng = wave % ngroups;
-  const int mt = wave / ngroups;
-  if (mt >= mtiles) return;
+  int wave = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int ng = wave % ngroups; wave /= ngroups;
+  const int mt = wave % mtiles;
+  const int ks = wave / mtiles;                 // K slice (split-K: few GEMM rows, long K -> more waves)
+  if (ks >= ksplit) return;
   const int px = lane & 15, kk = lane >> 4;
 
   int rf[RT], ry[RT], rx[RT], rm[RT];
@@ -77,15 +79,18 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvP p, int mtiles, int
   const size_t wstride = (size_t)ntiles * 64;   // f32x4 per K-chunk
   const int ch0 = chunks16(p.c0), ch1 = chunks16(p.c1);
   const int cps = ch0 + ch1;                    // K-chunks per tap: source 0 then source 1
+  const int total = TAPS * cps;
+  const int per = (total + ksplit - 1) / ksplit;
+  const int kbeg = ks * per;
+  const int kend = kbeg + per < total ? kbeg + per : total;
 
   // Fragment loads are UNCONDITIONAL (clamped addresses, value selected afterwards): a predicated
   // load becomes an exec-masked branch per load and serialises the wave's memory requests.
   // The next chunk's fragments are requested before the current chunk's MFMAs are issued.
-  int kc = 0;
-  for (int t = 0; t < TAPS; ++t) {
-    bool tv[RT];
-    const float* p0[RT];
-    const float* p1[RT];
+  bool tv[RT];
+  const float* p0[RT];
+  const float* p1[RT];
+  auto set_tap = [&](int t) {
 #pragma unroll
     for (int rt = 0; rt < RT; ++rt) {
       const int tex = rv[rt] ? conv_tap_texel<MODE>(p, rf[rt], ry[rt], rx[rt], t) : -1;
@@ -94,36 +99,54 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvP p, int mtiles, int
       p0[rt] = p.src0 + tx * p.ld0 + 4 * kk;
       p1[rt] = p.c1 ? p.src1 + tx * p.ld1 + 4 * kk : p0[rt];
     }
-    auto load_frags = [&](int r, int kci, f32x4 (&a)[CT], f32x4 (&b)[RT]) {
-      const bool s = r >= ch0;
-      const int k0 = (s ? r - ch0 : r) << 4;
-      const bool kin = (k0 + 4 * kk) < (s ? p.c1 : p.c0);
-      const int koff = kin ? k0 : -4 * kk;      // out-of-segment lanes re-read the row start
+  };
+  auto load_frags = [&](int r, int kci, f32x4 (&a)[CT], f32x4 (&b)[RT]) {
+    const bool s = r >= ch0;
+    const int k0 = (s ? r - ch0 : r) << 4;
+    const bool kin = (k0 + 4 * kk) < (s ? p.c1 : p.c0);
+    const int koff = kin ? k0 : -4 * kk;      // out-of-segment lanes re-read the row start
 #pragma unroll
-      for (int rt = 0; rt < RT; ++rt) {
-        const f32x4 v = *reinterpret_cast<const f32x4*>((s ? p1[rt] : p0[rt]) + koff);
-        const bool ok = kin && tv[rt];
-        b[rt] = (f32x4){ok ? v[0] : 0.f, ok ? v[1] : 0.f, ok ? v[2] : 0.f, ok ? v[3] : 0.f};
-      }
-#pragma unroll
-      for (int ct = 0; ct < CT; ++ct) a[ct] = wp[(size_t)kci * wstride + ct * 64];
-    };
-    f32x4 a_cur[CT], b_cur[RT], a_nxt[CT], b_nxt[RT];
-    load_frags(0, kc, a_cur, b_cur);
-    for (int r = 0; r < cps; ++r, ++kc) {
-      if (r + 1 < cps) load_frags(r + 1, kc + 1, a_nxt, b_nxt);
-#pragma unroll
-      for (int s4 = 0; s4 < 4; ++s4)
-#pragma unroll
-        for (int rt = 0; rt < RT; ++rt)
-#pragma unroll
-          for (int ct = 0; ct < CT; ++ct)
-            acc[rt][ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_cur[ct][s4], b_cur[rt][s4], acc[rt][ct], 0, 0, 0);
-#pragma unroll
-      for (int ct = 0; ct < CT; ++ct) a_cur[ct] = a_nxt[ct];
-#pragma unroll
-      for (int rt = 0; rt < RT; ++rt) b_cur[rt] = b_nxt[rt];
+    for (int rt = 0; rt < RT; ++rt) {
+      const f32x4 v = *reinterpret_cast<const f32x4*>((s ? p1[rt] : p0[rt]) + koff);
+      const bool ok = kin && tv[rt];
+      b[rt] = (f32x4){ok ? v[0] : 0.f, ok ? v[1] : 0.f, ok ? v[2] : 0.f, ok ? v[3] : 0.f};
     }
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct) a[ct] = wp[(size_t)kci * wstride + ct * 64];
+  };
+  f32x4 a_cur[CT], b_cur[RT], a_nxt[CT], b_nxt[RT];
+  int t_n = kbeg / cps, r_n = kbeg - t_n * cps;   // (tap, chunk-in-tap) of the NEXT load
+  if (kbeg < kend) {
+    set_tap(t_n);
+    load_frags(r_n, kbeg, a_cur, b_cur);
+  }
+  for (int kc = kbeg; kc < kend; ++kc) {
+    if (kc + 1 < kend) {
+      if (++r_n == cps) { r_n = 0; set_tap(++t_n); }
+      load_frags(r_n, kc + 1, a_nxt, b_nxt);
+    }
+#pragma unroll
+    for (int s4 = 0; s4 < 4; ++s4)
+#pragma unroll
+      for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct)
+          acc[rt][ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_cur[ct][s4], b_cur[rt][s4], acc[rt][ct], 0, 0, 0);
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct) a_cur[ct] = a_nxt[ct];
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt) b_cur[rt] = b_nxt[rt];
+  }
+
+  if (ksplit > 1) {                             // raw partial sums -> workspace [ks][M][ntiles*16]; nlt epilogue pass finishes
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct) {
+      const int ncol = (ng * CT + ct) * 16 + kk * 4;
+#pragma unroll
+      for (int rt = 0; rt < RT; ++rt)
+        if (rv[rt]) *reinterpret_cast<f32x4*>(ws + ((size_t)ks * p.M + rm[rt]) * (ntiles * 16) + ncol) = acc[rt][ct];
+    }
+    return;
   }
 
   // Epilogue: lane holds outputs [ncol, ncol+4) of texel px for every (rt, ct).
@@ -155,20 +178,62 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvP p, int mtiles, int
   }
 }
 
+// Second pass of a split-K launch: sums the K slices in slice order (deterministic), then bias / accumulate /
+// mask / LeakyReLU and the mode's output addressing, exactly as the single-pass epilogue.
+template <int MODE>
+__global__ __launch_bounds__(256) void splitk_epilogue_kernel(ConvP p, int ntiles, int ksplit, const float* __restrict__ ws) {
+  const int quads = p.N >> 2;
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (long)p.M * quads) return;
+  const int m = idx / quads;
+  const int ncol = (idx - (long)m * quads) * 4;
+  const int npad = ntiles * 16;
+  f32x4 v = *reinterpret_cast<const f32x4*>(ws + (size_t)m * npad + ncol);
+  for (int ks = 1; ks < ksplit; ++ks) v += *reinterpret_cast<const f32x4*>(ws + ((size_t)ks * p.M + m) * npad + ncol);
+  int oc = ncol, ab = 0;
+  if (MODE == NLT_DECONV_K2S2) { ab = ncol / p.cout; oc = ncol - ab * p.cout; }
+  int otex = m;
+  if (MODE == NLT_DECONV_K2S2) {
+    const int x = m % p.gw, y = (m / p.gw) % p.gh, f = m / (p.gw * p.gh);
+    otex = (f * p.oh + 2 * y + (ab >> 1)) * p.ow + 2 * x + (ab & 1);
+  }
+  v += *reinterpret_cast<const f32x4*>(p.bias + oc);
+  f32x4* o = reinterpret_cast<f32x4*>(p.out + (size_t)otex * p.ldo + oc);
+  if (p.accumulate) v += *o;
+  if (p.mask_src) {
+    const f32x4 mk = *reinterpret_cast<const f32x4*>(p.mask_src + (size_t)otex * p.ldm + oc);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) v[j] *= (mk[j] > 0.f) ? 1.f : p.alpha;
+  } else if (p.act) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) v[j] = v[j] > 0.f ? v[j] : p.alpha * v[j];
+  }
+  *o = v;
+}
+
+int taps_of(int mode) { return (mode == NLT_CONV1X1 || mode == NLT_DECONV_K2S2) ? 1 : 4; }
+
 template <int MODE, int RT, int CT>
-int launch_tile(const ConvP& p, hipStream_t s) {
+int launch_tile(const ConvP& p, int ksplit, float* ws, hipStream_t s) {
   const int ntiles = (p.N + 15) >> 4;
   const int ngroups = ntiles / CT;
   const int mtiles = (p.M + 16 * RT - 1) / (16 * RT);
-  const long waves = (long)mtiles * ngroups;
+  const int total = taps_of(MODE) * (chunks16(p.c0) + chunks16(p.c1));
+  if (ksplit > total) ksplit = total;
+  if (ksplit < 1 || !ws) ksplit = 1;
+  const long waves = (long)mtiles * ngroups * ksplit;
   const unsigned blocks = (unsigned)((waves + 3) / 4);
-  hipLaunchKernelGGL((conv_mfma_kernel<MODE, RT, CT>), dim3(blocks), dim3(256), 0, s, p, mtiles, ngroups, ntiles);
+  hipLaunchKernelGGL((conv_mfma_kernel<MODE, RT, CT>), dim3(blocks), dim3(256), 0, s, p, mtiles, ngroups, ntiles, ksplit, ws);
+  if (ksplit > 1) {
+    const long items = (long)p.M * (p.N >> 2);
+    hipLaunchKernelGGL(splitk_epilogue_kernel<MODE>, dim3((unsigned)((items + 255) / 256)), dim3(256), 0, s, p, ntiles, ksplit, ws);
+  }
   NLT_CHECK_LAUNCH();
   return NLT_OK;
 }
 
 template <int MODE>
-int launch_mode(const ConvP& p, int tile_hint, hipStream_t s) {
+int launch_mode(const ConvP& p, int tile_hint, int ksplit, float* ws, hipStream_t s) {
   const int ntiles = (p.N + 15) >> 4;
   int RT = 0, CT = 0;
   if (tile_hint > 0) { RT = tile_hint >> 4; CT = tile_hint & 15; }
@@ -184,14 +249,12 @@ int launch_mode(const ConvP& p, int tile_hint, hipStream_t s) {
     }
   }
   if (CT <= 0 || ntiles % CT) return NLT_ERR_UNSUPPORTED;
-#define NLT_TILE(R, C) if (RT == R && CT == C) return launch_tile<MODE, R, C>(p, s);
+#define NLT_TILE(R, C) if (RT == R && CT == C) return launch_tile<MODE, R, C>(p, ksplit, ws, s);
   NLT_TILE(4, 4) NLT_TILE(2, 4) NLT_TILE(4, 2) NLT_TILE(2, 2) NLT_TILE(1, 4)
   NLT_TILE(4, 1) NLT_TILE(1, 2) NLT_TILE(2, 1) NLT_TILE(1, 1)
 #undef NLT_TILE
   return NLT_ERR_UNSUPPORTED;
 }
-
-int taps_of(int mode) { return (mode == NLT_CONV1X1 || mode == NLT_DECONV_K2S2) ? 1 : 4; }
 
 }  // namespace
 
@@ -206,14 +269,14 @@ bool nlt_conv_mfma_supported(int mode, const ConvP& p) {
   return true;
 }
 
-int nlt_conv_mfma_launch(int mode, const ConvP& p, int tile_hint, hipStream_t s) {
+int nlt_conv_mfma_launch(int mode, const ConvP& p, int tile_hint, hipStream_t s, int ksplit, float* ws) {
   if (!nlt_conv_mfma_supported(mode, p)) return NLT_ERR_UNSUPPORTED;
   switch (mode) {
-    case NLT_CONV1X1: return launch_mode<NLT_CONV1X1>(p, tile_hint, s);
-    case NLT_CONV_K2S2: return launch_mode<NLT_CONV_K2S2>(p, tile_hint, s);
-    case NLT_CONV_K2S1: return launch_mode<NLT_CONV_K2S1>(p, tile_hint, s);
-    case NLT_DECONV_K2S2: return launch_mode<NLT_DECONV_K2S2>(p, tile_hint, s);
-    case NLT_DECONV_K2S1: return launch_mode<NLT_DECONV_K2S1>(p, tile_hint, s);
+    case NLT_CONV1X1: return launch_mode<NLT_CONV1X1>(p, tile_hint, ksplit, ws, s);
+    case NLT_CONV_K2S2: return launch_mode<NLT_CONV_K2S2>(p, tile_hint, ksplit, ws, s);
+    case NLT_CONV_K2S1: return launch_mode<NLT_CONV_K2S1>(p, tile_hint, ksplit, ws, s);
+    case NLT_DECONV_K2S2: return launch_mode<NLT_DECONV_K2S2>(p, tile_hint, ksplit, ws, s);
+    case NLT_DECONV_K2S1: return launch_mode<NLT_DECONV_K2S1>(p, tile_hint, ksplit, ws, s);
   }
   return NLT_ERR_BAD_ARG;
 }

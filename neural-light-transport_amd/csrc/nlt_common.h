@@ -83,5 +83,5 @@ static inline int nlt_fill_conv_params(ConvP& p, int mode, const float* src0, in
 
 // Entry points implemented per algorithm file.
 int nlt_conv_direct_launch(int mode, const ConvP& p, hipStream_t s);
-int nlt_conv_mfma_launch(int mode, const ConvP& p, int tile_hint, hipStream_t s);
+int nlt_conv_mfma_launch(int mode, const ConvP& p, int tile_hint, hipStream_t s, int ksplit = 1, float* ws = nullptr);
 bool nlt_conv_mfma_supported(int mode, const ConvP& p);

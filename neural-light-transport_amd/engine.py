@@ -60,7 +60,10 @@ class RenderPlan:
         self._ran_direct = set()
         self._trial_lds = 0             # autotune: try the LDS-tiled kernel with this many output channels per workgroup
         self._ran_lds = set()
-        self.lds_hints = {}             # label -> tn (32 / 64): launches that go to csrc/conv_tile.hip
+        self.lds_hints = {}             # label -> tn (32 / 64) [+256: observations unfolded]: launches that go to csrc/conv_tile.hip
+        self._trial_splitk = 0          # autotune: K slices to try on the small deep launches
+        self._ran_splitk = set()
+        self.splitk_hints = {}          # label -> K slices (split-K, csrc/conv_mfma.hip) for launches with few GEMM rows
         is_c = net_query.is_contracting
         self.n_down = sum(is_c) - 1                      # contracting Sequential blocks
         self.n_up = len(is_c) - sum(is_c) - 1            # expanding Sequential blocks
@@ -127,6 +130,18 @@ class RenderPlan:
         flops = 2 * rows * taps * (c0 + c1) * ncols
         if tile_hint and ((ncols + 15) // 16) % (tile_hint & 15):
             tile_hint = 0                # CT must divide the number of 16-column tiles
+        ks = self.splitk_hints.get(label, 1)
+        if self._trial_splitk and ok:
+            rt, ct = (tile_hint >> 4, tile_hint & 15) if tile_hint else (1, 1)
+            waves = -(-rows // (16 * rt)) * (-(-ncols // 16) // ct)
+            npad = -(-ncols // 16) * 16
+            ks = self._trial_splitk if (waves < 4096 and rows * npad * self._trial_splitk <= (1 << 24)) else 1
+        if ks > 1 and ok:
+            self._ran_splitk.add(label)
+            self._launch(label, nbytes, C.conv_forward_splitk, layer.mode, ks, src0, c0, ld0, src1, c1, ld1, n, h, w,
+                         layer.packed(c0, c1), layer.bias.detach(), layer.n_ch_out, out, ldo, act=act is not None,
+                         alpha=act.alpha if act is not None else 0.0, tile_hint=tile_hint, flops=flops)
+            return
         self._launch(label, nbytes, C.conv_forward, layer.mode, src0, c0, ld0, src1, c1, ld1, n, h, w, layer.kernel.detach(),
                        layer.packed(c0, c1) if ok else None, layer.bias.detach(), layer.n_ch_out, out, ldo,
                        act=act is not None, alpha=act.alpha if act is not None else 0.0,
@@ -138,22 +153,30 @@ class RenderPlan:
         observations (label + '.mean' when it needs its own launch).  Goes to the LDS-tiled kernel when the plan
         chose it for this launch, else to the register-tiled MFMA / direct kernels."""
         layer.build(cin, src.device)
-        tn = self.lds_hints.get(label, 0)
-        if self._trial_lds:
-            tn = self._trial_lds
+        hint = self._trial_lds or self.lds_hints.get(label, 0)
+        tn, unfold = hint & 255, bool(hint >> 8)       # +256: observations as separate frames, mean in its own launch
         ok = (tn and obs_weights is None and algo == C.ALGO_AUTO and layer.mode in (C.CONV_K2S2, C.CONV_K2S1)
               and layer.cin == cin and cin % 16 == 0 and layer.n_ch_out % tn == 0)
+        if ok and unfold and kobs == 1:
+            ok = self._trial_lds == 0                   # nothing to unfold here: leave this launch to the other trials
+            unfold = False
+        oh, ow = layer.out_hw(h, w)
         if ok:
-            oh, ow = layer.out_hw(h, w)
             nf = frames * kobs
             nbytes = 4 * (nf * h * w * cin + nf * oh * ow * layer.n_ch_out)
-            if mean_out is not None:
+            fold_mean = mean_out is not None and not unfold
+            if fold_mean:
                 nbytes += 4 * frames * oh * ow * layer.n_ch_out * (kobs + 1)       # what the separate mean launch would move
             flops = 2 * nf * oh * ow * 4 * cin * layer.n_ch_out
             self._ran_lds.add(label)
-            self._launch(label, nbytes, C.conv_tile_forward, layer.mode, src, ld, cin, frames, kobs, h, w,
-                         layer.packed_tile(tn), layer.bias.detach(), layer.n_ch_out, tn, out, ldo, mean_out, ldm,
-                         act=act is not None, alpha=act.alpha if act is not None else 0.0, flops=flops)
+            self._launch(label, nbytes, C.conv_tile_forward, layer.mode, src, ld, cin, nf if unfold else frames,
+                         1 if unfold else kobs, h, w, layer.packed_tile(tn), layer.bias.detach(), layer.n_ch_out, tn, out, ldo,
+                         mean_out if fold_mean else None, ldm, act=act is not None,
+                         alpha=act.alpha if act is not None else 0.0, flops=flops)
+            if mean_out is not None and unfold:
+                c = layer.n_ch_out
+                self._launch(label.replace('.s1', '.mean'), 4 * frames * oh * ow * c * (kobs + 1), C.obs_mean_forward,
+                             out, None, frames, kobs, oh * ow, c, mean_out, ldm)
             return
         self._conv(label, layer, act, src, cin, ld, None, 0, 0, frames * kobs, h, w, out, ldo, algo)
         if mean_out is not None:
@@ -173,15 +196,17 @@ class RenderPlan:
         trials = [('tile', 16 * r + c) for r in (1, 2, 4) for c in (1, 2, 4)]
         if not self.fuse_ends:
             trials.append(('direct', 0))    # only the 4/8-channel full-resolution layers ever preferred it
-        trials += [('lds', 32), ('lds', 64)]
-        saved_lds = dict(self.lds_hints)
+        trials += [('lds', 32), ('lds', 64), ('lds', 256 + 32), ('lds', 256 + 64)]
+        trials += [('splitk', (16 * r + c, ks)) for (r, c) in ((1, 1), (1, 2), (2, 2)) for ks in (4, 8, 16)]
+        saved_lds, saved_sk = dict(self.lds_hints), dict(self.splitk_hints)
         for kind, hint in trials:
-            self.tile_hints = {'*': hint} if kind == 'tile' else {}
+            self.tile_hints = {'*': hint} if kind == 'tile' else ({'*': hint[0]} if kind == 'splitk' else {})
             self.algo_hints = {}
-            self.lds_hints = {}
+            self.lds_hints, self.splitk_hints = {}, {}
             self._trial_direct = kind == 'direct'
             self._trial_lds = hint if kind == 'lds' else 0
-            self._ran_direct, self._ran_lds = set(), set()
+            self._trial_splitk = hint[1] if kind == 'splitk' else 0
+            self._ran_direct, self._ran_lds, self._ran_splitk = set(), set(), set()
             self.timer = None
             run()
             self.timer = OpTimer()
@@ -189,14 +214,14 @@ class RenderPlan:
             rec = self.timer.collect()
             for label, r in rec.items():
                 t = r[1] / r[0]
-                if kind == 'tile' and label.endswith('.o.s1') and label.replace('.s1', '.mean') in rec:
+                if label.endswith('.o.s1') and label.replace('.s1', '.mean') in rec:
                     m = rec[label.replace('.s1', '.mean')]
                     t += m[1] / m[0]        # the LDS kernel folds the mean in: compare like with like
-                if kind == 'tile' or label in self._ran_direct or label in self._ran_lds:
+                if kind == 'tile' or label in self._ran_direct or label in self._ran_lds or label in self._ran_splitk:
                     results.setdefault(label, []).append((t, kind, hint))
-        self._trial_direct, self._trial_lds = False, 0
+        self._trial_direct, self._trial_lds, self._trial_splitk = False, 0, 0
         self.timer, self.tile_hints, self.algo_hints = saved
-        self.lds_hints = saved_lds
+        self.lds_hints, self.splitk_hints = saved_lds, saved_sk
         for label, res in results.items():
             if '.s1' not in label and '.s2' not in label and label != 'L0.q':
                 continue
@@ -205,6 +230,9 @@ class RenderPlan:
                 self.algo_hints.setdefault(label, C.ALGO_DIRECT)
             elif kind == 'lds':
                 self.lds_hints.setdefault(label, hint)
+            elif kind == 'splitk':
+                if label not in self.tile_hints and label not in self.splitk_hints:
+                    self.tile_hints[label], self.splitk_hints[label] = hint
             else:
                 self.tile_hints.setdefault(label, hint)
         self.tuned = results
@@ -212,7 +240,8 @@ class RenderPlan:
     def save_tuning(self, path):
         import json
         with open(path, 'w') as f:
-            json.dump({'tile_hints': self.tile_hints, 'algo_hints': self.algo_hints, 'lds_hints': self.lds_hints}, f)
+            json.dump({'tile_hints': self.tile_hints, 'algo_hints': self.algo_hints, 'lds_hints': self.lds_hints,
+                       'splitk_hints': self.splitk_hints}, f)
 
     def load_tuning(self, path):
         """Re-uses tile choices measured by an earlier run (skips the plan-time trials)."""
@@ -221,6 +250,7 @@ class RenderPlan:
             d = json.load(f)
         self.tile_hints.update(d['tile_hints']); self.algo_hints.update(d['algo_hints'])
         self.lds_hints.update(d.get('lds_hints', {}))
+        self.splitk_hints.update(d.get('splitk_hints', {}))
         self.autotune = False
 
     # ------------------------------------------------------------------ forward

@@ -345,3 +345,8 @@ def install(monkeypatch):
     _install_fused(monkeypatch)
     for name in _TILE:
         monkeypatch.setattr(C, name, globals()[name])
+
+
+def conv_forward_splitk(mode, ksplit, src0, c0, ld0, src1, c1, ld1, n, h, w, w_packed, bias, cout, out, ldo,
+                        act=True, alpha=0.3, tile_hint=0, mask_src=None, ldm=0, accumulate=False):
+    raise AssertionError("split-K is a GPU-only plan choice; the CPU emulation never selects it")

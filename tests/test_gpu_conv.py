@@ -24,7 +24,7 @@ def oracle_conv(mode, x, wk, b, act, alpha):
     return y.numpy()
 
 
-def run_case(mode, n, h, w, c0, c1, cout, algo, tile_hint=0, act=True, alpha=0.3, pad0=0, pad1=0, pado=0, seed=0):
+def run_case(mode, n, h, w, c0, c1, cout, algo, tile_hint=0, act=True, alpha=0.3, pad0=0, pad1=0, pado=0, seed=0, ksplit=1):
     rng = np.random.default_rng(seed)
     k, s, tr = MODES[mode]
     cin = c0 + c1
@@ -39,8 +39,12 @@ def run_case(mode, n, h, w, c0, c1, cout, algo, tile_hint=0, act=True, alpha=0.3
     out = torch.full((n, oh, ow, cout + pado), -7.0, device='cuda')
     wd = d(wk)
     packed = C.pack_conv_weights(mode, wd, c0, c1, cout) if algo != C.ALGO_DIRECT else None
-    C.conv_forward(mode, d(x0), c0, c0 + pad0, d(x1), c1, c1 + pad1, n, h, w, wd, packed, d(b), cout, out,
-                   cout + pado, act=act, alpha=alpha, algo=algo, tile_hint=tile_hint)
+    if ksplit > 1:
+        C.conv_forward_splitk(mode, ksplit, d(x0), c0, c0 + pad0, d(x1), c1, c1 + pad1, n, h, w, packed, d(b), cout, out,
+                              cout + pado, act=act, alpha=alpha, tile_hint=tile_hint)
+    else:
+        C.conv_forward(mode, d(x0), c0, c0 + pad0, d(x1), c1, c1 + pad1, n, h, w, wd, packed, d(b), cout, out,
+                       cout + pado, act=act, alpha=alpha, algo=algo, tile_hint=tile_hint)
     torch.cuda.synchronize()
     got = out.cpu().numpy()
     scale = max(np.abs(ref).max(), 1.0)
@@ -96,6 +100,19 @@ def test_conv_deep_k2048(algo):
     # L6-like: K = 4*512, 256 outputs, tiny spatial extent (1x1 output grid per frame)
     run_case(C.CONV_K2S2, 3, 2, 2, 512, 0, 256, algo, seed=11)
     run_case(C.DECONV_K2S2, 2, 1, 1, 512, 512, 128, algo, seed=12)
+
+
+@pytest.mark.parametrize('mode', list(MODES))
+@pytest.mark.parametrize('ksplit,tile', [(2, 0x11), (3, 0x12), (8, 0x22), (64, 0x11)])
+def test_conv_split_k(mode, ksplit, tile):
+    # K slices that do not divide the chunk count, more slices than chunks (clamped), dual source, sliced output
+    run_case(mode, 2, 6, 10, 48, 16, 32, C.ALGO_MFMA, tile_hint=tile, pad0=8, pado=16, seed=ksplit, ksplit=ksplit)
+
+
+def test_conv_split_k_deep_levels():
+    run_case(C.CONV_K2S2, 4, 16, 16, 512, 0, 256, C.ALGO_MFMA, tile_hint=0x12, seed=21, ksplit=8)       # L6.q.s2 shape
+    run_case(C.DECONV_K2S2, 4, 8, 8, 512, 512, 128, C.ALGO_MFMA, tile_hint=0x12, seed=22, ksplit=8)     # L7.q.s2 shape
+    run_case(C.DECONV_K2S1, 4, 16, 16, 128, 0, 128, C.ALGO_MFMA, tile_hint=0x11, seed=23, ksplit=4)     # L7.q.s1 shape
 
 
 @pytest.mark.parametrize('algo', [C.ALGO_DIRECT, C.ALGO_MFMA])

@@ -72,5 +72,5 @@ def test_model_with_lds_tiled_encoder_vs_oracle(depth, uv, k, tn, mode):
     pm.plan.lds_hints = {'L%d.%s.%s' % (l, p, s): tn for l in range(1, nlev + 1) for p in 'qo' for s in ('s1', 's2')}
     p_vis = pm.call(to_device_batch(batch, nn), mode)[3]
     torch.cuda.synchronize()
-    assert 'L2.o.s1' in pm.plan._ran_lds and 'L%d.q.s2' % nlev in pm.plan._ran_lds
+    assert 'L3.o.s1' in pm.plan._ran_lds and 'L%d.q.s2' % nlev in pm.plan._ran_lds and ('L2.o.s1' in pm.plan._ran_lds) == (tn == 32)
     assert rel_l2(p_vis['pred'].cpu(), o_vis['pred']) <= 1e-4
