@@ -308,16 +308,17 @@ class RenderPlan:
         # L0 (both paths) + first observation mean
         q0, o0 = q.layers[0], o.layers[0]
         q0.build(5, dev); o0.build(3, dev)
-        if self.use_obs:
+        if run_obs:
             nbytes = 4 * n * h * w * (5 + 6 * k + 2 * cl[0] + k * cl[0])
             self._launch('L0.stem', nbytes, C.stem_forward, base, cvis, lvis, nn_rgb, nn_base, obs_weights,
                          n, k, h, w, cl[0], q0.kernel.detach(), q0.bias.detach(), o0.kernel.detach(),
                          o0.bias.detach(), b['fm'][0], b['obs'][0])
-            if obs_override is not None:
-                b['fm'][0][..., cl[0]:].copy_(obs_override[0].expand(n, -1, -1, -1))
         else:
+            # no observation path to run (use_obs = False, or its features are given): query L0 alone
             x5 = torch.cat((base, cvis, lvis), 3)
-            self._conv('L0.q', q0, None, x5, 5, 5, None, 0, 0, n, h, w, b['fm'][0], cl[0], algo)
+            self._conv('L0.q', q0, None, x5, 5, 5, None, 0, 0, n, h, w, b['fm'][0], mult * cl[0], algo)
+            if self.use_obs:
+                b['fm'][0][..., cl[0]:].copy_(obs_override[0].expand(n, -1, -1, -1))
 
         hh, ww = h, w
         for l in range(1, D + 1):

@@ -1,0 +1,61 @@
+"""Inference orchestration of the reference's nlt/nlt_test.py:78-127 on the HIP kernels.
+
+`extract_feat` runs the OBSERVATION path alone over training batches and averages every level's feature map
+over all frames; `infer` renders test batches with those averages standing in for the per-frame observation
+features (`obs_override`).  Unlike the reference, which still pushes a placeholder neighbour through the
+observation network on every test batch and throws the result away (nlt/models/nlt.py:154-155,172-173), the
+plan skips the observation convs entirely when an override is given, and the running average never
+concatenates all frames' features (nlt_test.py:116-121 keeps every frame of every level alive)."""
+import torch
+
+from . import _capi as C
+
+
+def _obs_features(model, x):
+    """[N,H,W,3] -> list of per-level observation feature maps, each [N,h,w,C] (nlt_test.py:108-114)."""
+    feats = []
+    for layer in model.net['obs'].layers:
+        x = layer(x.contiguous())
+        feats.append(x)
+    return feats
+
+
+def _mean_over_frames(x, weights=None):
+    """[F,h,w,C] -> [1,h,w,C] = sum_f w_f x_f / F with the observation-mean kernel (one group of F members)."""
+    f, h, w, c = x.shape
+    out = torch.empty((1, h, w, c), device=x.device, dtype=torch.float32)
+    C.obs_mean_forward(x.contiguous(), weights, 1, f, h * w, c, out, c)
+    return out
+
+
+def extract_feat(model, datapipe, n_obs_batches=-1):
+    """nlt_test.py:97-127.  datapipe: iterable of the model's 11-tuples (training batches).  Returns one
+    [1,h,w,C] tensor per encoder level: the mean of that level's observation features over every frame seen."""
+    per_batch, counts = [], []
+    for i, batch in enumerate(datapipe):
+        if 0 < n_obs_batches <= i:
+            break
+        base, rgb = batch[1], batch[5]
+        x = rgb - base                                              # nlt_test.py:107
+        per_batch.append([_mean_over_frames(f) for f in _obs_features(model, x)])
+        counts.append(base.shape[0])
+    if not per_batch:
+        raise ValueError("extract_feat needs at least one batch")
+    total = float(sum(counts))
+    nb = len(per_batch)
+    # mean over all frames = sum_b (n_b / total) * mean_b: one more pass of the same kernel, weights nb * n_b / total
+    w = torch.tensor([[nb * c / total for c in counts]], device=per_batch[0][0].device, dtype=torch.float32)
+    return [_mean_over_frames(torch.cat([pb[level] for pb in per_batch], 0), w) for level in range(len(per_batch[0]))]
+
+
+def infer(model, datapipe, feat_agg, on_batch=None):
+    """nlt_test.py:78-94: renders every test batch with the aggregated observation features; returns the list of
+    `to_vis` dicts (or hands each to `on_batch(i, to_vis)` -- the reference's model.vis_batch slot)."""
+    outs = []
+    for i, batch in enumerate(datapipe):
+        _, _, _, to_vis = model.call(batch, 'test', obs_override=feat_agg)
+        if on_batch is not None:
+            on_batch(i, to_vis)
+        else:
+            outs.append(to_vis)
+    return outs

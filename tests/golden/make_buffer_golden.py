@@ -6,6 +6,7 @@ for the buffer-assembly rows that are importable in the build container (no TF /
       its `cv2` module global -- None here, cv2 is not installable -- is replaced by a shim whose
       distanceTransform(x, DIST_L1, 3) is scipy.ndimage.distance_transform_cdt(x, 'taxicab'))
   xiuminglib/img.py:11-54                    normalize_uint / denormalize_float (run unmodified)
+  nlt/util/net.py:18-56                      gen_feat_n                 (run unmodified)
 
 Run in the build container only (/root/reference does not exist on the GPU box):
     python tests/golden/make_buffer_golden.py
@@ -61,6 +62,15 @@ f[0, :4] = [0.0, 1.0, 1 / 255, 254.999999 / 255]
 out['norm_u8'], out['norm_u8_out'] = u8, xm.img.normalize_uint(u8)
 out['norm_u16'], out['norm_u16_out'] = u16, xm.img.normalize_uint(u16)
 out['denorm_f'], out['denorm_f_out'] = f, xm.img.denormalize_float(f)
+
+# ---- channel schedule: nlt/util/net.py:18-56 imported and run
+sys.path.insert(0, os.path.join(REF, 'nlt', 'util'))
+import net as refnet              # noqa: E402
+combos = [(a, b, c) for a in (4, 8, 16, 32) for b in (16, 64, 128, 256, 1024) for c in (1, 3, 4) if b >= a and b >= c]
+out['feat_n_args'] = np.array(combos, np.int32)
+sched = [refnet.gen_feat_n(*x) for x in combos]
+out['feat_n_len'] = np.array([len(x) for x in sched], np.int32)
+out['feat_n_flat'] = np.array([v for x in sched for v in x], np.int32)
 
 np.savez_compressed(os.path.join(OUT, 'buffer_assembly.npz'), **out)
 print('wrote buffer_assembly.npz:', {k: v.shape for k, v in out.items()})

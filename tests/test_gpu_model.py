@@ -108,3 +108,20 @@ def test_golden_fixture_64():
     p_pred_c, _, _, p_vis = pm.call(to_device_batch(batch, nn), 'train')
     assert rel_l2(p_vis['pred'].cpu(), g['pred']) <= TOL
     assert rel_l2(p_pred_c.cpu(), g['pred_camspc']) <= TOL
+
+
+def test_nlt_test_orchestration_extract_feat_and_infer():
+    """nlt/nlt_test.py:78-127 on the GPU: averaged observation features -> obs_override rendering."""
+    from nlt_amd import nlt_test
+    om, pm = make_pair(depth=256, uv=64, im=32, seed=15)
+    train = [O.synth_batch(n, 64, 64, 32, 32, 32, 32, k=1, seed=60 + n) for n in (2, 3)]
+    test_b, test_nn = O.synth_batch(2, 64, 64, 32, 32, 32, 32, k=1, seed=70)
+    with torch.no_grad():
+        feats = [om._call(torch.cat((b[1], b[2], b[3]), 3), [b[5] - b[1]], return_feats=True)[1] for b, _ in train]
+        ref_agg = [torch.cat([f[l] for f in feats], 0).mean(0, keepdim=True) for l in range(len(feats[0]))]
+        ref = om.call(test_b, 'test', obs_override=[f.expand(2, -1, -1, -1) for f in ref_agg], nn_list=test_nn)[3]['pred']
+    agg = nlt_test.extract_feat(pm, [to_device_batch(b, nn) for b, nn in train])
+    for a, r in zip(agg, ref_agg):
+        assert rel_l2(a.cpu(), r) <= TOL
+    out = nlt_test.infer(pm, [to_device_batch(test_b, test_nn)], agg)
+    assert rel_l2(out[0]['pred'].cpu(), ref) <= TOL

@@ -155,3 +155,35 @@ def test_lds_tiled_encoder_launches_fold_the_observation_mean(monkeypatch, fused
     assert means == ([] if fused else ['L1.o.mean'])            # level 1 has 16 output channels: not eligible
     assert pm.plan._ran_lds >= {'L2.q.s2', 'L2.o.s2', 'L2.q.s1', 'L2.o.s1', 'L6.o.s1'}
     assert 'L1.q.s2' not in pm.plan._ran_lds
+
+
+def test_nlt_test_orchestration_extract_feat_and_infer(monkeypatch):
+    """nlt/nlt_test.py:78-127: observation features averaged over all training frames, then used as obs_override;
+    the observation convs are not launched at all during inference."""
+    fake_capi.install(monkeypatch)
+    from nlt_amd import nlt_test
+    from nlt_amd.engine import OpTimer
+
+    class Rec(OpTimer):
+        def launch(self, label, nbytes, fn, *a, **kw):
+            self.records[label] = [1, 0.0, nbytes]
+            fn(*a, **kw)
+    om, pm = make(256, 64, 32)
+    train = [O.synth_batch(n, 64, 64, 32, 32, 32, 32, k=1, seed=40 + n) for n in (2, 3)]     # unequal batch sizes
+    test_b, test_nn = O.synth_batch(2, 64, 64, 32, 32, 32, 32, k=1, seed=50)
+    with torch.no_grad():
+        feats = []
+        for b, _ in train:
+            _, f = om._call(torch.cat((b[1], b[2], b[3]), 3), [b[5] - b[1]], return_feats=True)   # x = rgb - base
+            feats.append(f)
+        ref_agg = [torch.cat([f[l] for f in feats], 0).mean(0, keepdim=True) for l in range(len(feats[0]))]
+        ref = om.call(test_b, 'test', obs_override=[f.expand(2, -1, -1, -1) for f in ref_agg], nn_list=test_nn)[3]['pred']
+    agg = nlt_test.extract_feat(pm, [cpu_batch(b, nn) for b, nn in train])
+    assert len(agg) == len(ref_agg) and all(a.shape == r.shape and rel_l2(a, r) < 1e-5 for a, r in zip(agg, ref_agg))
+    assert len(nlt_test.extract_feat(pm, [cpu_batch(b, nn) for b, nn in train], n_obs_batches=1)) == len(ref_agg)
+    pm.plan.timer = Rec()
+    out = nlt_test.infer(pm, [cpu_batch(test_b, test_nn)], agg)
+    assert rel_l2(out[0]['pred'], ref) < 1e-5
+    assert not any('.o.' in l or l == 'L0.stem' for l in pm.plan.timer.records)          # no observation launches
+    with pytest.raises(ValueError):
+        nlt_test.extract_feat(pm, [])

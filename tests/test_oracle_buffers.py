@@ -134,3 +134,14 @@ def test_assemble_batch_semantics():
     assert np.array_equal(b['base'][0], (store['diffuse'][3] / 255.0).astype(np.float32))
     assert not b['nn_base'][0, 1].any() and np.array_equal(b['nn_rgb'][1, 0], (store['rgb'][4] / 255.0).astype(np.float32))
     assert not B.assemble_batch(store, [3], [[1]], mode='test')['rgb'].any()
+
+
+def test_channel_schedule_matches_reference_gen_feat_n():
+    """nlt/util/net.py:18-56 run by the fixture script: oracle AND product schedule, 50+ (min, max, final) triples."""
+    from oracle import nlt_oracle as O
+    from nlt_amd.util.net import gen_feat_n
+    off = 0
+    for (a, b, c), n in zip(G['feat_n_args'].tolist(), G['feat_n_len'].tolist()):
+        ref = G['feat_n_flat'][off:off + n].tolist(); off += n
+        assert O.gen_feat_n(a, b, c) == ref, (a, b, c)
+        assert gen_feat_n(a, b, c) == ref, (a, b, c)
