@@ -134,7 +134,18 @@ __global__ __launch_bounds__(256) void front_kernel(
   const f32x4 bq2 = *reinterpret_cast<const f32x4*>(blob + OFF_BQ2 + 4 * kk);
   const f32x4 bo2 = *reinterpret_cast<const f32x4*>(blob + OFF_BO2 + 4 * kk);
   const float inv_k = 1.f / (float)k;
+  // stage-2 fragments are requested now, so their L2 latency hides behind stage 1 (the compiler would
+  // otherwise sink each load to its first use and serialise four round trips per workgroup)
+  f32x4 aq1[4], ao1[4];
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    aq1[t] = *reinterpret_cast<const f32x4*>(blob + OFF_AQ1 + (t * 64 + lane) * 4);
+    ao1[t] = *reinterpret_cast<const f32x4*>(blob + OFF_AO1 + (t * 64 + lane) * 4);
+  }
+  const f32x4 bq1 = *reinterpret_cast<const f32x4*>(blob + OFF_BQ1 + 4 * kk);
+  const f32x4 bo1 = *reinterpret_cast<const f32x4*>(blob + OFF_BO1 + 4 * kk);
 
+  constexpr int KU = 4;                                                // observations whose loads are issued together
   for (int mt = wave; mt < NT; mt += 4) {
     const int t = mt * 16 + j;
     const bool live = t < HT;
@@ -143,24 +154,49 @@ __global__ __launch_bounds__(256) void front_kernel(
     const bool inside = live && gy < h2 && gx < w2;                    // beyond the image: the s1 conv's zero padding
     const bool owned = inside && hy < TH && hx < TW;
     const int fy = inside ? 2 * gy + (kk >> 1) : 0, fx = inside ? 2 * gx + (kk & 1) : 0;
-    const long tex = (long)f * hw + (long)fy * w + fx;                 // this lane's full-resolution texel (tap kk)
-    float raw[8];
-    raw[0] = base[tex * 3]; raw[1] = base[tex * 3 + 1]; raw[2] = base[tex * 3 + 2];
-    raw[3] = cvis[tex]; raw[4] = lvis[tex];
+    const long pix = (long)fy * w + fx;
+    const long tex = (long)f * hw + pix;                               // this lane's full-resolution texel (tap kk)
+    // Every load of the tile is issued before the first use (a wave keeps 2*KU + 3 requests in flight; waiting
+    // per observation would leave the memory system idle).  The first observation group is peeled out of the
+    // loop so that no loop-carried wait separates its loads from the query-input loads.
     float xs0 = 0.f, xs1 = 0.f, xs2 = 0.f;
-    for (int i = 0; i < k; ++i) {
-      const long ot = ((long)f * k + i) * hw + (long)fy * w + fx;
-      const float d0 = nn_rgb[ot * 3] - nn_base[ot * 3];
-      const float d1 = nn_rgb[ot * 3 + 1] - nn_base[ot * 3 + 1];
-      const float d2 = nn_rgb[ot * 3 + 2] - nn_base[ot * 3 + 2];
-      xs0 += d0; xs1 += d1; xs2 += d2;
-      f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
-      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(ao2[0], d0, acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(ao2[1], d1, acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(ao2[2], d2, acc, 0, 0, 0);
-      acc = lrelu4(acc + bo2, alpha);
-      if (!inside) acc = (f32x4){0.f, 0.f, 0.f, 0.f};
-      if (live) *reinterpret_cast<f32x4*>(lds + ((size_t)(1 + i) * HT + t) * 16 + 4 * kk) = acc;
+    auto load_group = [&](int i0, float (&r)[KU][3], float (&b)[KU][3]) {
+#pragma unroll
+      for (int u = 0; u < KU; ++u) {
+        const int i = i0 + u < k ? i0 + u : k - 1;
+        const long ot = (((long)f * k + i) * hw + pix) * 3;
+        r[u][0] = nn_rgb[ot]; r[u][1] = nn_rgb[ot + 1]; r[u][2] = nn_rgb[ot + 2];
+        b[u][0] = nn_base[ot]; b[u][1] = nn_base[ot + 1]; b[u][2] = nn_base[ot + 2];
+      }
+    };
+    auto compute_group = [&](int i0, const float (&r)[KU][3], const float (&b)[KU][3]) {
+#pragma unroll
+      for (int u = 0; u < KU; ++u) {
+        if (i0 + u < k) {                                              // wave-uniform
+          const float d0 = r[u][0] - b[u][0], d1 = r[u][1] - b[u][1], d2 = r[u][2] - b[u][2];
+          xs0 += d0; xs1 += d1; xs2 += d2;
+          f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+          acc = __builtin_amdgcn_mfma_f32_16x16x4f32(ao2[0], d0, acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_16x16x4f32(ao2[1], d1, acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_16x16x4f32(ao2[2], d2, acc, 0, 0, 0);
+          acc = lrelu4(acc + bo2, alpha);
+          if (!inside) acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+          if (live) *reinterpret_cast<f32x4*>(lds + ((size_t)(1 + i0 + u) * HT + t) * 16 + 4 * kk) = acc;
+        }
+      }
+    };
+    float raw[8];
+    {
+      float r[KU][3], b[KU][3];
+      load_group(0, r, b);
+      raw[0] = base[tex * 3]; raw[1] = base[tex * 3 + 1]; raw[2] = base[tex * 3 + 2];
+      raw[3] = cvis[tex]; raw[4] = lvis[tex];
+      compute_group(0, r, b);
+    }
+    for (int i0 = KU; i0 < k; i0 += KU) {
+      float r[KU][3], b[KU][3];
+      load_group(i0, r, b);
+      compute_group(i0, r, b);
     }
     raw[5] = xs0 * inv_k; raw[6] = xs1 * inv_k; raw[7] = xs2 * inv_k;
     f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -172,54 +208,63 @@ __global__ __launch_bounds__(256) void front_kernel(
     if (owned) {                                                       // the head's share of the L0 features (+ base)
       float s0 = blob[OFF_BSK], s1 = blob[OFF_BSK + 1], s2 = blob[OFF_BSK + 2];
 #pragma unroll
-      for (int r = 0; r < 8; ++r) {
-        s0 = fmaf(raw[r], blob[OFF_WSK + r * 3], s0);
-        s1 = fmaf(raw[r], blob[OFF_WSK + r * 3 + 1], s1);
-        s2 = fmaf(raw[r], blob[OFF_WSK + r * 3 + 2], s2);
+      for (int rr = 0; rr < 8; ++rr) {
+        s0 = fmaf(raw[rr], blob[OFF_WSK + rr * 3], s0);
+        s1 = fmaf(raw[rr], blob[OFF_WSK + rr * 3 + 1], s1);
+        s2 = fmaf(raw[rr], blob[OFF_WSK + rr * 3 + 2], s2);
       }
       if (add_base) { s0 += raw[0]; s1 += raw[1]; s2 += raw[2]; }
       skip3[tex * 3] = s0; skip3[tex * 3 + 1] = s1; skip3[tex * 3 + 2] = s2;
     }
   }
+#pragma unroll
+  for (int t = 0; t < 4; ++t) asm volatile("" ::"v"(aq1[t]), "v"(ao1[t]));   // keep them resident (see above)
+  asm volatile("" ::"v"(bq1), "v"(bo1));
   __syncthreads();
 
-  // ---- stage 2: stride-1 convs (TF 'same': taps (y+a, x+b), zero beyond bottom/right) + observation mean
-  f32x4 aq1[4], ao1[4];
-#pragma unroll
-  for (int t = 0; t < 4; ++t) {
-    aq1[t] = *reinterpret_cast<const f32x4*>(blob + OFF_AQ1 + (t * 64 + lane) * 4);
-    ao1[t] = *reinterpret_cast<const f32x4*>(blob + OFF_AO1 + (t * 64 + lane) * 4);
-  }
-  const f32x4 bq1 = *reinterpret_cast<const f32x4*>(blob + OFF_BQ1 + 4 * kk);
-  const f32x4 bo1 = *reinterpret_cast<const f32x4*>(blob + OFF_BO1 + 4 * kk);
+  // ---- stage 2: stride-1 convs (TF 'same': taps (y+a, x+b), zero beyond bottom/right) + observation mean.
+  // A wave owns tile rows `wave` and `wave + 4` and runs them side by side: two independent accumulators keep
+  // the matrix pipe issuing every 32 cycles (one accumulator alone pays the 40-cycle dependent latency).
   const long hw2 = (long)h2 * w2;
-  for (int r = wave; r < TH; r += 4) {
-    const int gy = ty0 + r, gx = tx0 + j;
-    const bool inside = gy < h2 && gx < w2;
-    const long otex = (long)gy * w2 + gx;
-    f32x4 mean = (f32x4){0.f, 0.f, 0.f, 0.f}, qv = mean;
+  static_assert(TH == 8, "stage 2 pairs tile rows wave and wave + 4");
+  {
+    const int gx = tx0 + j;
+    const int gy[2] = {ty0 + wave, ty0 + wave + 4};
+    const bool inside[2] = {gy[0] < h2 && gx < w2, gy[1] < h2 && gx < w2};
+    const long otex[2] = {(long)gy[0] * w2 + gx, (long)gy[1] * w2 + gx};
+    f32x4 mean[2] = {(f32x4){0.f, 0.f, 0.f, 0.f}, (f32x4){0.f, 0.f, 0.f, 0.f}};
+    f32x4 qv[2] = {mean[0], mean[0]};
     for (int p = 0; p <= k; ++p) {
       const float* tilep = lds + (size_t)p * HT * 16;
-      f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+      f32x4 acc[2] = {(f32x4){0.f, 0.f, 0.f, 0.f}, (f32x4){0.f, 0.f, 0.f, 0.f}};
 #pragma unroll
       for (int t = 0; t < 4; ++t) {
-        const f32x4 b = *reinterpret_cast<const f32x4*>(tilep + ((r + (t >> 1)) * HW + j + (t & 1)) * 16 + 4 * kk);
+        const f32x4 b0 = *reinterpret_cast<const f32x4*>(tilep + ((wave + (t >> 1)) * HW + j + (t & 1)) * 16 + 4 * kk);
+        const f32x4 b1 = *reinterpret_cast<const f32x4*>(tilep + ((wave + 4 + (t >> 1)) * HW + j + (t & 1)) * 16 + 4 * kk);
         const f32x4 a = p ? ao1[t] : aq1[t];
 #pragma unroll
-        for (int s4 = 0; s4 < 4; ++s4) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s4], b[s4], acc, 0, 0, 0);
+        for (int s4 = 0; s4 < 4; ++s4) {
+          acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s4], b0[s4], acc[0], 0, 0, 0);
+          acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s4], b1[s4], acc[1], 0, 0, 0);
+        }
       }
-      acc = lrelu4(acc + (p ? bo1 : bq1), alpha);
-      if (p == 0) qv = acc;
-      else {
-        mean += acc;
-        if (inside) *reinterpret_cast<f32x4*>(obs1 + (((long)f * k + (p - 1)) * hw2 + otex) * 16 + 4 * kk) = acc;
+#pragma unroll
+      for (int e = 0; e < 2; ++e) {
+        const f32x4 v = lrelu4(acc[e] + (p ? bo1 : bq1), alpha);
+        if (p == 0) qv[e] = v;
+        else {
+          mean[e] += v;
+          if (inside[e]) *reinterpret_cast<f32x4*>(obs1 + (((long)f * k + (p - 1)) * hw2 + otex[e]) * 16 + 4 * kk) = v;
+        }
       }
     }
-    if (inside) {
-      float* o = fm1 + ((long)f * hw2 + otex) * 32 + 4 * kk;
-      *reinterpret_cast<f32x4*>(o) = qv;
-      *reinterpret_cast<f32x4*>(o + 16) = mean * inv_k;
-    }
+#pragma unroll
+    for (int e = 0; e < 2; ++e)
+      if (inside[e]) {
+        float* o = fm1 + ((long)f * hw2 + otex[e]) * 32 + 4 * kk;
+        *reinterpret_cast<f32x4*>(o) = qv[e];
+        *reinterpret_cast<f32x4*>(o + 16) = mean[e] * inv_k;
+      }
   }
 }
 
