@@ -146,38 +146,29 @@ __global__ __launch_bounds__(256) void front_kernel(
   const f32x4 bo1 = *reinterpret_cast<const f32x4*>(blob + OFF_BO1 + 4 * kk);
 
   constexpr int KU = 4;                                                // observations whose loads are issued together
-  struct TileIdx { int t; bool live, inside, owned; long pix, tex; };
-  struct TileRegs { float x5[5]; float r[KU][3], b[KU][3]; };
-  auto tile_index = [&](int mt) {
-    TileIdx ix;
-    ix.t = mt * 16 + j;
-    ix.live = ix.t < HT;
-    const int hy = ix.live ? ix.t / HW : 0, hx = ix.live ? ix.t % HW : 0;
+  for (int mt = wave; mt < NT; mt += 4) {
+    const int t = mt * 16 + j;
+    const bool live = t < HT;
+    const int hy = live ? t / HW : 0, hx = live ? t % HW : 0;
     const int gy = ty0 + hy, gx = tx0 + hx;
-    ix.inside = ix.live && gy < h2 && gx < w2;                         // beyond the image: the s1 conv's zero padding
-    ix.owned = ix.inside && hy < TH && hx < TW;
-    const int fy = ix.inside ? 2 * gy + (kk >> 1) : 0, fx = ix.inside ? 2 * gx + (kk & 1) : 0;
-    ix.pix = (long)fy * w + fx;
-    ix.tex = (long)f * hw + ix.pix;                                    // this lane's full-resolution texel (tap kk)
-    return ix;
-  };
-  auto load_group = [&](const TileIdx& ix, int i0, float (&r)[KU][3], float (&b)[KU][3]) {
-#pragma unroll
-    for (int u = 0; u < KU; ++u) {
-      const int i = i0 + u < k ? i0 + u : k - 1;
-      const long ot = (((long)f * k + i) * hw + ix.pix) * 3;
-      r[u][0] = nn_rgb[ot]; r[u][1] = nn_rgb[ot + 1]; r[u][2] = nn_rgb[ot + 2];
-      b[u][0] = nn_base[ot]; b[u][1] = nn_base[ot + 1]; b[u][2] = nn_base[ot + 2];
-    }
-  };
-  // Issues every load of a tile's first KU observations and its query inputs (2*KU + 3 requests per lane).
-  auto issue_tile = [&](const TileIdx& ix, TileRegs& L) {
-    load_group(ix, 0, L.r, L.b);
-    L.x5[0] = base[ix.tex * 3]; L.x5[1] = base[ix.tex * 3 + 1]; L.x5[2] = base[ix.tex * 3 + 2];
-    L.x5[3] = cvis[ix.tex]; L.x5[4] = lvis[ix.tex];
-  };
-  auto compute_tile = [&](const TileIdx& ix, const TileRegs& L) {
+    const bool inside = live && gy < h2 && gx < w2;                    // beyond the image: the s1 conv's zero padding
+    const bool owned = inside && hy < TH && hx < TW;
+    const int fy = inside ? 2 * gy + (kk >> 1) : 0, fx = inside ? 2 * gx + (kk & 1) : 0;
+    const long pix = (long)fy * w + fx;
+    const long tex = (long)f * hw + pix;                               // this lane's full-resolution texel (tap kk)
+    // Every load of the tile is issued before the first use (a wave keeps 2*KU + 3 requests in flight; waiting
+    // per observation would leave the memory system idle).  The first observation group is peeled out of the
+    // loop so that no loop-carried wait separates its loads from the query-input loads.
     float xs0 = 0.f, xs1 = 0.f, xs2 = 0.f;
+    auto load_group = [&](int i0, float (&r)[KU][3], float (&b)[KU][3]) {
+#pragma unroll
+      for (int u = 0; u < KU; ++u) {
+        const int i = i0 + u < k ? i0 + u : k - 1;
+        const long ot = (((long)f * k + i) * hw + pix) * 3;
+        r[u][0] = nn_rgb[ot]; r[u][1] = nn_rgb[ot + 1]; r[u][2] = nn_rgb[ot + 2];
+        b[u][0] = nn_base[ot]; b[u][1] = nn_base[ot + 1]; b[u][2] = nn_base[ot + 2];
+      }
+    };
     auto compute_group = [&](int i0, const float (&r)[KU][3], const float (&b)[KU][3]) {
 #pragma unroll
       for (int u = 0; u < KU; ++u) {
@@ -189,25 +180,32 @@ __global__ __launch_bounds__(256) void front_kernel(
           acc = __builtin_amdgcn_mfma_f32_16x16x4f32(ao2[1], d1, acc, 0, 0, 0);
           acc = __builtin_amdgcn_mfma_f32_16x16x4f32(ao2[2], d2, acc, 0, 0, 0);
           acc = lrelu4(acc + bo2, alpha);
-          if (!ix.inside) acc = (f32x4){0.f, 0.f, 0.f, 0.f};
-          if (ix.live) *reinterpret_cast<f32x4*>(lds + ((size_t)(1 + i0 + u) * HT + ix.t) * 16 + 4 * kk) = acc;
+          if (!inside) acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+          if (live) *reinterpret_cast<f32x4*>(lds + ((size_t)(1 + i0 + u) * HT + t) * 16 + 4 * kk) = acc;
         }
       }
     };
-    compute_group(0, L.r, L.b);
-    for (int i0 = KU; i0 < k; i0 += KU) {                              // k > KU: the remaining observations, group by group
+    float raw[8];
+    {
       float r[KU][3], b[KU][3];
-      load_group(ix, i0, r, b);
+      load_group(0, r, b);
+      raw[0] = base[tex * 3]; raw[1] = base[tex * 3 + 1]; raw[2] = base[tex * 3 + 2];
+      raw[3] = cvis[tex]; raw[4] = lvis[tex];
+      compute_group(0, r, b);
+    }
+    for (int i0 = KU; i0 < k; i0 += KU) {
+      float r[KU][3], b[KU][3];
+      load_group(i0, r, b);
       compute_group(i0, r, b);
     }
-    float raw[8] = {L.x5[0], L.x5[1], L.x5[2], L.x5[3], L.x5[4], xs0 * inv_k, xs1 * inv_k, xs2 * inv_k};
+    raw[5] = xs0 * inv_k; raw[6] = xs1 * inv_k; raw[7] = xs2 * inv_k;
     f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int m = 0; m < 8; ++m) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(aq2[m], raw[m], acc, 0, 0, 0);
     acc = lrelu4(acc + bq2, alpha);
-    if (!ix.inside) acc = (f32x4){0.f, 0.f, 0.f, 0.f};
-    if (ix.live) *reinterpret_cast<f32x4*>(lds + (size_t)ix.t * 16 + 4 * kk) = acc;
-    if (ix.owned) {                                                    // the head's share of the L0 features (+ base)
+    if (!inside) acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+    if (live) *reinterpret_cast<f32x4*>(lds + (size_t)t * 16 + 4 * kk) = acc;
+    if (owned) {                                                       // the head's share of the L0 features (+ base)
       float s0 = blob[OFF_BSK], s1 = blob[OFF_BSK + 1], s2 = blob[OFF_BSK + 2];
 #pragma unroll
       for (int rr = 0; rr < 8; ++rr) {
@@ -216,25 +214,7 @@ __global__ __launch_bounds__(256) void front_kernel(
         s2 = fmaf(raw[rr], blob[OFF_WSK + rr * 3 + 2], s2);
       }
       if (add_base) { s0 += raw[0]; s1 += raw[1]; s2 += raw[2]; }
-      skip3[ix.tex * 3] = s0; skip3[ix.tex * 3 + 1] = s1; skip3[ix.tex * 3 + 2] = s2;
-    }
-  };
-  // The wave's tiles are wave, wave + 4 (and wave + 8 for waves 0, 1): the next tile's loads are in flight
-  // while the current one is computed (two register sets), so stage 1 costs ~2 memory round trips, not 3.
-  static_assert(NT > 4 && NT <= 12, "stage 1 assumes 2-3 tiles per wave");
-  {
-    const TileIdx i0 = tile_index(wave), i1 = tile_index(wave + 4);
-    TileRegs A, B;
-    issue_tile(i0, A);
-    issue_tile(i1, B);
-    compute_tile(i0, A);
-    if (wave + 8 < NT) {
-      const TileIdx i2 = tile_index(wave + 8);
-      issue_tile(i2, A);
-      compute_tile(i1, B);
-      compute_tile(i2, A);
-    } else {
-      compute_tile(i1, B);
+      skip3[tex * 3] = s0; skip3[tex * 3 + 1] = s1; skip3[tex * 3 + 2] = s2;
     }
   }
 #pragma unroll
