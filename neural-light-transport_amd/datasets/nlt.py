@@ -4,13 +4,79 @@ The reference decodes six PNGs per sample on tf.data worker threads every step (
 the released config).  With 288 GB of HBM the whole dragon capture fits on the device as uint8, so
 a batch is assembled by ONE gather/convert pass (nlt_assemble_batch): frame ids in, float32 texel
 buffers out, bit-identical to `_load_data`'s uint8 -> float64/255 -> float32.
-PNG / .npy file reading is not part of this class: `store` holds decoded arrays."""
+`load_store` reads the reference's on-disk capture (the `<data_root>.json` index of data_gen/postproc.py:89-122,
+per-sample PNGs, `uv2cam.npy` fp16 maps, `nn.json`) once into that store."""
+import json
 import re
 from itertools import product
+from os.path import exists, join
 
+import numpy as np
 import torch
 
 from .. import _capi as C
+
+
+def load_store(data_root, device='cuda', ids=None):
+    """Decodes a capture laid out as the reference writes it (data_gen/render.py:196-206, postproc.py:66-122) into
+    the resident uint8 store.  Paths in `<data_root>.json` are relative to data_root (nlt/datasets/nlt.py:36-45).
+    Test samples have no rgb / rgb_camspc (postproc.py:104-107): their slots stay zero."""
+    from PIL import Image
+    status = data_root.rstrip('/') + '.json'
+    if not exists(status):
+        raise FileNotFoundError(("Data status JSON not found at \n\t%s\nRun "
+                                 "$REPO/data_gen/postproc.py to generate it") % status)
+    with open(status) as h:
+        paths = json.load(h)
+    ids = sorted(paths) if ids is None else list(ids)
+
+    def png(path, channels):
+        a = np.asarray(Image.open(path))
+        if a.dtype != np.uint8:
+            raise NotImplementedError("%s: %s PNGs (the resident store is uint8)" % (path, a.dtype))
+        if channels == 3:
+            if a.ndim == 2:
+                a = np.dstack([a] * 3)
+            return a[:, :, :3]                                   # [:, :, :3] as nlt/datasets/nlt.py:121,128-130
+        return a if a.ndim == 2 else a[:, :, 0]
+
+    cols = {k: [] for k in ('diffuse', 'rgb', 'cvis', 'lvis', 'rgb_camspc', 'uv2cam')}
+    nn, complete = {}, []
+    for id_ in ids:
+        p = {k: (v if k == 'complete' else join(data_root, v)) for k, v in paths[id_].items()}
+        complete.append(bool(p['complete']))
+        if not p['complete']:
+            for k in cols:
+                cols[k].append(None)
+            continue
+        cols['diffuse'].append(png(p['diffuse'], 3))
+        cols['cvis'].append(png(p['cvis'], 1))
+        cols['lvis'].append(png(p['lvis'], 1))
+        cols['uv2cam'].append(np.load(p['uv2cam']))
+        cols['rgb'].append(png(p['rgb'], 3) if 'rgb' in p else None)
+        cols['rgb_camspc'].append(png(p['rgb_camspc'], 3) if 'rgb_camspc' in p else None)
+        with open(p['nn']) as h:
+            nn[id_] = json.load(h)
+
+    def stack(key, dtype):
+        ref = next((a for a in cols[key] if a is not None), None)
+        if ref is None:
+            raise ValueError("no complete sample provides '%s'" % key)
+        for a in cols[key]:
+            if a is not None and a.shape != ref.shape:
+                raise NotImplementedError("'%s' comes in several resolutions (%s vs %s): the reference resizes with cv2"
+                                          % (key, a.shape, ref.shape))
+        out = np.zeros((len(ids),) + ref.shape, dtype)
+        for i, a in enumerate(cols[key]):
+            if a is not None:
+                out[i] = a
+        return torch.from_numpy(out).to(device)
+
+    store = {'ids': ids, 'nn': nn, 'complete': complete}
+    for key in ('diffuse', 'rgb', 'cvis', 'lvis', 'rgb_camspc'):
+        store[key] = stack(key, np.uint8)
+    store['uv2cam'] = stack('uv2cam', np.float16)
+    return store
 
 
 class Dataset:
@@ -18,13 +84,21 @@ class Dataset:
     'cvis','lvis' [F,H,W] uint8, 'uv2cam' [F,imh,imw,2] fp16, 'rgb_camspc' [F,imh,imw,3] uint8,
     'complete': [bool]}.  ids follow the reference's '{trainvali|test}_{i:09d}_{cam}_{light}'."""
 
-    def __init__(self, config, mode, store, k=1):
+    def __init__(self, config, mode, store=None, k=1, device='cuda'):
         if mode not in ('train', 'vali', 'test'):
-            raise ValueError(mode)
+            raise ValueError("Invalid mode: {provided}. Allowed modes: {allowed}".format(
+                provided=mode, allowed=('train', 'vali', 'test')))
+        if store is None:                                           # nlt/datasets/nlt.py:35-45
+            store = load_store(config.get('DEFAULT', 'data_root'), device)
+            uvh = config.getint('DEFAULT', 'uvh')
+            if store['cvis'].shape[1] != uvh:
+                raise NotImplementedError("stored UV resolution %d != uvh %d (the reference resizes with cv2)"
+                                          % (store['cvis'].shape[1], uvh))
         self.config, self.mode, self.store, self.k = config, mode, store, k
         self.index = {id_: i for i, id_ in enumerate(store['ids'])}
         self.bs = 1 if mode == 'test' else config.getint('DEFAULT', 'bs')     # datasets/base.py
         self.files = self._glob()
+        assert self.files, "No files to process into a dataset"           # nlt/datasets/base.py:38
 
     def _glob(self):
         """nlt/datasets/nlt.py:54-86: hold-out split by camera x light."""
