@@ -74,6 +74,7 @@ def parse():
     ap.add_argument('--dominant', type=str, default=None, help='label of the kernel to time in the timed region')
     ap.add_argument('--train-steps', type=int, default=-1, help='train steps to time for the train_step field (-1: steps//2, 0: skip)')
     ap.add_argument('--train-loss', type=str, default='l2')
+    ap.add_argument('--per-op-train', action='store_true', help='per-launch timing table of one train step (stderr)')
     return ap.parse_args()
 
 
@@ -161,6 +162,20 @@ def bench_train(args, device, world, rank, n_steps):
     gbs = world * args.frames
     for _ in range(3):
         trainvali.distributed_train_step(model, batch, opt, gbs)
+    if args.per_op_train and rank == 0:
+        from nlt_amd.engine import OpTimer
+        timer = OpTimer()
+        model.plan.timer = timer
+        for _ in range(3):
+            trainvali.distributed_train_step(model, batch, opt, gbs)
+        rec = timer.collect()
+        model.plan.timer = None
+        table = sorted(((r[1] / r[0], l, r[2]) for l, r in rec.items()), reverse=True)
+        tot = sum(t for t, _, _ in table)
+        sys.stderr.write("train step, plan launches only (loss / warp backward / Adam / all-reduce are outside the plan)\n")
+        for t, l, nb in table[:60]:
+            sys.stderr.write("%-22s %10.4f %6.1f%% %10.1f GB/s\n" % (l, t, 100 * t / tot, nb / t / 1e6))
+        sys.stderr.write("sum of plan launches %.3f ms (%d launches)\n" % (tot, len(table)))
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
