@@ -164,6 +164,17 @@ int nlt_conv_backward_weights(int mode, int algo,
                               const float* dpre, int ldp, int cout,
                               float* dw_keras, float* dbias, void* stream);
 
+/* nlt_conv_backward_weights, second generation (csrc/wgrad_tile.hip): 16-byte operand loads feeding 64 x 64 blocks of
+ * dW on the MFMA, row slices reduced through `workspace` in a fixed order (deterministic, no atomics).  Same
+ * arguments and accumulate-into semantics; channel counts and strides must be multiples of 4.
+ * workspace: nlt_wgrad_workspace_floats() floats. */
+long nlt_wgrad_workspace_floats(int mode, int c0, int c1, int n, int h, int w, int cout);
+int nlt_conv_backward_weights_tiled(int mode,
+                                    const float* src0, int ld0, int c0, const float* src1, int ld1, int c1,
+                                    int n, int h, int w, const float* dpre, int ldp, int cout,
+                                    float* dw_keras, float* dbias, float* workspace, long workspace_floats,
+                                    void* stream);
+
 /* out = g * (y > 0 ? 1 : alpha): LeakyReLU backward from the saved OUTPUT y (elements.py:72-73). */
 int nlt_lrelu_backward(const float* g, int ldg, const float* y, int ldy, int c, long texels, float alpha,
                        float* out, int ldo, void* stream);

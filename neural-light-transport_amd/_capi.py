@@ -38,6 +38,9 @@ SIGNATURES = {
     'nlt_mul_forward': (_c_int, [_vp, _vp, _c_long, _vp, _vp]),
     'nlt_conv_backward_weights': (_c_int, [_c_int, _c_int, _vp, _c_int, _c_int, _vp, _c_int, _c_int,
                                            _c_int, _c_int, _c_int, _vp, _c_int, _c_int, _vp, _vp, _vp]),
+    'nlt_wgrad_workspace_floats': (_c_long, [_c_int] * 7),
+    'nlt_conv_backward_weights_tiled': (_c_int, [_c_int, _vp, _c_int, _c_int, _vp, _c_int, _c_int, _c_int, _c_int, _c_int,
+                                                 _vp, _c_int, _c_int, _vp, _vp, _vp, _c_long, _vp]),
     'nlt_lrelu_backward': (_c_int, [_vp, _c_int, _vp, _c_int, _c_int, _c_long, _c_float, _vp, _c_int, _vp]),
     'nlt_obs_mean_backward': (_c_int, [_vp, _c_int, _vp, _vp, _vp, _c_int, _c_int, _c_int, _c_int, _c_float, _vp, _vp]),
     'nlt_stem_backward': (_c_int, [_vp] * 6 + [_c_int] * 5 + [_vp] * 6 + [_vp]),
@@ -196,6 +199,24 @@ def conv_backward_weights(mode, src0, c0, ld0, src1, c1, ld1, n, h, w, dpre, ldp
     _check(lib().nlt_conv_backward_weights(mode, algo, _ptr(src0), ld0, c0, _ptr(src1), ld1, c1, n, h, w,
                                            _ptr(dpre), ldp, cout, _ptr(dw), _ptr(db), _stream()),
            'nlt_conv_backward_weights')
+
+
+_wgrad_ws = {}
+
+
+def conv_backward_weights_tiled(mode, src0, c0, ld0, src1, c1, ld1, n, h, w, dpre, ldp, cout, dw, db):
+    """Second-generation weight gradient (deterministic two-pass); the slice workspace is cached per device."""
+    need = lib().nlt_wgrad_workspace_floats(mode, c0, c1, n, h, w, cout)
+    if need <= 0:
+        raise NLTError("nlt_wgrad_workspace_floats: unsupported (mode %d, c0 %d, c1 %d, cout %d)" % (mode, c0, c1, cout))
+    key = str(src0.device)
+    ws = _wgrad_ws.get(key)
+    if ws is None or ws.numel() < need:
+        ws = torch.empty(need, device=src0.device, dtype=torch.float32)
+        _wgrad_ws[key] = ws
+    _check(lib().nlt_conv_backward_weights_tiled(mode, _ptr(src0), ld0, c0, _ptr(src1), ld1, c1, n, h, w, _ptr(dpre), ldp,
+                                                 cout, _ptr(dw), _ptr(db), _ptr(ws), ws.numel(), _stream()),
+           'nlt_conv_backward_weights_tiled')
 
 
 def lrelu_backward(g, ldg, y, ldy, c, texels, alpha, out, ldo):

@@ -1,0 +1,222 @@
+// Weight / bias gradients, second generation:  dW[k][n] = sum_rows X[row][k] * dP[row][n].
+//
+// The reduction runs over texel rows, 4 per v_mfma_f32_16x16x4_f32 step, so operand traffic decides the speed.
+// Here both operands are fetched with ONE 16-byte NHWC load per lane per step and feed 16 MFMAs:
+//   lane (i = l & 15, kk = l >> 4) loads the channel QUAD i of row kk of X  -> A_e[i][kk] = quad[e], e = 0..3
+//   lane (j = l & 15, kk = l >> 4) loads the output  QUAD j of row kk of dP -> B_f[kk][j] = quad[f], f = 0..3
+//   D_{e,f} = A_e * B_f accumulates dW[channel 4*quad_i + e][output 4*quad_j + f]
+// i.e. a wave owns a 64 x 64 block of dW (16 k-quads x 16 n-quads; k-quads run over tap x virtual-concat channel
+// quads, n-quads over output channels or, for Conv2DTranspose k2s2, over (a,b,o)) for one slice of the rows.
+// Row slices write their partial blocks to a workspace with 16-byte stores; a second launch adds the slices in
+// order and accumulates into the Keras-layout gradient -- deterministic, and no atomics (the first-generation
+// kernel's thousands of waves adding into the 64 addresses of a 4 -> 4 layer were its bottleneck).
+#include "nlt_common.h"
+
+namespace {
+
+template <int MODE>
+__device__ __forceinline__ long keras_widx(int t, int c, int ncol, int cin, int cout) {
+  if (MODE == NLT_CONV1X1 || MODE == NLT_CONV_K2S2 || MODE == NLT_CONV_K2S1) return ((long)t * cin + c) * cout + ncol;
+  if (MODE == NLT_DECONV_K2S1) return ((long)t * cout + ncol) * cin + c;
+  return (long)ncol * cin + c;   // DECONV_K2S2: ncol = (a*2+b)*cout + o
+}
+
+struct WT {
+  ConvP c;            // geometry + X sources
+  const float* dp; int ldp;
+  float* dw; float* db;
+  float* ws; float* wsb;
+  int kq, nq;         // k-quads (taps * (c0 + c1) / 4), n-quads (N / 4)
+  int kblocks, nblocks, msplits, rows_per_split;
+};
+
+template <int MODE>
+__global__ __launch_bounds__(256) void wgrad_tile_kernel(WT w) {
+  const ConvP& p = w.c;
+  const int lane = threadIdx.x & 63;
+  int wave = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (wave >= w.kblocks * w.nblocks * w.msplits) return;
+  const int ms = wave % w.msplits; wave /= w.msplits;
+  const int nb = wave % w.nblocks;
+  const int kb = wave / w.nblocks;
+  const int i = lane & 15, kk = lane >> 4;
+  const int q0 = p.c0 >> 2, qpt = (p.c0 + p.c1) >> 2;
+
+  // A role: this lane's k-quad = (tap, channel quad of the virtual concat)
+  const int kq = kb * 16 + i;
+  const bool a_ok = kq < w.kq;
+  const int tap = a_ok ? kq / qpt : 0;
+  const int cq = a_ok ? kq - tap * qpt : 0;
+  const bool from1 = cq >= q0;
+  const float* asrc = from1 ? p.src1 + 4 * (cq - q0) : p.src0 + 4 * cq;
+  const int ald = from1 ? p.ld1 : p.ld0;
+  // B role: this lane's n-quad
+  const int nq = nb * 16 + i;
+  const bool b_ok = nq < w.nq;
+  const int ncol = b_ok ? 4 * nq : 0;
+  const int ab = MODE == NLT_DECONV_K2S2 ? ncol / p.cout : 0;
+  const int oc = MODE == NLT_DECONV_K2S2 ? ncol - ab * p.cout : ncol;
+
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int e = 0; e < 4; ++e)
+#pragma unroll
+    for (int f = 0; f < 4; ++f) acc[e][f] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  f32x4 bsum = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  const int m_begin = ms * w.rows_per_split;
+  int m_end = m_begin + w.rows_per_split;
+  if (m_end > p.M) m_end = p.M;
+  for (int m0 = m_begin; m0 < m_end; m0 += 4) {
+    const int m = m0 + kk;
+    const bool rv = m < m_end;
+    const int mc = rv ? m : m_begin;
+    const int x = mc % p.gw;
+    const int y = (mc / p.gw) % p.gh;
+    const int f = mc / (p.gw * p.gh);
+    const int tex = conv_tap_texel<MODE>(p, f, y, x, tap);
+    const size_t tx = tex >= 0 ? (size_t)tex : 0;
+    f32x4 av = *reinterpret_cast<const f32x4*>(asrc + tx * ald);              // unconditional, clamped address
+    if (!(rv && a_ok && tex >= 0)) av = (f32x4){0.f, 0.f, 0.f, 0.f};
+    size_t otex = (size_t)mc;
+    if (MODE == NLT_DECONV_K2S2) otex = ((size_t)f * p.oh + 2 * y + (ab >> 1)) * p.ow + 2 * x + (ab & 1);
+    f32x4 bv = *reinterpret_cast<const f32x4*>(w.dp + otex * w.ldp + oc);
+    if (!(rv && b_ok)) bv = (f32x4){0.f, 0.f, 0.f, 0.f};
+    bsum += bv;
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+#pragma unroll
+      for (int f4 = 0; f4 < 4; ++f4)
+        acc[e][f4] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[e], bv[f4], acc[e][f4], 0, 0, 0);
+  }
+
+  // partial block -> workspace [ms][kb][nb][e][f][lane] (f32x4 = the 4 D rows this lane holds)
+  f32x4* dst = reinterpret_cast<f32x4*>(w.ws) + ((((size_t)ms * w.kblocks + kb) * w.nblocks + nb) * 16) * 64 + lane;
+#pragma unroll
+  for (int e = 0; e < 4; ++e)
+#pragma unroll
+    for (int f = 0; f < 4; ++f) dst[(e * 4 + f) * 64] = acc[e][f];
+  if (w.wsb && kb == 0) {                                                       // column sums of dP for the bias
+#pragma unroll
+    for (int f = 0; f < 4; ++f) {
+      bsum[f] += __shfl_xor(bsum[f], 16);
+      bsum[f] += __shfl_xor(bsum[f], 32);
+    }
+    if (kk == 0) reinterpret_cast<f32x4*>(w.wsb)[((size_t)ms * w.nblocks + nb) * 16 + i] = bsum;
+  }
+}
+
+// Pass 2: one thread per dW element of the block layout; adds the row slices in slice order.
+template <int MODE>
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(WT w) {
+  const ConvP& p = w.c;
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long per_slice = (long)w.kblocks * w.nblocks * 4096;
+  if (idx >= per_slice) return;
+  const int r = idx & 3, lane = (idx >> 2) & 63, ef = (idx >> 8) & 15;
+  const long blk = idx >> 12;
+  const int nb = blk % w.nblocks, kb = blk / w.nblocks;
+  const int kq = kb * 16 + 4 * (lane >> 4) + r;         // D row = k-quad inside the block
+  const int nq = nb * 16 + (lane & 15);                 // D col = n-quad
+  if (kq >= w.kq || nq >= w.nq) return;
+  float s = 0.f;
+  for (int ms = 0; ms < w.msplits; ++ms) s += w.ws[(size_t)ms * per_slice + idx];
+  const int qpt = (p.c0 + p.c1) >> 2;
+  const int tap = kq / qpt;
+  const int c = 4 * (kq - tap * qpt) + (ef >> 2);
+  const int ncol = 4 * nq + (ef & 3);
+  w.dw[keras_widx<MODE>(tap, c, ncol, p.c0 + p.c1, p.cout)] += s;
+}
+
+template <int MODE>
+__global__ __launch_bounds__(256) void wgrad_bias_reduce_kernel(WT w) {
+  const ConvP& p = w.c;
+  const int oc = blockIdx.x * blockDim.x + threadIdx.x;
+  if (oc >= p.cout) return;
+  float s = 0.f;
+  const int nab = MODE == NLT_DECONV_K2S2 ? 4 : 1;
+  for (int ab = 0; ab < nab; ++ab) {
+    const int ncol = ab * p.cout + oc;
+    const int nq = ncol >> 2, f = ncol & 3;
+    for (int ms = 0; ms < w.msplits; ++ms) s += w.wsb[(((size_t)ms * w.nblocks + nq / 16) * 16 + nq % 16) * 4 + f];
+  }
+  w.db[oc] += s;
+}
+
+bool fill(WT& w, int mode, long* ws_floats) {
+  const ConvP& p = w.c;
+  const int taps = (mode == NLT_CONV1X1 || mode == NLT_DECONV_K2S2) ? 1 : 4;
+  w.kq = taps * ((p.c0 + p.c1) >> 2);
+  w.nq = p.N >> 2;
+  w.kblocks = (w.kq + 15) / 16;
+  w.nblocks = (w.nq + 15) / 16;
+  long want = 4096 / ((long)w.kblocks * w.nblocks);          // ~4 waves per SIMD
+  if (want < 1) want = 1;
+  long rows = (p.M + want - 1) / want;
+  if (rows < 64) rows = 64;
+  rows = (rows + 3) & ~3L;
+  w.msplits = (int)((p.M + rows - 1) / rows);
+  w.rows_per_split = (int)rows;
+  *ws_floats = (long)w.msplits * w.kblocks * w.nblocks * 4096 + (long)w.msplits * w.nblocks * 64;
+  return true;
+}
+
+template <int MODE>
+int run(WT& w, hipStream_t s) {
+  const long waves = (long)w.kblocks * w.nblocks * w.msplits;
+  hipLaunchKernelGGL(wgrad_tile_kernel<MODE>, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, s, w);
+  const long items = (long)w.kblocks * w.nblocks * 4096;
+  hipLaunchKernelGGL(wgrad_reduce_kernel<MODE>, dim3((unsigned)((items + 255) / 256)), dim3(256), 0, s, w);
+  if (w.db) hipLaunchKernelGGL(wgrad_bias_reduce_kernel<MODE>, dim3((unsigned)((w.c.cout + 255) / 256)), dim3(256), 0, s, w);
+  NLT_CHECK_LAUNCH();
+  return NLT_OK;
+}
+
+int prepare(WT& w, int mode, const float* src0, int ld0, int c0, const float* src1, int ld1, int c1, int n, int h, int wd,
+            const float* dpre, int ldp, int cout, float* dw, float* db, long* ws_floats) {
+  float* dummy = dw ? dw : reinterpret_cast<float*>(16);
+  const float* d0 = src0 ? src0 : dummy;
+  const int st = nlt_fill_conv_params(w.c, mode, d0, ld0, c0, c1 ? (src1 ? src1 : dummy) : nullptr, ld1, c1, n, h, wd, dummy, dummy,
+                                      cout, dummy, cout, 0, 0.f, nullptr, 0, 0);
+  if (st != NLT_OK) return st;
+  if ((c0 & 3) || (c1 & 3) || (cout & 3) || (ld0 & 3) || (c1 && (ld1 & 3)) || (ldp & 3) || ldp < cout) return NLT_ERR_UNSUPPORTED;
+  w.dp = dpre; w.ldp = ldp; w.dw = dw; w.db = db;
+  fill(w, mode, ws_floats);
+  return NLT_OK;
+}
+
+}  // namespace
+
+extern "C" long nlt_wgrad_workspace_floats(int mode, int c0, int c1, int n, int h, int w, int cout) {
+  WT t;
+  long need = -1;
+  if (prepare(t, mode, nullptr, c0 > 4 ? c0 : 4, c0, nullptr, c1 > 4 ? c1 : 4, c1, n, h, w, nullptr, cout, cout, nullptr, nullptr, &need) != NLT_OK)
+    return -1;
+  return need;
+}
+
+extern "C" int nlt_conv_backward_weights_tiled(int mode,
+                                               const float* src0, int ld0, int c0, const float* src1, int ld1, int c1,
+                                               int n, int h, int w, const float* dpre, int ldp, int cout,
+                                               float* dw_keras, float* dbias, float* workspace, long workspace_floats,
+                                               void* stream) {
+  if (!src0 || !dpre || !dw_keras || !workspace) return NLT_ERR_BAD_ARG;
+  if (c1 > 0 && !src1) return NLT_ERR_BAD_ARG;
+  WT t;
+  long need = 0;
+  const int st = prepare(t, mode, src0, ld0, c0, src1, ld1, c1, n, h, w, dpre, ldp, cout, dw_keras, dbias, &need);
+  if (st != NLT_OK) return st;
+  if (workspace_floats < need) return NLT_ERR_BAD_ARG;
+  if (!nlt_aligned16(src0) || (c1 && !nlt_aligned16(src1)) || !nlt_aligned16(dpre) || !nlt_aligned16(workspace)) return NLT_ERR_BAD_ARG;
+  t.ws = workspace;
+  t.wsb = dbias ? workspace + (long)t.msplits * t.kblocks * t.nblocks * 4096 : nullptr;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  switch (mode) {
+    case NLT_CONV1X1: return run<NLT_CONV1X1>(t, s);
+    case NLT_CONV_K2S2: return run<NLT_CONV_K2S2>(t, s);
+    case NLT_CONV_K2S1: return run<NLT_CONV_K2S1>(t, s);
+    case NLT_DECONV_K2S2: return run<NLT_DECONV_K2S2>(t, s);
+    case NLT_DECONV_K2S1: return run<NLT_DECONV_K2S1>(t, s);
+  }
+  return NLT_ERR_BAD_ARG;
+}

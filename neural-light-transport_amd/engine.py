@@ -56,6 +56,7 @@ class RenderPlan:
         self.autotune = os.environ.get('NLT_AUTOTUNE', '1') != '0'
         self.fuse_ends = os.environ.get('NLT_FUSED', '1') != '0'   # inference: csrc/fused.hip for layers 0-1 and the last block + head
         self._front_blob = None
+        self.wgrad_tiled = os.environ.get('NLT_WGRAD', 'tiled') != 'atomic'   # csrc/wgrad_tile.hip vs first-generation csrc/wgrad.hip
         self._trial_direct = False
         self._ran_direct = set()
         self._trial_lds = 0             # autotune: try the LDS-tiled kernel with this many output channels per workgroup
@@ -423,7 +424,10 @@ class RenderPlan:
     def _wgrad(self, label, layer, src0, c0, ld0, src1, c1, ld1, n, h, w, dpre, ldp):
         oh, ow = layer.out_hw(h, w)
         nbytes = 4 * (n * h * w * (c0 + c1) + n * oh * ow * layer.n_ch_out)
-        self._launch(label, nbytes, C.conv_backward_weights, layer.mode, src0, c0, ld0, src1, c1, ld1, n, h, w,
+        tiled = (self.wgrad_tiled and c0 % 4 == 0 and c1 % 4 == 0 and layer.n_ch_out % 4 == 0 and ld0 % 4 == 0
+                 and (c1 == 0 or ld1 % 4 == 0) and ldp % 4 == 0)
+        fn = C.conv_backward_weights_tiled if tiled else C.conv_backward_weights
+        self._launch(label, nbytes, fn, layer.mode, src0, c0, ld0, src1, c1, ld1, n, h, w,
                      dpre, ldp, layer.n_ch_out, layer.dkernel, layer.dbias)
 
     def _dgrad(self, label, layer, lo, hi, dpre, ldp, n, oh, ow, out, ldo, mask_src=None, ldm=0, mask_alpha=0.3,

@@ -350,3 +350,15 @@ def install(monkeypatch):
 def conv_forward_splitk(mode, ksplit, src0, c0, ld0, src1, c1, ld1, n, h, w, w_packed, bias, cout, out, ldo,
                         act=True, alpha=0.3, tile_hint=0, mask_src=None, ldm=0, accumulate=False):
     raise AssertionError("split-K is a GPU-only plan choice; the CPU emulation never selects it")
+
+
+def conv_backward_weights_tiled(mode, src0, c0, ld0, src1, c1, ld1, n, h, w, dpre, ldp, cout, dw, db):
+    conv_backward_weights(mode, src0, c0, ld0, src1, c1, ld1, n, h, w, dpre, ldp, cout, dw, db)
+
+
+_install_tile2 = install
+
+
+def install(monkeypatch):
+    _install_tile2(monkeypatch)
+    monkeypatch.setattr(C, 'conv_backward_weights_tiled', conv_backward_weights_tiled)

@@ -30,8 +30,11 @@ def wgrad_case(mode, n, h, w, c0, c1, cout, algo, pad0=0, pad1=0, padp=0, seed=0
     dp = rng.standard_normal((n, oh, ow, cout + padp)).astype(np.float32)
     gw, gb = torch.autograd.grad(y, (wz, bz), torch.tensor(dp[..., :cout]))
     dw = torch.zeros(wshape, device='cuda'); db = torch.zeros(cout, device='cuda')
-    C.conv_backward_weights(mode, d(x0), c0, c0 + pad0, d(x1), c1, c1 + pad1, n, h, w, d(dp), cout + padp, cout, dw, db,
-                            algo=algo)
+    if algo == 'tiled':
+        C.conv_backward_weights_tiled(mode, d(x0), c0, c0 + pad0, d(x1), c1, c1 + pad1, n, h, w, d(dp), cout + padp, cout, dw, db)
+    else:
+        C.conv_backward_weights(mode, d(x0), c0, c0 + pad0, d(x1), c1, c1 + pad1, n, h, w, d(dp), cout + padp, cout, dw, db,
+                                algo=algo)
     torch.cuda.synchronize()
     sw, sb = max(gw.abs().max().item(), 1.0), max(gb.abs().max().item(), 1.0)
     np.testing.assert_allclose(dw.cpu().numpy(), gw.numpy(), atol=3e-5 * sw)
@@ -39,20 +42,42 @@ def wgrad_case(mode, n, h, w, c0, c1, cout, algo, pad0=0, pad1=0, padp=0, seed=0
 
 
 @pytest.mark.parametrize('mode', list(MODES))
-@pytest.mark.parametrize('algo', [C.ALGO_DIRECT, C.ALGO_MFMA])
+@pytest.mark.parametrize('algo', [C.ALGO_DIRECT, C.ALGO_MFMA, 'tiled'])
 def test_wgrad_modes(mode, algo):
     wgrad_case(mode, 2, 6, 10, 16, 0, 16, algo, seed=mode)
 
 
 @pytest.mark.parametrize('mode', list(MODES))
-def test_wgrad_mfma_dual_source_slices_ragged(mode):
-    wgrad_case(mode, 3, 6, 10, 24, 40, 48, C.ALGO_MFMA, pad0=8, pad1=4, padp=16, seed=10 + mode)
+@pytest.mark.parametrize('algo', [C.ALGO_MFMA, 'tiled'])
+def test_wgrad_mfma_dual_source_slices_ragged(mode, algo):
+    wgrad_case(mode, 3, 6, 10, 24, 40, 48, algo, pad0=8, pad1=4, padp=16, seed=10 + mode)
 
 
 @pytest.mark.parametrize('mode,c0,c1,cout', [(C.DECONV_K2S2, 8, 32, 4), (C.DECONV_K2S1, 4, 0, 4), (C.CONV_K2S2, 512, 0, 256),
                                              (C.DECONV_K2S2, 512, 512, 128), (C.CONV1X1, 4, 32, 12)])
-def test_wgrad_mfma_shapes(mode, c0, c1, cout):
-    wgrad_case(mode, 2, 4, 4, c0, c1, cout, C.ALGO_MFMA, seed=20)
+@pytest.mark.parametrize('algo', [C.ALGO_MFMA, 'tiled'])
+def test_wgrad_mfma_shapes(mode, c0, c1, cout, algo):
+    wgrad_case(mode, 2, 4, 4, c0, c1, cout, algo, seed=20)
+
+
+def test_wgrad_tiled_many_row_slices_is_deterministic_and_accumulates():
+    # 2*64*96 = 12288 rows -> hundreds of row slices through the workspace
+    wgrad_case(C.CONV_K2S1, 2, 64, 96, 16, 0, 16, 'tiled', seed=40)
+    wgrad_case(C.DECONV_K2S2, 2, 48, 32, 8, 32, 4, 'tiled', padp=4, seed=41)
+    x = torch.randn(2, 40, 40, 32, device='cuda'); dp = torch.randn(2, 40, 40, 32, device='cuda')
+    outs = []
+    for _ in range(2):
+        dw = torch.ones(2, 2, 32, 32, device='cuda'); db = torch.ones(32, device='cuda')
+        C.conv_backward_weights_tiled(C.CONV_K2S1, x, 32, 32, None, 0, 0, 2, 40, 40, dp, 32, 32, dw, db)
+        outs.append((dw.cpu().numpy(), db.cpu().numpy()))
+    assert np.array_equal(outs[0][0], outs[1][0]) and np.array_equal(outs[0][1], outs[1][1])     # bit-identical run to run
+    dw0 = torch.zeros(2, 2, 32, 32, device='cuda'); db0 = torch.zeros(32, device='cuda')
+    C.conv_backward_weights_tiled(C.CONV_K2S1, x, 32, 32, None, 0, 0, 2, 40, 40, dp, 32, 32, dw0, db0)
+    np.testing.assert_allclose(outs[0][0] - 1, dw0.cpu().numpy(), atol=2e-4)
+    with pytest.raises(C.NLTError):                      # 5 input channels: not a multiple of 4 -> first-generation direct path only
+        C.conv_backward_weights_tiled(C.CONV1X1, torch.zeros(1, 4, 4, 5, device='cuda'), 5, 5, None, 0, 0, 1, 4, 4,
+                                      torch.zeros(1, 4, 4, 16, device='cuda'), 16, 16, torch.zeros(1, 1, 5, 16, device='cuda'),
+                                      torch.zeros(16, device='cuda'))
 
 
 def test_wgrad_direct_odd_channels_and_accumulation():

@@ -116,3 +116,119 @@ def test_wgrad_kernel_index_math(mode, n, h, w, c0, c1, cout, KT, NT, rows):
                            dp.reshape(-1), cout + padp, cout, KT, NT, rows)
     np.testing.assert_allclose(dw.reshape(wshape), gw.numpy(), atol=1e-4)
     np.testing.assert_allclose(db, gb.numpy(), atol=1e-4)
+
+
+# ---------------------------------------------------------------------------------------------------------
+# second generation: csrc/wgrad_tile.hip (quad-permuted operands, workspace slices, deterministic reduce)
+# ---------------------------------------------------------------------------------------------------------
+def emulate_wgrad_tiled(mode, src0, ld0, c0, src1, ld1, c1, n, h, w, dp, ldp, cout, rows_per_split):
+    gh, gw, oh, ow, N = h, w, h, w, cout
+    if mode == CONV_K2S2:
+        gh = oh = h // 2; gw = ow = w // 2
+    if mode == DECONV_K2S2:
+        oh, ow, N = 2 * h, 2 * w, 4 * cout
+    M = n * gh * gw
+    cin = c0 + c1
+    q0, qpt = c0 >> 2, cin >> 2
+    KQ, NQ = TAPS[mode] * qpt, N >> 2
+    kblocks, nblocks = -(-KQ // 16), -(-NQ // 16)
+    msplits = -(-M // rows_per_split)
+    per_slice = kblocks * nblocks * 4096
+    ws = np.zeros(msplits * per_slice, np.float32)
+    wsb = np.zeros(msplits * nblocks * 64, np.float32)
+    lane = np.arange(64); I, KKl = lane & 15, lane >> 4
+    for wave in range(kblocks * nblocks * msplits):
+        ms = wave % msplits; rest = wave // msplits
+        nb, kb = rest % nblocks, rest // nblocks
+        kq = kb * 16 + I
+        a_ok = kq < KQ
+        tap = np.where(a_ok, kq // qpt, 0); cq = np.where(a_ok, kq - tap * qpt, 0)
+        from1 = cq >= q0
+        nq = nb * 16 + I
+        b_ok = nq < NQ
+        ncol = np.where(b_ok, 4 * nq, 0)
+        ab = ncol // cout if mode == DECONV_K2S2 else np.zeros(64, int)
+        oc = ncol - ab * cout if mode == DECONV_K2S2 else ncol
+        acc = np.zeros((4, 4, 64, 4), np.float32)
+        bsum = np.zeros((64, 4), np.float32)
+        m_begin = ms * rows_per_split; m_end = min(m_begin + rows_per_split, M)
+        for m0 in range(m_begin, m_end, 4):
+            av = np.zeros((64, 4), np.float32); bv = np.zeros((64, 4), np.float32)
+            for l in range(64):
+                m = m0 + KKl[l]
+                rv = m < m_end
+                mc = m if rv else m_begin
+                x, y, f = mc % gw, (mc // gw) % gh, mc // (gw * gh)
+                tex = tap_texel(mode, h, w, f, y, x, int(tap[l]))
+                if rv and a_ok[l] and tex >= 0:
+                    base = (src1, tex * ld1 + 4 * (cq[l] - q0)) if from1[l] else (src0, tex * ld0 + 4 * cq[l])
+                    av[l] = base[0][base[1]:base[1] + 4]
+                otex = mc if mode != DECONV_K2S2 else (f * oh + 2 * y + (ab[l] >> 1)) * ow + 2 * x + (ab[l] & 1)
+                if rv and b_ok[l]:
+                    bv[l] = dp[otex * ldp + oc[l]: otex * ldp + oc[l] + 4]
+            bsum += bv
+            for e in range(4):
+                for f4 in range(4):
+                    mfma(av[:, e], bv[:, f4], acc[e, f4])
+        base = ((ms * kblocks + kb) * nblocks + nb) * 16
+        for e in range(4):
+            for f4 in range(4):
+                for l in range(64):
+                    a0 = ((base + e * 4 + f4) * 64 + l) * 4
+                    ws[a0:a0 + 4] = acc[e, f4, l]
+        if kb == 0:
+            for i in range(16):
+                tot = bsum[i] + bsum[i + 16] + bsum[i + 32] + bsum[i + 48]
+                a0 = ((ms * nblocks + nb) * 16 + i) * 4
+                wsb[a0:a0 + 4] = tot
+    dw = np.zeros(TAPS[mode] * cin * N, np.float64)
+    for idx in range(per_slice):
+        r, l, ef = idx & 3, (idx >> 2) & 63, (idx >> 8) & 15
+        blk = idx >> 12
+        nb, kb = blk % nblocks, blk // nblocks
+        kq = kb * 16 + 4 * (l >> 4) + r; nq = nb * 16 + (l & 15)
+        if kq >= KQ or nq >= NQ:
+            continue
+        s = sum(ws[ms * per_slice + idx] for ms in range(msplits))
+        tap = kq // qpt
+        c = 4 * (kq - tap * qpt) + (ef >> 2)
+        dw[keras_widx(mode, tap, c, 4 * nq + (ef & 3), cin, cout)] += s
+    db = np.zeros(cout, np.float64)
+    for oc in range(cout):
+        for ab in range(4 if mode == DECONV_K2S2 else 1):
+            nc = ab * cout + oc
+            nq, f = nc >> 2, nc & 3
+            for ms in range(msplits):
+                db[oc] += wsb[((ms * nblocks + nq // 16) * 16 + nq % 16) * 4 + f]
+    return dw, db
+
+
+@pytest.mark.parametrize('mode,n,h,w,c0,c1,cout,rows', [
+    (CONV1X1, 1, 3, 5, 16, 0, 16, 8),
+    (CONV_K2S2, 1, 4, 6, 8, 4, 32, 4),
+    (CONV_K2S1, 2, 3, 3, 16, 0, 16, 12),
+    (DECONV_K2S2, 1, 2, 3, 8, 32, 4, 4),
+    (DECONV_K2S2, 1, 3, 2, 16, 0, 20, 8),           # 80 columns -> 20 n-quads: two n-blocks, the second ragged
+    (DECONV_K2S1, 1, 3, 4, 4, 0, 4, 64),
+    (CONV_K2S1, 1, 2, 3, 72, 0, 8, 4),              # 4 taps x 18 quads = 72 k-quads: 5 k-blocks
+])
+def test_wgrad_tiled_kernel_index_math(mode, n, h, w, c0, c1, cout, rows):
+    rng = np.random.default_rng(mode * 7 + cout)
+    tr = mode in (DECONV_K2S2, DECONV_K2S1)
+    k = 1 if mode == CONV1X1 else 2
+    s = 2 if mode in (CONV_K2S2, DECONV_K2S2) else 1
+    cin = c0 + c1
+    pad0, pad1, padp = 4, 8, 4
+    x0 = rng.standard_normal((n, h, w, c0 + pad0)).astype(np.float32)
+    x1 = rng.standard_normal((n, h, w, c1 + pad1)).astype(np.float32)
+    x = np.concatenate((x0[..., :c0], x1[..., :c1]), -1) if c1 else x0[..., :c0]
+    wshape = (k, k, cout, cin) if tr else (k, k, cin, cout)
+    wz = torch.zeros(wshape, requires_grad=True); bz = torch.zeros(cout, requires_grad=True)
+    f = T.conv2d_transpose_same if tr else T.conv2d_same
+    y = f(torch.tensor(x), wz, bz, s)
+    dp = rng.standard_normal(tuple(y.shape[:3]) + (cout + padp,)).astype(np.float32)
+    gw, gb = torch.autograd.grad(y, (wz, bz), torch.tensor(dp[..., :cout]))
+    dw, db = emulate_wgrad_tiled(mode, x0.reshape(-1), c0 + pad0, c0, x1.reshape(-1), c1 + pad1, c1, n, h, w,
+                                 dp.reshape(-1), cout + padp, cout, rows)
+    np.testing.assert_allclose(dw.reshape(wshape), gw.numpy(), atol=1e-4)
+    np.testing.assert_allclose(db, gb.numpy(), atol=1e-4)
