@@ -32,13 +32,13 @@ struct WT {
 
 template <int MODE>
 __global__ __launch_bounds__(256) void wgrad_tile_kernel(WT w) {
+  __shared__ __attribute__((aligned(16))) f32x4 part[3][17][64];      // waves 1..3 -> wave 0 (16 blocks + bias sums)
   const ConvP& p = w.c;
-  const int lane = threadIdx.x & 63;
-  int wave = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (wave >= w.kblocks * w.nblocks * w.msplits) return;
-  const int ms = wave % w.msplits; wave /= w.msplits;
-  const int nb = wave % w.nblocks;
-  const int kb = wave / w.nblocks;
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  int blk = blockIdx.x;                                              // one workgroup = one (row slice, kb, nb)
+  const int ms = blk % w.msplits; blk /= w.msplits;
+  const int nb = blk % w.nblocks;
+  const int kb = blk / w.nblocks;
   const int i = lane & 15, kk = lane >> 4;
   const int q0 = p.c0 >> 2, qpt = (p.c0 + p.c1) >> 2;
 
@@ -64,10 +64,11 @@ __global__ __launch_bounds__(256) void wgrad_tile_kernel(WT w) {
     for (int f = 0; f < 4; ++f) acc[e][f] = (f32x4){0.f, 0.f, 0.f, 0.f};
   f32x4 bsum = (f32x4){0.f, 0.f, 0.f, 0.f};
 
+  // the slice's rows are dealt to the 4 waves in steps of 4 rows (wave wv takes steps wv, wv + 4, ...)
   const int m_begin = ms * w.rows_per_split;
   int m_end = m_begin + w.rows_per_split;
   if (m_end > p.M) m_end = p.M;
-  for (int m0 = m_begin; m0 < m_end; m0 += 4) {
+  for (int m0 = m_begin + 4 * wv; m0 < m_end; m0 += 16) {
     const int m = m0 + kk;
     const bool rv = m < m_end;
     const int mc = rv ? m : m_begin;
@@ -90,7 +91,25 @@ __global__ __launch_bounds__(256) void wgrad_tile_kernel(WT w) {
         acc[e][f4] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[e], bv[f4], acc[e][f4], 0, 0, 0);
   }
 
-  // partial block -> workspace [ms][kb][nb][e][f][lane] (f32x4 = the 4 D rows this lane holds)
+  // the 4 waves' partial blocks are added in wave order (fixed -> deterministic) through LDS ...
+  if (wv > 0) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+#pragma unroll
+      for (int f = 0; f < 4; ++f) part[wv - 1][e * 4 + f][lane] = acc[e][f];
+    part[wv - 1][16][lane] = bsum;
+  }
+  __syncthreads();
+  if (wv > 0) return;
+#pragma unroll
+  for (int o = 0; o < 3; ++o) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+#pragma unroll
+      for (int f = 0; f < 4; ++f) acc[e][f] += part[o][e * 4 + f][lane];
+    bsum += part[o][16][lane];
+  }
+  // ... and the slice's block goes to the workspace [ms][kb][nb][e][f][lane] (f32x4 = the 4 D rows this lane holds)
   f32x4* dst = reinterpret_cast<f32x4*>(w.ws) + ((((size_t)ms * w.kblocks + kb) * w.nblocks + nb) * 16) * 64 + lane;
 #pragma unroll
   for (int e = 0; e < 4; ++e)
@@ -106,21 +125,34 @@ __global__ __launch_bounds__(256) void wgrad_tile_kernel(WT w) {
   }
 }
 
-// Pass 2: one thread per dW element of the block layout; adds the row slices in slice order.
+// Pass 2: 64 dW elements of the block layout per workgroup; the slices are dealt to 4 waves x 4 running sums (16
+// independent load streams per element) and combined in a fixed order.
 template <int MODE>
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(WT w) {
+  __shared__ float part[4][64];
   const ConvP& p = w.c;
-  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const int lane = threadIdx.x & 63, g = threadIdx.x >> 6;
   const long per_slice = (long)w.kblocks * w.nblocks * 4096;
-  if (idx >= per_slice) return;
-  const int r = idx & 3, lane = (idx >> 2) & 63, ef = (idx >> 8) & 15;
+  const long idx = (long)blockIdx.x * 64 + lane;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  int ms = g;
+  for (; ms + 12 < w.msplits; ms += 16) {
+    s0 += w.ws[(size_t)ms * per_slice + idx];
+    s1 += w.ws[(size_t)(ms + 4) * per_slice + idx];
+    s2 += w.ws[(size_t)(ms + 8) * per_slice + idx];
+    s3 += w.ws[(size_t)(ms + 12) * per_slice + idx];
+  }
+  for (; ms < w.msplits; ms += 4) s0 += w.ws[(size_t)ms * per_slice + idx];
+  part[g][lane] = (s0 + s1) + (s2 + s3);
+  __syncthreads();
+  if (g) return;
+  const float s = (part[0][lane] + part[1][lane]) + (part[2][lane] + part[3][lane]);
+  const int r = idx & 3, ln = (idx >> 2) & 63, ef = (idx >> 8) & 15;
   const long blk = idx >> 12;
   const int nb = blk % w.nblocks, kb = blk / w.nblocks;
-  const int kq = kb * 16 + 4 * (lane >> 4) + r;         // D row = k-quad inside the block
-  const int nq = nb * 16 + (lane & 15);                 // D col = n-quad
+  const int kq = kb * 16 + 4 * (ln >> 4) + r;           // D row = k-quad inside the block
+  const int nq = nb * 16 + (ln & 15);                   // D col = n-quad
   if (kq >= w.kq || nq >= w.nq) return;
-  float s = 0.f;
-  for (int ms = 0; ms < w.msplits; ++ms) s += w.ws[(size_t)ms * per_slice + idx];
   const int qpt = (p.c0 + p.c1) >> 2;
   const int tap = kq / qpt;
   const int c = 4 * (kq - tap * qpt) + (ef >> 2);
@@ -150,11 +182,11 @@ bool fill(WT& w, int mode, long* ws_floats) {
   w.nq = p.N >> 2;
   w.kblocks = (w.kq + 15) / 16;
   w.nblocks = (w.nq + 15) / 16;
-  long want = 4096 / ((long)w.kblocks * w.nblocks);          // ~4 waves per SIMD
+  long want = 1024 / ((long)w.kblocks * w.nblocks);          // ~4 workgroups (16 waves) per CU
   if (want < 1) want = 1;
   long rows = (p.M + want - 1) / want;
-  if (rows < 64) rows = 64;
-  rows = (rows + 3) & ~3L;
+  if (rows < 256) rows = 256;                                 // >= 16 MFMA steps per wave
+  rows = (rows + 15) & ~15L;
   w.msplits = (int)((p.M + rows - 1) / rows);
   w.rows_per_split = (int)rows;
   *ws_floats = (long)w.msplits * w.kblocks * w.nblocks * 4096 + (long)w.msplits * w.nblocks * 64;
@@ -163,10 +195,10 @@ bool fill(WT& w, int mode, long* ws_floats) {
 
 template <int MODE>
 int run(WT& w, hipStream_t s) {
-  const long waves = (long)w.kblocks * w.nblocks * w.msplits;
-  hipLaunchKernelGGL(wgrad_tile_kernel<MODE>, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, s, w);
+  const long groups = (long)w.kblocks * w.nblocks * w.msplits;
+  hipLaunchKernelGGL(wgrad_tile_kernel<MODE>, dim3((unsigned)groups), dim3(256), 0, s, w);
   const long items = (long)w.kblocks * w.nblocks * 4096;
-  hipLaunchKernelGGL(wgrad_reduce_kernel<MODE>, dim3((unsigned)((items + 255) / 256)), dim3(256), 0, s, w);
+  hipLaunchKernelGGL(wgrad_reduce_kernel<MODE>, dim3((unsigned)(items / 64)), dim3(256), 0, s, w);
   if (w.db) hipLaunchKernelGGL(wgrad_bias_reduce_kernel<MODE>, dim3((unsigned)((w.c.cout + 255) / 256)), dim3(256), 0, s, w);
   NLT_CHECK_LAUNCH();
   return NLT_OK;
