@@ -64,31 +64,56 @@ __global__ __launch_bounds__(256) void wgrad_tile_kernel(WT w) {
     for (int f = 0; f < 4; ++f) acc[e][f] = (f32x4){0.f, 0.f, 0.f, 0.f};
   f32x4 bsum = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-  // the slice's rows are dealt to the 4 waves in steps of 4 rows (wave wv takes steps wv, wv + 4, ...)
+  // The slice's rows are dealt to the 4 waves in steps of 4 rows (wave wv takes steps wv, wv + 4, ...).  Operand
+  // loads run two steps ahead of the MFMAs (three register sets), and the (frame, y, x) of a lane's row is advanced
+  // incrementally instead of being re-derived by integer division every step.
   const int m_begin = ms * w.rows_per_split;
   int m_end = m_begin + w.rows_per_split;
   if (m_end > p.M) m_end = p.M;
-  for (int m0 = m_begin + 4 * wv; m0 < m_end; m0 += 16) {
-    const int m = m0 + kk;
+  int m = m_begin + 4 * wv + kk;                                   // this lane's row of the NEXT step to be loaded
+  int rx, ry, rf;
+  {
+    const int mc = m < p.M ? m : p.M - 1;
+    rx = mc % p.gw; ry = (mc / p.gw) % p.gh; rf = mc / (p.gw * p.gh);
+  }
+  auto issue = [&](f32x4& av, f32x4& bv) {
     const bool rv = m < m_end;
-    const int mc = rv ? m : m_begin;
-    const int x = mc % p.gw;
-    const int y = (mc / p.gw) % p.gh;
-    const int f = mc / (p.gw * p.gh);
-    const int tex = conv_tap_texel<MODE>(p, f, y, x, tap);
-    const size_t tx = tex >= 0 ? (size_t)tex : 0;
-    f32x4 av = *reinterpret_cast<const f32x4*>(asrc + tx * ald);              // unconditional, clamped address
+    const int tex = conv_tap_texel<MODE>(p, rf, ry, rx, tap);
+    const size_t tx = (rv && tex >= 0) ? (size_t)tex : 0;
+    av = *reinterpret_cast<const f32x4*>(asrc + tx * ald);                      // unconditional, clamped address
     if (!(rv && a_ok && tex >= 0)) av = (f32x4){0.f, 0.f, 0.f, 0.f};
-    size_t otex = (size_t)mc;
-    if (MODE == NLT_DECONV_K2S2) otex = ((size_t)f * p.oh + 2 * y + (ab >> 1)) * p.ow + 2 * x + (ab & 1);
-    f32x4 bv = *reinterpret_cast<const f32x4*>(w.dp + otex * w.ldp + oc);
+    size_t otex = rv ? ((size_t)rf * p.gh + ry) * p.gw + rx : 0;
+    if (MODE == NLT_DECONV_K2S2) otex = rv ? ((size_t)rf * p.oh + 2 * ry + (ab >> 1)) * p.ow + 2 * rx + (ab & 1) : 0;
+    bv = *reinterpret_cast<const f32x4*>(w.dp + otex * w.ldp + oc);
     if (!(rv && b_ok)) bv = (f32x4){0.f, 0.f, 0.f, 0.f};
+    m += 16; rx += 16;                                               // the wave's next step is 16 rows further
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {                                    // gw >= 4 (checked by the host): at most 4 wraps, branch-free
+      const bool wx = rx >= p.gw;
+      rx -= wx ? p.gw : 0;
+      ry += wx ? 1 : 0;
+      const bool wy = ry >= p.gh;
+      ry = wy ? 0 : ry;
+      rf += wy ? 1 : 0;
+    }
+  };
+  auto compute = [&](const f32x4& av, const f32x4& bv) {
     bsum += bv;
 #pragma unroll
     for (int e = 0; e < 4; ++e)
 #pragma unroll
       for (int f4 = 0; f4 < 4; ++f4)
         acc[e][f4] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[e], bv[f4], acc[e][f4], 0, 0, 0);
+  };
+  const int first = m_begin + 4 * wv;
+  const int nsteps = first < m_end ? (m_end - first + 15) / 16 : 0;
+  f32x4 a0, b0, a1, b1, a2, b2;
+  issue(a0, b0);
+  issue(a1, b1);
+  for (int s3 = 0; s3 < nsteps; s3 += 3) {                           // steps past nsteps carry zero operands
+    issue(a2, b2); compute(a0, b0);
+    issue(a0, b0); compute(a1, b1);
+    issue(a1, b1); compute(a2, b2);
   }
 
   // the 4 waves' partial blocks are added in wave order (fixed -> deterministic) through LDS ...
@@ -212,6 +237,7 @@ int prepare(WT& w, int mode, const float* src0, int ld0, int c0, const float* sr
                                       cout, dummy, cout, 0, 0.f, nullptr, 0, 0);
   if (st != NLT_OK) return st;
   if ((c0 & 3) || (c1 & 3) || (cout & 3) || (ld0 & 3) || (c1 && (ld1 & 3)) || (ldp & 3) || ldp < cout) return NLT_ERR_UNSUPPORTED;
+  if (w.c.gw < 4) return NLT_ERR_UNSUPPORTED;                      // the incremental row walk assumes >= 4 texels per grid row
   w.dp = dpre; w.ldp = ldp; w.dw = dw; w.db = db;
   fill(w, mode, ws_floats);
   return NLT_OK;

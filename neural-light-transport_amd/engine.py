@@ -424,8 +424,9 @@ class RenderPlan:
     def _wgrad(self, label, layer, src0, c0, ld0, src1, c1, ld1, n, h, w, dpre, ldp):
         oh, ow = layer.out_hw(h, w)
         nbytes = 4 * (n * h * w * (c0 + c1) + n * oh * ow * layer.n_ch_out)
+        gw = w // 2 if layer.mode == C.CONV_K2S2 else w
         tiled = (self.wgrad_tiled and c0 % 4 == 0 and c1 % 4 == 0 and layer.n_ch_out % 4 == 0 and ld0 % 4 == 0
-                 and (c1 == 0 or ld1 % 4 == 0) and ldp % 4 == 0)
+                 and (c1 == 0 or ld1 % 4 == 0) and ldp % 4 == 0 and gw >= 4)
         fn = C.conv_backward_weights_tiled if tiled else C.conv_backward_weights
         self._launch(label, nbytes, fn, layer.mode, src0, c0, ld0, src1, c1, ld1, n, h, w,
                      dpre, ldp, layer.n_ch_out, layer.dkernel, layer.dbias)
