@@ -185,19 +185,30 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(WT w) {
   w.dw[keras_widx<MODE>(tap, c, ncol, p.c0 + p.c1, p.cout)] += s;
 }
 
+// Bias: one workgroup per quad of output channels; 256 threads share the (slice, ab) terms, fixed-order LDS tree.
 template <int MODE>
 __global__ __launch_bounds__(256) void wgrad_bias_reduce_kernel(WT w) {
+  __shared__ f32x4 part[256];
   const ConvP& p = w.c;
-  const int oc = blockIdx.x * blockDim.x + threadIdx.x;
-  if (oc >= p.cout) return;
-  float s = 0.f;
+  const int ocq = blockIdx.x, t = threadIdx.x;
   const int nab = MODE == NLT_DECONV_K2S2 ? 4 : 1;
-  for (int ab = 0; ab < nab; ++ab) {
-    const int ncol = ab * p.cout + oc;
-    const int nq = ncol >> 2, f = ncol & 3;
-    for (int ms = 0; ms < w.msplits; ++ms) s += w.wsb[(((size_t)ms * w.nblocks + nq / 16) * 16 + nq % 16) * 4 + f];
+  const f32x4* wsb4 = reinterpret_cast<const f32x4*>(w.wsb);
+  f32x4 s = (f32x4){0.f, 0.f, 0.f, 0.f};
+  for (int it = t; it < nab * w.msplits; it += 256) {
+    const int ab = it % nab, ms = it / nab;
+    const int nq = ((ab * p.cout) >> 2) + ocq;                       // n-quad of column ab*cout + 4*ocq
+    s += wsb4[((size_t)ms * w.nblocks + nq / 16) * 16 + nq % 16];
   }
-  w.db[oc] += s;
+  part[t] = s;
+  __syncthreads();
+  for (int off = 128; off > 0; off >>= 1) {
+    if (t < off) part[t] += part[t + off];
+    __syncthreads();
+  }
+  if (t == 0) {
+    const f32x4 v = part[0];
+    w.db[4 * ocq] += v[0]; w.db[4 * ocq + 1] += v[1]; w.db[4 * ocq + 2] += v[2]; w.db[4 * ocq + 3] += v[3];
+  }
 }
 
 bool fill(WT& w, int mode, long* ws_floats) {
@@ -224,7 +235,7 @@ int run(WT& w, hipStream_t s) {
   hipLaunchKernelGGL(wgrad_tile_kernel<MODE>, dim3((unsigned)groups), dim3(256), 0, s, w);
   const long items = (long)w.kblocks * w.nblocks * 4096;
   hipLaunchKernelGGL(wgrad_reduce_kernel<MODE>, dim3((unsigned)(items / 64)), dim3(256), 0, s, w);
-  if (w.db) hipLaunchKernelGGL(wgrad_bias_reduce_kernel<MODE>, dim3((unsigned)((w.c.cout + 255) / 256)), dim3(256), 0, s, w);
+  if (w.db) hipLaunchKernelGGL(wgrad_bias_reduce_kernel<MODE>, dim3((unsigned)(w.c.cout / 4)), dim3(256), 0, s, w);
   NLT_CHECK_LAUNCH();
   return NLT_OK;
 }

@@ -194,12 +194,13 @@ def emulate_wgrad_tiled(mode, src0, ld0, c0, src1, ld1, c1, n, h, w, dp, ldp, co
         c = 4 * (kq - tap * qpt) + (ef >> 2)
         dw[keras_widx(mode, tap, c, 4 * nq + (ef & 3), cin, cout)] += s
     db = np.zeros(cout, np.float64)
-    for oc in range(cout):
-        for ab in range(4 if mode == DECONV_K2S2 else 1):
-            nc = ab * cout + oc
-            nq, f = nc >> 2, nc & 3
-            for ms in range(msplits):
-                db[oc] += wsb[((ms * nblocks + nq // 16) * 16 + nq % 16) * 4 + f]
+    nab = 4 if mode == DECONV_K2S2 else 1
+    for ocq in range(cout // 4):                                     # wgrad_bias_reduce_kernel: one workgroup per output quad
+        for it in range(nab * msplits):
+            ab, ms = it % nab, it // nab
+            nq = ((ab * cout) >> 2) + ocq
+            a0 = ((ms * nblocks + nq // 16) * 16 + nq % 16) * 4
+            db[4 * ocq: 4 * ocq + 4] += wsb[a0:a0 + 4]
     return dw, db
 
 
