@@ -306,7 +306,7 @@ def conv_forward_splitk(mode, ksplit, src0, c0, ld0, src1, c1, ld1, n, h, w, w_p
     need = lib().nlt_conv_splitk_workspace_floats(mode, n, h, w, cout, ksplit)
     if need <= 0:
         raise NLTError("nlt_conv_splitk_workspace_floats failed")
-    key = str(src0.device)
+    key = (str(src0.device), _stream())          # per stream: the query and observation paths may run concurrently
     ws = _splitk_ws.get(key)
     if ws is None or ws.numel() < need:
         ws = torch.empty(need, device=src0.device, dtype=torch.float32)

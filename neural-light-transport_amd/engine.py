@@ -56,6 +56,8 @@ class RenderPlan:
         self.autotune = os.environ.get('NLT_AUTOTUNE', '1') != '0'
         self.fuse_ends = os.environ.get('NLT_FUSED', '1') != '0'   # inference: csrc/fused.hip for layers 0-1 and the last block + head
         self._front_blob = None
+        self.two_streams = os.environ.get('NLT_STREAMS', '2') != '1'   # inference: query-path encoder convs on a side stream
+        self._side = None               # (side stream, [events]) created on first use
         self.wgrad_tiled = os.environ.get('NLT_WGRAD', 'tiled') != 'atomic'   # csrc/wgrad_tile.hip vs first-generation csrc/wgrad.hip
         self._trial_direct = False
         self._ran_direct = set()
@@ -377,17 +379,42 @@ class RenderPlan:
         flops = 2 * n * (h // 2) * (w // 2) * ((32 + 64) * 16 + k * (12 + 64) * 16) + 2 * n * h * w * 24
         self._launch('F.front', nbytes, C.front_forward, base, cvis, lvis, nn_rgb, nn_base, n, k, h, w, blob,
                      skip_connect_base, alpha, b['fm'][1], b['obs'][1], b['skip3'], flops=flops, moved=moved)
+        # Levels 2..D.  The observation chain (k frames per frame: three quarters of the encoder's work at k = 4)
+        # never waits for the query path; the query convs of a level only need the previous level's observation mean.
+        # With two HIP streams the small deep-level launches of one path fill the CUs the other leaves idle.
+        concurrent = (self.two_streams and base.is_cuda and (self.timer is None or getattr(self.timer, 'only', None) is not None)
+                      and not self._trial_lds and not self._trial_splitk and not self._trial_direct)
+        if concurrent:
+            if self._side is None:
+                self._side = (torch.cuda.Stream(device=base.device), [torch.cuda.Event() for _ in range(D + 3)])
+            side, ev = self._side
+            main = torch.cuda.current_stream()
+            ev[0].record(main)                                      # front kernel done: fm[1], obs[1]
+            side.wait_event(ev[0])
         hh, ww = h // 2, w // 2
         for l in range(2, D + 1):
             (qa, qact_a), (qb, qact_b) = q.layers[l].convs()
             (oa, oact_a), (ob, oact_b) = o.layers[l].convs()
             cin = 2 * cl[l - 1]
-            self._conv_enc('L%d.q.s2' % l, qa, qact_a, b['fm'][l - 1], cin, cin, n, 1, hh, ww, b['qtmp'][l], cl[l], algo)
             self._conv_enc('L%d.o.s2' % l, oa, oact_a, b['obs'][l - 1], cl[l - 1], cl[l - 1], n, k, hh, ww, b['otmp'][l], cl[l], algo)
-            hh, ww = hh // 2, ww // 2
-            self._conv_enc('L%d.q.s1' % l, qb, qact_b, b['qtmp'][l], cl[l], cl[l], n, 1, hh, ww, b['fm'][l], 2 * cl[l], algo)
-            self._conv_enc('L%d.o.s1' % l, ob, oact_b, b['otmp'][l], cl[l], cl[l], n, k, hh, ww, b['obs'][l], cl[l], algo,
+            self._conv_enc('L%d.o.s1' % l, ob, oact_b, b['otmp'][l], cl[l], cl[l], n, k, hh // 2, ww // 2, b['obs'][l], cl[l], algo,
                            mean_out=b['fm'][l].view(-1)[cl[l]:], ldm=2 * cl[l])
+            if concurrent:
+                ev[l].record(main)                                  # fm[l]'s observation half is complete
+                with torch.cuda.stream(side):
+                    if l > 2:
+                        side.wait_event(ev[l - 1])
+                    self._conv_enc('L%d.q.s2' % l, qa, qact_a, b['fm'][l - 1], cin, cin, n, 1, hh, ww, b['qtmp'][l], cl[l], algo)
+                    self._conv_enc('L%d.q.s1' % l, qb, qact_b, b['qtmp'][l], cl[l], cl[l], n, 1, hh // 2, ww // 2, b['fm'][l],
+                                   2 * cl[l], algo)
+            else:
+                self._conv_enc('L%d.q.s2' % l, qa, qact_a, b['fm'][l - 1], cin, cin, n, 1, hh, ww, b['qtmp'][l], cl[l], algo)
+                self._conv_enc('L%d.q.s1' % l, qb, qact_b, b['qtmp'][l], cl[l], cl[l], n, 1, hh // 2, ww // 2, b['fm'][l],
+                               2 * cl[l], algo)
+            hh, ww = hh // 2, ww // 2
+        if concurrent:
+            ev[D + 1].record(side)
+            main.wait_event(ev[D + 1])                              # the decoder needs both halves of every fm[l]
         x, cx = b['fm'][D], 2 * cl[D]
         for j in range(U - 1):
             (da, dact_a), (db, dact_b) = q.layers[D + 1 + j].convs()

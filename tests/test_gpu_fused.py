@@ -129,3 +129,23 @@ def test_front_weights_are_refolded_after_an_update():
         ref = om2.call(batch, 'test', nn_list=nn)[3]['pred']
     second = pm.call(db, 'test')[3]['pred']
     assert rel_l2(second.cpu(), ref) <= TOL and rel_l2(first.cpu(), ref) > 1e-2
+
+
+def test_fused_vs_layer_by_layer_at_2048():
+    """BASELINE config 5's UV size (2048^2), one frame, k = 1, in fp32: the two forward plans agree and the frame's
+    corner texel is the background sink.  (bf16 storage is not built; this pins the kernels' 32-bit index arithmetic
+    and tiling at the largest listed resolution.)"""
+    import nlt_amd
+    import bench
+    from nlt_amd.models import get_model_class
+    dev = torch.device('cuda', 0)
+    model = get_model_class('nlt')(nlt_amd.make_config(uvh=2048, uvw=2048, imh=512, imw=512)).build(dev)
+    model.plan.autotune = False
+    batch = bench.synth_device_batch(1, 2048, 512, 1, dev, seed=9)
+    a = model.call(batch, 'test')
+    pred_a = a[3]['pred'].clone()
+    model.plan.fuse_ends = False
+    b = model.call(batch, 'test')
+    torch.cuda.synchronize()
+    assert rel_l2(pred_a.cpu(), b[3]['pred'].cpu()) <= 1e-5
+    assert not pred_a[:, 0, 0].any() and torch.isfinite(pred_a).all()

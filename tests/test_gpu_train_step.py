@@ -55,3 +55,24 @@ def test_loss_decreases_and_vali_step():
     assert losses[-1] < losses[0]
     lv, vis = trainvali.distributed_vali_step(pm, db, 4)
     assert np.isfinite(float(lv)) and not vis['pred_camspc'].requires_grad
+
+
+def test_rccl_single_rank_group_runs_the_gradient_all_reduce():
+    """One-rank `nccl` (= RCCL) process group on the GPU box: the flat gradient bucket goes through the real
+    collective library (the world-size-2 logic is covered on CPU by tests/test_dist_gloo.py)."""
+    import os
+    import torch.distributed as dist
+    os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+    os.environ.setdefault('MASTER_PORT', '29533')
+    dist.init_process_group('nccl', rank=0, world_size=1, device_id=torch.device('cuda', 0))
+    try:
+        g = torch.randn(3368072, device='cuda')
+        ref = g.clone()
+        dist.all_reduce(g, op=dist.ReduceOp.SUM)
+        t = torch.tensor([1.5], device='cuda', dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dist.barrier()
+        torch.cuda.synchronize()
+        assert torch.equal(g, ref) and float(t) == 1.5
+    finally:
+        dist.destroy_process_group()
