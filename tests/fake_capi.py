@@ -88,11 +88,6 @@ def mul_forward(a, b):
     return a * b
 
 
-def install(monkeypatch):
-    for name in ('conv_forward', 'pack_conv_weights', 'stem_forward', 'obs_mean_forward', 'head_forward',
-                 'warp_forward', 'resize_bilinear_forward', 'mul_forward'):
-        monkeypatch.setattr(C, name, globals()[name])
-
 
 # ------------------------------------------------------------------ train-step ops (TEST-ONLY emulation)
 from oracle import barron as _B
@@ -206,13 +201,6 @@ def adam_amsgrad_step(param, grad, m, v, vhat, lr_t, beta1, beta2, eps):
 _TRAIN = ('conv_backward_weights', 'lrelu_backward', 'obs_mean_backward', 'stem_backward', 'head_backward',
           'warp_backward', 'resize_bilinear_backward', 'l2_loss_forward', 'l2_loss_backward', 'barron_loss',
           'scale_rows', 'adam_amsgrad_step')
-_install_fwd = install
-
-
-def install(monkeypatch):
-    _install_fwd(monkeypatch)
-    for name in _TRAIN:
-        monkeypatch.setattr(C, name, globals()[name])
 
 
 # ------------------------------------------------------------------ texel-buffer assembly (TEST-ONLY emulation)
@@ -269,13 +257,6 @@ def assemble_batch(diffuse_store, rgb_store, cvis_store, lvis_store, ids, nn_ids
 
 _BUFFERS = ('cosine_map', 'albedo', 'diffuse_base', 'remap_bilinear', 'uv_index_map', 'knn_indices', 'gather_frames_u8',
             'assemble_batch')
-_install_train = install
-
-
-def install(monkeypatch):
-    _install_train(monkeypatch)
-    for name in _BUFFERS:
-        monkeypatch.setattr(C, name, globals()[name])
 
 
 # ------------------------------------------------------------------ fused inference ends (TEST-ONLY emulation)
@@ -308,13 +289,6 @@ def back_forward(x, fm1, skip3, n, h2, w2, w_s2, b_s2, w_s1, b_s1, w_head, alpha
 
 
 _FUSED = ('front_pack_weights', 'front_forward', 'back_forward')
-_install_buffers = install
-
-
-def install(monkeypatch):
-    _install_buffers(monkeypatch)
-    for name in _FUSED:
-        monkeypatch.setattr(C, name, globals()[name])
 
 
 # ------------------------------------------------------------------ LDS-tiled encoder convs (TEST-ONLY emulation)
@@ -338,13 +312,6 @@ def conv_tile_forward(mode, src, ld, cin, frames, kobs, h, w, packed, bias, cout
 
 
 _TILE = ('pack_conv_tile_weights', 'conv_tile_forward')
-_install_fused = install
-
-
-def install(monkeypatch):
-    _install_fused(monkeypatch)
-    for name in _TILE:
-        monkeypatch.setattr(C, name, globals()[name])
 
 
 def conv_forward_splitk(mode, ksplit, src0, c0, ld0, src1, c1, ld1, n, h, w, w_packed, bias, cout, out, ldo,
@@ -356,9 +323,11 @@ def conv_backward_weights_tiled(mode, src0, c0, ld0, src1, c1, ld1, n, h, w, dpr
     conv_backward_weights(mode, src0, c0, ld0, src1, c1, ld1, n, h, w, dpre, ldp, cout, dw, db)
 
 
-_install_tile2 = install
+_FORWARD = ('conv_forward', 'pack_conv_weights', 'stem_forward', 'obs_mean_forward', 'head_forward', 'warp_forward',
+            'resize_bilinear_forward', 'mul_forward')
 
 
 def install(monkeypatch):
-    _install_tile2(monkeypatch)
-    monkeypatch.setattr(C, 'conv_backward_weights_tiled', conv_backward_weights_tiled)
+    """Replaces every Python-level C-ABI adapter of nlt_amd._capi by its CPU emulation above."""
+    for name in _FORWARD + _TRAIN + _BUFFERS + _FUSED + _TILE + ('conv_forward_splitk', 'conv_backward_weights_tiled'):
+        monkeypatch.setattr(C, name, globals()[name])
