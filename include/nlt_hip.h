@@ -347,6 +347,20 @@ int nlt_front_forward(const float* base, const float* cvis, const float* lvis, c
                       const float* nn_base, int n, int k, int h, int w, const float* packed,
                       int add_base, float alpha, float* fm1, float* obs1, float* skip3, void* stream);
 
+/* Front kernel that also runs LEVEL 2's stride-2 convs (k <= 4, h and w multiples of 4): the workgroup's 8 x 16 tile
+ * of level 1 is exactly a 4 x 8 tile of level 2 (k2s2 needs no halo), so the per-observation level-1 maps never leave
+ * the chip.  packed_l2 = nlt_front_pack_l2_weights(query level-2 strided kernel (2,2,32,32), obs (2,2,16,32)).
+ * Outputs: fm1, skip3 as nlt_front_forward; qtmp2 [n,h/4,w/4,32], otmp2 [n,k,h/4,w/4,32] = LeakyReLU(Conv2D k2s2)
+ * of fm1 / of each observation's level-1 map (the inputs of level 2's stride-1 convs).
+ *   replaces, on top of nlt_front_forward: the first Conv2D + LeakyReLU of the third entries of net['query'].layers /
+ *   net['obs'].layers (convnet.py:50-53). */
+long nlt_front_l2_packed_floats(void);
+int nlt_front_pack_l2_weights(const float* wq, const float* bq, const float* wo, const float* bo, float* packed, void* stream);
+int nlt_front2_forward(const float* base, const float* cvis, const float* lvis, const float* nn_rgb,
+                       const float* nn_base, int n, int k, int h, int w, const float* packed,
+                       const float* packed_l2, int add_base, float alpha, float* fm1, float* skip3,
+                       float* qtmp2, float* otmp2, void* stream);
+
 /*
  * Last expanding block + output head: Conv2DTranspose k2s2 (8 + 32 -> 4) + LeakyReLU, Conv2DTranspose k2s1
  * (4 -> 4) + LeakyReLU, 1x1 head on those 4 channels + skip3, texel (0,0) of every frame forced to 0.

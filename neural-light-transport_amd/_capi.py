@@ -57,6 +57,9 @@ SIGNATURES = {
     'nlt_front_packed_floats': (_c_long, []),
     'nlt_front_pack_weights': (_c_int, [_vp] * 15 + [_vp]),
     'nlt_front_forward': (_c_int, [_vp] * 5 + [_c_int] * 4 + [_vp, _c_int, _c_float, _vp, _vp, _vp, _vp]),
+    'nlt_front_l2_packed_floats': (_c_long, []),
+    'nlt_front_pack_l2_weights': (_c_int, [_vp] * 5 + [_vp]),
+    'nlt_front2_forward': (_c_int, [_vp] * 5 + [_c_int] * 4 + [_vp, _vp, _c_int, _c_float, _vp, _vp, _vp, _vp, _vp]),
     'nlt_back_forward': (_c_int, [_vp] * 3 + [_c_int] * 3 + [_vp] * 5 + [_c_float, _vp, _vp]),
     'nlt_conv_splitk_workspace_floats': (_c_long, [_c_int] * 6),
     'nlt_conv_forward_splitk': (_c_int, [_c_int, _c_int, _c_int, _vp, _vp, _c_int, _c_int, _vp, _c_int, _c_int,
@@ -352,6 +355,21 @@ def front_forward(base, cvis, lvis, nn_rgb, nn_base, n, k, h, w, packed, add_bas
     _check(lib().nlt_front_forward(_ptr(base), _ptr(cvis), _ptr(lvis), _ptr(nn_rgb), _ptr(nn_base), n, k, h, w,
                                    _ptr(packed), 1 if add_base else 0, float(alpha), _ptr(fm1), _ptr(obs1), _ptr(skip3),
                                    _stream()), 'nlt_front_forward')
+
+
+def front_pack_l2_weights(wq, bq, wo, bo):
+    out = torch.empty(lib().nlt_front_l2_packed_floats(), device=wq.device, dtype=torch.float32)
+    _check(lib().nlt_front_pack_l2_weights(_ptr(_dense(wq, 'wq')), _ptr(bq), _ptr(_dense(wo, 'wo')), _ptr(bo), _ptr(out),
+                                           _stream()), 'nlt_front_pack_l2_weights')
+    return out
+
+
+def front2_forward(base, cvis, lvis, nn_rgb, nn_base, n, k, h, w, packed, packed_l2, add_base, alpha, fm1, skip3, qtmp2, otmp2):
+    for t, nm in ((base, 'base'), (cvis, 'cvis'), (lvis, 'lvis'), (nn_rgb, 'nn_rgb'), (nn_base, 'nn_base')):
+        _dense(t, nm)
+    _check(lib().nlt_front2_forward(_ptr(base), _ptr(cvis), _ptr(lvis), _ptr(nn_rgb), _ptr(nn_base), n, k, h, w,
+                                    _ptr(packed), _ptr(packed_l2), 1 if add_base else 0, float(alpha), _ptr(fm1), _ptr(skip3),
+                                    _ptr(qtmp2), _ptr(otmp2), _stream()), 'nlt_front2_forward')
 
 
 def back_forward(x, fm1, skip3, n, h2, w2, w_s2, b_s2, w_s1, b_s1, w_head, alpha, pred):

@@ -101,6 +101,30 @@ __global__ void front_pack_kernel(FrontW w, float* __restrict__ blob) {
   blob[idx] = v;
 }
 
+// second blob: level 2's stride-2 convs (fused into the front kernel when k <= 4)
+constexpr int OFF3_AQ = 0;                 // [2 rt][8 = slab*4 + c4][64][4]  query (2,2,32,32): slab 0 = q1, 1 = mean o1
+constexpr int OFF3_AO = 4096;              // [2 rt][4 c4][64][4]             obs   (2,2,16,32)
+constexpr int OFF3_BQ = 6144, OFF3_BO = 6176, BLOB3 = 6208;
+
+__global__ void front_pack_l2_kernel(const float* __restrict__ wq, const float* __restrict__ bq,
+                                     const float* __restrict__ wo, const float* __restrict__ bo, float* __restrict__ blob) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= BLOB3) return;
+  float v;
+  if (idx < OFF3_AO) {
+    const int e = idx & 3, lane = (idx >> 2) & 63, c8 = (idx >> 8) & 7, rt = idx >> 11;
+    const int tap = lane >> 4, o = rt * 16 + (lane & 15), c = 16 * (c8 >> 2) + 4 * (c8 & 3) + e;
+    v = wq[((tap * 32) + c) * 32 + o];
+  } else if (idx < OFF3_BQ) {
+    const int r = idx - OFF3_AO;
+    const int e = r & 3, lane = (r >> 2) & 63, c4 = (r >> 8) & 3, rt = r >> 10;
+    const int tap = lane >> 4, o = rt * 16 + (lane & 15);
+    v = wo[((tap * 16) + 4 * c4 + e) * 32 + o];
+  } else if (idx < OFF3_BO) v = bq[idx - OFF3_BQ];
+  else v = bo[idx - OFF3_BO];
+  blob[idx] = v;
+}
+
 // XCD-aware tile order: the dispatcher places workgroup b on XCD b % 8; give each XCD a contiguous run
 // of tiles so that neighbouring tiles (which share halo lines) meet in the same L2.
 __device__ __forceinline__ int xcd_tile(int b, int nblocks) {
@@ -110,11 +134,15 @@ __device__ __forceinline__ int xcd_tile(int b, int nblocks) {
 // ---------------------------------------------------------------------------------------
 // front kernel
 // ---------------------------------------------------------------------------------------
+// L2S2 = true (k <= 4): the workgroup also runs level 2's stride-2 convs on its 8 x 16 level-1 tile (a 4 x 8 tile of
+// level 2; k2s2 needs no halo) and writes qtmp2 / otmp2 instead of the per-observation level-1 maps.
+template <bool L2S2>
 __global__ __launch_bounds__(256) void front_kernel(
     const float* __restrict__ base, const float* __restrict__ cvis, const float* __restrict__ lvis,
     const float* __restrict__ nn_rgb, const float* __restrict__ nn_base, int k, int h, int w,
     int tiles_y, int tiles_x, const float* __restrict__ blob, int add_base, float alpha,
-    float* __restrict__ fm1, float* __restrict__ obs1, float* __restrict__ skip3) {
+    float* __restrict__ fm1, float* __restrict__ obs1, float* __restrict__ skip3,
+    const float* __restrict__ blob3, float* __restrict__ qtmp2, float* __restrict__ otmp2) {
   extern __shared__ __attribute__((aligned(16))) float lds[];          // [1 + k][HT][16]: q, then obs i
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int kk = lane >> 4, j = lane & 15;
@@ -234,7 +262,8 @@ __global__ __launch_bounds__(256) void front_kernel(
     const long otex[2] = {(long)gy[0] * w2 + gx, (long)gy[1] * w2 + gx};
     f32x4 mean[2] = {(f32x4){0.f, 0.f, 0.f, 0.f}, (f32x4){0.f, 0.f, 0.f, 0.f}};
     f32x4 qv[2] = {mean[0], mean[0]};
-    for (int p = 0; p <= k; ++p) {
+    f32x4 o1[L2S2 ? 4 : 1][2];                                         // L2S2: the observations' level-1 outputs stay in registers
+    auto path = [&](int p, f32x4 (&out)[2]) {
       const float* tilep = lds + (size_t)p * HT * 16;
       f32x4 acc[2] = {(f32x4){0.f, 0.f, 0.f, 0.f}, (f32x4){0.f, 0.f, 0.f, 0.f}};
 #pragma unroll
@@ -248,23 +277,91 @@ __global__ __launch_bounds__(256) void front_kernel(
           acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s4], b1[s4], acc[1], 0, 0, 0);
         }
       }
+      out[0] = lrelu4(acc[0] + (p ? bo1 : bq1), alpha);
+      out[1] = lrelu4(acc[1] + (p ? bo1 : bq1), alpha);
+    };
+    path(0, qv);
+    if (L2S2) {
 #pragma unroll
-      for (int e = 0; e < 2; ++e) {
-        const f32x4 v = lrelu4(acc[e] + (p ? bo1 : bq1), alpha);
-        if (p == 0) qv[e] = v;
-        else {
-          mean[e] += v;
-          if (inside[e]) *reinterpret_cast<f32x4*>(obs1 + (((long)f * k + (p - 1)) * hw2 + otex[e]) * 16 + 4 * kk) = v;
+      for (int i = 0; i < 4; ++i)
+        if (i < k) {                                                   // wave-uniform; static register indices
+          path(1 + i, o1[i]);
+          mean[0] += o1[i][0]; mean[1] += o1[i][1];
+        }
+    } else {
+      for (int p = 1; p <= k; ++p) {
+        f32x4 v[2];
+        path(p, v);
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+          mean[e] += v[e];
+          if (inside[e]) *reinterpret_cast<f32x4*>(obs1 + (((long)f * k + (p - 1)) * hw2 + otex[e]) * 16 + 4 * kk) = v[e];
         }
       }
     }
+    mean[0] *= inv_k; mean[1] *= inv_k;
 #pragma unroll
     for (int e = 0; e < 2; ++e)
       if (inside[e]) {
         float* o = fm1 + ((long)f * hw2 + otex[e]) * 32 + 4 * kk;
         *reinterpret_cast<f32x4*>(o) = qv[e];
-        *reinterpret_cast<f32x4*>(o + 16) = mean[e] * inv_k;
+        *reinterpret_cast<f32x4*>(o + 16) = mean[e];
       }
+
+    if (L2S2) {
+      // ---- stage 3: level 2's stride-2 convs.  The level-1 tile goes back into LDS as [slab][8 x 16 texels][16]
+      // (slab 0 = q1, 1 = mean o1, 2 + i = o1 of observation i); lane group kk is tap (a, b) again, wave = (column
+      // tile of the 32 level-2 texels, row tile of the 32 outputs).
+      __syncthreads();                                                 // every wave is done reading the stage-1 tiles
+#pragma unroll
+      for (int e = 0; e < 2; ++e) {
+        float* dst = lds + ((wave + 4 * e) * 16 + j) * 16 + 4 * kk;
+        *reinterpret_cast<f32x4*>(dst) = qv[e];
+        *reinterpret_cast<f32x4*>(dst + 2048) = mean[e];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+          if (i < k) *reinterpret_cast<f32x4*>(dst + (2 + i) * 2048) = o1[i][e];
+      }
+      __syncthreads();
+      const int ct = wave & 1, rt = wave >> 1;
+      const int t2 = ct * 16 + j;                                      // level-2 texel of the 4 x 8 tile
+      const int Y = t2 >> 3, X = t2 & 7;
+      const float* src = lds + ((2 * Y + (kk >> 1)) * 16 + 2 * X + (kk & 1)) * 16;
+      const int gy2 = (ty0 >> 1) + Y, gx2 = (tx0 >> 1) + X;
+      const int h4 = h2 >> 1, w4 = w2 >> 1;
+      const bool in2 = gy2 < h4 && gx2 < w4;
+      const long tex2 = (long)gy2 * w4 + gx2;
+      const int oc = rt * 16 + 4 * kk;
+      {
+        f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int c8 = 0; c8 < 8; ++c8) {
+          const f32x4 v = *reinterpret_cast<const f32x4*>(src + (c8 >> 2) * 2048 + 4 * (c8 & 3));
+          const f32x4 a = *reinterpret_cast<const f32x4*>(blob3 + OFF3_AQ + ((rt * 8 + c8) * 64 + lane) * 4);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[e], v[e], acc, 0, 0, 0);
+        }
+        acc = lrelu4(acc + *reinterpret_cast<const f32x4*>(blob3 + OFF3_BQ + oc), alpha);
+        if (in2) *reinterpret_cast<f32x4*>(qtmp2 + ((long)f * h4 * w4 + tex2) * 32 + oc) = acc;
+      }
+      f32x4 ao3[4];
+#pragma unroll
+      for (int c4 = 0; c4 < 4; ++c4) ao3[c4] = *reinterpret_cast<const f32x4*>(blob3 + OFF3_AO + ((rt * 4 + c4) * 64 + lane) * 4);
+      const f32x4 bo3 = *reinterpret_cast<const f32x4*>(blob3 + OFF3_BO + oc);
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        if (i < k) {
+          f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int c4 = 0; c4 < 4; ++c4) {
+            const f32x4 v = *reinterpret_cast<const f32x4*>(src + (2 + i) * 2048 + 4 * c4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(ao3[c4][e], v[e], acc, 0, 0, 0);
+          }
+          acc = lrelu4(acc + bo3, alpha);
+          if (in2) *reinterpret_cast<f32x4*>(otmp2 + (((long)f * k + i) * h4 * w4 + tex2) * 32 + oc) = acc;
+        }
+    }
   }
 }
 
@@ -380,11 +477,44 @@ extern "C" int nlt_front_forward(const float* base, const float* cvis, const flo
   const int ty = (h / 2 + TH - 1) / TH, tx = (w / 2 + TW - 1) / TW;
   const long blocks = (long)n * ty * tx;
   if (lds_bytes > 64 * 1024) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(front_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(front_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)lds_bytes) != hipSuccess) return NLT_ERR_LAUNCH;
   }
-  hipLaunchKernelGGL(front_kernel, dim3((unsigned)blocks), dim3(256), lds_bytes, static_cast<hipStream_t>(stream),
-                     base, cvis, lvis, nn_rgb, nn_base, k, h, w, ty, tx, packed, add_base, alpha, fm1, obs1, skip3);
+  hipLaunchKernelGGL(front_kernel<false>, dim3((unsigned)blocks), dim3(256), lds_bytes, static_cast<hipStream_t>(stream),
+                     base, cvis, lvis, nn_rgb, nn_base, k, h, w, ty, tx, packed, add_base, alpha, fm1, obs1, skip3,
+                     nullptr, nullptr, nullptr);
+  NLT_CHECK_LAUNCH();
+  return NLT_OK;
+}
+
+extern "C" long nlt_front_l2_packed_floats(void) { return BLOB3; }
+
+extern "C" int nlt_front_pack_l2_weights(const float* wq, const float* bq, const float* wo, const float* bo, float* packed,
+                                         void* stream) {
+  if (!wq || !bq || !wo || !bo || !packed || !nlt_aligned16(packed)) return NLT_ERR_BAD_ARG;
+  hipLaunchKernelGGL(front_pack_l2_kernel, dim3((BLOB3 + 255) / 256), dim3(256), 0, static_cast<hipStream_t>(stream), wq, bq, wo, bo, packed);
+  NLT_CHECK_LAUNCH();
+  return NLT_OK;
+}
+
+extern "C" int nlt_front2_forward(const float* base, const float* cvis, const float* lvis, const float* nn_rgb,
+                                  const float* nn_base, int n, int k, int h, int w, const float* packed,
+                                  const float* packed_l2, int add_base, float alpha, float* fm1, float* skip3,
+                                  float* qtmp2, float* otmp2, void* stream) {
+  if (!base || !cvis || !lvis || !nn_rgb || !nn_base || !packed || !packed_l2 || !fm1 || !skip3 || !qtmp2 || !otmp2) return NLT_ERR_BAD_ARG;
+  if (n <= 0 || k <= 0 || h <= 0 || w <= 0) return NLT_ERR_BAD_ARG;
+  if (((h | w) & 3) || k > 4) return NLT_ERR_UNSUPPORTED;              // level 2 halves the half-resolution grid again
+  if (!nlt_aligned16(packed) || !nlt_aligned16(packed_l2) || !nlt_aligned16(fm1) || !nlt_aligned16(qtmp2) || !nlt_aligned16(otmp2))
+    return NLT_ERR_BAD_ARG;
+  if ((long long)n * k * h * w * 3 >= (1ll << 31)) return NLT_ERR_UNSUPPORTED;
+  size_t lds_floats = (size_t)(1 + k) * HT * 16;
+  if ((size_t)(2 + k) * 2048 > lds_floats) lds_floats = (size_t)(2 + k) * 2048;
+  const size_t lds_bytes = lds_floats * sizeof(float);
+  const int ty = (h / 2 + TH - 1) / TH, tx = (w / 2 + TW - 1) / TW;
+  const long blocks = (long)n * ty * tx;
+  hipLaunchKernelGGL(front_kernel<true>, dim3((unsigned)blocks), dim3(256), lds_bytes, static_cast<hipStream_t>(stream),
+                     base, cvis, lvis, nn_rgb, nn_base, k, h, w, ty, tx, packed, add_base, alpha, fm1, nullptr, skip3,
+                     packed_l2, qtmp2, otmp2);
   NLT_CHECK_LAUNCH();
   return NLT_OK;
 }

@@ -56,6 +56,7 @@ class RenderPlan:
         self.autotune = os.environ.get('NLT_AUTOTUNE', '1') != '0'
         self.fuse_ends = os.environ.get('NLT_FUSED', '1') != '0'   # inference: csrc/fused.hip for layers 0-1 and the last block + head
         self._front_blob = None
+        self.front_l2 = os.environ.get('NLT_FRONT_L2', '1') != '0'      # front kernel also runs level 2's stride-2 convs (k <= 4)
         self.two_streams = os.environ.get('NLT_STREAMS', '2') != '1'   # inference: query-path encoder convs on a side stream
         self._side = None               # (side stream, [events]) created on first use
         self.wgrad_tiled = os.environ.get('NLT_WGRAD', 'tiled') != 'atomic'   # csrc/wgrad_tile.hip vs first-generation csrc/wgrad.hip
@@ -280,11 +281,18 @@ class RenderPlan:
         head.build(36, dev)
         convs = (q0, o0, qa, qb, oa, ob, head)
         ver = tuple((c.kernel.data_ptr(), c.kernel._version, c.bias._version, c._epoch[0]) for c in convs)
+        (qa2, _), _ = q.layers[2].convs()
+        (oa2, _), _ = o.layers[2].convs()
+        qa2.build(32, dev); oa2.build(16, dev)
+        ver += tuple((c.kernel.data_ptr(), c.kernel._version, c.bias._version, c._epoch[0]) for c in (qa2, oa2))
         if self._front_blob is None or self._front_blob[0] != ver:
             w = lambda c: (c.kernel.detach(), c.bias.detach())
             blob = C.front_pack_weights(*w(q0), *w(o0), *w(qa), *w(qb), *w(oa), *w(ob), *w(head))
-            self._front_blob = (ver, blob)
-        return self._front_blob[1]
+            blob_l2 = None
+            if qa2.n_ch_out == 32 and oa2.n_ch_out == 32 and qa2.cin == 32 and oa2.cin == 16:
+                blob_l2 = C.front_pack_l2_weights(*w(qa2), *w(oa2))
+            self._front_blob = (ver, blob, blob_l2)
+        return self._front_blob[1], self._front_blob[2]
 
     def forward(self, base, cvis, lvis, nn_rgb, nn_base, obs_weights=None, obs_override=None,
                 skip_connect_base=True, algo=C.ALGO_AUTO, inference=False):
@@ -371,14 +379,23 @@ class RenderPlan:
         alpha = q.layers[1].convs()[0][1].alpha
         if b['skip3'] is None:
             b['skip3'] = torch.empty((n, h, w, 3), device=base.device, dtype=torch.float32)
-        blob = self._front_weights(base.device)
-        # SURVEY 8d accounting of what this launch replaces: L0 + L1 of both paths (+ the two means)
-        nbytes = 4 * n * h * w * ((5 + 3 * k + 16 + 16 * k) + (36 + 20 * k + 8 + 8 * k))
-        # what the fused launch itself must move: raw inputs + skip3 out, fm1 + obs1 out (per texel: 5+6k+3 | (32+16k)/4)
-        moved = 4 * n * h * w * (5 + 6 * k + 3 + 8 + 4 * k)
+        blob, blob_l2 = self._front_weights(base.device)
+        # With k <= 4 the front kernel also runs level 2's stride-2 convs (its 8 x 16 level-1 tile is a 4 x 8 tile of
+        # level 2): the per-observation level-1 maps never reach HBM and L2.{q,o}.s2 are not launched.
+        front2 = (self.front_l2 and blob_l2 is not None and k <= 4 and h % 4 == 0 and w % 4 == 0 and not self._trial_direct)
+        nbytes = 4 * n * h * w * ((5 + 3 * k + 16 + 16 * k) + (36 + 20 * k + 8 + 8 * k))     # L0 + L1 (+ means)
         flops = 2 * n * (h // 2) * (w // 2) * ((32 + 64) * 16 + k * (12 + 64) * 16) + 2 * n * h * w * 24
-        self._launch('F.front', nbytes, C.front_forward, base, cvis, lvis, nn_rgb, nn_base, n, k, h, w, blob,
-                     skip_connect_base, alpha, b['fm'][1], b['obs'][1], b['skip3'], flops=flops, moved=moved)
+        if front2:
+            nbytes += 4 * n * (h // 2) * (w // 2) * (32 + 16 * k) + 4 * n * (h // 4) * (w // 4) * 32 * (1 + k)   # + the two L2 s2 launches
+            flops += 2 * n * (h // 4) * (w // 4) * 32 * (128 + 64 * k)
+            moved = 4 * n * h * w * (5 + 6 * k + 3 + 8) + 4 * n * (h // 4) * (w // 4) * 32 * (1 + k)   # in + skip3 + fm1 | qtmp2 + otmp2
+            self._launch('F.front', nbytes, C.front2_forward, base, cvis, lvis, nn_rgb, nn_base, n, k, h, w, blob, blob_l2,
+                         skip_connect_base, alpha, b['fm'][1], b['skip3'], b['qtmp'][2], b['otmp'][2], flops=flops, moved=moved)
+        else:
+            # what the fused launch itself must move: raw inputs + skip3 out, fm1 + obs1 out (per texel: 5+6k+3 | (32+16k)/4)
+            moved = 4 * n * h * w * (5 + 6 * k + 3 + 8 + 4 * k)
+            self._launch('F.front', nbytes, C.front_forward, base, cvis, lvis, nn_rgb, nn_base, n, k, h, w, blob,
+                         skip_connect_base, alpha, b['fm'][1], b['obs'][1], b['skip3'], flops=flops, moved=moved)
         # Levels 2..D.  The observation chain (k frames per frame: three quarters of the encoder's work at k = 4)
         # never waits for the query path; the query convs of a level only need the previous level's observation mean.
         # With two HIP streams the small deep-level launches of one path fill the CUs the other leaves idle.
@@ -396,7 +413,9 @@ class RenderPlan:
             (qa, qact_a), (qb, qact_b) = q.layers[l].convs()
             (oa, oact_a), (ob, oact_b) = o.layers[l].convs()
             cin = 2 * cl[l - 1]
-            self._conv_enc('L%d.o.s2' % l, oa, oact_a, b['obs'][l - 1], cl[l - 1], cl[l - 1], n, k, hh, ww, b['otmp'][l], cl[l], algo)
+            s2_done = front2 and l == 2                             # the front kernel already wrote qtmp[2] / otmp[2]
+            if not s2_done:
+                self._conv_enc('L%d.o.s2' % l, oa, oact_a, b['obs'][l - 1], cl[l - 1], cl[l - 1], n, k, hh, ww, b['otmp'][l], cl[l], algo)
             self._conv_enc('L%d.o.s1' % l, ob, oact_b, b['otmp'][l], cl[l], cl[l], n, k, hh // 2, ww // 2, b['obs'][l], cl[l], algo,
                            mean_out=b['fm'][l].view(-1)[cl[l]:], ldm=2 * cl[l])
             if concurrent:
@@ -404,11 +423,13 @@ class RenderPlan:
                 with torch.cuda.stream(side):
                     if l > 2:
                         side.wait_event(ev[l - 1])
-                    self._conv_enc('L%d.q.s2' % l, qa, qact_a, b['fm'][l - 1], cin, cin, n, 1, hh, ww, b['qtmp'][l], cl[l], algo)
+                    if not s2_done:
+                        self._conv_enc('L%d.q.s2' % l, qa, qact_a, b['fm'][l - 1], cin, cin, n, 1, hh, ww, b['qtmp'][l], cl[l], algo)
                     self._conv_enc('L%d.q.s1' % l, qb, qact_b, b['qtmp'][l], cl[l], cl[l], n, 1, hh // 2, ww // 2, b['fm'][l],
                                    2 * cl[l], algo)
             else:
-                self._conv_enc('L%d.q.s2' % l, qa, qact_a, b['fm'][l - 1], cin, cin, n, 1, hh, ww, b['qtmp'][l], cl[l], algo)
+                if not s2_done:
+                    self._conv_enc('L%d.q.s2' % l, qa, qact_a, b['fm'][l - 1], cin, cin, n, 1, hh, ww, b['qtmp'][l], cl[l], algo)
                 self._conv_enc('L%d.q.s1' % l, qb, qact_b, b['qtmp'][l], cl[l], cl[l], n, 1, hh // 2, ww // 2, b['fm'][l],
                                2 * cl[l], algo)
             hh, ww = hh // 2, ww // 2

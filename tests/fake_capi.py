@@ -323,6 +323,21 @@ def conv_backward_weights_tiled(mode, src0, c0, ld0, src1, c1, ld1, n, h, w, dpr
     conv_backward_weights(mode, src0, c0, ld0, src1, c1, ld1, n, h, w, dpre, ldp, cout, dw, db)
 
 
+def front_pack_l2_weights(wq, bq, wo, bo):
+    return dict(wq=wq, bq=bq, wo=wo, bo=bo)
+
+
+def front2_forward(base, cvis, lvis, nn_rgb, nn_base, n, k, h, w, P, P2, add_base, alpha, fm1, skip3, qtmp2, otmp2):
+    obs1 = torch.empty((n, k, h // 2, w // 2, 16))
+    front_forward(base, cvis, lvis, nn_rgb, nn_base, n, k, h, w, P, add_base, alpha, fm1, obs1, skip3)
+    lr = lambda x: T.leaky_relu(x, alpha)
+    qtmp2.copy_(lr(T.conv2d_same(fm1, P2['wq'], P2['bq'], 2)))
+    otmp2.copy_(torch.stack([lr(T.conv2d_same(obs1[:, i], P2['wo'], P2['bo'], 2)) for i in range(k)], 1))
+
+
+_FUSED = _FUSED + ('front_pack_l2_weights', 'front2_forward')
+
+
 _FORWARD = ('conv_forward', 'pack_conv_weights', 'stem_forward', 'obs_mean_forward', 'head_forward', 'warp_forward',
             'resize_bilinear_forward', 'mul_forward')
 

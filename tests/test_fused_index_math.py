@@ -84,7 +84,7 @@ def xcd_tile(b, nblocks):
     return b if nblocks & 7 else (b & 7) * (nblocks >> 3) + (b >> 3)
 
 
-def front(base, cvis, lvis, nn_rgb, nn_base, blob, add_base, alpha):
+def front(base, cvis, lvis, nn_rgb, nn_base, blob, add_base, alpha, blob3=None):
     n, h, w, _ = base.shape
     k = nn_rgb.shape[1]
     h2, w2 = h // 2, w // 2
@@ -93,6 +93,9 @@ def front(base, cvis, lvis, nn_rgb, nn_base, blob, add_base, alpha):
     fm1 = np.full((n * h2 * w2 * 32,), np.nan, np.float32)
     obs1 = np.full((n * k * h2 * w2 * 16,), np.nan, np.float32)
     skip3 = np.full((n * h * w * 3,), np.nan, np.float32)
+    h4, w4 = h2 // 2, w2 // 2
+    qtmp2 = np.full((n * h4 * w4 * 32,), np.nan, np.float32)
+    otmp2 = np.full((n * k * h4 * w4 * 32,), np.nan, np.float32)
     B_, C_, L_, R_, NB_ = (a.reshape(-1) for a in (base, cvis, lvis, nn_rgb, nn_base))
     hw, hw2 = h * w, h2 * w2
     inv_k = np.float32(1.0 / k)
@@ -102,7 +105,8 @@ def front(base, cvis, lvis, nn_rgb, nn_base, blob, add_base, alpha):
         tx0 = (tile % tx) * TW; tile //= tx
         ty0 = (tile % ty) * TH
         f = tile // ty
-        lds = np.full(((1 + k) * HT * 16,), np.nan, np.float32)
+        lds = np.full((max((1 + k) * HT * 16, (2 + k) * 2048),), np.nan, np.float32)
+        keep = {}                                              # L2S2: (wave, e) -> (qv, mean, [o1_i]) kept in registers
         for wave in range(4):
             aq2 = [blob[OFF_AQ2 + m * 64 + LANE] for m in range(8)]
             ao2 = [blob[OFF_AO2 + m * 64 + LANE] for m in range(3)]
@@ -161,6 +165,7 @@ def front(base, cvis, lvis, nn_rgb, nn_base, blob, add_base, alpha):
                 inside = (gy < h2) & (gx < w2)
                 otex = gy * w2 + gx
                 mean = np.zeros((64, 4), np.float32); qv = None
+                o1s = []
                 for p in range(k + 1):
                     acc = np.zeros((64, 4), np.float32)
                     for t_ in range(4):
@@ -175,15 +180,85 @@ def front(base, cvis, lvis, nn_rgb, nn_base, blob, add_base, alpha):
                         qv = acc
                     else:
                         mean = mean + acc
+                        o1s.append(acc)
                         for l in np.nonzero(inside)[0]:
                             a0 = ((f * k + (p - 1)) * hw2 + otex[l]) * 16 + 4 * KK[l]
                             obs1[a0:a0 + 4] = acc[l]
+                mean = mean * inv_k
+                keep[(wave, r)] = (qv, mean, o1s)
                 for l in np.nonzero(inside)[0]:
                     a0 = (f * hw2 + otex[l]) * 32 + 4 * KK[l]
                     fm1[a0:a0 + 4] = qv[l]
-                    fm1[a0 + 16:a0 + 20] = mean[l] * inv_k
+                    fm1[a0 + 16:a0 + 20] = mean[l]
+        if blob3 is not None:
+            # __syncthreads(); level-1 tile -> LDS [slab][8 x 16][16]; __syncthreads(); level 2's stride-2 convs
+            lds[:] = np.nan
+            for (wave, r), (qv, mean, o1s) in keep.items():
+                for l in range(64):
+                    d0 = (r * 16 + J[l]) * 16 + 4 * KK[l]
+                    lds[d0:d0 + 4] = qv[l]; lds[d0 + 2048:d0 + 2052] = mean[l]
+                    for i, o in enumerate(o1s):
+                        lds[d0 + (2 + i) * 2048: d0 + (2 + i) * 2048 + 4] = o[l]
+            for wave in range(4):
+                ct, rt = wave & 1, wave >> 1
+                t2 = ct * 16 + J
+                Y, X = t2 >> 3, t2 & 7
+                src = ((2 * Y + (KK >> 1)) * 16 + 2 * X + (KK & 1)) * 16
+                gy2, gx2 = (ty0 >> 1) + Y, (tx0 >> 1) + X
+                in2 = (gy2 < h4) & (gx2 < w4)
+                tex2 = gy2 * w4 + gx2
+                oc = rt * 16 + 4 * KK
+                acc = np.zeros((64, 4), np.float32)
+                for c8 in range(8):
+                    v = np.stack([lds[src + (c8 >> 2) * 2048 + 4 * (c8 & 3) + e] for e in range(4)], 1)
+                    assert not np.isnan(v).any()
+                    a = np.stack([blob3[OFF3_AQ + ((rt * 8 + c8) * 64 + LANE) * 4 + e] for e in range(4)], 1)
+                    for e in range(4):
+                        acc = mfma(a[:, e], v[:, e], acc)
+                acc = lrelu(acc + np.stack([blob3[OFF3_BQ + oc + e] for e in range(4)], 1), alpha)
+                for l in np.nonzero(in2)[0]:
+                    a0 = (f * h4 * w4 + tex2[l]) * 32 + oc[l]
+                    assert np.isnan(qtmp2[a0]); qtmp2[a0:a0 + 4] = acc[l]
+                for i in range(k):
+                    acc = np.zeros((64, 4), np.float32)
+                    for c4 in range(4):
+                        v = np.stack([lds[src + (2 + i) * 2048 + 4 * c4 + e] for e in range(4)], 1)
+                        assert not np.isnan(v).any()
+                        a = np.stack([blob3[OFF3_AO + ((rt * 4 + c4) * 64 + LANE) * 4 + e] for e in range(4)], 1)
+                        for e in range(4):
+                            acc = mfma(a[:, e], v[:, e], acc)
+                    acc = lrelu(acc + np.stack([blob3[OFF3_BO + oc + e] for e in range(4)], 1), alpha)
+                    for l in np.nonzero(in2)[0]:
+                        a0 = ((f * k + i) * h4 * w4 + tex2[l]) * 32 + oc[l]
+                        assert np.isnan(otmp2[a0]); otmp2[a0:a0 + 4] = acc[l]
     assert seen == set(range(nblocks))
-    return fm1.reshape(n, h2, w2, 32), obs1.reshape(n, k, h2, w2, 16), skip3.reshape(n, h, w, 3)
+    out = (fm1.reshape(n, h2, w2, 32), obs1.reshape(n, k, h2, w2, 16), skip3.reshape(n, h, w, 3))
+    if blob3 is not None:
+        out += (qtmp2.reshape(n, h4, w4, 32), otmp2.reshape(n, k, h4, w4, 32))
+    return out
+
+
+OFF3_AQ, OFF3_AO, OFF3_BQ, OFF3_BO, BLOB3 = 0, 4096, 6144, 6176, 6208
+
+
+def pack_l2(wq, bq, wo, bo):
+    """front_pack_l2_kernel."""
+    wq, bq, wo, bo = (np.asarray(a, np.float32).reshape(-1) for a in (wq, bq, wo, bo))
+    blob = np.zeros(BLOB3, np.float32)
+    for idx in range(BLOB3):
+        if idx < OFF3_AO:
+            e, lane, c8, rt = idx & 3, (idx >> 2) & 63, (idx >> 8) & 7, idx >> 11
+            tap, o, c = lane >> 4, rt * 16 + (lane & 15), 16 * (c8 >> 2) + 4 * (c8 & 3) + e
+            blob[idx] = wq[((tap * 32) + c) * 32 + o]
+        elif idx < OFF3_BQ:
+            r = idx - OFF3_AO
+            e, lane, c4, rt = r & 3, (r >> 2) & 63, (r >> 8) & 3, r >> 10
+            blob[idx] = wo[(((lane >> 4) * 16) + 4 * c4 + e) * 32 + rt * 16 + (lane & 15)]
+        elif idx < OFF3_BO:
+            blob[idx] = bq[idx - OFF3_BQ]
+        else:
+            blob[idx] = bo[idx - OFF3_BO]
+    return blob
 
 
 FH, FW = 2 * TH + 1, 2 * TW + 1
@@ -305,8 +380,16 @@ def test_fused_ends_emulation_matches_oracle(uv, k, add_base):
     blob = pack(dict(wq0=wq0, bq0=bq0, wo0=wo0, bo0=bo0, wqa=wqa, bqa=bqa, wqb=wqb, bqb=bqb, woa=woa, boa=boa,
                      wob=wob, bob=bob, wh=wh, bh=bh))
     nn_rgb = np.stack([g(r) for _, r in nn], 1); nn_base = np.stack([g(b) for b, _ in nn], 1)
-    fm1, obs1, skip3 = front(g(base), g(cvis), g(lvis), nn_rgb, nn_base, blob, add_base, 0.3)
+    (wqa2, bqa2), _ = W['query'][2]; (woa2, boa2), _ = W['obs'][2]
+    fm1, obs1, skip3, qtmp2, otmp2 = front(g(base), g(cvis), g(lvis), nn_rgb, nn_base, blob, add_base, 0.3,
+                                           blob3=pack_l2(wqa2, bqa2, woa2, boa2))
     assert not np.isnan(fm1).any() and not np.isnan(obs1).any() and not np.isnan(skip3).any()
+    with torch.no_grad():                                       # level 2's stride-2 convs (convnet.py:50-53)
+        q2 = T.leaky_relu(T.conv2d_same(feats['fm1'], torch.from_numpy(wqa2), torch.from_numpy(bqa2), 2))
+        o2 = torch.stack([T.leaky_relu(T.conv2d_same(feats['obs1'][:, i], torch.from_numpy(woa2), torch.from_numpy(boa2), 2))
+                          for i in range(k)], 1)
+    assert not np.isnan(qtmp2).any() and not np.isnan(otmp2).any()
+    assert _rel(qtmp2, g(q2)) < 2e-6 and _rel(otmp2, g(o2)) < 2e-6
     assert _rel(fm1, g(feats['fm1'])) < 2e-6
     assert _rel(obs1, g(feats['obs1'])) < 2e-6
     fm0 = g(feats['fm0'])
@@ -341,9 +424,15 @@ def test_fused_ends_emulation_partial_tiles():
         fm1_ref = torch.cat((O.apply_layer(om.layers[1], om.wq[1], fm0), torch.stack(o1, -1).mean(-1)), -1)
     blob = pack(dict(wq0=wq0, bq0=bq0, wo0=wo0, bo0=bo0, wqa=wqa, bqa=bqa, wqb=wqb, bqb=bqb, woa=woa, boa=boa,
                      wob=wob, bob=bob, wh=wh, bh=bh))
-    fm1, obs1, skip3 = front(g(base), g(cvis), g(lvis), np.stack([g(r) for _, r in nn], 1), np.stack([g(b) for b, _ in nn], 1),
-                             blob, True, 0.3)
+    (wqa2, bqa2), _ = W['query'][2]; (woa2, boa2), _ = W['obs'][2]
+    fm1, obs1, skip3, qtmp2, otmp2 = front(g(base), g(cvis), g(lvis), np.stack([g(r) for _, r in nn], 1),
+                                           np.stack([g(b) for b, _ in nn], 1), blob, True, 0.3, blob3=pack_l2(wqa2, bqa2, woa2, boa2))
     assert not np.isnan(fm1).any() and not np.isnan(obs1).any() and not np.isnan(skip3).any()
+    with torch.no_grad():
+        q2 = T.leaky_relu(T.conv2d_same(fm1_ref, torch.from_numpy(wqa2), torch.from_numpy(bqa2), 2))
+        o2 = torch.stack([T.leaky_relu(T.conv2d_same(o, torch.from_numpy(woa2), torch.from_numpy(boa2), 2)) for o in o1], 1)
+    assert not np.isnan(qtmp2).any() and not np.isnan(otmp2).any()
+    assert _rel(qtmp2, g(q2)) < 2e-6 and _rel(otmp2, g(o2)) < 2e-6
     assert _rel(fm1, g(fm1_ref)) < 2e-6 and _rel(obs1, np.stack([g(o) for o in o1], 1)) < 2e-6
     ref_skip = (g(fm0) @ wh[0, 0, 4:, :] + bh + g(base)).astype(np.float32)
     assert _rel(skip3, ref_skip) < 2e-6

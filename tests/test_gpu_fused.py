@@ -26,7 +26,7 @@ def _weights(om):
 
 
 @pytest.mark.parametrize('n,h,w,k,add_base', [(1, 64, 64, 2, True), (2, 40, 56, 3, False), (1, 16, 32, 1, True),
-                                              (1, 2, 2, 1, True), (2, 128, 256, 4, True)])
+                                              (1, 2, 2, 1, True), (2, 128, 256, 4, True), (1, 36, 44, 5, True)])
 def test_front_and_back_kernels_vs_oracle_layers(n, h, w, k, add_base):
     om = O.OracleModel(depth=256, uvh=64, uvw=64, imh=32, imw=32, seed=n + h + k)
     rng = np.random.default_rng(h * 7 + w)
@@ -57,6 +57,22 @@ def test_front_and_back_kernels_vs_oracle_layers(n, h, w, k, add_base):
     assert rel_l2(fm1.cpu(), fm1_ref) <= 1e-5
     assert rel_l2(obs1.cpu(), torch.stack(o1, 1)) <= 1e-5
     assert rel_l2(skip3.cpu(), skip_ref) <= 1e-5
+    if k <= 4 and h % 4 == 0 and w % 4 == 0:                       # the variant that also runs level 2's stride-2 convs
+        W = om.numpy_weights()
+        (wqa2, bqa2), _ = W['query'][2]; (woa2, boa2), _ = W['obs'][2]
+        with torch.no_grad():
+            q2 = T.leaky_relu(T.conv2d_same(fm1_ref, torch.from_numpy(wqa2), torch.from_numpy(bqa2), 2))
+            o2 = torch.stack([T.leaky_relu(T.conv2d_same(o, torch.from_numpy(woa2), torch.from_numpy(boa2), 2)) for o in o1], 1)
+        blob2 = C.front_pack_l2_weights(dev(wqa2), dev(bqa2), dev(woa2), dev(boa2))
+        fm1b = torch.full_like(fm1, float('nan')); skip3b = torch.full_like(skip3, float('nan'))
+        qt = torch.full((n, h // 4, w // 4, 32), float('nan'), device='cuda')
+        ot = torch.full((n, k, h // 4, w // 4, 32), float('nan'), device='cuda')
+        C.front2_forward(dev(base), dev(cvis), dev(lvis), dev(torch.stack([r for _, r in nn], 1)), dev(torch.stack([b for b, _ in nn], 1)),
+                         n, k, h, w, blob, blob2, add_base, 0.3, fm1b, skip3b, qt, ot)
+        torch.cuda.synchronize()
+        assert torch.equal(fm1b, fm1) and torch.equal(skip3b, skip3)                 # same arithmetic as the plain front kernel
+        assert not torch.isnan(qt).any() and not torch.isnan(ot).any()
+        assert rel_l2(qt.cpu(), q2) <= 1e-5 and rel_l2(ot.cpu(), o2) <= 1e-5
     pred = torch.full((n, h, w, 3), float('nan'), device='cuda')
     C.back_forward(dev(x), dev(fm1_ref), dev(skip_ref), n, h // 2, w // 2, dev(w_s2), dev(b_s2), dev(w_s1), dev(b_s1), dev(wh),
                    0.3, pred)
@@ -78,8 +94,10 @@ def _labels(pm, db, mode):
     return out, labels
 
 
-@pytest.mark.parametrize('depth,uv,k,n', [(256, 64, 1, 2), (256, 64, 2, 2), (256, 64, 4, 1), (256, 128, 3, 1), (1024, 256, 1, 1)])
+@pytest.mark.parametrize('depth,uv,k,n', [(256, 64, 1, 2), (256, 64, 2, 2), (256, 64, 4, 1), (256, 128, 3, 1), (1024, 256, 1, 1),
+                                          (256, 64, 5, 1)])
 def test_model_call_with_fused_ends_vs_oracle(depth, uv, k, n):
+    # k <= 4: the front kernel also runs level 2's stride-2 convs; the (256, 64, 5, 1) case below takes the plain front
     om, pm = make_pair(depth=depth, uv=uv, im=uv // 2, seed=depth + k)
     batch, nn = O.synth_batch(n, uv, uv, uv // 2, uv // 2, uv // 2, uv // 2, k=k, seed=20 + k)
     with torch.no_grad():
@@ -88,6 +106,7 @@ def test_model_call_with_fused_ends_vs_oracle(depth, uv, k, n):
     (p_pred_c, p_gt_c, _, p_vis), labels = _labels(pm, db, 'vali')
     torch.cuda.synchronize()
     assert 'F.front' in labels and 'F.back' in labels and 'L0.stem' not in labels
+    assert ('L2.o.s2' in labels) == (k > 4) and ('L2.q.s2' in labels) == (k > 4) and 'L2.o.s1' in labels
     assert rel_l2(p_vis['pred'].cpu(), o_vis['pred']) <= TOL
     assert rel_l2(p_pred_c.cpu(), o_pred_c) <= TOL and rel_l2(p_gt_c.cpu(), o_gt_c) <= 1e-6
     pm.plan.fuse_ends = False

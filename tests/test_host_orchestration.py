@@ -105,7 +105,8 @@ def test_op_labels_and_algorithmic_bytes(monkeypatch):
             if not fused:
                 extra += 4 * 64 * 64 * (3 * k + 16) + 4 * 64 * 64 * 3
             assert abs((total - extra) / (64 * 64) - per_texel) < 1e-6, (k, fused, (total - extra) / 4096)
-            assert len(pm.plan.timer.records) == (1 + 5 * 5 + 5 * 2 + 1 if fused else 1 + 6 * 5 + 6 * 2 + 1)
+            # fused: front (L0, L1 and, with k <= 4, level 2's two stride-2 convs) + 5 levels x 5 - 2 + 5 decoder blocks x 2 + back
+            assert len(pm.plan.timer.records) == (1 + 5 * 5 - 2 + 5 * 2 + 1 if fused else 1 + 6 * 5 + 6 * 2 + 1)
             assert ('F.front' in pm.plan.timer.records) == fused and ('L0.stem' in pm.plan.timer.records) != fused
 
 
@@ -153,7 +154,8 @@ def test_lds_tiled_encoder_launches_fold_the_observation_mean(monkeypatch, fused
     rec = pm.plan.timer.records
     means = sorted(l for l in rec if l.endswith('.o.mean'))
     assert means == ([] if fused else ['L1.o.mean'])            # level 1 has 16 output channels: not eligible
-    assert pm.plan._ran_lds >= {'L2.q.s2', 'L2.o.s2', 'L2.q.s1', 'L2.o.s1', 'L6.o.s1'}
+    assert pm.plan._ran_lds >= {'L3.q.s2', 'L3.o.s2', 'L2.q.s1', 'L2.o.s1', 'L6.o.s1'}
+    assert ('L2.o.s2' in pm.plan._ran_lds) != fused             # fused: level 2's stride-2 convs ran inside the front kernel
     assert 'L1.q.s2' not in pm.plan._ran_lds
 
 
