@@ -128,6 +128,8 @@ def test_fused_ends_match_unfused_and_are_skipped_when_they_must_be(monkeypatch)
     assert not pm.plan.can_fuse(bufs, None, [None])                  # obs_override (nlt_test.py) -> layer-by-layer
     pm.plan.fuse_ends = False
     assert not pm.plan.can_fuse(bufs, None, None)
+    pm.plan.fuse_ends = True
+    assert not pm.plan.can_fuse(pm.plan._buffers(1, 16, 64, 64, cb[1].device), None, None)   # k = 16: LDS of the front kernel
 
 
 @pytest.mark.parametrize('fused', [False, True])
