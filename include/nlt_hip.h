@@ -401,6 +401,20 @@ int nlt_conv_tile_forward(int mode, const float* src, int ld, int cin, int frame
                           const float* packed, const float* bias, int cout, int tn,
                           float* out, int ldo, float* mean_out, int ldm, int act, float alpha, void* stream);
 
+/* ======================= bf16 channel mix (csrc/chmix_bf16.hip) =======================
+ * 1x1 conv with bf16 activations / weights and fp32 accumulation on v_mfma_f32_16x16x32_bf16: the literal dense GEMM
+ * of the path, used as the HBM-roofline stress point of BASELINE config 5 (2048^2 UV, bf16; SURVEY.md 8d "x64-ch").
+ *   out[t][o] = act(sum_c x[t][c] * W[c][o] + b[o]);  x [texels,cin], out [texels,cout] bf16 (uint16 bit patterns),
+ *   bias fp32; cin, cout in {32, 64, 128}.  W comes from a Keras (1,1,cin,cout) fp32 kernel through
+ *   nlt_chmix_bf16_pack (rounded to bf16, round-to-nearest-even).
+ *   replaces: tf.keras Conv2D(kernel_size=1) as built by nlt/networks/elements.py:26-31 (convnet.py:44,85), at a
+ *   64-channel width and in bf16 -- a shape the released network does not contain (its 1x1 layers are 5->16 and 36->3).
+ * Parity: against the oracle on bf16-rounded operands, within 1 bf16 ulp of the output. */
+long nlt_chmix_bf16_packed_elems(int cin, int cout);
+int nlt_chmix_bf16_pack(const float* w_keras, int cin, int cout, unsigned short* packed, void* stream);
+int nlt_chmix_bf16_forward(const unsigned short* x, long texels, int cin, const unsigned short* packed,
+                           const float* bias, int cout, int act, float alpha, unsigned short* out, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

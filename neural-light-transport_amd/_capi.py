@@ -69,6 +69,9 @@ SIGNATURES = {
     'nlt_pack_conv_tile_weights': (_c_int, [_c_int, _vp, _c_int, _c_int, _c_int, _vp, _vp]),
     'nlt_conv_tile_forward': (_c_int, [_c_int, _vp, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _vp, _vp, _c_int, _c_int,
                                        _vp, _c_int, _vp, _c_int, _c_int, _c_float, _vp]),
+    'nlt_chmix_bf16_packed_elems': (_c_long, [_c_int, _c_int]),
+    'nlt_chmix_bf16_pack': (_c_int, [_vp, _c_int, _c_int, _vp, _vp]),
+    'nlt_chmix_bf16_forward': (_c_int, [_vp, _c_long, _c_int, _vp, _vp, _c_int, _c_int, _c_float, _vp, _vp]),
     'nlt_cosine_map': (_c_int, [_vp] * 4 + [_c_double] * 3 + [_c_long, _vp, _vp, _vp]),
     'nlt_albedo': (_c_int, [_vp, _c_int, _c_long, _vp, _vp, _vp]),
     'nlt_diffuse_base': (_c_int, [_vp, _vp, _c_int, _c_long, _vp, _vp]),
@@ -339,6 +342,28 @@ def conv_tile_forward(mode, src, ld, cin, frames, kobs, h, w, packed, bias, cout
     _check(lib().nlt_conv_tile_forward(mode, _ptr(src), ld, cin, frames, kobs, h, w, _ptr(packed), _ptr(bias), cout, tn,
                                        _ptr(out), ldo, _ptr(mean_out), ldm, 1 if act else 0, float(alpha), _stream()),
            'nlt_conv_tile_forward')
+
+
+# ---------------------------------------------------------------- bf16 channel mix
+def chmix_bf16_pack(w_keras):
+    """Keras (1,1,cin,cout) fp32 kernel -> bf16 MFMA fragments."""
+    cin, cout = w_keras.shape[2], w_keras.shape[3]
+    n = lib().nlt_chmix_bf16_packed_elems(cin, cout)
+    if n <= 0:
+        raise NLTError("chmix_bf16: unsupported channel counts %d -> %d" % (cin, cout))
+    out = torch.empty(n, device=w_keras.device, dtype=torch.bfloat16)
+    _check(lib().nlt_chmix_bf16_pack(_ptr(_dense(w_keras, 'w_keras')), cin, cout, out.data_ptr(), _stream()), 'nlt_chmix_bf16_pack')
+    return out
+
+
+def chmix_bf16_forward(x, packed, bias, cout, act=True, alpha=0.3):
+    """x [..., cin] bf16 (dense NHWC) -> [..., cout] bf16."""
+    cin = x.shape[-1]
+    out = torch.empty(tuple(x.shape[:-1]) + (cout,), device=x.device, dtype=torch.bfloat16)
+    _check(lib().nlt_chmix_bf16_forward(_tptr(x, torch.bfloat16, 'x'), x.numel() // cin, cin,
+                                        _tptr(packed, torch.bfloat16, 'packed'), _ptr(bias), cout, 1 if act else 0, float(alpha),
+                                        out.data_ptr(), _stream()), 'nlt_chmix_bf16_forward')
+    return out
 
 
 # ---------------------------------------------------------------- fused inference ends

@@ -237,3 +237,18 @@ def glorot_uniform(rng, shape_hw_a_b):
     kh, kw, a, b = shape_hw_a_b
     limit = np.sqrt(6.0 / (kh * kw * a + kh * kw * b))
     return rng.uniform(-limit, limit, size=shape_hw_a_b).astype(np.float32)
+
+
+# ----------------------------------------------------------------------------
+# bf16 1x1 channel mix (BASELINE config 5): Conv2D(kernel_size=1) of
+# nlt/networks/elements.py:26-31 on bf16-rounded operands, fp32 accumulation
+# ----------------------------------------------------------------------------
+def conv1x1_bf16(x_bf16, w_hwio, b, act=True, alpha=LRELU_ALPHA):
+    """x [...,Cin] bfloat16; w_hwio (1,1,Cin,Cout) fp32 (rounded to bf16 here, round-to-nearest-even, as the
+    kernel's packer does); b fp32.  Products exact in fp32, sum in fp32 (float64 here: the summation order is the
+    kernel's business), bias, LeakyReLU, one final rounding to bf16."""
+    w = w_hwio[0, 0].to(torch.bfloat16).to(torch.float64)
+    y = x_bf16.to(torch.float64) @ w + b.to(torch.float64)
+    if act:
+        y = torch.where(y > 0, y, alpha * y)
+    return y.to(torch.float32).to(torch.bfloat16)
