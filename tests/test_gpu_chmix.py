@@ -1,6 +1,7 @@
 """-m gpu: bf16 1x1 channel mix (csrc/chmix_bf16.hip, v_mfma_f32_16x16x32_bf16) against the oracle on bf16-rounded
-operands.  Tolerance: the fp32 sums differ only by summation order, so outputs agree except where that difference
-straddles a bf16 rounding boundary -- at most 1 bf16 ulp, on a small fraction of elements."""
+operands.  Tolerance: the fp32 sums differ only by summation order (<= ~1e-5 absolute at these magnitudes), so outputs
+agree except where that difference straddles a bf16 rounding boundary -- at most 1 bf16 ulp, on a small fraction of
+elements."""
 import numpy as np
 import pytest
 import torch
@@ -28,7 +29,9 @@ def test_chmix_bf16_vs_oracle(cin, cout, shape, act):
     got = C.chmix_bf16_forward(x.cuda(), packed, b.cuda(), cout, act=act).cpu()
     assert got.shape == ref.shape and got.dtype == torch.bfloat16
     diff = (got.float() - ref.float()).abs()
-    assert bool((diff <= ulp_bf16(ref) * 1.001).all()), float((diff / ulp_bf16(ref)).max())
+    # 1 bf16 ulp of the result, plus the fp32 summation-order slack (<= cin * 2^-24 * sum|x w| ~ 1e-5 here), which is
+    # what decides the few results that cancel to nearly zero
+    assert bool((diff <= ulp_bf16(ref) * 1.001 + 1e-5).all()), float((diff / ulp_bf16(ref)).max())
     assert float((diff > 0).float().mean()) < 0.02                    # rounding-boundary cases only
     rel = float((got.float() - ref.float()).norm() / ref.float().norm())
     assert rel < 1e-3
