@@ -74,36 +74,37 @@ __global__ __launch_bounds__(256) void obs_mean_kernel(const float* __restrict__
 
 // ---------------------------------------------------------------------------------------
 // Head: convnet.py:85 over [dec | skip] -> 3, + base (nlt.py:101-102), corner zero (:110).
-// thread = texel; 3 accumulators; 16-byte loads of the texel vectors.
+// 8 lanes per texel: lane q takes channel quads q, q + 8, ... of the virtual concat, so a wave's loads of the
+// 32-channel skip are 1 KB contiguous (one thread per texel made every 16-byte load touch 64 different cache
+// lines); the three partial dot products are combined with 3 xor-shuffles and lane 0 finishes the texel.
 // ---------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void head_kernel(const float* __restrict__ dec, int ldd, int cd,
                                                    const float* __restrict__ skip, int lds, int cs,
                                                    const float* __restrict__ wk, const float* __restrict__ bias,
                                                    const float* __restrict__ base, int hw, long total,
                                                    float* __restrict__ pred) {
-  const long tex = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (tex >= total) return;
-  float a0 = bias[0], a1 = bias[1], a2 = bias[2];
-  const float* d = dec + tex * ldd;
-  for (int c = 0; c < cd; c += 4) {
-    const f32x4 v = *reinterpret_cast<const f32x4*>(d + c);
+  const long tid = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long tex = tid >> 3;
+  const int q = tid & 7;
+  const bool live = tex < total;
+  const long tc = live ? tex : total - 1;                    // clamped: every lane of the shuffle group stays active
+  const int qd = cd >> 2, quads = (cd + cs) >> 2;
+  float a0 = 0.f, a1 = 0.f, a2 = 0.f;
+  for (int qq = q; qq < quads; qq += 8) {
+    const f32x4 v = qq < qd ? *reinterpret_cast<const f32x4*>(dec + tc * ldd + 4 * qq)
+                            : *reinterpret_cast<const f32x4*>(skip + tc * lds + 4 * (qq - qd));
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      const float* wr = wk + (c + j) * 3;
+      const float* wr = wk + (4 * qq + j) * 3;
       a0 = fmaf(v[j], wr[0], a0); a1 = fmaf(v[j], wr[1], a1); a2 = fmaf(v[j], wr[2], a2);
     }
   }
-  if (cs > 0) {
-    const float* sk = skip + tex * lds;
-    for (int c = 0; c < cs; c += 4) {
-      const f32x4 v = *reinterpret_cast<const f32x4*>(sk + c);
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const float* wr = wk + (cd + c + j) * 3;
-        a0 = fmaf(v[j], wr[0], a0); a1 = fmaf(v[j], wr[1], a1); a2 = fmaf(v[j], wr[2], a2);
-      }
-    }
+  for (int off = 1; off < 8; off <<= 1) {
+    a0 += __shfl_xor(a0, off); a1 += __shfl_xor(a1, off); a2 += __shfl_xor(a2, off);
   }
+  if (!live || q) return;
+  a0 += bias[0]; a1 += bias[1]; a2 += bias[2];
   if (base) { a0 += base[tex * 3 + 0]; a1 += base[tex * 3 + 1]; a2 += base[tex * 3 + 2]; }
   if (tex % hw == 0) { a0 = 0.f; a1 = 0.f; a2 = 0.f; }     // texel (0,0) of every frame
   pred[tex * 3 + 0] = a0; pred[tex * 3 + 1] = a1; pred[tex * 3 + 2] = a2;
@@ -161,7 +162,7 @@ extern "C" int nlt_head_forward(const float* dec, int ldd, int cd, const float* 
   if ((cd & 3) || (cs & 3) || (ldd & 3) || (cs > 0 && (lds & 3))) return NLT_ERR_UNSUPPORTED;
   if (!nlt_aligned16(dec) || (cs > 0 && !nlt_aligned16(skip))) return NLT_ERR_BAD_ARG;
   const long total = (long)n * h * w;
-  hipLaunchKernelGGL(head_kernel, dim3(blocks_for(total)), dim3(256), 0, static_cast<hipStream_t>(stream),
+  hipLaunchKernelGGL(head_kernel, dim3(blocks_for(total * 8)), dim3(256), 0, static_cast<hipStream_t>(stream),
                      dec, ldd, cd, skip, lds, cs, w_keras, bias, base, h * w, total, pred);
   NLT_CHECK_LAUNCH();
   return NLT_OK;
