@@ -66,6 +66,8 @@ def parse():
     ap.add_argument('--depth', type=int, default=256)
     ap.add_argument('--algo', type=str, default='auto', choices=['auto', 'direct'])
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--graph', action='store_true', help='replay the forward as one hipGraph (model.use_graphs); the dominant '
+                    'kernel is then timed in an eager pass of the same steps right after the timed region')
     ap.add_argument('--no-fused', action='store_true', help='layer-by-layer plan (disable csrc/fused.hip) for A/B runs')
     ap.add_argument('--tune-cache', type=str, default=None, help='JSON of tile choices: loaded if present, else written')
     ap.add_argument('--cpu-baseline-worker', action='store_true', help=argparse.SUPPRESS)
@@ -229,6 +231,7 @@ def main():
         model.conv_algo = capi.ALGO_DIRECT
     if args.no_fused:
         model.plan.fuse_ends = False
+    model.use_graphs = bool(args.graph)
     if args.tune_cache and os.path.exists(args.tune_cache):
         model.plan.load_tuning(args.tune_cache)
     batch = synth_device_batch(args.frames, args.uv, args.cam, args.k, device, seed=100 + rank)
@@ -260,7 +263,7 @@ def main():
     for _ in range(args.warmup):
         step()
     dom = OpTimer(); dom.only = {dominant}
-    model.plan.timer = dom
+    model.plan.timer = None if args.graph else dom      # events cannot be recorded inside a replayed graph
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
@@ -271,6 +274,13 @@ def main():
     if world > 1:
         dist.barrier()
     elapsed = time.perf_counter() - t0
+    if args.graph:                                      # same steps, eager, only to time the dominant launch
+        model.use_graphs = False
+        model.plan.timer = dom
+        for _ in range(args.steps):
+            step()
+        torch.cuda.synchronize()
+        model.use_graphs = True
     model.plan.timer = None
     if world > 1:
         te = torch.tensor([elapsed], device=device, dtype=torch.float64)
@@ -314,7 +324,8 @@ def main():
                                    "%d frames/GPU, %d^2 UV, k=%d obs maps, %d^2 camera warp"
                                    % (args.depth, args.frames, args.uv, args.k, args.cam),
                        "frames_per_gpu": args.frames, "uv": args.uv, "k": args.k, "cam": args.cam,
-                       "conv_algo": args.algo, "plan": "layer-by-layer" if args.no_fused else "fused ends", "parallelism": "dp%d (frames sharded, no forward collective)" % world},
+                       "conv_algo": args.algo, "plan": "layer-by-layer" if args.no_fused else "fused ends",
+                       "launch": "hipGraph replay" if args.graph else "eager, two HIP streams", "parallelism": "dp%d (frames sharded, no forward collective)" % world},
             "roofline": roof,
             "roofline_whole_pass": {"algorithmic_bytes_per_texel": bpt,
                                     "achieved": round(value / world * 1e6 * bpt / 1e9, 1), "unit": "GB/s per GPU",

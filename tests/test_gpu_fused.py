@@ -168,3 +168,36 @@ def test_fused_vs_layer_by_layer_at_2048():
     torch.cuda.synchronize()
     assert rel_l2(pred_a.cpu(), b[3]['pred'].cpu()) <= 1e-5
     assert not pred_a[:, 0, 0].any() and torch.isfinite(pred_a).all()
+
+
+def test_hipgraph_replay_matches_eager_and_tracks_inputs():
+    """model.use_graphs: third call with the same input tensors replays a captured hipGraph (two streams inside);
+    results equal the eager launch bit for bit, follow in-place changes of the inputs, and a batch at other addresses
+    falls back to eager launches."""
+    import nlt_amd
+    import bench
+    from nlt_amd.models import get_model_class
+    dev = torch.device('cuda', 0)
+    model = get_model_class('nlt')(nlt_amd.make_config(uvh=256, uvw=256, imh=128, imw=128)).build(dev)
+    batch = bench.synth_device_batch(2, 256, 128, 2, dev, seed=3)
+    ref = model.call(batch, 'test')
+    ref_pred, ref_cam = ref[3]['pred'].clone(), ref[0].clone()
+    model.use_graphs = True
+    for i in range(4):
+        out = model.call(batch, 'test')
+        torch.cuda.synchronize()
+        assert torch.equal(out[3]['pred'], ref_pred) and torch.equal(out[0], ref_cam), i
+    assert model._graph['graph'] is not None and model._graph['hits'] >= 2
+    batch[1].mul_(0.5)                                            # base changes in place: same addresses -> replay sees it
+    out = model.call(batch, 'test')
+    model.use_graphs = False
+    eager = model.call(batch, 'test')
+    torch.cuda.synchronize()
+    assert torch.equal(out[3]['pred'], eager[3]['pred']) and not torch.equal(out[3]['pred'], ref_pred)
+    model.use_graphs = True
+    other = bench.synth_device_batch(2, 256, 128, 2, dev, seed=4)
+    o2 = model.call(other, 'test')                               # new addresses: eager again
+    model.use_graphs = False
+    e2 = model.call(other, 'test')
+    torch.cuda.synchronize()
+    assert torch.equal(o2[3]['pred'], e2[3]['pred'])
