@@ -48,3 +48,27 @@ def test_no_cpu_fallback_for_cpu_tensors():
     x = torch.zeros(4)
     with pytest.raises(C.NLTError):
         C.mul_forward(x, x) if False else C._ptr(x)
+
+
+def test_bad_arguments_return_status_codes_without_a_gpu():
+    """Null pointers / empty shapes are rejected by the argument checks before anything is launched, so these calls are
+    safe on a machine with no GPU: every entry point answers NLT_ERR_BAD_ARG (-1) or NLT_ERR_UNSUPPORTED (-2)."""
+    L = C.lib()
+    n = None
+    assert L.nlt_conv_forward(C.CONV_K2S1, C.ALGO_DIRECT, 0, n, 16, 16, n, 0, 0, 1, 4, 4, n, n, n, 16, n, 16, 1, 0.3, n, 0, 0, n) == -1
+    assert L.nlt_stem_forward(n, n, n, n, n, n, 1, 1, 4, 4, 16, n, n, n, n, n, n, n) == -1
+    assert L.nlt_head_forward(n, 4, 4, n, 32, 32, n, n, n, 1, 4, 4, n, n) == -1
+    assert L.nlt_warp_forward(n, n, n, 1, 4, 4, 2, 2, n, n, n, n, n) == -1
+    assert L.nlt_front_forward(n, n, n, n, n, 1, 1, 4, 4, n, 1, 0.3, n, n, n, n) == -1
+    assert L.nlt_back_forward(n, n, n, 1, 2, 2, n, n, n, n, n, 0.3, n, n) == -1
+    assert L.nlt_conv_tile_forward(C.CONV_K2S1, n, 16, 16, 1, 1, 4, 4, n, n, 32, 32, n, 32, n, 0, 1, 0.3, n) == -1
+    assert L.nlt_conv_backward_weights_tiled(C.CONV_K2S1, n, 16, 16, n, 0, 0, 1, 4, 4, n, 16, 16, n, n, n, 0, n) == -1
+    assert L.nlt_knn_indices(n, 0, n, 0, 1, n, n) == -1
+    assert L.nlt_uv_index_map(n, n, 0, 1, 4, 4, 4, 0.0, n, n, n, n) == -1
+    assert L.nlt_remap_bilinear_u8(n, 4, 4, 1, n, 0, 2, 4, 4, 1, n, n) == -1
+    assert L.nlt_assemble_batch(n, n, n, n, n, n, 0, 0, 16, 0, n, n, n, n, n, n, n) == -1
+    assert L.nlt_adam_amsgrad_step(n, n, n, n, n, 0, 1e-3, 0.9, 0.999, 1e-7, n) == -1
+    assert L.nlt_chmix_bf16_forward(n, 0, 64, n, n, 64, 1, 0.3, n, n) == -1
+    # sizes the kernels do not implement are "unsupported", not "bad"
+    assert L.nlt_conv_tile_packed_floats(C.CONV_K2S1, 24, 32, 32) == -1 and L.nlt_chmix_bf16_packed_elems(48, 64) == -1
+    assert L.nlt_wgrad_workspace_floats(C.CONV1X1, 5, 0, 1, 8, 8, 16) == -1
