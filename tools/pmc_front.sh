@@ -6,7 +6,8 @@ rocprofv3 --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_
 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_LDS_IDX_ACTIVE SQ_INST_CYCLES_VMEM GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $R/gpurun_out/pmc_sq2 -- python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --train-steps 0 --tune-cache $R/gpurun_out/tune_fused.json > /dev/null 2>&1
 cd $R
 python - <<'PY'
-import csv, glob, collections
+import csv, glob, collections, json
+summary = {}
 for d in ('pmc_sq', 'pmc_sq2'):
     acc = collections.defaultdict(lambda: collections.defaultdict(list))
     for p in glob.glob('gpurun_out/%s/**/*counter_collection*.csv' % d, recursive=True):
@@ -15,5 +16,12 @@ for d in ('pmc_sq', 'pmc_sq2'):
             if 'front_kernel' in n or 'back_kernel' in n or 'conv_tile' in n or 'warp_kernel' in n:
                 acc[n[:48]][r['Counter_Name']].append(float(r['Counter_Value']))
     for k, dd in acc.items():
-        print(d, k, {c: round(sum(x)/len(x)) for c, x in dd.items()})
+        row = {c: round(sum(x)/len(x)) for c, x in dd.items()}
+        summary.setdefault(k, {}).update(row)
+        print(d, k, row)
+for k, r in summary.items():
+    if 'SQ_VALU_MFMA_BUSY_CYCLES' in r and 'GRBM_GUI_ACTIVE' in r:
+        # GRBM_GUI_ACTIVE is summed over the 8 XCDs; MFMA busy cycles over the 1024 SIMDs
+        r['mfma_pipe_utilisation'] = round(r['SQ_VALU_MFMA_BUSY_CYCLES'] / 1024.0 / (r['GRBM_GUI_ACTIVE'] / 8.0), 3)
+json.dump(summary, open('gpurun_out/pmc_sq.json', 'w'), indent=1)
 PY
