@@ -24,6 +24,9 @@ constexpr int TH = 8, TW = 16;             // half-resolution tile owned by one 
 constexpr int HH = TH + 1, HW = TW + 1;    // with the 1-texel halo the stride-1 conv needs
 constexpr int HT = HH * HW;                // 153 haloed texels
 constexpr int NT = (HT + 15) / 16;         // 10 MFMA column tiles
+constexpr int PLT = 160;                   // LDS plane of one channel quad of one path's haloed tile (153 -> 160 slots)
+constexpr int PATH = 4 * PLT * 4;          // floats per path: [kk][PLT][4] -- planar by channel quad, so the 16 lanes
+                                           // a ds_read_b128 services together hit 16 different 16-byte slots
 
 // packed-blob offsets (floats); written by front_pack_kernel, read by front_kernel
 constexpr int OFF_AQ2 = 0;                 // [8][64]     folded q stride-2 conv, MFMA m x lane
@@ -143,7 +146,7 @@ __global__ __launch_bounds__(256) void front_kernel(
     int tiles_y, int tiles_x, const float* __restrict__ blob, int add_base, float alpha,
     float* __restrict__ fm1, float* __restrict__ obs1, float* __restrict__ skip3,
     const float* __restrict__ blob3, float* __restrict__ qtmp2, float* __restrict__ otmp2) {
-  extern __shared__ __attribute__((aligned(16))) float lds[];          // [1 + k][HT][16]: q, then obs i
+  extern __shared__ __attribute__((aligned(16))) float lds[];          // [1 + k][4 kk][PLT][4]: q, then obs i
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int kk = lane >> 4, j = lane & 15;
   const int h2 = h >> 1, w2 = w >> 1;
@@ -209,7 +212,7 @@ __global__ __launch_bounds__(256) void front_kernel(
           acc = __builtin_amdgcn_mfma_f32_16x16x4f32(ao2[2], d2, acc, 0, 0, 0);
           acc = lrelu4(acc + bo2, alpha);
           if (!inside) acc = (f32x4){0.f, 0.f, 0.f, 0.f};
-          if (live) *reinterpret_cast<f32x4*>(lds + ((size_t)(1 + i0 + u) * HT + t) * 16 + 4 * kk) = acc;
+          if (live) *reinterpret_cast<f32x4*>(lds + (size_t)(1 + i0 + u) * PATH + (kk * PLT + t) * 4) = acc;
         }
       }
     };
@@ -232,7 +235,7 @@ __global__ __launch_bounds__(256) void front_kernel(
     for (int m = 0; m < 8; ++m) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(aq2[m], raw[m], acc, 0, 0, 0);
     acc = lrelu4(acc + bq2, alpha);
     if (!inside) acc = (f32x4){0.f, 0.f, 0.f, 0.f};
-    if (live) *reinterpret_cast<f32x4*>(lds + (size_t)t * 16 + 4 * kk) = acc;
+    if (live) *reinterpret_cast<f32x4*>(lds + (kk * PLT + t) * 4) = acc;
     if (owned) {                                                       // the head's share of the L0 features (+ base)
       float s0 = blob[OFF_BSK], s1 = blob[OFF_BSK + 1], s2 = blob[OFF_BSK + 2];
 #pragma unroll
@@ -264,12 +267,12 @@ __global__ __launch_bounds__(256) void front_kernel(
     f32x4 qv[2] = {mean[0], mean[0]};
     f32x4 o1[L2S2 ? 4 : 1][2];                                         // L2S2: the observations' level-1 outputs stay in registers
     auto path = [&](int p, f32x4 (&out)[2]) {
-      const float* tilep = lds + (size_t)p * HT * 16;
+      const float* tilep = lds + (size_t)p * PATH + kk * PLT * 4;
       f32x4 acc[2] = {(f32x4){0.f, 0.f, 0.f, 0.f}, (f32x4){0.f, 0.f, 0.f, 0.f}};
 #pragma unroll
       for (int t = 0; t < 4; ++t) {
-        const f32x4 b0 = *reinterpret_cast<const f32x4*>(tilep + ((wave + (t >> 1)) * HW + j + (t & 1)) * 16 + 4 * kk);
-        const f32x4 b1 = *reinterpret_cast<const f32x4*>(tilep + ((wave + 4 + (t >> 1)) * HW + j + (t & 1)) * 16 + 4 * kk);
+        const f32x4 b0 = *reinterpret_cast<const f32x4*>(tilep + ((wave + (t >> 1)) * HW + j + (t & 1)) * 4);
+        const f32x4 b1 = *reinterpret_cast<const f32x4*>(tilep + ((wave + 4 + (t >> 1)) * HW + j + (t & 1)) * 4);
         const f32x4 a = p ? ao1[t] : aq1[t];
 #pragma unroll
         for (int s4 = 0; s4 < 4; ++s4) {
@@ -309,13 +312,17 @@ __global__ __launch_bounds__(256) void front_kernel(
       }
 
     if (L2S2) {
-      // ---- stage 3: level 2's stride-2 convs.  The level-1 tile goes back into LDS as [slab][8 x 16 texels][16]
-      // (slab 0 = q1, 1 = mean o1, 2 + i = o1 of observation i); lane group kk is tap (a, b) again, wave = (column
-      // tile of the 32 level-2 texels, row tile of the 32 outputs).
+      // ---- stage 3: level 2's stride-2 convs.  The level-1 tile goes back into LDS as [slab][channel quad][x parity]
+      // [row 8][x/2 8][4] (slab 0 = q1, 1 = mean o1, 2 + i = o1 of observation i), planar per channel quad and split by
+      // x parity so that the stride-2 reads of 16 lanes are 16 different 16-byte slots; rows whose pair index (row/2)
+      // is odd, xor the x parity, sit in the other half of the 16 slots (the ^ 8), which keeps both the row-major
+      // writes (both parities of one row) and the reads (rows 2Y + a and 2Y + 2 + a) free of bank conflicts.  Lane
+      // group kk is tap (a, b) again, wave = (column tile of the 32 level-2 texels, row tile of the 32 outputs).
       __syncthreads();                                                 // every wave is done reading the stage-1 tiles
 #pragma unroll
       for (int e = 0; e < 2; ++e) {
-        float* dst = lds + ((wave + 4 * e) * 16 + j) * 16 + 4 * kk;
+        const int r = wave + 4 * e, par = j & 1;
+        float* dst = lds + (kk * 128 + par * 64 + ((r * 8 + (j >> 1)) ^ ((((r >> 1) & 1) ^ par) * 8))) * 4;
         *reinterpret_cast<f32x4*>(dst) = qv[e];
         *reinterpret_cast<f32x4*>(dst + 2048) = mean[e];
 #pragma unroll
@@ -326,7 +333,7 @@ __global__ __launch_bounds__(256) void front_kernel(
       const int ct = wave & 1, rt = wave >> 1;
       const int t2 = ct * 16 + j;                                      // level-2 texel of the 4 x 8 tile
       const int Y = t2 >> 3, X = t2 & 7;
-      const float* src = lds + ((2 * Y + (kk >> 1)) * 16 + 2 * X + (kk & 1)) * 16;
+      const float* src = lds + ((kk & 1) * 64 + (((2 * Y + (kk >> 1)) * 8 + X) ^ (((Y & 1) ^ (kk & 1)) * 8))) * 4;
       const int gy2 = (ty0 >> 1) + Y, gx2 = (tx0 >> 1) + X;
       const int h4 = h2 >> 1, w4 = w2 >> 1;
       const bool in2 = gy2 < h4 && gx2 < w4;
@@ -336,7 +343,7 @@ __global__ __launch_bounds__(256) void front_kernel(
         f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int c8 = 0; c8 < 8; ++c8) {
-          const f32x4 v = *reinterpret_cast<const f32x4*>(src + (c8 >> 2) * 2048 + 4 * (c8 & 3));
+          const f32x4 v = *reinterpret_cast<const f32x4*>(src + (c8 >> 2) * 2048 + 512 * (c8 & 3));
           const f32x4 a = *reinterpret_cast<const f32x4*>(blob3 + OFF3_AQ + ((rt * 8 + c8) * 64 + lane) * 4);
 #pragma unroll
           for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[e], v[e], acc, 0, 0, 0);
@@ -354,7 +361,7 @@ __global__ __launch_bounds__(256) void front_kernel(
           f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
           for (int c4 = 0; c4 < 4; ++c4) {
-            const f32x4 v = *reinterpret_cast<const f32x4*>(src + (2 + i) * 2048 + 4 * c4);
+            const f32x4 v = *reinterpret_cast<const f32x4*>(src + (2 + i) * 2048 + 512 * c4);
 #pragma unroll
             for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(ao3[c4][e], v[e], acc, 0, 0, 0);
           }
@@ -471,8 +478,8 @@ extern "C" int nlt_front_forward(const float* base, const float* cvis, const flo
   if (n <= 0 || k <= 0 || h <= 0 || w <= 0) return NLT_ERR_BAD_ARG;
   if ((h | w) & 1) return NLT_ERR_UNSUPPORTED;
   if (!nlt_aligned16(packed) || !nlt_aligned16(fm1) || !nlt_aligned16(obs1)) return NLT_ERR_BAD_ARG;
-  const size_t lds_bytes = (size_t)(1 + k) * HT * 16 * sizeof(float);
-  if (lds_bytes > 160 * 1024) return NLT_ERR_UNSUPPORTED;              // k <= 15
+  const size_t lds_bytes = (size_t)(1 + k) * PATH * sizeof(float);
+  if (k > 14) return NLT_ERR_UNSUPPORTED;                              // (1 + k) * 10 KB of LDS, 160 KB per CU
   if ((long long)n * k * h * w * 3 >= (1ll << 31)) return NLT_ERR_UNSUPPORTED;
   const int ty = (h / 2 + TH - 1) / TH, tx = (w / 2 + TW - 1) / TW;
   const long blocks = (long)n * ty * tx;
@@ -507,7 +514,7 @@ extern "C" int nlt_front2_forward(const float* base, const float* cvis, const fl
   if (!nlt_aligned16(packed) || !nlt_aligned16(packed_l2) || !nlt_aligned16(fm1) || !nlt_aligned16(qtmp2) || !nlt_aligned16(otmp2))
     return NLT_ERR_BAD_ARG;
   if ((long long)n * k * h * w * 3 >= (1ll << 31)) return NLT_ERR_UNSUPPORTED;
-  size_t lds_floats = (size_t)(1 + k) * HT * 16;
+  size_t lds_floats = (size_t)(1 + k) * PATH;
   if ((size_t)(2 + k) * 2048 > lds_floats) lds_floats = (size_t)(2 + k) * 2048;
   const size_t lds_bytes = lds_floats * sizeof(float);
   const int ty = (h / 2 + TH - 1) / TH, tx = (w / 2 + TW - 1) / TW;

@@ -264,7 +264,7 @@ class RenderPlan:
         q, D, U, cl = self.q, self.n_down, self.n_up, b['C']
         if not (self.fuse_ends and self.use_obs and obs_weights is None and obs_override is None and D >= 2 and U >= 2):
             return False
-        if b['obs'][0].shape[1] > 15:                   # the front kernel keeps (1 + k) haloed tiles in LDS (160 KB per CU)
+        if b['obs'][0].shape[1] > 14:                   # the front kernel keeps (1 + k) haloed tiles in LDS (160 KB per CU)
             return False
         last = q.layers[D + U].convs()
         prev = q.layers[D + U - 1].convs()

@@ -14,6 +14,8 @@ TH, TW = 8, 16
 HH, HW = TH + 1, TW + 1
 HT = HH * HW
 NT = (HT + 15) // 16
+PLT = 160
+PATH = 4 * PLT * 4
 OFF_AQ2, OFF_AO2, OFF_AQ1, OFF_AO1 = 0, 512, 704, 1728
 OFF_BQ2, OFF_BO2, OFF_BQ1, OFF_BO1, OFF_WSK, OFF_BSK, BLOB = 2752, 2768, 2784, 2800, 2816, 2840, 2848
 LANE = np.arange(64)
@@ -105,7 +107,7 @@ def front(base, cvis, lvis, nn_rgb, nn_base, blob, add_base, alpha, blob3=None):
         tx0 = (tile % tx) * TW; tile //= tx
         ty0 = (tile % ty) * TH
         f = tile // ty
-        lds = np.full((max((1 + k) * HT * 16, (2 + k) * 2048),), np.nan, np.float32)
+        lds = np.full((max((1 + k) * PATH, (2 + k) * 2048),), np.nan, np.float32)
         keep = {}                                              # L2S2: (wave, e) -> (qv, mean, [o1_i]) kept in registers
         for wave in range(4):
             aq2 = [blob[OFF_AQ2 + m * 64 + LANE] for m in range(8)]
@@ -134,7 +136,7 @@ def front(base, cvis, lvis, nn_rgb, nn_base, blob, add_base, alpha, blob3=None):
                     acc = lrelu(acc + bo2, alpha)
                     acc[~inside] = 0
                     for l in np.nonzero(live)[0]:
-                        a0 = ((1 + i) * HT + t[l]) * 16 + 4 * KK[l]
+                        a0 = (1 + i) * PATH + (KK[l] * PLT + t[l]) * 4
                         lds[a0:a0 + 4] = acc[l]
                 raw += [xs[c] * inv_k for c in range(3)]
                 acc = np.zeros((64, 4), np.float32)
@@ -143,7 +145,7 @@ def front(base, cvis, lvis, nn_rgb, nn_base, blob, add_base, alpha, blob3=None):
                 acc = lrelu(acc + bq2, alpha)
                 acc[~inside] = 0
                 for l in np.nonzero(live)[0]:
-                    a0 = t[l] * 16 + 4 * KK[l]
+                    a0 = (KK[l] * PLT + t[l]) * 4
                     lds[a0:a0 + 4] = acc[l]
                 for l in np.nonzero(owned)[0]:
                     s = [blob[OFF_BSK + o] for o in range(3)]
@@ -169,7 +171,7 @@ def front(base, cvis, lvis, nn_rgb, nn_base, blob, add_base, alpha, blob3=None):
                 for p in range(k + 1):
                     acc = np.zeros((64, 4), np.float32)
                     for t_ in range(4):
-                        a0 = p * HT * 16 + ((r + (t_ >> 1)) * HW + J + (t_ & 1)) * 16 + 4 * KK
+                        a0 = p * PATH + (KK * PLT + (r + (t_ >> 1)) * HW + J + (t_ & 1)) * 4
                         b = np.stack([lds[a0 + s4] for s4 in range(4)], 1)
                         assert not np.isnan(b).any()
                         a = ao1[t_] if p else aq1[t_]
@@ -191,11 +193,12 @@ def front(base, cvis, lvis, nn_rgb, nn_base, blob, add_base, alpha, blob3=None):
                     fm1[a0:a0 + 4] = qv[l]
                     fm1[a0 + 16:a0 + 20] = mean[l]
         if blob3 is not None:
-            # __syncthreads(); level-1 tile -> LDS [slab][8 x 16][16]; __syncthreads(); level 2's stride-2 convs
+            # __syncthreads(); level-1 tile -> LDS [slab][quad][x parity][8][8][4], swizzled; __syncthreads(); level 2's stride-2 convs
             lds[:] = np.nan
             for (wave, r), (qv, mean, o1s) in keep.items():
                 for l in range(64):
-                    d0 = (r * 16 + J[l]) * 16 + 4 * KK[l]
+                    par = J[l] & 1
+                    d0 = (KK[l] * 128 + par * 64 + ((r * 8 + (J[l] >> 1)) ^ ((((r >> 1) & 1) ^ par) * 8))) * 4
                     lds[d0:d0 + 4] = qv[l]; lds[d0 + 2048:d0 + 2052] = mean[l]
                     for i, o in enumerate(o1s):
                         lds[d0 + (2 + i) * 2048: d0 + (2 + i) * 2048 + 4] = o[l]
@@ -203,14 +206,14 @@ def front(base, cvis, lvis, nn_rgb, nn_base, blob, add_base, alpha, blob3=None):
                 ct, rt = wave & 1, wave >> 1
                 t2 = ct * 16 + J
                 Y, X = t2 >> 3, t2 & 7
-                src = ((2 * Y + (KK >> 1)) * 16 + 2 * X + (KK & 1)) * 16
+                src = ((KK & 1) * 64 + (((2 * Y + (KK >> 1)) * 8 + X) ^ (((Y & 1) ^ (KK & 1)) * 8))) * 4
                 gy2, gx2 = (ty0 >> 1) + Y, (tx0 >> 1) + X
                 in2 = (gy2 < h4) & (gx2 < w4)
                 tex2 = gy2 * w4 + gx2
                 oc = rt * 16 + 4 * KK
                 acc = np.zeros((64, 4), np.float32)
                 for c8 in range(8):
-                    v = np.stack([lds[src + (c8 >> 2) * 2048 + 4 * (c8 & 3) + e] for e in range(4)], 1)
+                    v = np.stack([lds[src + (c8 >> 2) * 2048 + 512 * (c8 & 3) + e] for e in range(4)], 1)
                     assert not np.isnan(v).any()
                     a = np.stack([blob3[OFF3_AQ + ((rt * 8 + c8) * 64 + LANE) * 4 + e] for e in range(4)], 1)
                     for e in range(4):
@@ -222,7 +225,7 @@ def front(base, cvis, lvis, nn_rgb, nn_base, blob, add_base, alpha, blob3=None):
                 for i in range(k):
                     acc = np.zeros((64, 4), np.float32)
                     for c4 in range(4):
-                        v = np.stack([lds[src + (2 + i) * 2048 + 4 * c4 + e] for e in range(4)], 1)
+                        v = np.stack([lds[src + (2 + i) * 2048 + 512 * c4 + e] for e in range(4)], 1)
                         assert not np.isnan(v).any()
                         a = np.stack([blob3[OFF3_AO + ((rt * 4 + c4) * 64 + LANE) * 4 + e] for e in range(4)], 1)
                         for e in range(4):
@@ -446,3 +449,25 @@ def test_fused_ends_emulation_partial_tiles():
     (w_s2, b_s2), (w_s1, b_s1) = W['query'][n_layers - 2]
     got = back(g(x), g(fm1_ref), ref_skip, w_s2, b_s2, w_s1, b_s1, wh[0, 0, :4, :], 0.3)
     assert not np.isnan(got).any() and _rel(got, g(pred)) < 2e-6
+
+
+def test_front_lds_patterns_are_bank_conflict_free():
+    """ds_read/write_b128 serves 16 lanes per pass (16 lanes x 16 B = all 64 banks): every 16-lane group of the
+    front kernel's LDS accesses must touch 16 different 16-byte slots modulo 16 (fused.hip stages 1-3)."""
+    def free(addr_floats):
+        slots = (np.asarray(addr_floats) // 4).reshape(4, 16) % 16
+        return all(len(set(g)) == 16 for g in slots)
+    for mt in range(NT - 1):                                           # stage-1 writes (the last tile is ragged)
+        assert free((KK * PLT + mt * 16 + J) * 4)
+    for r in range(8):                                                 # stage-2 reads, both rows of a wave
+        for t_ in range(4):
+            assert free((KK * PLT + (r + (t_ >> 1)) * HW + J + (t_ & 1)) * 4)
+    for r in range(8):                                                 # stage-3 writes
+        par = J & 1
+        assert free((KK * 128 + par * 64 + ((r * 8 + (J >> 1)) ^ ((((r >> 1) & 1) ^ par) * 8))) * 4)
+    for ct in range(2):                                                # stage-3 reads
+        t2 = ct * 16 + J
+        Y, X = t2 >> 3, t2 & 7
+        src = ((KK & 1) * 64 + (((2 * Y + (KK >> 1)) * 8 + X) ^ (((Y & 1) ^ (KK & 1)) * 8))) * 4
+        for c4 in range(4):
+            assert free(src + 512 * c4)
