@@ -374,6 +374,44 @@ int nlt_back_forward(const float* x, const float* fm1, const float* skip3, int n
                      const float* w_s2, const float* b_s2, const float* w_s1, const float* b_s1,
                      const float* w_head, float alpha, float* pred, void* stream);
 
+/*
+ * TRAINING forms of the fused ends.  The forward passes are the same launches as nlt_front_forward / nlt_back_forward
+ * and additionally keep what the backward pass needs:
+ *   qtmp1 [n,h/2,w/2,16], otmp1 [n,k,h/2,w/2,16] = LeakyReLU(Conv2D k2s2) of level 1 (inputs of its stride-1 convs);
+ *   u [n,2h2,2w2,4] = LeakyReLU(Conv2DTranspose k2s2), v [n,2h2,2w2,4] = LeakyReLU(Conv2DTranspose k2s1) of the last block.
+ *   replaces (train mode): the same reference lines as the inference forms, run under the GradientTape of
+ *             nlt/trainvali.py:272-274.
+ */
+int nlt_front_forward_train(const float* base, const float* cvis, const float* lvis, const float* nn_rgb,
+                            const float* nn_base, int n, int k, int h, int w, const float* packed,
+                            int add_base, float alpha, float* fm1, float* obs1, float* skip3,
+                            float* qtmp1, float* otmp1, void* stream);
+int nlt_back_forward_train(const float* x, const float* fm1, const float* skip3, int n, int h2, int w2,
+                           const float* w_s2, const float* b_s2, const float* w_s1, const float* b_s1,
+                           const float* w_head, float alpha, float* pred, float* u, float* v, void* stream);
+
+/*
+ * Backward of layers 0-1's linear part without any full-resolution feature tensor (csrc/train_fused.hip):
+ * L0 is a 1x1 conv with no activation, so the weight gradients of L0 (both paths), of level 1's two stride-2 convs
+ * and of the head's 32 skip rows are small matrix products with texel sums of (raw channels x gradients), which one
+ * pass over the raw buffers forms on the matrix cores (deterministic two-pass reduction).
+ *   replaces: tape.gradient (nlt/trainvali.py:279) through nlt/models/nlt.py:95-96 and the i = 0, 1 layer iterations
+ *             (nlt.py:153-180) for those weights, i.e. of the unfused plan: nlt_stem_backward, the skip half of
+ *             nlt_head_backward, nlt_conv_backward_weights + backward-data of L1.{q,o}.s2.
+ * dy1q [n,h/2,w/2,16] / dy1o [n,k,h/2,w/2,16]: gradients w.r.t. the PRE-activation outputs of level 1's stride-2
+ * convs; dpred [n,h,w,3] (texel (0,0) ignored: set_left_top_corner).  h even, w a multiple of 8.
+ * Weights in Keras layouts: wq0 (1,1,5,16), wo0 (1,1,3,16), wqa (2,2,32,16), woa (2,2,16,16), wh (1,1,36,3).
+ * Gradients are ACCUMULATED (+=): dwq0, dbq0, dwo0, dbo0, dwqa, dbqa, dwoa, dboa and rows 4..35 of dwh.
+ * workspace: nlt_front_backward_workspace_floats(n, h, w) floats (-1: unsupported shape).
+ */
+long nlt_front_backward_workspace_floats(int n, int h, int w);
+int nlt_front_backward(const float* base, const float* cvis, const float* lvis, const float* nn_rgb,
+                       const float* nn_base, int n, int k, int h, int w, const float* dy1q, const float* dy1o,
+                       const float* dpred, const float* wq0, const float* bq0, const float* wo0,
+                       const float* bo0, const float* wqa, const float* woa, const float* wh,
+                       float* dwq0, float* dbq0, float* dwo0, float* dbo0, float* dwqa, float* dbqa,
+                       float* dwoa, float* dboa, float* dwh, float* workspace, void* stream);
+
 /* nlt_conv_forward on the MFMA path with the K loop split into `ksplit` slices run by different waves (for
  * the deep levels: a few hundred texels x thousands of input channels would otherwise occupy a fraction of the
  * chip).  Slices write raw partial sums to `workspace` (nlt_conv_splitk_workspace_floats() floats); a second

@@ -61,6 +61,10 @@ SIGNATURES = {
     'nlt_front_pack_l2_weights': (_c_int, [_vp] * 5 + [_vp]),
     'nlt_front2_forward': (_c_int, [_vp] * 5 + [_c_int] * 4 + [_vp, _vp, _c_int, _c_float, _vp, _vp, _vp, _vp, _vp]),
     'nlt_back_forward': (_c_int, [_vp] * 3 + [_c_int] * 3 + [_vp] * 5 + [_c_float, _vp, _vp]),
+    'nlt_front_forward_train': (_c_int, [_vp] * 5 + [_c_int] * 4 + [_vp, _c_int, _c_float] + [_vp] * 6),
+    'nlt_back_forward_train': (_c_int, [_vp] * 3 + [_c_int] * 3 + [_vp] * 5 + [_c_float] + [_vp] * 4),
+    'nlt_front_backward_workspace_floats': (_c_long, [_c_int] * 3),
+    'nlt_front_backward': (_c_int, [_vp] * 5 + [_c_int] * 4 + [_vp] * 21),
     'nlt_conv_splitk_workspace_floats': (_c_long, [_c_int] * 6),
     'nlt_conv_forward_splitk': (_c_int, [_c_int, _c_int, _c_int, _vp, _vp, _c_int, _c_int, _vp, _c_int, _c_int,
                                          _c_int, _c_int, _c_int, _vp, _vp, _c_int, _vp, _c_int, _c_int, _c_float,
@@ -208,6 +212,17 @@ def conv_backward_weights(mode, src0, c0, ld0, src1, c1, ld1, n, h, w, dpre, ldp
 
 
 _wgrad_ws = {}
+_named_ws = {}
+
+
+def _workspace(name, device, need):
+    """Scratch floats for the two-pass (deterministic) reductions, cached per (kernel family, device), grown on demand."""
+    key = (name, str(device))
+    ws = _named_ws.get(key)
+    if ws is None or ws.numel() < need:
+        ws = torch.empty(need, device=device, dtype=torch.float32)
+        _named_ws[key] = ws
+    return ws
 
 
 def conv_backward_weights_tiled(mode, src0, c0, ld0, src1, c1, ld1, n, h, w, dpre, ldp, cout, dw, db):
@@ -401,6 +416,37 @@ def back_forward(x, fm1, skip3, n, h2, w2, w_s2, b_s2, w_s1, b_s1, w_head, alpha
     _check(lib().nlt_back_forward(_ptr(_dense(x, 'x')), _ptr(_dense(fm1, 'fm1')), _ptr(_dense(skip3, 'skip3')), n, h2, w2,
                                   _ptr(w_s2), _ptr(b_s2), _ptr(w_s1), _ptr(b_s1), _ptr(w_head), float(alpha), _ptr(pred),
                                   _stream()), 'nlt_back_forward')
+
+
+def front_forward_train(base, cvis, lvis, nn_rgb, nn_base, n, k, h, w, packed, add_base, alpha, fm1, obs1, skip3, qtmp1, otmp1):
+    for t, nm in ((base, 'base'), (cvis, 'cvis'), (lvis, 'lvis'), (nn_rgb, 'nn_rgb'), (nn_base, 'nn_base')):
+        _dense(t, nm)
+    _check(lib().nlt_front_forward_train(_ptr(base), _ptr(cvis), _ptr(lvis), _ptr(nn_rgb), _ptr(nn_base), n, k, h, w,
+                                         _ptr(packed), 1 if add_base else 0, float(alpha), _ptr(fm1), _ptr(obs1),
+                                         _ptr(skip3), _ptr(_dense(qtmp1, 'qtmp1')), _ptr(_dense(otmp1, 'otmp1')),
+                                         _stream()), 'nlt_front_forward_train')
+
+
+def back_forward_train(x, fm1, skip3, n, h2, w2, w_s2, b_s2, w_s1, b_s1, w_head, alpha, pred, u, v):
+    _check(lib().nlt_back_forward_train(_ptr(_dense(x, 'x')), _ptr(_dense(fm1, 'fm1')), _ptr(_dense(skip3, 'skip3')),
+                                        n, h2, w2, _ptr(w_s2), _ptr(b_s2), _ptr(w_s1), _ptr(b_s1), _ptr(w_head),
+                                        float(alpha), _ptr(pred), _ptr(_dense(u, 'u')), _ptr(_dense(v, 'v')), _stream()),
+           'nlt_back_forward_train')
+
+
+def front_backward(base, cvis, lvis, nn_rgb, nn_base, n, k, h, w, dy1q, dy1o, dpred, weights, grads):
+    """weights = (wq0, bq0, wo0, bo0, wqa, woa, wh); grads = (dwq0, dbq0, dwo0, dbo0, dwqa, dbqa, dwoa, dboa, dwh),
+    accumulated in place (views of the flat gradient bucket)."""
+    need = lib().nlt_front_backward_workspace_floats(n, h, w)
+    if need < 0:
+        raise NLTError("nlt_front_backward: unsupported shape %dx%d" % (h, w))
+    ws = _workspace('front_bwd', base.device, need)
+    for t, nm in ((base, 'base'), (cvis, 'cvis'), (lvis, 'lvis'), (nn_rgb, 'nn_rgb'), (nn_base, 'nn_base'),
+                  (dy1q, 'dy1q'), (dy1o, 'dy1o'), (dpred, 'dpred')):
+        _dense(t, nm)
+    args = [_ptr(t) for t in (base, cvis, lvis, nn_rgb, nn_base)] + [n, k, h, w, _ptr(dy1q), _ptr(dy1o), _ptr(dpred)]
+    args += [_ptr(_dense(t, 'weight')) for t in weights] + [_ptr(_dense(t, 'grad')) for t in grads]
+    _check(lib().nlt_front_backward(*args, _ptr(ws), _stream()), 'nlt_front_backward')
 
 
 # ---------------------------------------------------------------- texel-buffer assembly

@@ -145,7 +145,8 @@ __global__ __launch_bounds__(256) void front_kernel(
     const float* __restrict__ nn_rgb, const float* __restrict__ nn_base, int k, int h, int w,
     int tiles_y, int tiles_x, const float* __restrict__ blob, int add_base, float alpha,
     float* __restrict__ fm1, float* __restrict__ obs1, float* __restrict__ skip3,
-    const float* __restrict__ blob3, float* __restrict__ qtmp2, float* __restrict__ otmp2) {
+    const float* __restrict__ blob3, float* __restrict__ qtmp2, float* __restrict__ otmp2,
+    float* __restrict__ qsave, float* __restrict__ osave) {
   extern __shared__ __attribute__((aligned(16))) float lds[];          // [1 + k][4 kk][PLT][4]: q, then obs i
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int kk = lane >> 4, j = lane & 15;
@@ -213,6 +214,8 @@ __global__ __launch_bounds__(256) void front_kernel(
           acc = lrelu4(acc + bo2, alpha);
           if (!inside) acc = (f32x4){0.f, 0.f, 0.f, 0.f};
           if (live) *reinterpret_cast<f32x4*>(lds + (size_t)(1 + i0 + u) * PATH + (kk * PLT + t) * 4) = acc;
+          if (osave && owned)                                          // training: backward needs the stride-2 outputs
+            *reinterpret_cast<f32x4*>(osave + ((((long)f * k + i0 + u) * h2 + gy) * w2 + gx) * 16 + 4 * kk) = acc;
         }
       }
     };
@@ -236,6 +239,7 @@ __global__ __launch_bounds__(256) void front_kernel(
     acc = lrelu4(acc + bq2, alpha);
     if (!inside) acc = (f32x4){0.f, 0.f, 0.f, 0.f};
     if (live) *reinterpret_cast<f32x4*>(lds + (kk * PLT + t) * 4) = acc;
+    if (qsave && owned) *reinterpret_cast<f32x4*>(qsave + (((long)f * h2 + gy) * w2 + gx) * 16 + 4 * kk) = acc;
     if (owned) {                                                       // the head's share of the L0 features (+ base)
       float s0 = blob[OFF_BSK], s1 = blob[OFF_BSK + 1], s2 = blob[OFF_BSK + 2];
 #pragma unroll
@@ -384,7 +388,8 @@ __global__ __launch_bounds__(256) void back_kernel(
     const float* __restrict__ x, const float* __restrict__ fm1, const float* __restrict__ skip3,
     int h2, int w2, int tiles_y, int tiles_x,
     const float* __restrict__ w_s2, const float* __restrict__ b_s2, const float* __restrict__ w_s1,
-    const float* __restrict__ b_s1, const float* __restrict__ w_head, float alpha, float* __restrict__ pred) {
+    const float* __restrict__ b_s1, const float* __restrict__ w_head, float alpha, float* __restrict__ pred,
+    float* __restrict__ usave, float* __restrict__ vsave) {
   __shared__ __attribute__((aligned(16))) float tile_lds[FH * FW * 4];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int kk = lane >> 4, j = lane & 15;
@@ -424,6 +429,8 @@ __global__ __launch_bounds__(256) void back_kernel(
     if (!inside) acc = (f32x4){0.f, 0.f, 0.f, 0.f};                    // zero padding above / left of the image
     const int ly = 2 * hy + (kk >> 1) - 1, lx = 2 * hx + (kk & 1) - 1;  // lane kk holds output sub-texel (a,b) = kk
     if (live && ly >= 0 && lx >= 0) *reinterpret_cast<f32x4*>(tile_lds + (ly * FW + lx) * 4) = acc;
+    if (usave && inside && hy >= 1 && hx >= 1)                          // training: the block's own texels of the 4-channel map
+      *reinterpret_cast<f32x4*>(usave + (((long)f * 2 * h2 + 2 * gy + (kk >> 1)) * 2 * w2 + 2 * gx + (kk & 1)) * 4) = acc;
   }
   __syncthreads();
 
@@ -444,6 +451,8 @@ __global__ __launch_bounds__(256) void back_kernel(
     }
     const long tex = ((long)f * h + y) * w + xg;
     float p0 = skip3[tex * 3], p1 = skip3[tex * 3 + 1], p2 = skip3[tex * 3 + 2];
+    if (vsave)
+      *reinterpret_cast<f32x4*>(vsave + tex * 4) = lrelu4((f32x4){d[0], d[1], d[2], d[3]}, alpha);
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
       const float dv = d[c] > 0.f ? d[c] : alpha * d[c];
@@ -471,9 +480,10 @@ extern "C" int nlt_front_pack_weights(const float* wq0, const float* bq0, const 
   return NLT_OK;
 }
 
-extern "C" int nlt_front_forward(const float* base, const float* cvis, const float* lvis, const float* nn_rgb,
-                                 const float* nn_base, int n, int k, int h, int w, const float* packed,
-                                 int add_base, float alpha, float* fm1, float* obs1, float* skip3, void* stream) {
+static int front_launch(const float* base, const float* cvis, const float* lvis, const float* nn_rgb,
+                        const float* nn_base, int n, int k, int h, int w, const float* packed,
+                        int add_base, float alpha, float* fm1, float* obs1, float* skip3, float* qtmp1, float* otmp1,
+                        void* stream) {
   if (!base || !cvis || !lvis || !nn_rgb || !nn_base || !packed || !fm1 || !obs1 || !skip3) return NLT_ERR_BAD_ARG;
   if (n <= 0 || k <= 0 || h <= 0 || w <= 0) return NLT_ERR_BAD_ARG;
   if ((h | w) & 1) return NLT_ERR_UNSUPPORTED;
@@ -489,9 +499,25 @@ extern "C" int nlt_front_forward(const float* base, const float* cvis, const flo
   }
   hipLaunchKernelGGL(front_kernel<false>, dim3((unsigned)blocks), dim3(256), lds_bytes, static_cast<hipStream_t>(stream),
                      base, cvis, lvis, nn_rgb, nn_base, k, h, w, ty, tx, packed, add_base, alpha, fm1, obs1, skip3,
-                     nullptr, nullptr, nullptr);
+                     nullptr, nullptr, nullptr, qtmp1, otmp1);
   NLT_CHECK_LAUNCH();
   return NLT_OK;
+}
+
+extern "C" int nlt_front_forward(const float* base, const float* cvis, const float* lvis, const float* nn_rgb,
+                                 const float* nn_base, int n, int k, int h, int w, const float* packed,
+                                 int add_base, float alpha, float* fm1, float* obs1, float* skip3, void* stream) {
+  return front_launch(base, cvis, lvis, nn_rgb, nn_base, n, k, h, w, packed, add_base, alpha, fm1, obs1, skip3,
+                      nullptr, nullptr, stream);
+}
+
+extern "C" int nlt_front_forward_train(const float* base, const float* cvis, const float* lvis, const float* nn_rgb,
+                                       const float* nn_base, int n, int k, int h, int w, const float* packed,
+                                       int add_base, float alpha, float* fm1, float* obs1, float* skip3,
+                                       float* qtmp1, float* otmp1, void* stream) {
+  if (!qtmp1 || !otmp1 || !nlt_aligned16(qtmp1) || !nlt_aligned16(otmp1)) return NLT_ERR_BAD_ARG;
+  return front_launch(base, cvis, lvis, nn_rgb, nn_base, n, k, h, w, packed, add_base, alpha, fm1, obs1, skip3,
+                      qtmp1, otmp1, stream);
 }
 
 extern "C" long nlt_front_l2_packed_floats(void) { return BLOB3; }
@@ -521,14 +547,14 @@ extern "C" int nlt_front2_forward(const float* base, const float* cvis, const fl
   const long blocks = (long)n * ty * tx;
   hipLaunchKernelGGL(front_kernel<true>, dim3((unsigned)blocks), dim3(256), lds_bytes, static_cast<hipStream_t>(stream),
                      base, cvis, lvis, nn_rgb, nn_base, k, h, w, ty, tx, packed, add_base, alpha, fm1, nullptr, skip3,
-                     packed_l2, qtmp2, otmp2);
+                     packed_l2, qtmp2, otmp2, nullptr, nullptr);
   NLT_CHECK_LAUNCH();
   return NLT_OK;
 }
 
-extern "C" int nlt_back_forward(const float* x, const float* fm1, const float* skip3, int n, int h2, int w2,
-                                const float* w_s2, const float* b_s2, const float* w_s1, const float* b_s1,
-                                const float* w_head, float alpha, float* pred, void* stream) {
+static int back_launch(const float* x, const float* fm1, const float* skip3, int n, int h2, int w2,
+                       const float* w_s2, const float* b_s2, const float* w_s1, const float* b_s1,
+                       const float* w_head, float alpha, float* pred, float* u, float* v, void* stream) {
   if (!x || !fm1 || !skip3 || !w_s2 || !b_s2 || !w_s1 || !b_s1 || !w_head || !pred) return NLT_ERR_BAD_ARG;
   if (n <= 0 || h2 <= 0 || w2 <= 0) return NLT_ERR_BAD_ARG;
   if (!nlt_aligned16(x) || !nlt_aligned16(fm1) || !nlt_aligned16(w_s2) || !nlt_aligned16(b_s2)) return NLT_ERR_BAD_ARG;
@@ -536,7 +562,20 @@ extern "C" int nlt_back_forward(const float* x, const float* fm1, const float* s
   const int ty = (h2 + TH - 1) / TH, tx = (w2 + TW - 1) / TW;
   const long blocks = (long)n * ty * tx;
   hipLaunchKernelGGL(back_kernel, dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(stream),
-                     x, fm1, skip3, h2, w2, ty, tx, w_s2, b_s2, w_s1, b_s1, w_head, alpha, pred);
+                     x, fm1, skip3, h2, w2, ty, tx, w_s2, b_s2, w_s1, b_s1, w_head, alpha, pred, u, v);
   NLT_CHECK_LAUNCH();
   return NLT_OK;
+}
+
+extern "C" int nlt_back_forward(const float* x, const float* fm1, const float* skip3, int n, int h2, int w2,
+                                const float* w_s2, const float* b_s2, const float* w_s1, const float* b_s1,
+                                const float* w_head, float alpha, float* pred, void* stream) {
+  return back_launch(x, fm1, skip3, n, h2, w2, w_s2, b_s2, w_s1, b_s1, w_head, alpha, pred, nullptr, nullptr, stream);
+}
+
+extern "C" int nlt_back_forward_train(const float* x, const float* fm1, const float* skip3, int n, int h2, int w2,
+                                      const float* w_s2, const float* b_s2, const float* w_s1, const float* b_s1,
+                                      const float* w_head, float alpha, float* pred, float* u, float* v, void* stream) {
+  if (!u || !v || !nlt_aligned16(u) || !nlt_aligned16(v)) return NLT_ERR_BAD_ARG;
+  return back_launch(x, fm1, skip3, n, h2, w2, w_s2, b_s2, w_s1, b_s1, w_head, alpha, pred, u, v, stream);
 }

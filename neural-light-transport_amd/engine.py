@@ -57,6 +57,7 @@ class RenderPlan:
         self.fuse_ends = os.environ.get('NLT_FUSED', '1') != '0'   # inference: csrc/fused.hip for layers 0-1 and the last block + head
         self._front_blob = None
         self.front_l2 = os.environ.get('NLT_FRONT_L2', '1') != '0'      # front kernel also runs level 2's stride-2 convs (k <= 4)
+        self.fuse_train = os.environ.get('NLT_FUSED_TRAIN', '1') != '0'   # fused ends in the train step too (csrc/train_fused.hip)
         self.two_streams = os.environ.get('NLT_STREAMS', '2') != '1'   # inference: query-path encoder convs on a side stream
         self._side = None               # (side stream, [events]) created on first use
         self.wgrad_tiled = os.environ.get('NLT_WGRAD', 'tiled') != 'atomic'   # csrc/wgrad_tile.hip vs first-generation csrc/wgrad.hip
@@ -306,8 +307,11 @@ class RenderPlan:
         k = nn_rgb.shape[1]
         dev = base.device
         b = self._buffers(n, k, h, w, dev)
-        fused = inference and self.can_fuse(b, obs_weights, obs_override)
-        tuned_key = 'tuned_fused' if fused else 'tuned'
+        fused = (inference or self.fuse_train) and self.can_fuse(b, obs_weights, obs_override)
+        if fused and not inference and w % 8:                           # the training ends: w/2 in groups of 4 texels
+            fused = False
+        b['train_fused'] = fused and not inference
+        tuned_key = ('tuned_fused' if inference else 'tuned_train') if fused else 'tuned'
         if self.autotune and not b.get(tuned_key) and base.is_cuda:
             b[tuned_key] = True
             self._autotune(lambda: self.forward(base, cvis, lvis, nn_rgb, nn_base, obs_weights, obs_override,
@@ -316,7 +320,7 @@ class RenderPlan:
         mult = 2 if self.use_obs else 1
         run_obs = self.use_obs and obs_override is None
         if fused:
-            return self._forward_fused(b, base, cvis, lvis, nn_rgb, nn_base, skip_connect_base, algo)
+            return self._forward_fused(b, base, cvis, lvis, nn_rgb, nn_base, skip_connect_base, algo, train=not inference)
 
         # L0 (both paths) + first observation mean
         q0, o0 = q.layers[0], o.layers[0]
@@ -373,8 +377,10 @@ class RenderPlan:
                      base if skip_connect_base else None, n, h, w, b['pred'])
         return b['pred'], b
 
-    def _forward_fused(self, b, base, cvis, lvis, nn_rgb, nn_base, skip_connect_base, algo):
-        """front kernel (layers 0-1) -> unfused levels 2..D and decoder blocks -> back kernel."""
+    def _forward_fused(self, b, base, cvis, lvis, nn_rgb, nn_base, skip_connect_base, algo, train=False):
+        """front kernel (layers 0-1) -> unfused levels 2..D and decoder blocks -> back kernel.
+        train=True keeps the activations the backward pass reads (qtmp[1], otmp[1], obs[1], the last block's two
+        4-channel maps) and leaves level 2's stride-2 convs to their own launches (their inputs must be stored anyway)."""
         n, h, w, _ = base.shape
         k = nn_rgb.shape[1]
         q, o, D, U, cl = self.q, self.o, self.n_down, self.n_up, b['C']
@@ -384,7 +390,8 @@ class RenderPlan:
         blob, blob_l2 = self._front_weights(base.device)
         # With k <= 4 the front kernel also runs level 2's stride-2 convs (its 8 x 16 level-1 tile is a 4 x 8 tile of
         # level 2): the per-observation level-1 maps never reach HBM and L2.{q,o}.s2 are not launched.
-        front2 = (self.front_l2 and blob_l2 is not None and k <= 4 and h % 4 == 0 and w % 4 == 0 and not self._trial_direct)
+        front2 = (self.front_l2 and blob_l2 is not None and k <= 4 and h % 4 == 0 and w % 4 == 0 and not self._trial_direct
+                  and not train)
         nbytes = 4 * n * h * w * ((5 + 3 * k + 16 + 16 * k) + (36 + 20 * k + 8 + 8 * k))     # L0 + L1 (+ means)
         flops = 2 * n * (h // 2) * (w // 2) * ((32 + 64) * 16 + k * (12 + 64) * 16) + 2 * n * h * w * 24
         if front2:
@@ -396,8 +403,14 @@ class RenderPlan:
         else:
             # what the fused launch itself must move: raw inputs + skip3 out, fm1 + obs1 out (per texel: 5+6k+3 | (32+16k)/4)
             moved = 4 * n * h * w * (5 + 6 * k + 3 + 8 + 4 * k)
-            self._launch('F.front', nbytes, C.front_forward, base, cvis, lvis, nn_rgb, nn_base, n, k, h, w, blob,
-                         skip_connect_base, alpha, b['fm'][1], b['obs'][1], b['skip3'], flops=flops, moved=moved)
+            if train:
+                moved += 4 * n * h * w * (4 + 4 * k)
+                self._launch('F.front', nbytes, C.front_forward_train, base, cvis, lvis, nn_rgb, nn_base, n, k, h, w, blob,
+                             skip_connect_base, alpha, b['fm'][1], b['obs'][1], b['skip3'], b['qtmp'][1], b['otmp'][1],
+                             flops=flops, moved=moved)
+            else:
+                self._launch('F.front', nbytes, C.front_forward, base, cvis, lvis, nn_rgb, nn_base, n, k, h, w, blob,
+                             skip_connect_base, alpha, b['fm'][1], b['obs'][1], b['skip3'], flops=flops, moved=moved)
         # Levels 2..D.  The observation chain (k frames per frame: three quarters of the encoder's work at k = 4)
         # never waits for the query path; the query convs of a level only need the previous level's observation mean.
         # With two HIP streams the small deep-level launches of one path fill the CUs the other leaves idle.
@@ -454,9 +467,11 @@ class RenderPlan:
         assert (hh, ww) == (h // 2, w // 2) and cx == 8 and da.cin == 40
         # last block (40 -> 4 -> 4 at full resolution) + head (36 -> 3) in SURVEY 8d accounting
         nbytes = 4 * n * h * w * ((10 + 4) + (4 + 4) + (36 + 3))
-        self._launch('F.back', nbytes, C.back_forward, x, b['fm'][1], b['skip3'], n, hh, ww, da.kernel.detach(),
-                     da.bias.detach(), db.kernel.detach(), db.bias.detach(), head.kernel.detach(), alpha, b['pred'],
-                     flops=2 * n * hh * ww * 40 * 16 + 2 * n * h * w * (64 + 12), moved=4 * n * h * w * (10 + 3 + 3))
+        extra = (b['dtmp'][U - 1], b['dec'][U - 1]) if train else ()
+        self._launch('F.back', nbytes, C.back_forward_train if train else C.back_forward, x, b['fm'][1], b['skip3'], n, hh, ww,
+                     da.kernel.detach(), da.bias.detach(), db.kernel.detach(), db.bias.detach(), head.kernel.detach(), alpha,
+                     b['pred'], *extra, flops=2 * n * hh * ww * 40 * 16 + 2 * n * h * w * (64 + 12),
+                     moved=4 * n * h * w * (10 + 3 + 3 + (8 if train else 0)))
         return b['pred'], b
 
     # ------------------------------------------------------------------ backward
@@ -513,8 +528,14 @@ class RenderPlan:
         x_last = b['dec'][U - 1]
         cx = x_last.shape[-1]
         cs = 2 * cl[0]
-        self._launch('bwd.head', 4 * n * h * w * (2 * (cx + cs) + 3), C.head_backward, x_last, cx, cx, b['fm'][0], cs, cs,
-                     head.kernel.detach(), dpred, n, h, w, g['dec'][U - 1], cx, g['fm'][0], cs, head.dkernel, head.dbias)
+        fused = bool(b.get('train_fused'))
+        if fused:
+            # the skip rows of the head (and everything else that touches the full-resolution L0 features) are F.front.bwd's
+            self._launch('bwd.head', 4 * n * h * w * (2 * cx + 3), C.head_backward, x_last, cx, cx, None, 0, 0,
+                         head.kernel.detach(), dpred, n, h, w, g['dec'][U - 1], cx, None, 0, head.dkernel, head.dbias)
+        else:
+            self._launch('bwd.head', 4 * n * h * w * (2 * (cx + cs) + 3), C.head_backward, x_last, cx, cx, b['fm'][0], cs, cs,
+                         head.kernel.detach(), dpred, n, h, w, g['dec'][U - 1], cx, g['fm'][0], cs, head.dkernel, head.dbias)
 
         # ---- decoder (expanding blocks), last to first
         hh, ww = h, w
@@ -559,21 +580,32 @@ class RenderPlan:
             self._wgrad(lab + '.q.s1.wgrad', qb, b['qtmp'][l], c, c, None, 0, 0, n, hh, ww, g['fm'][l], 2 * c)
             self._dgrad(lab + '.q.s1.dgrad', qb, 0, c, g['fm'][l], 2 * c, n, hh, ww, g['qtmp'][l], c,
                         mask_src=b['qtmp'][l], ldm=c, mask_alpha=qact_a.alpha, zero_bias=zb)
-            self._wgrad(lab + '.q.s2.wgrad', qa, b['fm'][l - 1], 2 * cp, 2 * cp, None, 0, 0, n, 2 * hh, 2 * ww,
-                        g['qtmp'][l], c)
-            self._dgrad(lab + '.q.s2.dgrad', qa, 0, 2 * cp, g['qtmp'][l], c, n, hh, ww, g['fm'][l - 1], 2 * cp,
-                        accumulate=True, zero_bias=zb)
+            if not (fused and l == 1):
+                self._wgrad(lab + '.q.s2.wgrad', qa, b['fm'][l - 1], 2 * cp, 2 * cp, None, 0, 0, n, 2 * hh, 2 * ww,
+                            g['qtmp'][l], c)
+                self._dgrad(lab + '.q.s2.dgrad', qa, 0, 2 * cp, g['qtmp'][l], c, n, hh, ww, g['fm'][l - 1], 2 * cp,
+                            accumulate=True, zero_bias=zb)
             # o.s1 / o.s2 (n*k observation frames)
             self._wgrad(lab + '.o.s1.wgrad', ob, b['otmp'][l], c, c, None, 0, 0, n * k, hh, ww, g['obs'][l], c)
             self._dgrad(lab + '.o.s1.dgrad', ob, 0, c, g['obs'][l], c, n * k, hh, ww, g['otmp'][l], c,
                         mask_src=b['otmp'][l], ldm=c, mask_alpha=oact_a.alpha, zero_bias=zb)
-            self._wgrad(lab + '.o.s2.wgrad', oa, b['obs'][l - 1], cp, cp, None, 0, 0, n * k, 2 * hh, 2 * ww,
-                        g['otmp'][l], c)
-            self._dgrad(lab + '.o.s2.dgrad', oa, 0, cp, g['otmp'][l], c, n * k, hh, ww, g['obs'][l - 1], cp, zero_bias=zb)
+            if not (fused and l == 1):
+                self._wgrad(lab + '.o.s2.wgrad', oa, b['obs'][l - 1], cp, cp, None, 0, 0, n * k, 2 * hh, 2 * ww,
+                            g['otmp'][l], c)
+                self._dgrad(lab + '.o.s2.dgrad', oa, 0, cp, g['otmp'][l], c, n * k, hh, ww, g['obs'][l - 1], cp, zero_bias=zb)
             hh, ww = hh * 2, ww * 2
 
         # ---- L0 (both paths)
         q0, o0 = q.layers[0], o.layers[0]
+        if fused:
+            (qa, _), _ = q.layers[1].convs()
+            (oa, _), _ = o.layers[1].convs()
+            D_ = lambda t: t.detach()
+            self._launch('F.front.bwd', 4 * n * h * w * (5 + 6 * k + 3) + 4 * n * (h // 2) * (w // 2) * 16 * (1 + k),
+                         C.front_backward, base, cvis, lvis, nn_rgb, nn_base, n, k, h, w, g['qtmp'][1], g['otmp'][1], dpred,
+                         (D_(q0.kernel), D_(q0.bias), D_(o0.kernel), D_(o0.bias), D_(qa.kernel), D_(oa.kernel), D_(head.kernel)),
+                         (q0.dkernel, q0.dbias, o0.dkernel, o0.dbias, qa.dkernel, qa.dbias, oa.dkernel, oa.dbias, head.dkernel))
+            return
         self._launch('bwd.L0.stem', 4 * n * h * w * (5 + 6 * k + 2 * cl[0] + k * cl[0]), C.stem_backward,
                      base, cvis, lvis, nn_rgb, nn_base, obs_weights, n, k, h, w, cl[0], g['fm'][0], g['obs'][0],
                      q0.dkernel, q0.dbias, o0.dkernel, o0.dbias)

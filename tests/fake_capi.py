@@ -143,13 +143,16 @@ def stem_backward(base, cvis, lvis, nn_rgb, nn_base, obs_weights, n, k, h, w, c,
 
 
 def head_backward(dec, ldd, cd, skip, lds, cs, w_keras, dpred, n, h, w, d_dec, ldgd, d_skip, ldgs, dw, db):
-    x = torch.cat((_view(dec, n, h, w, cd, ldd), _view(skip, n, h, w, cs, lds)), -1)
+    x = _view(dec, n, h, w, cd, ldd)
+    if cs:
+        x = torch.cat((x, _view(skip, n, h, w, cs, lds)), -1)
     g = dpred.clone()
     g[:, 0, 0, :] = 0
-    dx = g @ w_keras[0, 0].t()
+    dx = g @ w_keras[0, 0, :cd + cs].t()
     _view(d_dec, n, h, w, cd, ldgd).copy_(dx[..., :cd])
-    _view(d_skip, n, h, w, cs, ldgs).copy_(dx[..., cd:])
-    dw += (x.reshape(-1, cd + cs).t() @ g.reshape(-1, 3)).reshape(dw.shape)
+    if cs:
+        _view(d_skip, n, h, w, cs, ldgs).copy_(dx[..., cd:])
+    dw.view(-1, 3)[:cd + cs] += x.reshape(-1, cd + cs).t() @ g.reshape(-1, 3)      # cs = 0: the first cd rows only
     db += g.reshape(-1, 3).sum(0)
 
 
@@ -288,7 +291,46 @@ def back_forward(x, fm1, skip3, n, h2, w2, w_s2, b_s2, w_s1, b_s1, w_head, alpha
     pred.copy_(y)
 
 
-_FUSED = ('front_pack_weights', 'front_forward', 'back_forward')
+def front_forward_train(base, cvis, lvis, nn_rgb, nn_base, n, k, h, w, P, add_base, alpha, fm1, obs1, skip3, qtmp1, otmp1):
+    front_forward(base, cvis, lvis, nn_rgb, nn_base, n, k, h, w, P, add_base, alpha, fm1, obs1, skip3)
+    lr = lambda x: T.leaky_relu(x, alpha)
+    q0 = torch.cat((base, cvis, lvis), -1) @ P['wq0'][0, 0] + P['bq0']
+    o0 = (nn_rgb - nn_base) @ P['wo0'][0, 0] + P['bo0']
+    qtmp1.copy_(lr(T.conv2d_same(torch.cat((q0, o0.mean(1)), -1), P['wqa'], P['bqa'], 2)))
+    otmp1.copy_(torch.stack([lr(T.conv2d_same(o0[:, i], P['woa'], P['boa'], 2)) for i in range(k)], 1))
+
+
+def back_forward_train(x, fm1, skip3, n, h2, w2, w_s2, b_s2, w_s1, b_s1, w_head, alpha, pred, u, v):
+    lr = lambda t: T.leaky_relu(t, alpha)
+    u.copy_(lr(T.conv2d_transpose_same(torch.cat((x, fm1), -1), w_s2, b_s2, 2)))
+    v.copy_(lr(T.conv2d_transpose_same(u, w_s1, b_s1, 1)))
+    y = v @ w_head.reshape(-1, 3)[:4] + skip3
+    y[:, 0, 0, :] = 0
+    pred.copy_(y)
+
+
+def front_backward(base, cvis, lvis, nn_rgb, nn_base, n, k, h, w, dy1q, dy1o, dpred, weights, grads):
+    """Autograd through the (unfolded) linear part: L0, the PRE-activation stride-2 convs of level 1, the head's skip rows."""
+    g = dpred.clone()
+    g[:, 0, 0, :] = 0
+    with torch.enable_grad():
+        wq0, bq0, wo0, bo0, wqa, woa, wh = [t.detach().clone().requires_grad_(True) for t in weights]
+        q0 = torch.cat((base, cvis, lvis), -1) @ wq0[0, 0] + bq0
+        o0 = (nn_rgb - nn_base) @ wo0[0, 0] + bo0
+        fm0 = torch.cat((q0, o0.mean(1)), -1)
+        zero = torch.zeros(16)
+        s = (T.conv2d_same(fm0, wqa, zero, 2) * dy1q).sum() + (fm0 @ wh[0, 0, 4:, :] * g).sum()
+        for i in range(k):
+            s = s + (T.conv2d_same(o0[:, i], woa, zero, 2) * dy1o.reshape(n, k, h // 2, w // 2, 16)[:, i]).sum()
+        gr = torch.autograd.grad(s, (wq0, bq0, wo0, bo0, wqa, woa, wh))
+    dwq0, dbq0, dwo0, dbo0, dwqa, dbqa, dwoa, dboa, dwh = grads
+    for dst, src in ((dwq0, gr[0]), (dbq0, gr[1]), (dwo0, gr[2]), (dbo0, gr[3]), (dwqa, gr[4]), (dwoa, gr[5]), (dwh, gr[6])):
+        dst += src.reshape(dst.shape)
+    dbqa += dy1q.reshape(-1, 16).sum(0)
+    dboa += dy1o.reshape(-1, 16).sum(0)
+
+
+_FUSED = ('front_pack_weights', 'front_forward', 'back_forward', 'front_forward_train', 'back_forward_train', 'front_backward')
 
 
 # ------------------------------------------------------------------ LDS-tiled encoder convs (TEST-ONLY emulation)
