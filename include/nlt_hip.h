@@ -412,6 +412,23 @@ int nlt_front_backward(const float* base, const float* cvis, const float* lvis, 
                        float* dwq0, float* dbq0, float* dwo0, float* dbo0, float* dwqa, float* dbqa,
                        float* dwoa, float* dboa, float* dwh, float* workspace, void* stream);
 
+/*
+ * Backward of the last expanding block + head in one pass (csrc/train_back.hip), from the maps nlt_back_forward_train kept.
+ *   replaces: tape.gradient (nlt/trainvali.py:279) through the last two entries of net['query'].layers
+ *             (convnet.py:67-76,85; nlt.py:182-195) and nlt.py:99-102,110, i.e. of the unfused plan: nlt_head_backward (decoder
+ *             rows), nlt_lrelu_backward, 2x nlt_conv_backward_weights and 3x backward-data nlt_conv_forward.
+ * x [n,h2,w2,8], fm1 [n,h2,w2,32] (the block's two inputs), u / v [n,2h2,2w2,4] (its two LeakyReLU outputs), dpred
+ * [n,2h2,2w2,3] (texel (0,0) ignored).  Keras weights w_s2 (2,2,4,40), w_s1 (2,2,4,4), w_head (1,1,36,3) (rows 0..3 used).
+ * Writes dx [n,h2,w2,8] and dfm1 [n,h2,w2,32] (gradients w.r.t. the two inputs; dx is w.r.t. the POST-activation x).
+ * ACCUMULATES (+=) dw_s2, db_s2, dw_s1, db_s1, rows 0..3 of dw_head, db_head.
+ * workspace: nlt_back_backward_workspace_floats(n, h2, w2) floats.
+ */
+long nlt_back_backward_workspace_floats(int n, int h2, int w2);
+int nlt_back_backward(const float* x, const float* fm1, const float* u, const float* v, const float* dpred,
+                      int n, int h2, int w2, const float* w_s2, const float* w_s1, const float* w_head,
+                      float alpha, float* dx, float* dfm1, float* dw_s2, float* db_s2, float* dw_s1,
+                      float* db_s1, float* dw_head, float* db_head, float* workspace, void* stream);
+
 /* nlt_conv_forward on the MFMA path with the K loop split into `ksplit` slices run by different waves (for
  * the deep levels: a few hundred texels x thousands of input channels would otherwise occupy a fraction of the
  * chip).  Slices write raw partial sums to `workspace` (nlt_conv_splitk_workspace_floats() floats); a second

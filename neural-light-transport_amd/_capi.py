@@ -65,6 +65,8 @@ SIGNATURES = {
     'nlt_back_forward_train': (_c_int, [_vp] * 3 + [_c_int] * 3 + [_vp] * 5 + [_c_float] + [_vp] * 4),
     'nlt_front_backward_workspace_floats': (_c_long, [_c_int] * 3),
     'nlt_front_backward': (_c_int, [_vp] * 5 + [_c_int] * 4 + [_vp] * 21),
+    'nlt_back_backward_workspace_floats': (_c_long, [_c_int] * 3),
+    'nlt_back_backward': (_c_int, [_vp] * 5 + [_c_int] * 3 + [_vp] * 3 + [_c_float] + [_vp] * 10),
     'nlt_conv_splitk_workspace_floats': (_c_long, [_c_int] * 6),
     'nlt_conv_forward_splitk': (_c_int, [_c_int, _c_int, _c_int, _vp, _vp, _c_int, _c_int, _vp, _c_int, _c_int,
                                          _c_int, _c_int, _c_int, _vp, _vp, _c_int, _vp, _c_int, _c_int, _c_float,
@@ -447,6 +449,18 @@ def front_backward(base, cvis, lvis, nn_rgb, nn_base, n, k, h, w, dy1q, dy1o, dp
     args = [_ptr(t) for t in (base, cvis, lvis, nn_rgb, nn_base)] + [n, k, h, w, _ptr(dy1q), _ptr(dy1o), _ptr(dpred)]
     args += [_ptr(_dense(t, 'weight')) for t in weights] + [_ptr(_dense(t, 'grad')) for t in grads]
     _check(lib().nlt_front_backward(*args, _ptr(ws), _stream()), 'nlt_front_backward')
+
+
+def back_backward(x, fm1, u, v, dpred, n, h2, w2, w_s2, w_s1, w_head, alpha, dx, dfm1, dw_s2, db_s2, dw_s1, db_s1, dw_head, db_head):
+    """Gradients of the last expanding block + head; dx / dfm1 written, weight gradients accumulated in place."""
+    need = lib().nlt_back_backward_workspace_floats(n, h2, w2)
+    if need <= 0:
+        raise NLTError("nlt_back_backward_workspace_floats(%d,%d,%d) failed" % (n, h2, w2))
+    ws = _workspace('back_bwd', x.device, need)
+    ins = [_ptr(_dense(t, nm)) for t, nm in ((x, 'x'), (fm1, 'fm1'), (u, 'u'), (v, 'v'), (dpred, 'dpred'))]
+    wts = [_ptr(_dense(t, 'weight')) for t in (w_s2, w_s1, w_head)]
+    outs = [_ptr(_dense(t, 'grad')) for t in (dx, dfm1, dw_s2, db_s2, dw_s1, db_s1, dw_head, db_head)]
+    _check(lib().nlt_back_backward(*ins, n, h2, w2, *wts, float(alpha), *outs, _ptr(ws), _stream()), 'nlt_back_backward')
 
 
 # ---------------------------------------------------------------- texel-buffer assembly

@@ -530,16 +530,21 @@ class RenderPlan:
         cs = 2 * cl[0]
         fused = bool(b.get('train_fused'))
         if fused:
-            # the skip rows of the head (and everything else that touches the full-resolution L0 features) are F.front.bwd's
-            self._launch('bwd.head', 4 * n * h * w * (2 * cx + 3), C.head_backward, x_last, cx, cx, None, 0, 0,
-                         head.kernel.detach(), dpred, n, h, w, g['dec'][U - 1], cx, None, 0, head.dkernel, head.dbias)
+            # last expanding block + head in one launch (csrc/train_back.hip); the head's skip rows are F.front.bwd's
+            (da, act_a), (db, _) = q.layers[D + U].convs()
+            self._launch('F.back.bwd', 4 * n * h * w * (4 + 4 + 3 + 20), C.back_backward, b['dec'][U - 2], b['fm'][1],
+                         b['dtmp'][U - 1], b['dec'][U - 1], dpred, n, h // 2, w // 2, da.kernel.detach(), db.kernel.detach(),
+                         head.kernel.detach(), act_a.alpha, g['dec'][U - 2], g['fm'][1], da.dkernel, da.dbias, db.dkernel,
+                         db.dbias, head.dkernel, head.dbias)
         else:
             self._launch('bwd.head', 4 * n * h * w * (2 * (cx + cs) + 3), C.head_backward, x_last, cx, cx, b['fm'][0], cs, cs,
                          head.kernel.detach(), dpred, n, h, w, g['dec'][U - 1], cx, g['fm'][0], cs, head.dkernel, head.dbias)
 
         # ---- decoder (expanding blocks), last to first
         hh, ww = h, w
-        for j in range(U - 1, -1, -1):
+        if fused:
+            hh, ww = h // 2, w // 2
+        for j in range(U - 2 if fused else U - 1, -1, -1):
             (da, act_a), (db, act_b) = q.layers[D + 1 + j].convs()
             nl = db.n_ch_out
             lab = 'bwd.L%d.q' % (D + 1 + j)

@@ -330,7 +330,29 @@ def front_backward(base, cvis, lvis, nn_rgb, nn_base, n, k, h, w, dy1q, dy1o, dp
     dboa += dy1o.reshape(-1, 16).sum(0)
 
 
-_FUSED = ('front_pack_weights', 'front_forward', 'back_forward', 'front_forward_train', 'back_forward_train', 'front_backward')
+def back_backward(x, fm1, u, v, dpred, n, h2, w2, w_s2, w_s1, w_head, alpha, dx, dfm1, dw_s2, db_s2, dw_s1, db_s1, dw_head, db_head):
+    g = dpred.clone()
+    g[:, 0, 0, :] = 0
+    with torch.enable_grad():
+        xin = torch.cat((x, fm1), -1).detach().clone().requires_grad_(True)
+        ws2, ws1, wh = [t.detach().clone().requires_grad_(True) for t in (w_s2, w_s1, w_head)]
+        b2, b1 = torch.zeros(4, requires_grad=True), torch.zeros(4, requires_grad=True)
+        # values = the saved activations (the biases are not passed in), gradients = through the linear maps and the
+        # LeakyReLU slopes those activations imply
+        slope = lambda a: torch.where(a > 0, torch.ones_like(a), torch.full_like(a, alpha))
+        zu = T.conv2d_transpose_same(xin, ws2, b2, 2) * slope(u)
+        uu = u.detach() + (zu - zu.detach())
+        zv = T.conv2d_transpose_same(uu, ws1, b1, 1) * slope(v)
+        vv = v.detach() + (zv - zv.detach())
+        s = ((vv @ wh[0, 0, :4]) * g).sum()
+        gr = torch.autograd.grad(s, (xin, ws2, b2, ws1, b1, wh))
+    dx.copy_(gr[0][..., :8]); dfm1.copy_(gr[0][..., 8:])
+    dw_s2 += gr[1]; db_s2 += gr[2]; dw_s1 += gr[3]; db_s1 += gr[4]; dw_head += gr[5]
+    db_head += g.reshape(-1, 3).sum(0)
+
+
+_FUSED = ('front_pack_weights', 'front_forward', 'back_forward', 'front_forward_train', 'back_forward_train', 'front_backward',
+          'back_backward')
 
 
 # ------------------------------------------------------------------ LDS-tiled encoder convs (TEST-ONLY emulation)

@@ -112,3 +112,44 @@ def test_front_backward_matches_autograd_through_the_unfolded_layers(n, h, w, k)
                      tuple(dev(P[k_]) for k_ in names), tuple(again[k_] for k_ in gnames))
     torch.cuda.synchronize()
     assert all(torch.equal(again[k_], grads[k_]) for k_ in gnames)
+
+
+@pytest.mark.parametrize('n,h2,w2', [(1, 8, 16), (2, 12, 20), (1, 3, 5), (1, 32, 64), (3, 40, 24), (2, 128, 256)])
+def test_back_backward_matches_autograd_through_the_last_block(n, h2, w2):
+    rng = np.random.default_rng(h2 * 11 + w2)
+    S = lambda *s: torch.from_numpy(rng.random(s, dtype=np.float32) - 0.5)
+    x, fm1, dpred = S(n, h2, w2, 8), S(n, h2, w2, 32), S(n, 2 * h2, 2 * w2, 3)
+    P = dict(w_s2=S(2, 2, 4, 40), b_s2=S(4), w_s1=S(2, 2, 4, 4), b_s1=S(4), wh=S(1, 1, 36, 3))
+    g = dpred.clone(); g[:, 0, 0, :] = 0
+    with torch.enable_grad():
+        xin = torch.cat((x, fm1), -1).requires_grad_(True)
+        wt = {k_: a.clone().requires_grad_(True) for k_, a in P.items()}
+        u = T.leaky_relu(T.conv2d_transpose_same(xin, wt['w_s2'], wt['b_s2'], 2), 0.3)
+        v = T.leaky_relu(T.conv2d_transpose_same(u, wt['w_s1'], wt['b_s1'], 1), 0.3)
+        s = ((v @ wt['wh'][0, 0, :4]) * g).sum()
+        names = ('w_s2', 'b_s2', 'w_s1', 'b_s1', 'wh')
+        gr = torch.autograd.grad(s, [xin] + [wt[k_] for k_ in names])
+    ref = dict(zip(names, gr[1:]))
+    ref['bh'] = g.reshape(-1, 3).sum(0)
+    dev = lambda a: a.detach().cuda().contiguous()
+    init = {k_: torch.from_numpy(rng.random(tuple(ref[k_].shape), dtype=np.float32)) for k_ in ref}
+    grads = {k_: dev(init[k_]) for k_ in ref}
+    dx = torch.full((n, h2, w2, 8), float('nan'), device='cuda')
+    dfm1 = torch.full((n, h2, w2, 32), float('nan'), device='cuda')
+    run = lambda G: C.back_backward(dev(x), dev(fm1), dev(u), dev(v), dev(dpred), n, h2, w2, dev(P['w_s2']), dev(P['w_s1']),
+                                    dev(P['wh']), 0.3, dx, dfm1, G['w_s2'], G['b_s2'], G['w_s1'], G['b_s1'], G['wh'], G['bh'])
+    run(grads)
+    torch.cuda.synchronize()
+    assert not torch.isnan(dx).any() and not torch.isnan(dfm1).any()
+    assert rel_l2(dx.cpu(), gr[0][..., :8]) <= 1e-5 and rel_l2(dfm1.cpu(), gr[0][..., 8:]) <= 1e-5
+    for k_ in ref:
+        got = grads[k_].cpu() - init[k_]
+        r = ref[k_]
+        if k_ == 'wh':
+            assert float(got[0, 0, 4:].abs().max()) <= 1e-6              # the skip rows belong to the front side
+            got, r = got[0, 0, :4], r[0, 0, :4]
+        assert rel_l2(got, r) <= 3e-5, (k_, rel_l2(got, r))
+    again = {k_: dev(init[k_]) for k_ in ref}
+    run(again)
+    torch.cuda.synchronize()
+    assert all(torch.equal(again[k_], grads[k_]) for k_ in ref)
