@@ -374,6 +374,19 @@ int nlt_back_forward(const float* x, const float* fm1, const float* skip3, int n
                      const float* w_s2, const float* b_s2, const float* w_s1, const float* b_s1,
                      const float* w_head, float alpha, float* pred, void* stream);
 
+/* Weight / bias gradient for the NARROW layers (csrc/wgrad_narrow.hip): N = cout (4 * cout for Conv2DTranspose k2s2)
+ * <= 32 output columns and K = taps * (c0 + c1) <= 128, modes NLT_CONV_K2S2 / K2S1 / NLT_DECONV_K2S2 / K2S1, any channel
+ * count (4-byte operand loads; the MFMA tile is [K index 16] x [output channel 16], so 8 / 16 / 32-channel layers waste
+ * no matrix-core work).  Same arguments, accumulation and determinism as nlt_conv_backward_weights_tiled.
+ *   replaces: the same tape.gradient terms (nlt/trainvali.py:279) as nlt_conv_backward_weights.
+ * nlt_wgrad_narrow_workspace_floats(): workspace size in floats, -1 when the layer is not narrow / unsupported. */
+long nlt_wgrad_narrow_workspace_floats(int mode, int c0, int c1, int n, int h, int w, int cout);
+int nlt_conv_backward_weights_narrow(int mode,
+                                     const float* src0, int ld0, int c0, const float* src1, int ld1, int c1,
+                                     int n, int h, int w, const float* dpre, int ldp, int cout,
+                                     float* dw_keras, float* dbias, float* workspace, long workspace_floats,
+                                     void* stream);
+
 /*
  * TRAINING forms of the fused ends.  The forward passes are the same launches as nlt_front_forward / nlt_back_forward
  * and additionally keep what the backward pass needs:

@@ -41,6 +41,9 @@ SIGNATURES = {
     'nlt_wgrad_workspace_floats': (_c_long, [_c_int] * 7),
     'nlt_conv_backward_weights_tiled': (_c_int, [_c_int, _vp, _c_int, _c_int, _vp, _c_int, _c_int, _c_int, _c_int, _c_int,
                                                  _vp, _c_int, _c_int, _vp, _vp, _vp, _c_long, _vp]),
+    'nlt_wgrad_narrow_workspace_floats': (_c_long, [_c_int] * 7),
+    'nlt_conv_backward_weights_narrow': (_c_int, [_c_int, _vp, _c_int, _c_int, _vp, _c_int, _c_int, _c_int, _c_int, _c_int,
+                                                 _vp, _c_int, _c_int, _vp, _vp, _vp, _c_long, _vp]),
     'nlt_lrelu_backward': (_c_int, [_vp, _c_int, _vp, _c_int, _c_int, _c_long, _c_float, _vp, _c_int, _vp]),
     'nlt_obs_mean_backward': (_c_int, [_vp, _c_int, _vp, _vp, _vp, _c_int, _c_int, _c_int, _c_int, _c_float, _vp, _vp]),
     'nlt_stem_backward': (_c_int, [_vp] * 6 + [_c_int] * 5 + [_vp] * 6 + [_vp]),
@@ -240,6 +243,21 @@ def conv_backward_weights_tiled(mode, src0, c0, ld0, src1, c1, ld1, n, h, w, dpr
     _check(lib().nlt_conv_backward_weights_tiled(mode, _ptr(src0), ld0, c0, _ptr(src1), ld1, c1, n, h, w, _ptr(dpre), ldp,
                                                  cout, _ptr(dw), _ptr(db), _ptr(ws), ws.numel(), _stream()),
            'nlt_conv_backward_weights_tiled')
+
+
+def wgrad_narrow_supported(mode, c0, c1, n, h, w, cout):
+    return lib().nlt_wgrad_narrow_workspace_floats(mode, c0, c1, n, h, w, cout) > 0
+
+
+def conv_backward_weights_narrow(mode, src0, c0, ld0, src1, c1, ld1, n, h, w, dpre, ldp, cout, dw, db):
+    """Weight gradient of a narrow layer (<= 32 output columns, K <= 128): MFMA tile matched to the layer."""
+    need = lib().nlt_wgrad_narrow_workspace_floats(mode, c0, c1, n, h, w, cout)
+    if need <= 0:
+        raise NLTError("nlt_wgrad_narrow_workspace_floats: unsupported (mode %d, c0 %d, c1 %d, cout %d)" % (mode, c0, c1, cout))
+    ws = _workspace('wgrad_narrow', src0.device, need)
+    _check(lib().nlt_conv_backward_weights_narrow(mode, _ptr(src0), ld0, c0, _ptr(src1), ld1, c1, n, h, w, _ptr(dpre), ldp,
+                                                  cout, _ptr(dw), _ptr(db), _ptr(ws), ws.numel(), _stream()),
+           'nlt_conv_backward_weights_narrow')
 
 
 def lrelu_backward(g, ldg, y, ldy, c, texels, alpha, out, ldo):

@@ -1,0 +1,311 @@
+// Weight / bias gradients of the NARROW layers (few output columns):  dW[k][n] = sum_rows X[row][k] * dP[row][n]
+// with N = cout (4 * cout for Conv2DTranspose k2s2) <= 32 and K = taps * cin <= 128.
+//
+// wgrad_tile.hip feeds 16 MFMAs from two 16-byte loads, but its 64 x 64 block of dW is mostly padding when the layer
+// has 8 / 16 / 32 output channels (16 -> 16: a quarter of the matrix-core work is useful, and that work was the
+// kernel's time).  Here the MFMA tile is matched to the layer instead: rows of dW = K index (tap, channel), 16 per
+// M tile; columns = output channel, 16 per N tile; the reduction (MFMA K dimension) runs over texel rows, 4 per
+// v_mfma_f32_16x16x4_f32.  Operands are 4-byte loads -- lane (i, kk) reads X[row kk][k = 16 mt + i] and
+// dP[row kk][n = 16 nt + i], 16 consecutive floats per row -- MT + NT loads feed MT * NT MFMAs, all of them useful.
+// Any channel count works (no quad alignment).  Row slices -> workspace -> fixed-order reduction, as in wgrad_tile.
+#include "nlt_common.h"
+
+namespace {
+
+template <int MODE>
+__device__ __forceinline__ long keras_widx_n(int t, int c, int ncol, int cin, int cout) {
+  if (MODE == NLT_CONV_K2S2 || MODE == NLT_CONV_K2S1) return ((long)t * cin + c) * cout + ncol;
+  if (MODE == NLT_DECONV_K2S1) return ((long)t * cout + ncol) * cin + c;
+  return (long)ncol * cin + c;   // DECONV_K2S2: ncol = (a*2+b)*cout + o
+}
+
+struct WN {
+  ConvP c;
+  const float* dp; int ldp;
+  float* dw; float* db; float* ws;
+  int K, N;                     // taps * (c0 + c1), GEMM columns
+  int msplits, rows_per_split;
+};
+
+template <int MODE, int MT, int NT>
+__global__ __launch_bounds__(256) void wgrad_narrow_kernel(WN w) {
+  extern __shared__ float xch[];                                       // one wave's block: [MT*16][NT*16] + [NT*16] column sums
+  const ConvP& p = w.c;
+  constexpr int TAPS = MODE == NLT_DECONV_K2S2 ? 1 : 4;
+  constexpr int S = MODE == NLT_CONV_K2S2 ? 2 : 1;                     // input rows per GEMM-grid row
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int i = lane & 15, kk = lane >> 4;
+  const int ms = blockIdx.x;
+  const int cin = p.c0 + p.c1;
+
+  // A role, per M tile: K index 16 mt + i = (tap, channel of the virtual concat)
+  const float* ap[MT]; int ald[MT], oy[MT], ox[MT], tdelta[MT]; bool aok[MT];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) {
+    const int kidx = mt * 16 + i;
+    aok[mt] = kidx < w.K;
+    const int tap = aok[mt] ? kidx / cin : 0;
+    const int c = aok[mt] ? kidx - tap * cin : 0;
+    const bool from1 = c >= p.c0;
+    ap[mt] = from1 ? p.src1 + (c - p.c0) : p.src0 + c;
+    ald[mt] = from1 ? p.ld1 : p.ld0;
+    const int a = TAPS == 4 ? tap >> 1 : 0, b = TAPS == 4 ? tap & 1 : 0;
+    oy[mt] = MODE == NLT_DECONV_K2S1 ? -a : a;                         // input texel = (S * y + oy, S * x + ox)
+    ox[mt] = MODE == NLT_DECONV_K2S1 ? -b : b;
+    tdelta[mt] = oy[mt] * p.w + ox[mt];
+  }
+  // B role, per N tile
+  int boff[NT], bdelta[NT]; bool bok[NT];
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) {
+    const int n = nt * 16 + i;
+    bok[nt] = n < w.N;
+    const int nn = bok[nt] ? n : 0;
+    if (MODE == NLT_DECONV_K2S2) {
+      const int ab = nn / p.cout;
+      boff[nt] = nn - ab * p.cout;
+      bdelta[nt] = (ab >> 1) * p.ow + (ab & 1);
+    } else {
+      boff[nt] = nn;
+      bdelta[nt] = 0;
+    }
+  }
+
+  f32x4 acc[MT][NT];
+  float bsum[NT];
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) {
+    bsum[nt] = 0.f;
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) acc[mt][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  }
+
+  const int m_begin = ms * w.rows_per_split;
+  int m_end = m_begin + w.rows_per_split;
+  if (m_end > p.M) m_end = p.M;
+  int m = m_begin + 4 * wv + kk;                                       // this lane's row of the NEXT step to be loaded
+  int rx, ry, rf;
+  {
+    const int mc = m < p.M ? m : p.M - 1;
+    rx = mc % p.gw; ry = (mc / p.gw) % p.gh; rf = mc / (p.gw * p.gh);
+  }
+  auto issue = [&](float (&av)[MT], float (&bv)[NT]) {
+    const bool rv = m < m_end;
+    const int ys = S * ry, xs = S * rx;
+    const int rowtex = (rf * p.h + ys) * p.w + xs;
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+      const bool ok = rv && aok[mt] && (unsigned)(ys + oy[mt]) < (unsigned)p.h && (unsigned)(xs + ox[mt]) < (unsigned)p.w;
+      const int tex = ok ? rowtex + tdelta[mt] : 0;
+      const float v = ap[mt][(size_t)tex * ald[mt]];                   // unconditional, clamped address
+      av[mt] = ok ? v : 0.f;
+    }
+    const int rowo = MODE == NLT_DECONV_K2S2 ? (rf * p.oh + 2 * ry) * p.ow + 2 * rx : m;
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      const bool ok = rv && bok[nt];
+      const int otex = ok ? rowo + bdelta[nt] : 0;
+      const float v = w.dp[(size_t)otex * w.ldp + boff[nt]];
+      bv[nt] = ok ? v : 0.f;
+    }
+    m += 16; rx += 16;                                                 // the wave's next step is 16 rows further
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {                                      // gw >= 4 (checked by the host): at most 4 wraps, branch-free
+      const bool wx = rx >= p.gw;
+      rx -= wx ? p.gw : 0;
+      ry += wx ? 1 : 0;
+      const bool wy = ry >= p.gh;
+      ry = wy ? 0 : ry;
+      rf += wy ? 1 : 0;
+    }
+  };
+  auto compute = [&](const float (&av)[MT], const float (&bv)[NT]) {
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      bsum[nt] += bv[nt];
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[mt], bv[nt], acc[mt][nt], 0, 0, 0);
+    }
+  };
+  const int first = m_begin + 4 * wv;
+  const int nsteps = first < m_end ? (m_end - first + 15) / 16 : 0;
+  float a0[MT], b0[NT], a1[MT], b1[NT], a2[MT], b2[NT];
+  issue(a0, b0);
+  issue(a1, b1);
+  for (int s3 = 0; s3 < nsteps; s3 += 3) {                             // steps past nsteps carry zero operands
+    issue(a2, b2); compute(a0, b0);
+    issue(a0, b0); compute(a1, b1);
+    issue(a1, b1); compute(a2, b2);
+  }
+
+  // waves 1..3 hand their blocks to wave 0 one after the other (fixed order -> deterministic)
+  constexpr int NC = NT * 16, KN = MT * 16 * NC;
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) {
+    bsum[nt] += __shfl_xor(bsum[nt], 16);
+    bsum[nt] += __shfl_xor(bsum[nt], 32);
+  }
+  for (int src = 1; src < 4; ++src) {
+    if (wv == src) {
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) xch[(mt * 16 + 4 * kk + r) * NC + nt * 16 + i] = acc[mt][nt][r];
+      if (kk == 0)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) xch[KN + nt * 16 + i] = bsum[nt];
+    }
+    __syncthreads();
+    if (wv == 0) {
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) acc[mt][nt][r] += xch[(mt * 16 + 4 * kk + r) * NC + nt * 16 + i];
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) bsum[nt] += xch[KN + nt * 16 + i];
+    }
+    __syncthreads();
+  }
+  if (wv) return;
+  float* dst = w.ws + (size_t)ms * (KN + NC);
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) dst[(mt * 16 + 4 * kk + r) * NC + nt * 16 + i] = acc[mt][nt][r];
+  if (kk == 0)
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) dst[KN + nt * 16 + i] = bsum[nt];
+}
+
+// Pass 2: 16 entries of the [K pad][N pad] block (+ the column sums) per workgroup, the slices dealt to 16 thread groups x 4
+// running sums (64 independent load streams per entry; a serial walk over ~500 slices is pure latency), fixed order.
+template <int MODE, int MT, int NT>
+__global__ __launch_bounds__(256) void wgrad_narrow_reduce_kernel(WN w) {
+  __shared__ float part[16][17];
+  constexpr int NC = NT * 16, KN = MT * 16 * NC, PER = KN + NC;
+  const ConvP& p = w.c;
+  const int e = threadIdx.x & 15, g = threadIdx.x >> 4;
+  const int idx = blockIdx.x * 16 + e;                                 // PER is a multiple of 16
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  int ms = g;
+  for (; ms + 48 < w.msplits; ms += 64) {
+    s0 += w.ws[(size_t)ms * PER + idx];
+    s1 += w.ws[(size_t)(ms + 16) * PER + idx];
+    s2 += w.ws[(size_t)(ms + 32) * PER + idx];
+    s3 += w.ws[(size_t)(ms + 48) * PER + idx];
+  }
+  for (; ms < w.msplits; ms += 16) s0 += w.ws[(size_t)ms * PER + idx];
+  part[g][e] = (s0 + s1) + (s2 + s3);
+  __syncthreads();
+  if (g) return;
+  float s = 0.f;
+#pragma unroll
+  for (int q = 0; q < 16; ++q) s += part[q][e];
+  const int cin = p.c0 + p.c1;
+  if (idx < KN) {
+    const int kidx = idx / NC, n = idx - kidx * NC;
+    if (kidx >= w.K || n >= w.N) return;
+    const int tap = kidx / cin, c = kidx - tap * cin;
+    w.dw[keras_widx_n<MODE>(tap, c, n, cin, p.cout)] += s;
+  } else if (w.db) {
+    const int n = idx - KN;
+    if (n >= w.N) return;
+    if (MODE != NLT_DECONV_K2S2) w.db[n] += s;
+    else w.ws[(size_t)w.msplits * PER + n] = s;                        // 4 (a,b) column groups per output channel: next launch
+  }
+}
+
+// Conv2DTranspose k2s2 bias: db[o] = sum_ab colsum[ab * cout + o]
+template <int MT, int NT>
+__global__ void wgrad_narrow_bias_k2s2_kernel(WN w) {
+  constexpr int NC = NT * 16, KN = MT * 16 * NC, PER = KN + NC;
+  const int o = threadIdx.x;
+  if (o >= w.c.cout) return;
+  const float* tot = w.ws + (size_t)w.msplits * PER;
+  w.db[o] += (tot[o] + tot[w.c.cout + o]) + (tot[2 * w.c.cout + o] + tot[3 * w.c.cout + o]);
+}
+
+template <int MODE, int MT, int NT>
+int run_narrow(WN& w, hipStream_t s) {
+  constexpr int PER = MT * 16 * NT * 16 + NT * 16;
+  hipLaunchKernelGGL((wgrad_narrow_kernel<MODE, MT, NT>), dim3((unsigned)w.msplits), dim3(256), PER * sizeof(float), s, w);
+  hipLaunchKernelGGL((wgrad_narrow_reduce_kernel<MODE, MT, NT>), dim3(PER / 16), dim3(256), 0, s, w);
+  if (MODE == NLT_DECONV_K2S2 && w.db) hipLaunchKernelGGL((wgrad_narrow_bias_k2s2_kernel<MT, NT>), dim3(1), dim3(64), 0, s, w);
+  NLT_CHECK_LAUNCH();
+  return NLT_OK;
+}
+
+template <int MODE>
+int dispatch(WN& w, int mt, int nt, hipStream_t s) {
+#define NLT_WN(M_, N_) if (mt == M_ && nt == N_) return run_narrow<MODE, M_, N_>(w, s);
+  NLT_WN(2, 1) NLT_WN(4, 1) NLT_WN(8, 1) NLT_WN(2, 2) NLT_WN(4, 2) NLT_WN(8, 2)
+#undef NLT_WN
+  return NLT_ERR_UNSUPPORTED;
+}
+
+int tiles_m(int K) { return K <= 32 ? 2 : (K <= 64 ? 4 : 8); }
+
+int prepare_narrow(WN& w, int mode, const float* src0, int ld0, int c0, const float* src1, int ld1, int c1, int n, int h, int wd,
+                   const float* dpre, int ldp, int cout, float* dw, float* db, long* ws_floats) {
+  if (mode != NLT_CONV_K2S2 && mode != NLT_CONV_K2S1 && mode != NLT_DECONV_K2S2 && mode != NLT_DECONV_K2S1) return NLT_ERR_UNSUPPORTED;
+  float* dummy = dw ? dw : reinterpret_cast<float*>(16);
+  const float* d0 = src0 ? src0 : dummy;
+  const int st = nlt_fill_conv_params(w.c, mode, d0, ld0, c0, c1 ? (src1 ? src1 : dummy) : nullptr, ld1, c1, n, h, wd, dummy, dummy,
+                                      cout, dummy, cout, 0, 0.f, nullptr, 0, 0);
+  if (st != NLT_OK) return st;
+  if (ldp < cout) return NLT_ERR_BAD_ARG;
+  const int taps = mode == NLT_DECONV_K2S2 ? 1 : 4;
+  w.K = taps * (c0 + c1);
+  w.N = w.c.N;
+  if (w.K > 128 || w.N > 32) return NLT_ERR_UNSUPPORTED;
+  if (w.c.gw < 4) return NLT_ERR_UNSUPPORTED;                          // the incremental row walk assumes >= 4 texels per grid row
+  w.dp = dpre; w.ldp = ldp; w.dw = dw; w.db = db;
+  long rows = (w.c.M + 511) / 512;                                     // ~512 workgroups (2 per CU, 8 waves)
+  if (rows < 256) rows = 256;                                          // >= 16 MFMA steps per wave
+  rows = (rows + 15) & ~15L;
+  w.msplits = (int)((w.c.M + rows - 1) / rows);
+  w.rows_per_split = (int)rows;
+  const int mt = tiles_m(w.K), nt = w.N <= 16 ? 1 : 2;
+  *ws_floats = ((long)w.msplits + 1) * (mt * 16 * nt * 16 + nt * 16);
+  return NLT_OK;
+}
+
+}  // namespace
+
+extern "C" long nlt_wgrad_narrow_workspace_floats(int mode, int c0, int c1, int n, int h, int w, int cout) {
+  WN t;
+  long need = -1;
+  if (prepare_narrow(t, mode, nullptr, c0, c0, nullptr, c1, c1, n, h, w, nullptr, cout, cout, nullptr, nullptr, &need) != NLT_OK)
+    return -1;
+  return need;
+}
+
+extern "C" int nlt_conv_backward_weights_narrow(int mode,
+                                                const float* src0, int ld0, int c0, const float* src1, int ld1, int c1,
+                                                int n, int h, int w, const float* dpre, int ldp, int cout,
+                                                float* dw_keras, float* dbias, float* workspace, long workspace_floats,
+                                                void* stream) {
+  if (!src0 || !dpre || !dw_keras || !workspace) return NLT_ERR_BAD_ARG;
+  if (c1 > 0 && !src1) return NLT_ERR_BAD_ARG;
+  WN t;
+  long need = 0;
+  const int st = prepare_narrow(t, mode, src0, ld0, c0, src1, ld1, c1, n, h, w, dpre, ldp, cout, dw_keras, dbias, &need);
+  if (st != NLT_OK) return st;
+  if (workspace_floats < need) return NLT_ERR_BAD_ARG;
+  t.ws = workspace;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const int mt = tiles_m(t.K), nt = t.N <= 16 ? 1 : 2;
+  switch (mode) {
+    case NLT_CONV_K2S2: return dispatch<NLT_CONV_K2S2>(t, mt, nt, s);
+    case NLT_CONV_K2S1: return dispatch<NLT_CONV_K2S1>(t, mt, nt, s);
+    case NLT_DECONV_K2S2: return dispatch<NLT_DECONV_K2S2>(t, mt, nt, s);
+    case NLT_DECONV_K2S1: return dispatch<NLT_DECONV_K2S1>(t, mt, nt, s);
+  }
+  return NLT_ERR_BAD_ARG;
+}

@@ -61,6 +61,7 @@ class RenderPlan:
         self.two_streams = os.environ.get('NLT_STREAMS', '2') != '1'   # inference: query-path encoder convs on a side stream
         self._side = None               # (side stream, [events]) created on first use
         self.wgrad_tiled = os.environ.get('NLT_WGRAD', 'tiled') != 'atomic'   # csrc/wgrad_tile.hip vs first-generation csrc/wgrad.hip
+        self.wgrad_narrow = os.environ.get('NLT_WGRAD_NARROW', '1') != '0'
         self._trial_direct = False
         self._ran_direct = set()
         self._trial_lds = 0             # autotune: try the LDS-tiled kernel with this many output channels per workgroup
@@ -493,6 +494,10 @@ class RenderPlan:
         tiled = (self.wgrad_tiled and c0 % 4 == 0 and c1 % 4 == 0 and layer.n_ch_out % 4 == 0 and ld0 % 4 == 0
                  and (c1 == 0 or ld1 % 4 == 0) and ldp % 4 == 0 and gw >= 4)
         fn = C.conv_backward_weights_tiled if tiled else C.conv_backward_weights
+        ncols = layer.n_ch_out * (4 if layer.mode == C.DECONV_K2S2 else 1)
+        kdim = (c0 + c1) * (1 if layer.mode in (C.DECONV_K2S2, C.CONV1X1) else 4)
+        if self.wgrad_narrow and ncols <= 32 and kdim <= 128 and layer.mode != C.CONV1X1 and gw >= 4:
+            fn = C.conv_backward_weights_narrow     # few output columns: MFMA tile matched to the layer (csrc/wgrad_narrow.hip)
         self._launch(label, nbytes, fn, layer.mode, src0, c0, ld0, src1, c1, ld1, n, h, w,
                      dpre, ldp, layer.n_ch_out, layer.dkernel, layer.dbias)
 

@@ -387,6 +387,10 @@ def conv_backward_weights_tiled(mode, src0, c0, ld0, src1, c1, ld1, n, h, w, dpr
     conv_backward_weights(mode, src0, c0, ld0, src1, c1, ld1, n, h, w, dpre, ldp, cout, dw, db)
 
 
+def conv_backward_weights_narrow(mode, src0, c0, ld0, src1, c1, ld1, n, h, w, dpre, ldp, cout, dw, db):
+    conv_backward_weights(mode, src0, c0, ld0, src1, c1, ld1, n, h, w, dpre, ldp, cout, dw, db)
+
+
 def front_pack_l2_weights(wq, bq, wo, bo):
     return dict(wq=wq, bq=bq, wo=wo, bo=bo)
 
@@ -408,5 +412,5 @@ _FORWARD = ('conv_forward', 'pack_conv_weights', 'stem_forward', 'obs_mean_forwa
 
 def install(monkeypatch):
     """Replaces every Python-level C-ABI adapter of nlt_amd._capi by its CPU emulation above."""
-    for name in _FORWARD + _TRAIN + _BUFFERS + _FUSED + _TILE + ('conv_forward_splitk', 'conv_backward_weights_tiled'):
+    for name in _FORWARD + _TRAIN + _BUFFERS + _FUSED + _TILE + ('conv_forward_splitk', 'conv_backward_weights_tiled', 'conv_backward_weights_narrow'):
         monkeypatch.setattr(C, name, globals()[name])

@@ -30,7 +30,9 @@ def wgrad_case(mode, n, h, w, c0, c1, cout, algo, pad0=0, pad1=0, padp=0, seed=0
     dp = rng.standard_normal((n, oh, ow, cout + padp)).astype(np.float32)
     gw, gb = torch.autograd.grad(y, (wz, bz), torch.tensor(dp[..., :cout]))
     dw = torch.zeros(wshape, device='cuda'); db = torch.zeros(cout, device='cuda')
-    if algo == 'tiled':
+    if algo == 'narrow':
+        C.conv_backward_weights_narrow(mode, d(x0), c0, c0 + pad0, d(x1), c1, c1 + pad1, n, h, w, d(dp), cout + padp, cout, dw, db)
+    elif algo == 'tiled':
         C.conv_backward_weights_tiled(mode, d(x0), c0, c0 + pad0, d(x1), c1, c1 + pad1, n, h, w, d(dp), cout + padp, cout, dw, db)
     else:
         C.conv_backward_weights(mode, d(x0), c0, c0 + pad0, d(x1), c1, c1 + pad1, n, h, w, d(dp), cout + padp, cout, dw, db,
@@ -59,6 +61,36 @@ def test_wgrad_mfma_dual_source_slices_ragged(mode, algo):
 def test_wgrad_mfma_shapes(mode, c0, c1, cout, algo):
     hw = 8 if algo == 'tiled' else 4          # the tiled kernel needs >= 4 texels per GEMM grid row (4 after the stride-2 conv)
     wgrad_case(mode, 2, hw, hw, c0, c1, cout, algo, seed=20)
+
+
+NARROW = [(C.CONV_K2S1, 16, 0, 16), (C.CONV_K2S1, 32, 0, 32), (C.CONV_K2S2, 32, 0, 32), (C.CONV_K2S2, 16, 0, 32),
+          (C.CONV_K2S2, 32, 0, 16), (C.DECONV_K2S1, 8, 0, 8), (C.DECONV_K2S1, 16, 0, 16), (C.DECONV_K2S1, 4, 0, 4),
+          (C.DECONV_K2S2, 16, 64, 8), (C.DECONV_K2S2, 8, 32, 4), (C.CONV_K2S1, 5, 0, 7), (C.CONV_K2S2, 3, 6, 12)]
+
+
+@pytest.mark.parametrize('mode,c0,c1,cout', NARROW)
+def test_wgrad_narrow_layers(mode, c0, c1, cout):
+    """csrc/wgrad_narrow.hip: the released net's 8/16/32-column layers (+ odd channel counts), ragged leading dims."""
+    wgrad_case(mode, 2, 12, 20, c0, c1, cout, 'narrow', pad0=4, pad1=8 if c1 else 0, padp=4, seed=60 + cout)
+    wgrad_case(mode, 1, 8, 8, c0, c1, cout, 'narrow', seed=61)               # a single partial step per wave
+
+
+def test_wgrad_narrow_many_row_slices_is_deterministic_accumulates_and_rejects_wide_layers():
+    wgrad_case(C.CONV_K2S1, 2, 128, 96, 16, 0, 16, 'narrow', seed=62)        # 24576 rows -> ~100 row slices
+    wgrad_case(C.DECONV_K2S2, 2, 64, 64, 16, 64, 8, 'narrow', seed=63)
+    x = torch.randn(2, 80, 40, 32, device='cuda'); dp = torch.randn(2, 80, 40, 32, device='cuda')
+    outs = []
+    for _ in range(2):
+        dw = torch.ones(2, 2, 32, 32, device='cuda'); db = torch.ones(32, device='cuda')
+        C.conv_backward_weights_narrow(C.CONV_K2S1, x, 32, 32, None, 0, 0, 2, 80, 40, dp, 32, 32, dw, db)
+        outs.append((dw.cpu().numpy(), db.cpu().numpy()))
+    assert np.array_equal(outs[0][0], outs[1][0]) and np.array_equal(outs[0][1], outs[1][1])     # bit-identical run to run
+    dw0 = torch.zeros(2, 2, 32, 32, device='cuda'); db0 = torch.zeros(32, device='cuda')
+    C.conv_backward_weights_narrow(C.CONV_K2S1, x, 32, 32, None, 0, 0, 2, 80, 40, dp, 32, 32, dw0, db0)
+    np.testing.assert_allclose(outs[0][0] - 1, dw0.cpu().numpy(), atol=3e-4)
+    assert not C.wgrad_narrow_supported(C.CONV_K2S1, 64, 0, 2, 16, 16, 64)   # 64 columns: wgrad_tile's job
+    assert not C.wgrad_narrow_supported(C.CONV_K2S1, 64, 0, 2, 16, 16, 16)   # K = 256 > 128
+    assert C.wgrad_narrow_supported(C.CONV_K2S2, 32, 0, 2, 16, 16, 32)
 
 
 def test_wgrad_tiled_many_row_slices_is_deterministic_and_accumulates():
