@@ -76,6 +76,9 @@ def parse():
     ap.add_argument('--dominant', type=str, default=None, help='label of the kernel to time in the timed region')
     ap.add_argument('--train-steps', type=int, default=-1, help='train steps to time for the train_step field (-1: steps//2, 0: skip)')
     ap.add_argument('--train-loss', type=str, default='l2')
+    ap.add_argument('--train-graph', action='store_true',
+                    help='train step: replay forward + loss + backward as one hipGraph (trainvali.GraphedTrainStep); measured '
+                         'slower than eager launches on ROCm 7.0 (5.15 vs 4.75 ms), so off by default')
     ap.add_argument('--per-op-train', action='store_true', help='per-launch timing table of one train step (stderr)')
     return ap.parse_args()
 
@@ -162,8 +165,12 @@ def bench_train(args, device, world, rank, n_steps):
     opt = trainvali.make_optimizer(model, cfg)
     batch = synth_device_batch(args.frames, args.uv, args.cam, 1, device, seed=200 + rank)
     gbs = world * args.frames
-    for _ in range(3):
-        trainvali.distributed_train_step(model, batch, opt, gbs)
+    step = trainvali.GraphedTrainStep(model, opt, gbs) if args.train_graph else trainvali.distributed_train_step
+    run = (lambda: step(batch)) if args.train_graph else (lambda: step(model, batch, opt, gbs))
+    for _ in range(4):                                               # eager warm-ups (autotune), then the graph capture
+        run()
+    if args.train_graph and step.static_batch() is not None:
+        batch = step.static_batch()                                  # synthetic data resident in the graph's input buffers
     if args.per_op_train and rank == 0:
         from nlt_amd.engine import OpTimer
         timer = OpTimer()
@@ -183,7 +190,8 @@ def bench_train(args, device, world, rank, n_steps):
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(n_steps):
-        loss, _ = trainvali.distributed_train_step(model, batch, opt, gbs)
+        loss, _ = run()
+    enq = time.perf_counter() - t0                                   # host enqueue time (the GPU may still be running)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -193,7 +201,11 @@ def bench_train(args, device, world, rank, n_steps):
         dist.all_reduce(te, op=dist.ReduceOp.MAX)
         el = float(te.item())
     return {"value": round(world * args.frames * args.uv * args.uv * n_steps / el / 1e6, 2), "unit": "Mtexels/s",
-            "ms_per_step": round(1e3 * el / n_steps, 3), "steps": n_steps, "global_batch": gbs,
+            "ms_per_step": round(1e3 * el / n_steps, 3), "host_enqueue_ms_per_step": round(1e3 * enq / n_steps, 3),
+            "steps": n_steps, "global_batch": gbs,
+            "launch": ("eager" if not args.train_graph or step.graph is None else
+                       "hipGraph replay of forward + loss + backward; all-reduce and Adam-AMSGrad eager"),
+            "graph_error": step.failed if args.train_graph else None,
             "workload": "BASELINE config 4: %d frames/GPU, %d^2 UV, k=1, loss %s, Adam-AMSGrad, flat %d-float "
                         "gradient bucket all-reduce" % (args.frames, args.uv, args.train_loss, model.flat_params.numel()),
             "final_loss": float(loss)}

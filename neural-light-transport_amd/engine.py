@@ -60,6 +60,7 @@ class RenderPlan:
         self.fuse_train = os.environ.get('NLT_FUSED_TRAIN', '1') != '0'   # fused ends in the train step too (csrc/train_fused.hip)
         self.two_streams = os.environ.get('NLT_STREAMS', '2') != '1'   # inference: query-path encoder convs on a side stream
         self._side = None               # (side stream, [events]) created on first use
+        self._bside = None              # backward: (side stream for the weight gradients, [events], cursor)
         self.wgrad_tiled = os.environ.get('NLT_WGRAD', 'tiled') != 'atomic'   # csrc/wgrad_tile.hip vs first-generation csrc/wgrad.hip
         self.wgrad_narrow = os.environ.get('NLT_WGRAD_NARROW', '1') != '0'
         self._trial_direct = False
@@ -488,6 +489,24 @@ class RenderPlan:
         return g
 
     def _wgrad(self, label, layer, src0, c0, ld0, src1, c1, ld1, n, h, w, dpre, ldp):
+        """Weight + bias gradient of one conv.  Nothing downstream of it in the backward pass reads the result, so with
+        two streams it is queued on the side stream (after an event on the gradient it consumes) and the backward-data
+        chain -- the critical path -- carries on; `backward` joins the streams at the end."""
+        bs = self._bside
+        if bs is not None and bs[2] is not None:
+            side, events, cur = bs
+            if cur[0] == len(events):
+                events.append(torch.cuda.Event())
+            ev = events[cur[0]]
+            cur[0] += 1
+            ev.record(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                side.wait_event(ev)
+                self._wgrad_now(label, layer, src0, c0, ld0, src1, c1, ld1, n, h, w, dpre, ldp)
+            return
+        self._wgrad_now(label, layer, src0, c0, ld0, src1, c1, ld1, n, h, w, dpre, ldp)
+
+    def _wgrad_now(self, label, layer, src0, c0, ld0, src1, c1, ld1, n, h, w, dpre, ldp):
         oh, ow = layer.out_hw(h, w)
         nbytes = 4 * (n * h * w * (c0 + c1) + n * oh * ow * layer.n_ch_out)
         gw = w // 2 if layer.mode == C.CONV_K2S2 else w
@@ -525,6 +544,25 @@ class RenderPlan:
         k = nn_rgb.shape[1]
         b = self._buffers(n, k, h, w, base.device)
         g = self._grad_buffers(b)
+        q, o, D, U, cl = self.q, self.o, self.n_down, self.n_up, b['C']
+        zb = g['zero_bias']
+        concurrent = self.two_streams and dpred.is_cuda and self.timer is None
+        if concurrent:
+            if self._bside is None:
+                self._bside = [torch.cuda.Stream(device=dpred.device), [], None]
+            self._bside[2] = [0]                                     # event cursor: weight gradients go to the side stream
+        try:
+            self._backward_plan(dpred, base, cvis, lvis, nn_rgb, nn_base, obs_weights, b, g, n, h, w, k)
+        finally:
+            if concurrent:
+                side, events, cur = self._bside
+                self._bside[2] = None
+                if cur[0] == len(events):
+                    events.append(torch.cuda.Event())
+                events[cur[0]].record(side)
+                torch.cuda.current_stream().wait_event(events[cur[0]])   # the optimizer step needs every gradient
+
+    def _backward_plan(self, dpred, base, cvis, lvis, nn_rgb, nn_base, obs_weights, b, g, n, h, w, k):
         q, o, D, U, cl = self.q, self.o, self.n_down, self.n_up, b['C']
         zb = g['zero_bias']
 

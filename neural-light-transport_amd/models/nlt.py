@@ -34,18 +34,8 @@ class _RenderFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, d_pred_c, *unused):
-        model = ctx.model
-        base, cvis, lvis, warp, nn_rgb, nn_base, obs_weights = ctx.inputs
-        n, hc, wc, _ = warp.shape
-        model.flat_grads.zero_()
-        if d_pred_c is not None:
-            d_pred_c = d_pred_c.contiguous()
-            if (hc, wc) != (model.imh, model.imw):
-                d_pred_c = C.resize_bilinear_backward(d_pred_c, hc, wc)
-            dpred = torch.empty((n, model.uvh, model.uvw, 3), device=base.device, dtype=torch.float32)
-            C.warp_backward(d_pred_c, warp, n, model.uvh, model.uvw, hc, wc, dpred)
-            model.plan.backward(dpred, base, cvis, lvis, nn_rgb, nn_base, obs_weights)
-        return model.flat_grads, None, None, None
+        ctx.model._render_backward(d_pred_c, ctx.inputs)
+        return ctx.model.flat_grads, None, None, None
 
 
 class Model(BaseModel):
@@ -181,6 +171,43 @@ class Model(BaseModel):
             base_camspc = C.resize_bilinear_forward(base_camspc, self.imh, self.imw)
             pred_camspc = C.resize_bilinear_forward(pred_camspc, self.imh, self.imw)
         return pred, pred_camspc, base_camspc, fg_camspc, idx
+
+    def _render_backward(self, d_pred_c, inputs):
+        """Fills the flat gradient bucket from dL/d(pred_camspc): resize / warp (TFA resampler) adjoints, then the
+        hand-ordered backward plan over the activations the last inference=False forward left behind."""
+        base, cvis, lvis, warp, nn_rgb, nn_base, obs_weights = inputs
+        n, hc, wc, _ = warp.shape
+        self.flat_grads.zero_()
+        if d_pred_c is not None:
+            d_pred_c = d_pred_c.contiguous()
+            if (hc, wc) != (self.imh, self.imw):
+                d_pred_c = C.resize_bilinear_backward(d_pred_c, hc, wc)
+            dpred = torch.empty((n, self.uvh, self.uvw, 3), device=base.device, dtype=torch.float32)
+            C.warp_backward(d_pred_c, warp, n, self.uvh, self.uvw, hc, wc, dpred)
+            self.plan.backward(dpred, base, cvis, lvis, nn_rgb, nn_base, obs_weights)
+
+    def train_forward_backward(self, batch, global_bs):
+        """One train step's forward + loss + backward WITHOUT the torch.autograd tape around the network (only the loss
+        is differentiated, with autograd.grad -- no AccumulateGrad node, so the whole thing can be captured in a
+        hipGraph): returns (loss summed over this rank's examples / global_bs, to_vis) and leaves the gradients in
+        `flat_grads`.  Same arithmetic as `call(batch, 'train')` + `compute_loss` + `.backward()`."""
+        id_, base, cvis, lvis, warp, rgb, rgb_camspc, nn_id, nn_base, nn_rgb, nn_rgb_camspc = batch
+        if nn_rgb.dim() == 4:
+            nn_rgb, nn_base = nn_rgb.unsqueeze(1), nn_base.unsqueeze(1)
+        nn_rgb, nn_base = nn_rgb.contiguous(), nn_base.contiguous()
+        with torch.no_grad():
+            pred, pred_camspc, base_camspc, fg_camspc, _ = self._render(base, cvis, lvis, warp, nn_rgb, nn_base, None, None,
+                                                                        False, inference=False)
+            gt_camspc = C.mul_forward(rgb_camspc, fg_camspc)
+        leaf = pred_camspc.detach().requires_grad_(True)
+        with torch.enable_grad():
+            loss = self.compute_loss(leaf, gt_camspc, keep_batch=True).sum() / global_bs
+            (d_pred_c,) = torch.autograd.grad(loss, leaf)
+        with torch.no_grad():
+            self._render_backward(d_pred_c, (base, cvis, lvis, warp, nn_rgb, nn_base, None))
+            to_vis = {'id': id_, 'nn_id': nn_id, 'base_camspc': base_camspc, 'pred': pred.clone(), 'pred_camspc': pred_camspc,
+                      'nn_camspc': nn_rgb_camspc, 'gt': rgb, 'gt_camspc': gt_camspc}
+        return loss.detach(), to_vis
 
     def _render_maybe_graphed(self, base, cvis, lvis, warp, nn_rgb, nn_base, obs_weights, obs_override, want_indices):
         """`_render` (+ the copy of pred) either launched kernel by kernel or, with use_graphs, replayed as one

@@ -37,6 +37,70 @@ def distributed_train_step(model, batch, optimizer, global_bs, group=None):
     return loss, to_vis
 
 
+class GraphedTrainStep:
+    """`distributed_train_step` with forward + loss + backward captured ONCE as a hipGraph and replayed: the step is
+    ~170 small launches, and issuing them one by one from Python costs about as much wall time as the GPU needs to
+    run them.  The gradient all-reduce (RCCL) and the Adam-AMSGrad launch (its bias-correction scalars change every
+    step) stay eager, after the replay.
+
+    The graph is tied to tensor ADDRESSES: the batch is copied into static buffers owned by this object (a no-op when
+    the caller already passes them back), shapes must not change, and the returned loss / to_vis tensors are the
+    graph's static outputs -- consume them before the next call.  The first `warmup` calls run eagerly (plan-time
+    autotune, workspace allocation); any failure to capture falls back to the eager step for good."""
+
+    TENSORS = (1, 2, 3, 4, 5, 6, 8, 9, 10)       # tensor entries of the 11-tuple batch (nlt/models/nlt.py:91-92)
+
+    def __init__(self, model, optimizer, global_bs, group=None, warmup=2):
+        self.model, self.optimizer, self.global_bs, self.group = model, optimizer, global_bs, group
+        self.warmup, self.seen = warmup, 0
+        self.graph, self.static, self.out, self.failed = None, None, None, None
+
+    def static_batch(self):
+        """The graph's own input tensors (None before the capture): a loader that fills THESE and passes them back
+        skips the per-step device-to-device copies."""
+        return tuple(self.static) if self.graph is not None else None
+
+    def _body(self, batch):
+        loss, to_vis = self.model.train_forward_backward(batch, self.global_bs)
+        return loss.clone(), to_vis
+
+    def _finish(self, loss):
+        grad = self.model.flat_grads
+        self.model.flat_params.grad = grad
+        if _world(self.group) > 1:
+            dist.all_reduce(grad, op=dist.ReduceOp.SUM, group=self.group)
+            dist.all_reduce(loss, op=dist.ReduceOp.SUM, group=self.group)
+        self.optimizer.step(grad)
+        return loss
+
+    def __call__(self, batch):
+        dev_ok = isinstance(batch[1], torch.Tensor) and batch[1].is_cuda and self.model.plan.timer is None
+        if self.failed is not None or not dev_ok or self.seen < self.warmup:
+            self.seen += 1
+            return distributed_train_step(self.model, batch, self.optimizer, self.global_bs, self.group)
+        if self.graph is None:
+            try:
+                self.static = list(batch)
+                for i in self.TENSORS:
+                    self.static[i] = batch[i].clone()
+                torch.cuda.synchronize()
+                graph = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(graph):
+                    self.out = self._body(tuple(self.static))
+                self.graph = graph
+            except Exception as e:                       # capture is an optimisation, never a requirement
+                self.failed = repr(e)
+                self.graph = None
+                torch.cuda.synchronize()
+                return distributed_train_step(self.model, batch, self.optimizer, self.global_bs, self.group)
+        for i in self.TENSORS:
+            if batch[i].data_ptr() != self.static[i].data_ptr():
+                self.static[i].copy_(batch[i])
+        self.graph.replay()
+        loss, to_vis = self.out
+        return self._finish(loss.clone()), to_vis
+
+
 def distributed_vali_step(model, batch, global_bs, group=None):
     with torch.no_grad():
         pred, gt, loss_kwargs, to_vis = model(batch, mode='vali')

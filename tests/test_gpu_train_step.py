@@ -57,6 +57,29 @@ def test_loss_decreases_and_vali_step():
     assert np.isfinite(float(lv)) and not vis['pred_camspc'].requires_grad
 
 
+def test_graphed_train_step_replays_the_same_step_as_the_eager_one():
+    """trainvali.GraphedTrainStep: forward + loss + backward as one hipGraph (new batches copied into its static inputs)
+    against the kernel-by-kernel step from the same initial weights; differences = float atomics in the warp scatter."""
+    batches = [to_device_batch(*O.synth_batch(2, 64, 64, 32, 32, 32, 32, k=2, seed=40 + i)) for i in range(3)]
+    results = []
+    for graphed in (False, True):
+        _, pm = make_pair(depth=256, uv=64, im=32, loss='l2', seed=9)
+        pm.build('cuda')
+        opt = nlt_amd.optim.AdamAMSGrad(pm, 1e-3)
+        step = trainvali.GraphedTrainStep(pm, opt, 2, warmup=1) if graphed else None
+        losses = []
+        for it in range(6):
+            b = batches[it % 3]
+            loss, vis = step(b) if graphed else trainvali.distributed_train_step(pm, b, opt, 2)
+            losses.append(float(loss))
+        if graphed:
+            assert step.failed is None and step.graph is not None and step.static_batch() is not None
+        results.append((losses, pm.flat_params.detach().clone()))
+    (l0, p0), (l1, p1) = results
+    np.testing.assert_allclose(l1, l0, rtol=2e-5)
+    assert float((p0 - p1).abs().max()) < 2e-5
+
+
 def test_rccl_single_rank_group_runs_the_gradient_all_reduce():
     """One-rank `nccl` (= RCCL) process group on the GPU box: the flat gradient bucket goes through the real
     collective library (the world-size-2 logic is covered on CPU by tests/test_dist_gloo.py)."""

@@ -63,3 +63,26 @@ def test_vali_step_and_no_grad_paths(monkeypatch):
     loss, vis = trainvali.distributed_vali_step(pm, cpu_batch(batch, nn), 2)
     assert abs(float(loss) - float(ref)) < 1e-5
     assert not vis['pred_camspc'].requires_grad
+
+
+def test_tape_free_train_forward_backward_equals_the_autograd_path(monkeypatch):
+    """Model.train_forward_backward (what trainvali.GraphedTrainStep captures in a hipGraph) fills the same flat
+    gradient bucket and returns the same loss as call('train') + compute_loss + backward()."""
+    fake_capi.install(monkeypatch)
+    _, pm = make(256, 64, 32, loss='barron,2e+0l2')
+    pm.build('cpu'); pm.register_trainable()
+    batch, nn = O.synth_batch(2, 64, 64, 32, 32, 32, 32, k=2, seed=11)
+    b = cpu_batch(batch, nn)
+    pred, gt, kw, _ = pm(b, mode='train')
+    loss = pm.compute_loss(pred, gt, keep_batch=True).sum() / 4
+    pm.flat_params.grad = None
+    loss.backward()
+    ref = pm.flat_params.grad.clone()
+    loss2, vis = pm.train_forward_backward(b, 4)
+    assert abs(float(loss2) - float(loss)) <= 1e-6 * abs(float(loss))
+    assert torch.equal(pm.flat_grads, ref)
+    assert set(vis) >= {'pred', 'pred_camspc', 'gt_camspc', 'base_camspc'}
+    # the graphed-step object degrades to the eager step off the GPU
+    step = trainvali.GraphedTrainStep(pm, nlt_amd.optim.AdamAMSGrad(pm, 1e-3), 4, warmup=0)
+    l3, _ = step(b)
+    assert step.graph is None and abs(float(l3) - float(loss)) <= 1e-6 * abs(float(loss))
