@@ -374,6 +374,33 @@ int nlt_back_forward(const float* x, const float* fm1, const float* skip3, int n
                      const float* w_s2, const float* b_s2, const float* w_s1, const float* b_s1,
                      const float* w_head, float alpha, float* pred, void* stream);
 
+/*
+ * Refresh every packed weight buffer of a model with ONE launch (csrc/repack.hip).  After an optimizer step the train
+ * loop needs the fragment arrays of every conv again (nlt_pack_conv_weights for the forward family, the same for the
+ * adjoint family of each backward-data launch, nlt_pack_conv_tile_weights); the buffers keep their addresses, and a
+ * table of descriptors in DEVICE memory tells the kernel how to refill each from the Keras-layout arrays.
+ *   replaces: nothing in the reference (Keras reads its variables in place); it is the packed-layout bookkeeping of
+ *             this library, per step instead of per layer.
+ * kind NLT_REPACK_MFMA: dst = what nlt_pack_conv_weights(mode, src, c0, c1, cout) writes, with `src` read as the slice
+ *   [lo, lo + cout) (conv families: of the output-channel axis; transposed families: of their (kh,kw,Cout,Cin) array's
+ *   Cout axis) of an array whose sliced axis has `full` entries -- lo = 0, full = cout for a whole kernel.  This is how
+ *   backward-data w.r.t. input channels [lo, hi) of a forward layer reads that layer's own array as the adjoint family.
+ * kind NLT_REPACK_TILE: dst = what nlt_pack_conv_tile_weights(mode, src, cin = c0, cout, tn) writes.
+ * first_block: exclusive prefix sum of ceil(total / 256) over the table; total_blocks = its grand total.
+ */
+typedef enum { NLT_REPACK_MFMA = 0, NLT_REPACK_TILE = 1 } nlt_repack_kind;
+typedef struct {
+  const float* src;
+  float* dst;
+  long total;          /* floats in dst */
+  long first_block;
+  int kind, mode;
+  int c0, c1, cout;
+  int tn;
+  int lo, full;
+} nlt_repack_desc;
+int nlt_repack_weights(const nlt_repack_desc* descs_device, int n_desc, long total_blocks, void* stream);
+
 /* Weight / bias gradient for the NARROW layers (csrc/wgrad_narrow.hip): N = cout (4 * cout for Conv2DTranspose k2s2)
  * <= 32 output columns and K = taps * (c0 + c1) <= 128, modes NLT_CONV_K2S2 / K2S1 / NLT_DECONV_K2S2 / K2S1, any channel
  * count (4-byte operand loads; the MFMA tile is [K index 16] x [output channel 16], so 8 / 16 / 32-channel layers waste

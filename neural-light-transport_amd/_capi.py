@@ -41,6 +41,7 @@ SIGNATURES = {
     'nlt_wgrad_workspace_floats': (_c_long, [_c_int] * 7),
     'nlt_conv_backward_weights_tiled': (_c_int, [_c_int, _vp, _c_int, _c_int, _vp, _c_int, _c_int, _c_int, _c_int, _c_int,
                                                  _vp, _c_int, _c_int, _vp, _vp, _vp, _c_long, _vp]),
+    'nlt_repack_weights': (_c_int, [_vp, _c_int, _c_long, _vp]),
     'nlt_wgrad_narrow_workspace_floats': (_c_long, [_c_int] * 7),
     'nlt_conv_backward_weights_narrow': (_c_int, [_c_int, _vp, _c_int, _c_int, _vp, _c_int, _c_int, _c_int, _c_int, _c_int,
                                                  _vp, _c_int, _c_int, _vp, _vp, _vp, _c_long, _vp]),
@@ -355,6 +356,30 @@ def conv_forward_splitk(mode, ksplit, src0, c0, ld0, src1, c1, ld1, n, h, w, w_p
     _check(lib().nlt_conv_forward_splitk(mode, tile_hint, ksplit, _ptr(ws), _ptr(src0), ld0, c0, _ptr(src1), ld1, c1, n, h, w,
                                          _ptr(w_packed), _ptr(bias), cout, _ptr(out), ldo, 1 if act else 0, float(alpha),
                                          _ptr(mask_src), ldm, 1 if accumulate else 0, _stream()), 'nlt_conv_forward_splitk')
+
+
+# ---------------------------------------------------------------- one-launch refresh of all packed weights
+REPACK_MFMA, REPACK_TILE = 0, 1
+REPACK_FIELDS = [('src', 'u8'), ('dst', 'u8'), ('total', 'i8'), ('first_block', 'i8'), ('kind', 'i4'), ('mode', 'i4'),
+                 ('c0', 'i4'), ('c1', 'i4'), ('cout', 'i4'), ('tn', 'i4'), ('lo', 'i4'), ('full', 'i4')]   # = nlt_repack_desc
+
+
+def repack_table(entries, device):
+    """entries: dicts with the nlt_repack_desc fields except first_block (src / dst as tensors).  Returns the device
+    table (uint8 tensor), the number of descriptors and the grid size for nlt_repack_weights."""
+    import numpy as np
+    tab = np.zeros(len(entries), dtype=np.dtype(REPACK_FIELDS))
+    blocks = 0
+    for i, e in enumerate(entries):
+        tab[i] = (e['src'].data_ptr(), e['dst'].data_ptr(), e['dst'].numel(), blocks, e['kind'], e['mode'], e['c0'], e['c1'],
+                  e['cout'], e['tn'], e['lo'], e['full'])
+        blocks += (e['dst'].numel() + 255) // 256
+    return torch.from_numpy(tab.view(np.uint8)).to(device), len(entries), blocks
+
+
+def repack_weights(table, n_desc, total_blocks):
+    _check(lib().nlt_repack_weights(_tptr(table, torch.uint8, 'repack table'), n_desc, total_blocks, _stream()),
+           'nlt_repack_weights')
 
 
 # ---------------------------------------------------------------- LDS-tiled encoder convs

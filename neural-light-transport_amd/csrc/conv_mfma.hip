@@ -10,6 +10,7 @@
 // four consecutive MFMA k-steps.  No LDS, no barriers: every texel element is used by exactly
 // one wave (register-level reuse across its CT column tiles) and the weights are L2-resident.
 #include "nlt_common.h"
+#include "pack_common.h"
 
 namespace {
 
@@ -27,21 +28,7 @@ __global__ void pack_weights_kernel(const float* __restrict__ wk, int c0, int c1
                                     int ntiles, long total, float* __restrict__ wp) {
   const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= total) return;
-  const int s4 = idx & 3;
-  const int lane = (idx >> 2) & 63;
-  const long tile = idx >> 8;
-  const int nt = tile % ntiles;
-  const int kc = tile / ntiles;
-  const int ch0 = chunks16(c0), ch1 = chunks16(c1);
-  const int t = kc / (ch0 + ch1);
-  const int r = kc % (ch0 + ch1);
-  const int s = r >= ch0;
-  const int cl = (s ? r - ch0 : r) * 16 + 4 * (lane >> 4) + s4;
-  const int cs = s ? c1 : c0;
-  const int ncol = nt * 16 + (lane & 15);
-  float v = 0.f;
-  if (cl < cs && ncol < N) v = wk[keras_widx<MODE>(t, (s ? c0 : 0) + cl, ncol, c0 + c1, cout)];
-  wp[idx] = v;
+  wp[idx] = nlt_mfma_fragment<MODE>(wk, idx, c0, c1, cout, N, ntiles, cout, 0);
 }
 
 template <int MODE, int RT, int CT>

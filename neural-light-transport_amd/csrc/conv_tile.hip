@@ -16,6 +16,7 @@
 // and keeps their mean in registers -> the interleaved [query | mean] slice of fm[l] is written here and
 // the separate reduce_mean pass (nlt/models/nlt.py:161-164) disappears.
 #include "nlt_common.h"
+#include "pack_common.h"
 
 namespace {
 
@@ -44,16 +45,7 @@ template <int MODE>
 __global__ void pack_tile_kernel(const float* __restrict__ wk, int cin, int cout, int tnt, long total, float* __restrict__ wp) {
   const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= total) return;
-  const int s4 = idx & 3, lane = (idx >> 2) & 63;
-  long r = idx >> 8;
-  const int ct = r % tnt; r /= tnt;
-  const int t = r & 3; r >>= 2;
-  const int ncc = cin >> 4;
-  const int cc = r % ncc;
-  const int g = r / ncc;
-  const int c = cc * 16 + 4 * (lane >> 4) + s4;
-  const int o = (g * tnt + ct) * 16 + (lane & 15);
-  wp[idx] = wk[((long)t * cin + c) * cout + o];                       // Keras (kh,kw,Cin,Cout), t = a*2+b
+  wp[idx] = nlt_tile_fragment(wk, idx, cin, cout, tnt);               // Keras (kh,kw,Cin,Cout), t = a*2+b
 }
 
 template <int MODE, int TNT>

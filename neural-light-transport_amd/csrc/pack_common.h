@@ -1,0 +1,52 @@
+// Fragment layouts of the packed conv weights, shared by the per-layer pack launches (conv_mfma.hip, conv_tile.hip)
+// and the one-launch refresh of every packed buffer after an optimizer step (repack.hip).
+#pragma once
+#include "nlt_common.h"
+
+__host__ __device__ inline int nlt_chunks16(int c) { return (c + 15) >> 4; }
+
+// Keras array index of (tap t, input channel c, GEMM column ncol) for the conv family MODE, when the array handed in is
+// the slice [lo, lo + cout) of a wider array along its COLUMN axis (`full` = that axis' extent in memory; full = cout,
+// lo = 0 for an unsliced kernel).  Backward-data packs the ADJOINT family from the forward layer's own array, sliced
+// along the forward-input axis (networks/elements.py packed_adjoint), without materialising the slice.
+template <int MODE>
+__device__ __forceinline__ long nlt_keras_widx(int t, int c, int ncol, int cin, int cout, int full, int lo) {
+  if (MODE == NLT_CONV1X1 || MODE == NLT_CONV_K2S2 || MODE == NLT_CONV_K2S1) return ((long)t * cin + c) * full + lo + ncol;
+  if (MODE == NLT_DECONV_K2S1) return ((long)t * full + lo + ncol) * cin + c;
+  const int ab = ncol / cout, o = ncol - ab * cout;                    // DECONV_K2S2: ncol = (a*2+b)*cout + o
+  return ((long)ab * full + lo + o) * cin + c;
+}
+
+// register-tiled MFMA kernel (conv_mfma.hip): [tap][16-channel chunk of (c0 | c1)][column tile][lane 64][s4]
+template <int MODE>
+__device__ __forceinline__ float nlt_mfma_fragment(const float* __restrict__ wk, long idx, int c0, int c1, int cout, int N,
+                                                   int ntiles, int full, int lo) {
+  const int s4 = idx & 3;
+  const int lane = (idx >> 2) & 63;
+  const long tile = idx >> 8;
+  const int nt = tile % ntiles;
+  const int kc = tile / ntiles;
+  const int ch0 = nlt_chunks16(c0), ch1 = nlt_chunks16(c1);
+  const int t = kc / (ch0 + ch1);
+  const int r = kc % (ch0 + ch1);
+  const int s = r >= ch0;
+  const int cl = (s ? r - ch0 : r) * 16 + 4 * (lane >> 4) + s4;
+  const int cs = s ? c1 : c0;
+  const int ncol = nt * 16 + (lane & 15);
+  if (cl < cs && ncol < N) return wk[nlt_keras_widx<MODE>(t, (s ? c0 : 0) + cl, ncol, c0 + c1, cout, full, lo)];
+  return 0.f;
+}
+
+// LDS-tiled kernel (conv_tile.hip): [g = cout / TN][cc = cin / 16][tap 4][ct TNT][lane 64][s4]; Keras (kh,kw,Cin,Cout)
+__device__ __forceinline__ float nlt_tile_fragment(const float* __restrict__ wk, long idx, int cin, int cout, int tnt) {
+  const int s4 = idx & 3, lane = (idx >> 2) & 63;
+  long r = idx >> 8;
+  const int ct = r % tnt; r /= tnt;
+  const int t = r & 3; r >>= 2;
+  const int ncc = cin >> 4;
+  const int cc = r % ncc;
+  const int g = r / ncc;
+  const int c = cc * 16 + 4 * (lane >> 4) + s4;
+  const int o = (g * tnt + ct) * 16 + (lane & 15);
+  return wk[((long)t * cin + c) * cout + o];
+}

@@ -129,6 +129,8 @@ class Model(BaseModel):
         self.flat_grads = torch.zeros_like(flat)
         self.n_params = sum(n for _, n, _ in slots)
         self._epoch = [0]
+        from ..networks.elements import PackRegistry
+        self.pack_registry = PackRegistry(lambda: (self.flat_params._version, self._epoch[0]))
         it = iter(slots)
         for c in convs:
             for name in ('kernel', 'bias'):
@@ -137,6 +139,7 @@ class Model(BaseModel):
                 setattr(c, 'd' + name, self.flat_grads[o:o + n].view(shp))
             c._epoch = self._epoch
             c._packed = {}
+            c._registry = self.pack_registry
 
     def mark_weights_updated(self):
         """Call after writing the flat bucket through a raw pointer (optimizer kernel): packed

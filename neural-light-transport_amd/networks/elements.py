@@ -53,6 +53,7 @@ class Conv2D(Layer):
         self.cin = None
         self._packed = {}
         self._epoch = [0]                       # shared "weights were rewritten" counter (optimizer bumps it)
+        self._registry = None                   # PackRegistry of the owning model (one-launch refresh of all fragments)
 
     def build(self, cin, device='cuda', seed=None):
         if not self.built:
@@ -81,30 +82,46 @@ class Conv2D(Layer):
             self.bias = bias.to(dev).contiguous()
         self.cin, self.built = cin, True
         self._packed = {}
+        if self._registry is not None:
+            self._registry.drop(self)
 
     def variables(self):
         return [self.kernel, self.bias]
 
+    def _version(self):
+        return (self.kernel.data_ptr(), self.kernel._version, self._epoch[0])
+
+    def _cached_pack(self, key, make, desc):
+        """Packed-fragment cache shared by the three layouts below.  A miss allocates + packs (`make`); a STALE entry
+        (the kernel was rewritten: optimizer step) is refreshed in place -- together with every other packed buffer of
+        the model in ONE launch when the layer belongs to a PackRegistry, by re-running `make` otherwise."""
+        ent = self._packed.get(key)
+        ver = self._version()
+        if ent is not None and ent[0] == ver:
+            return ent[1]
+        reg = self._registry
+        if ent is not None and reg is not None and reg.owns(self, key):
+            reg.refresh()
+            return self._packed[key][1]
+        buf = make()
+        self._packed[key] = (ver, buf)
+        if reg is not None:
+            reg.add(self, key, buf, desc)
+        return buf
+
     def packed(self, c0, c1):
         """MFMA fragment layout of the kernel for a (c0 | c1) input split; re-packed when the
         kernel tensor has been written (optimizer step / set_weights)."""
-        key = (c0, c1)
-        ent = self._packed.get(key)
-        ver = (self.kernel.data_ptr(), self.kernel._version, self._epoch[0])
-        if ent is None or ent[0] != ver:
-            ent = (ver, C.pack_conv_weights(self.mode, self.kernel.detach(), c0, c1, self.n_ch_out))
-            self._packed[key] = ent
-        return ent[1]
+        return self._cached_pack((c0, c1), lambda: C.pack_conv_weights(self.mode, self.kernel.detach(), c0, c1, self.n_ch_out),
+                                 dict(kind=C.REPACK_MFMA, mode=self.mode, c0=c0, c1=c1, cout=self.n_ch_out, tn=0, lo=0,
+                                      full=self.n_ch_out))
 
     def packed_tile(self, tn):
         """Fragment layout of the kernel for the LDS-tiled conv (csrc/conv_tile.hip), re-made on weight change."""
-        key = ('tile', tn)
-        ent = self._packed.get(key)
-        ver = (self.kernel.data_ptr(), self.kernel._version, self._epoch[0])
-        if ent is None or ent[0] != ver:
-            ent = (ver, C.pack_conv_tile_weights(self.mode, self.kernel.detach(), self.cin, self.n_ch_out, tn))
-            self._packed[key] = ent
-        return ent[1]
+        return self._cached_pack(('tile', tn),
+                                 lambda: C.pack_conv_tile_weights(self.mode, self.kernel.detach(), self.cin, self.n_ch_out, tn),
+                                 dict(kind=C.REPACK_TILE, mode=self.mode, c0=self.cin, c1=0, cout=self.n_ch_out, tn=tn, lo=0,
+                                      full=self.n_ch_out))
 
     ADJOINT = {C.CONV_K2S2: C.DECONV_K2S2, C.CONV_K2S1: C.DECONV_K2S1,
                C.DECONV_K2S2: C.CONV_K2S2, C.DECONV_K2S1: C.CONV_K2S1}
@@ -112,17 +129,15 @@ class Conv2D(Layer):
     def packed_adjoint(self, lo, hi):
         """Fragments for backward-DATA w.r.t. forward input channels [lo, hi): the adjoint conv
         family reads the SAME Keras array (a conv kernel (kh,kw,Cin,Cout) is the transposed
-        conv's (kh,kw,Cout',Cin') and vice versa), sliced along the forward-input axis."""
-        key = ('adj', lo, hi)
-        ent = self._packed.get(key)
-        ver = (self.kernel.data_ptr(), self.kernel._version, self._epoch[0])
-        if ent is None or ent[0] != ver:
-            k = self.kernel.detach()
-            ks = k[..., lo:hi] if self.transpose else k[:, :, lo:hi, :]
-            ks = ks.contiguous()
-            ent = (ver, C.pack_conv_weights(self.ADJOINT[self.mode], ks, self.n_ch_out, 0, hi - lo), ks)
-            self._packed[key] = ent
-        return ent[1], ent[2]
+        conv's (kh,kw,Cout',Cin') and vice versa), sliced along the forward-input axis.
+        Returns (fragments, slice view); the view is NOT contiguous -- the GPU path reads the fragments only."""
+        k = self.kernel.detach()
+        ks = k[..., lo:hi] if self.transpose else k[:, :, lo:hi, :]
+        adj = self.ADJOINT[self.mode]
+        buf = self._cached_pack(('adj', lo, hi), lambda: C.pack_conv_weights(adj, ks.contiguous(), self.n_ch_out, 0, hi - lo),
+                                dict(kind=C.REPACK_MFMA, mode=adj, c0=self.n_ch_out, c1=0, cout=hi - lo, tn=0, lo=lo,
+                                     full=self.cin))
+        return buf, ks
 
     def out_hw(self, h, w):
         if self.mode == C.CONV_K2S2:
@@ -144,6 +159,53 @@ class Conv2D(Layer):
                        self.n_ch_out, out, self.n_ch_out, act=act is not None,
                        alpha=act.alpha if act is not None else 0.0)
         return out
+
+
+class PackRegistry:
+    """Every packed-fragment buffer of a model's convs, so that ONE launch (nlt_repack_weights) refills them all after
+    an optimizer step instead of one allocation + pack launch (+ slice copy) per layer and layout."""
+
+    def __init__(self, state_fn=None):
+        self.entries = {}            # (id(layer), key) -> (layer, key, buffer, descriptor fields)
+        self.table = None
+        self.state_fn = state_fn     # () -> hashable that changes whenever any kernel of the model is rewritten
+        self.state = None
+
+    def owns(self, layer, key):
+        return (id(layer), key) in self.entries
+
+    def add(self, layer, key, buf, desc):
+        self.entries[(id(layer), key)] = (layer, key, buf, desc)
+        self.table = None
+
+    def drop(self, layer):
+        self.entries = {k: v for k, v in self.entries.items() if v[0] is not layer}
+        self.table = None
+
+    def prepare(self):
+        """Builds the device descriptor table (a host-to-device copy: must not happen inside a graph capture)."""
+        if self.table is None and self.entries:
+            ents = list(self.entries.values())
+            rows = [dict(d, src=layer.kernel, dst=buf) for layer, _, buf, d in ents]
+            self.table = C.repack_table(rows, ents[0][2].device)
+
+    def refresh(self):
+        if not self.entries:
+            return
+        self.prepare()
+        C.repack_weights(*self.table)
+        for layer, key, buf, _ in self.entries.values():
+            layer._packed[key] = (layer._version(), buf)
+        if self.state_fn is not None:
+            self.state = self.state_fn()
+
+    def refresh_if_stale(self):
+        """Called by the plan at the top of a forward pass, on the main stream, BEFORE any other stream is forked:
+        every consumer of a packed buffer (the side-stream query convs, the backward pass) is ordered after the
+        refresh.  (A lazy refresh at the first stale access could run on one stream while another stream's convs
+        were already reading their fragments.)"""
+        if self.state_fn is not None and self.entries and self.state_fn() != self.state:
+            self.refresh()
 
 
 class Act(Layer):

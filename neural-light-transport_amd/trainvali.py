@@ -83,6 +83,11 @@ class GraphedTrainStep:
                 self.static = list(batch)
                 for i in self.TENSORS:
                     self.static[i] = batch[i].clone()
+                reg = getattr(self.model, 'pack_registry', None)
+                if reg is not None:                      # the refresh of the packed weights must be IN the graph, its
+                    reg.prepare()                        # descriptor upload must not
+                    reg.state = None
+                self.model.plan._front_blob = None       # ... and so must the folded front-kernel weights
                 torch.cuda.synchronize()
                 graph = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(graph):

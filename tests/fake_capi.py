@@ -38,6 +38,14 @@ def pack_conv_weights(mode, w_keras, c0, c1, cout):
     return torch.zeros(1)
 
 
+def repack_table(entries, device):
+    return (None, len(entries), 0)
+
+
+def repack_weights(table, n_desc, total_blocks):
+    pass                                   # the emulated kernels read the Keras arrays themselves
+
+
 def stem_forward(base, cvis, lvis, nn_rgb, nn_base, obs_weights, n, k, h, w, c, wq, bq, wo, bo, fm0, obs0):
     x = torch.cat((base, cvis, lvis), -1)
     fm0[..., :c] = x @ wq[0, 0] + bq
@@ -406,7 +414,7 @@ def front2_forward(base, cvis, lvis, nn_rgb, nn_base, n, k, h, w, P, P2, add_bas
 _FUSED = _FUSED + ('front_pack_l2_weights', 'front2_forward')
 
 
-_FORWARD = ('conv_forward', 'pack_conv_weights', 'stem_forward', 'obs_mean_forward', 'head_forward', 'warp_forward',
+_FORWARD = ('conv_forward', 'pack_conv_weights', 'repack_table', 'repack_weights', 'stem_forward', 'obs_mean_forward', 'head_forward', 'warp_forward',
             'resize_bilinear_forward', 'mul_forward')
 
 
