@@ -165,10 +165,15 @@ def bench_train(args, device, world, rank, n_steps):
     opt = trainvali.make_optimizer(model, cfg)
     batch = synth_device_batch(args.frames, args.uv, args.cam, 1, device, seed=200 + rank)
     gbs = world * args.frames
+    tune_train = args.tune_cache + '.train' if args.tune_cache else None
+    if tune_train and os.path.exists(tune_train):
+        model.plan.load_tuning(tune_train)                           # the train plan's own tile choices (k = 1, keeps activations)
     step = trainvali.GraphedTrainStep(model, opt, gbs) if args.train_graph else trainvali.distributed_train_step
     run = (lambda: step(batch)) if args.train_graph else (lambda: step(model, batch, opt, gbs))
     for _ in range(4):                                               # eager warm-ups (autotune), then the graph capture
         run()
+    if tune_train and not os.path.exists(tune_train) and rank == 0:
+        model.plan.save_tuning(tune_train)
     if args.train_graph and step.static_batch() is not None:
         batch = step.static_batch()                                  # synthetic data resident in the graph's input buffers
     if args.per_op_train and rank == 0:
