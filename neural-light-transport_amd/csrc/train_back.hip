@@ -68,7 +68,10 @@ __global__ __launch_bounds__(256) void back_bwd_kernel(
     const int Y0 = 2 * ty0, X0 = 2 * tx0;
 
     // ---- phase 1
-    for (int e = threadIdx.x; e < (BFH + 1) * (BFW + 1); e += 256) {
+#pragma unroll
+    for (int it = 0; it < 3; ++it) {                                   // 17 * 33 = 561 texels, all loads of the 3 trips in flight together
+      const int e = threadIdx.x + 256 * it;
+      if (e >= (BFH + 1) * (BFW + 1)) break;
       const int ly = e / (BFW + 1), lx = e - ly * (BFW + 1);
       const int y = Y0 + ly, xg = X0 + lx;
       f32x4 d = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -140,7 +143,9 @@ __global__ __launch_bounds__(256) void back_bwd_kernel(
     // ---- phase 3a: dW_s2^T, rows n = (a, b, o), columns c, K = half-resolution texels
     {
       const int na = j >> 3, nb = (j >> 2) & 1, no = j & 3;
-      for (int gi = wave; gi < 32; gi += 4) {
+#pragma unroll
+      for (int g8 = 0; g8 < 8; ++g8) {                                 // unrolled: the 24 operand loads of a tile are issued together
+        const int gi = wave + 4 * g8;
         const int ii = gi >> 2, jj = (gi & 3) * 4 + kk;
         const int gy = ty0 + ii, gx = tx0 + jj;
         const bool inside = gy < h2 && gx < w2;
@@ -206,16 +211,26 @@ __global__ __launch_bounds__(256) void back_bwd_kernel(
 struct BackBwdOut { float *dw_s2, *db_s2, *dw_s1, *db_s1, *dw_head, *db_head; };
 
 __global__ __launch_bounds__(256) void back_bwd_reduce_kernel(const float* __restrict__ ws, int nblocks, BackBwdOut out) {
-  __shared__ float part[4][64];
-  const int o = threadIdx.x & 63, s = threadIdx.x >> 6;
-  const int idx = blockIdx.x * 64 + o;
-  float acc = 0.f;
-  if (idx < BB_TOT - 1)
-    for (int bl = s; bl < nblocks; bl += 4) acc += ws[(long)bl * BB_TOT + idx];
-  part[s][o] = acc;
+  __shared__ float part[16][17];                                       // 16 entries x 16 row groups (x 4 running sums), fixed order
+  const int e = threadIdx.x & 15, g = threadIdx.x >> 4;
+  const int idx = blockIdx.x * 16 + e;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  int bl = g;
+  if (idx < BB_TOT - 1) {
+    for (; bl + 48 < nblocks; bl += 64) {
+      s0 += ws[(long)bl * BB_TOT + idx];
+      s1 += ws[(long)(bl + 16) * BB_TOT + idx];
+      s2 += ws[(long)(bl + 32) * BB_TOT + idx];
+      s3 += ws[(long)(bl + 48) * BB_TOT + idx];
+    }
+    for (; bl < nblocks; bl += 16) s0 += ws[(long)bl * BB_TOT + idx];
+  }
+  part[g][e] = (s0 + s1) + (s2 + s3);
   __syncthreads();
-  if (s != 0 || idx >= BB_TOT - 1) return;
-  const float t = (part[0][o] + part[1][o]) + (part[2][o] + part[3][o]);
+  if (g || idx >= BB_TOT - 1) return;
+  float t = 0.f;
+#pragma unroll
+  for (int q = 0; q < 16; ++q) t += part[q][e];
   if (idx < BB_DW1) out.dw_s2[idx] += t;
   else if (idx < BB_DWH) out.dw_s1[idx - BB_DW1] += t;
   else if (idx < BB_DBH) out.dw_head[idx - BB_DWH] += t;
@@ -254,7 +269,7 @@ extern "C" int nlt_back_backward(const float* x, const float* fm1, const float* 
                      w_head, alpha, dx, dfm1, workspace);
   NLT_CHECK_LAUNCH();
   BackBwdOut out = {dw_s2, db_s2, dw_s1, db_s1, dw_head, db_head};
-  hipLaunchKernelGGL(back_bwd_reduce_kernel, dim3((BB_TOT + 63) / 64), dim3(256), 0, s, workspace, blocks, out);
+  hipLaunchKernelGGL(back_bwd_reduce_kernel, dim3((BB_TOT + 15) / 16), dim3(256), 0, s, workspace, blocks, out);
   NLT_CHECK_LAUNCH();
   return NLT_OK;
 }

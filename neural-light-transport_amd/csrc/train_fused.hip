@@ -118,17 +118,28 @@ __global__ __launch_bounds__(256) void front_bwd_kernel(
     ws[(long)blockIdx.x * T_TOT + idx] = (part[0][idx] + part[1][idx]) + (part[2][idx] + part[3][idx]);
 }
 
-// totals[idx] = sum over the nblocks partial rows, fixed order (4 strided running sums, then a tree)
+// totals[idx] = sum over the nblocks partial rows: 16 entries per workgroup, rows dealt to 16 thread groups x 4 running sums
+// (a serial walk over ~1000 rows is pure load latency), combined in a fixed order
 __global__ __launch_bounds__(256) void front_bwd_reduce_kernel(const float* __restrict__ ws, int nblocks, float* __restrict__ totals) {
-  __shared__ float part[4][64];
-  const int o = threadIdx.x & 63, s = threadIdx.x >> 6;
-  const int idx = blockIdx.x * 64 + o;
-  float acc = 0.f;
-  if (idx < T_TOT)
-    for (int bl = s; bl < nblocks; bl += 4) acc += ws[(long)bl * T_TOT + idx];
-  part[s][o] = acc;
+  __shared__ float part[16][17];
+  const int e = threadIdx.x & 15, g = threadIdx.x >> 4;
+  const int idx = blockIdx.x * 16 + e;                                 // T_TOT is a multiple of 16
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  int bl = g;
+  for (; bl + 48 < nblocks; bl += 64) {
+    s0 += ws[(long)bl * T_TOT + idx];
+    s1 += ws[(long)(bl + 16) * T_TOT + idx];
+    s2 += ws[(long)(bl + 32) * T_TOT + idx];
+    s3 += ws[(long)(bl + 48) * T_TOT + idx];
+  }
+  for (; bl < nblocks; bl += 16) s0 += ws[(long)bl * T_TOT + idx];
+  part[g][e] = (s0 + s1) + (s2 + s3);
   __syncthreads();
-  if (s == 0 && idx < T_TOT) totals[idx] = (part[0][o] + part[1][o]) + (part[2][o] + part[3][o]);
+  if (g) return;
+  float s = 0.f;
+#pragma unroll
+  for (int q = 0; q < 16; ++q) s += part[q][e];
+  totals[idx] = s;
 }
 
 struct FrontBwdW {
@@ -216,7 +227,7 @@ __global__ __launch_bounds__(256) void front_bwd_epilogue_kernel(const float* __
 
 int front_bwd_blocks(long groups) {
   long blocks = (groups + 3) / 4;
-  if (blocks > 1024) blocks = 1024;
+  if (blocks > 1536) blocks = 1536;                                    // 6 waves / SIMD resident
   return (int)blocks;
 }
 
@@ -247,7 +258,8 @@ extern "C" int nlt_front_backward(const float* base, const float* cvis, const fl
   hipLaunchKernelGGL(front_bwd_kernel, dim3(blocks), dim3(256), 0, s, base, cvis, lvis, nn_rgb, nn_base, dy1q, dy1o, dpred,
                      k, h, w, groups, workspace);
   NLT_CHECK_LAUNCH();
-  hipLaunchKernelGGL(front_bwd_reduce_kernel, dim3((T_TOT + 63) / 64), dim3(256), 0, s, workspace, blocks, totals);
+  static_assert(T_TOT % 16 == 0, "reduce kernel: 16 entries per workgroup");
+  hipLaunchKernelGGL(front_bwd_reduce_kernel, dim3(T_TOT / 16), dim3(256), 0, s, workspace, blocks, totals);
   NLT_CHECK_LAUNCH();
   FrontBwdW fw = {wq0, bq0, wo0, bo0, wqa, woa, wh, dwq0, dbq0, dwo0, dbo0, dwqa, dbqa, dwoa, dboa, dwh};
   hipLaunchKernelGGL(front_bwd_epilogue_kernel, dim3(1), dim3(256), 0, s, totals, fw);
