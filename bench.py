@@ -342,7 +342,8 @@ def main():
                                    % (args.depth, args.frames, args.uv, args.k, args.cam),
                        "frames_per_gpu": args.frames, "uv": args.uv, "k": args.k, "cam": args.cam,
                        "conv_algo": args.algo, "plan": "layer-by-layer" if args.no_fused else "fused ends",
-                       "launch": "hipGraph replay" if args.graph else "eager, two HIP streams", "parallelism": "dp%d (frames sharded, no forward collective)" % world},
+                       "launch": "hipGraph replay" if args.graph else "eager, two HIP streams",
+                       "launch_tape_replays": int(model.plan.tape_replays), "parallelism": "dp%d (frames sharded, no forward collective)" % world},
             "roofline": roof,
             "roofline_whole_pass": {"algorithmic_bytes_per_texel": bpt,
                                     "achieved": round(value / world * 1e6 * bpt / 1e9, 1), "unit": "GB/s per GPU",

@@ -94,13 +94,13 @@ SIGNATURES = {
     'nlt_assemble_batch': (_c_int, [_vp] * 6 + [_c_int, _c_int, _c_long, _c_int] + [_vp] * 6 + [_vp]),
 }
 
-_lib = None
+_real = None
 
 
-def lib():
+def _load():
     """Loads libnlt_hip.so once; raises (loudly) when it has not been built."""
-    global _lib
-    if _lib is None:
+    global _real
+    if _real is None:
         if not os.path.exists(LIB_PATH):
             raise RuntimeError(
                 "libnlt_hip.so not found at %s -- build it with `python __graft_entry__.py` or "
@@ -109,8 +109,97 @@ def lib():
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(L, name)
             fn.restype, fn.argtypes = res, args
-        _lib = L
-    return _lib
+        _real = L
+    return _real
+
+
+# ---------------------------------------------------------------- launch tape
+# A plan (engine.RenderPlan) issues the same ~40 (forward) / ~130 (backward) C calls with the same arguments every
+# step: same buffers, same weights, same streams.  Deriving those arguments again in Python (tensor -> pointer, layout
+# checks, fragment-cache lookups, .detach() views) costs ~15-20 us per launch -- as much wall time as the GPU needs for
+# the whole step at the training shape.  While a tape is open every launching C call is ALSO appended to it as
+# (function, resolved arguments); a later step with the same inputs replays the list with nothing but the ctypes
+# calls.  (hipGraph replay of the same sequence measured slower than eager launches on ROCm 7.0; see DESIGN.md.)
+_tape = None
+_tape_epoch = [0]
+_alloc_epoch = [0]          # bumped whenever a cached device buffer the C calls point into is re-allocated
+
+
+class _TapeLib:
+    """Stand-in for the CDLL while a tape is open: launching entry points (int status) are recorded after they ran."""
+
+    def __init__(self, real):
+        self._real = real
+
+    def __getattr__(self, name):
+        fn = getattr(self._real, name)
+        if SIGNATURES[name][0] is not _c_int:
+            return fn                                   # size queries etc.: pure, not part of the step
+
+        def recorded(*args):
+            rc = fn(*args)
+            if _tape is not None and rc == 0:
+                _tape.append((fn, args))
+            return rc
+        setattr(self, name, recorded)
+        return recorded
+
+
+_tape_lib = None
+
+
+def lib():
+    global _tape_lib
+    if _tape is None:
+        return _real if _real is not None else _load()
+    if _tape_lib is None:
+        _tape_lib = _TapeLib(_load())
+    return _tape_lib
+
+
+def tape_begin():
+    global _tape
+    if _tape is not None:
+        raise NLTError("a launch tape is already open")
+    _tape = []
+    _tape_epoch[0] = _alloc_epoch[0]
+
+
+def tape_end(tag=None):
+    """Closes the tape and returns (launch list, allocation epoch it is valid for, caller's validity tag)."""
+    global _tape
+    t, _tape = _tape, None
+    if _tape_epoch[0] != _alloc_epoch[0]:
+        return None                                     # a cached buffer was re-allocated while recording: pointers are stale
+    return t, _alloc_epoch[0], tag
+
+
+def tape_abort():
+    global _tape
+    _tape = None
+
+
+def tape_valid(tape, tag=None):
+    return tape is not None and tape[1] == _alloc_epoch[0] and tape[2] == tag
+
+
+def replay(tape):
+    for fn, args in tape[0]:
+        rc = fn(*args)
+        if rc:                                          # event helpers return None
+            raise NLTError("replayed launch failed: %s" % lib().nlt_status_string(rc).decode())
+
+
+def record_event(ev, stream):
+    ev.record(stream)
+    if _tape is not None:
+        _tape.append((ev.record, (stream,)))
+
+
+def wait_event(stream, ev):
+    stream.wait_event(ev)
+    if _tape is not None:
+        _tape.append((stream.wait_event, (ev,)))
 
 
 class NLTError(RuntimeError):
@@ -228,6 +317,7 @@ def _workspace(name, device, need):
     if ws is None or ws.numel() < need:
         ws = torch.empty(need, device=device, dtype=torch.float32)
         _named_ws[key] = ws
+        _alloc_epoch[0] += 1                         # recorded launch tapes point into the old buffer
     return ws
 
 
@@ -241,6 +331,7 @@ def conv_backward_weights_tiled(mode, src0, c0, ld0, src1, c1, ld1, n, h, w, dpr
     if ws is None or ws.numel() < need:
         ws = torch.empty(need, device=src0.device, dtype=torch.float32)
         _wgrad_ws[key] = ws
+        _alloc_epoch[0] += 1
     _check(lib().nlt_conv_backward_weights_tiled(mode, _ptr(src0), ld0, c0, _ptr(src1), ld1, c1, n, h, w, _ptr(dpre), ldp,
                                                  cout, _ptr(dw), _ptr(db), _ptr(ws), ws.numel(), _stream()),
            'nlt_conv_backward_weights_tiled')
@@ -353,6 +444,7 @@ def conv_forward_splitk(mode, ksplit, src0, c0, ld0, src1, c1, ld1, n, h, w, w_p
     if ws is None or ws.numel() < need:
         ws = torch.empty(need, device=src0.device, dtype=torch.float32)
         _splitk_ws[key] = ws
+        _alloc_epoch[0] += 1
     _check(lib().nlt_conv_forward_splitk(mode, tile_hint, ksplit, _ptr(ws), _ptr(src0), ld0, c0, _ptr(src1), ld1, c1, n, h, w,
                                          _ptr(w_packed), _ptr(bias), cout, _ptr(out), ldo, 1 if act else 0, float(alpha),
                                          _ptr(mask_src), ldm, 1 if accumulate else 0, _stream()), 'nlt_conv_forward_splitk')
@@ -427,8 +519,10 @@ def chmix_bf16_forward(x, packed, bias, cout, act=True, alpha=0.3):
 
 
 # ---------------------------------------------------------------- fused inference ends
-def front_pack_weights(wq0, bq0, wo0, bo0, wqa, bqa, wqb, bqb, woa, boa, wob, bob, wh, bh):
-    out = torch.empty(lib().nlt_front_packed_floats(), device=wq0.device, dtype=torch.float32)
+def front_pack_weights(wq0, bq0, wo0, bo0, wqa, bqa, wqb, bqb, woa, boa, wob, bob, wh, bh, out=None):
+    """out: a blob from an earlier call to refill in place (keeps its address: launch tapes, hipGraphs)."""
+    if out is None:
+        out = torch.empty(lib().nlt_front_packed_floats(), device=wq0.device, dtype=torch.float32)
     args = [_ptr(_dense(t, 'weight')) for t in (wq0, bq0, wo0, bo0, wqa, bqa, wqb, bqb, woa, boa, wob, bob, wh, bh)]
     _check(lib().nlt_front_pack_weights(*args, _ptr(out), _stream()), 'nlt_front_pack_weights')
     return out
@@ -442,8 +536,9 @@ def front_forward(base, cvis, lvis, nn_rgb, nn_base, n, k, h, w, packed, add_bas
                                    _stream()), 'nlt_front_forward')
 
 
-def front_pack_l2_weights(wq, bq, wo, bo):
-    out = torch.empty(lib().nlt_front_l2_packed_floats(), device=wq.device, dtype=torch.float32)
+def front_pack_l2_weights(wq, bq, wo, bo, out=None):
+    if out is None:
+        out = torch.empty(lib().nlt_front_l2_packed_floats(), device=wq.device, dtype=torch.float32)
     _check(lib().nlt_front_pack_l2_weights(_ptr(_dense(wq, 'wq')), _ptr(bq), _ptr(_dense(wo, 'wo')), _ptr(bo), _ptr(out),
                                            _stream()), 'nlt_front_pack_l2_weights')
     return out

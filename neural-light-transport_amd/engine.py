@@ -65,6 +65,10 @@ class RenderPlan:
         self.wgrad_narrow = os.environ.get('NLT_WGRAD_NARROW', '1') != '0'
         # weight gradients on a side stream, off the backward-data chain (config 4: 5.17 -> 4.63 ms / step)
         self.bwd_streams = os.environ.get('NLT_BWD_STREAMS', '1') != '0'
+        # launch tape: replay a step's C calls with their resolved arguments instead of re-deriving them (see _capi.py)
+        self.use_tape = os.environ.get('NLT_TAPE', '1') != '0'
+        self._tuning = False
+        self.tape_replays = 0
         self._trial_direct = False
         self._ran_direct = set()
         self._trial_lds = 0             # autotune: try the LDS-tiled kernel with this many output channels per workgroup
@@ -201,6 +205,7 @@ class RenderPlan:
         bound); a few 4/8-channel layers are faster on the direct kernel.  Times every candidate
         with HIP events on this shape and keeps the fastest."""
         saved = (self.timer, dict(self.tile_hints), dict(self.algo_hints))
+        self._tuning = True                 # no launch tapes while trial plans run
         results = {}
         trials = [('tile', 16 * r + c) for r in (1, 2, 4) for c in (1, 2, 4)]
         if not self.fuse_ends:
@@ -245,6 +250,12 @@ class RenderPlan:
             else:
                 self.tile_hints.setdefault(label, hint)
         self.tuned = results
+        self._tuning = False
+        self._drop_tapes()
+
+    def _drop_tapes(self):
+        for b in self._bufs.values():
+            b.pop('tapes', None)
 
     def save_tuning(self, path):
         import json
@@ -261,6 +272,7 @@ class RenderPlan:
         self.lds_hints.update(d.get('lds_hints', {}))
         self.splitk_hints.update(d.get('splitk_hints', {}))
         self.autotune = False
+        self._drop_tapes()
 
     # ------------------------------------------------------------------ forward
     def can_fuse(self, b, obs_weights, obs_override):
@@ -294,11 +306,12 @@ class RenderPlan:
         ver += tuple((c.kernel.data_ptr(), c.kernel._version, c.bias._version, c._epoch[0]) for c in (qa2, oa2))
         if self._front_blob is None or self._front_blob[0] != ver:
             w = lambda c: (c.kernel.detach(), c.bias.detach())
-            blob = C.front_pack_weights(*w(q0), *w(o0), *w(qa), *w(qb), *w(oa), *w(ob), *w(head))
+            old = self._front_blob                          # refilled in place: launch tapes / graphs keep the addresses
+            blob = C.front_pack_weights(*w(q0), *w(o0), *w(qa), *w(qb), *w(oa), *w(ob), *w(head), out=old[1] if old else None)
             blob_l2 = None
             if qa2.n_ch_out == 32 and oa2.n_ch_out == 32 and qa2.cin == 32 and oa2.cin == 16:
-                blob_l2 = C.front_pack_l2_weights(*w(qa2), *w(oa2))
-            self._front_blob = (ver, blob, blob_l2)
+                blob_l2 = C.front_pack_l2_weights(*w(qa2), *w(oa2), out=old[2] if old else None)
+            self._front_blob = [ver, blob, blob_l2]
         return self._front_blob[1], self._front_blob[2]
 
     def forward(self, base, cvis, lvis, nn_rgb, nn_base, obs_weights=None, obs_override=None,
@@ -323,6 +336,41 @@ class RenderPlan:
             b[tuned_key] = True
             self._autotune(lambda: self.forward(base, cvis, lvis, nn_rgb, nn_base, obs_weights, obs_override,
                                                 skip_connect_base, algo, inference))
+        # launch tape (second sight of the same inputs records, later sights replay)
+        if fused:
+            self._front_weights(dev)        # folded front-kernel weights, refreshed in place OUTSIDE any tape
+        tkey = None
+        if (self.use_tape and base.is_cuda and self.timer is None and not self._tuning and reg is not None
+                and obs_weights is None and obs_override is None):
+            tkey = ('fwd', base.data_ptr(), cvis.data_ptr(), lvis.data_ptr(), nn_rgb.data_ptr(), nn_base.data_ptr(),
+                    bool(skip_connect_base), algo, inference, fused, C._stream())
+            tapes = b.setdefault('tapes', {})
+            ent = tapes.get(tkey, 0)
+            if isinstance(ent, tuple):
+                if C.tape_valid(ent, reg.version):
+                    C.replay(ent)
+                    self.tape_replays += 1
+                    return b['pred'], b
+                ent = 1
+            tapes[tkey] = 1
+            if ent == 1:
+                C.tape_begin()
+                try:
+                    out = self._forward_body(b, base, cvis, lvis, nn_rgb, nn_base, obs_weights, obs_override, skip_connect_base,
+                                             algo, fused, inference)
+                except BaseException:
+                    C.tape_abort()
+                    raise
+                tapes[tkey] = C.tape_end(reg.version) or 1  # (None: a workspace grew while recording -> record again)
+                return out
+        return self._forward_body(b, base, cvis, lvis, nn_rgb, nn_base, obs_weights, obs_override, skip_connect_base, algo,
+                                  fused, inference)
+
+    def _forward_body(self, b, base, cvis, lvis, nn_rgb, nn_base, obs_weights, obs_override, skip_connect_base, algo, fused,
+                      inference):
+        n, h, w, _ = base.shape
+        k = nn_rgb.shape[1]
+        dev = base.device
         q, o, D, cl = self.q, self.o, self.n_down, b['C']
         mult = 2 if self.use_obs else 1
         run_obs = self.use_obs and obs_override is None
@@ -428,8 +476,8 @@ class RenderPlan:
                 self._side = (torch.cuda.Stream(device=base.device), [torch.cuda.Event() for _ in range(D + 3)])
             side, ev = self._side
             main = torch.cuda.current_stream()
-            ev[0].record(main)                                      # front kernel done: fm[1], obs[1]
-            side.wait_event(ev[0])
+            C.record_event(ev[0], main)                             # front kernel done: fm[1], obs[1]
+            C.wait_event(side, ev[0])
         hh, ww = h // 2, w // 2
         for l in range(2, D + 1):
             (qa, qact_a), (qb, qact_b) = q.layers[l].convs()
@@ -441,10 +489,10 @@ class RenderPlan:
             self._conv_enc('L%d.o.s1' % l, ob, oact_b, b['otmp'][l], cl[l], cl[l], n, k, hh // 2, ww // 2, b['obs'][l], cl[l], algo,
                            mean_out=b['fm'][l].view(-1)[cl[l]:], ldm=2 * cl[l])
             if concurrent:
-                ev[l].record(main)                                  # fm[l]'s observation half is complete
+                C.record_event(ev[l], main)                         # fm[l]'s observation half is complete
                 with torch.cuda.stream(side):
                     if l > 2:
-                        side.wait_event(ev[l - 1])
+                        C.wait_event(side, ev[l - 1])
                     if not s2_done:
                         self._conv_enc('L%d.q.s2' % l, qa, qact_a, b['fm'][l - 1], cin, cin, n, 1, hh, ww, b['qtmp'][l], cl[l], algo)
                     self._conv_enc('L%d.q.s1' % l, qb, qact_b, b['qtmp'][l], cl[l], cl[l], n, 1, hh // 2, ww // 2, b['fm'][l],
@@ -456,8 +504,8 @@ class RenderPlan:
                                2 * cl[l], algo)
             hh, ww = hh // 2, ww // 2
         if concurrent:
-            ev[D + 1].record(side)
-            main.wait_event(ev[D + 1])                              # the decoder needs both halves of every fm[l]
+            C.record_event(ev[D + 1], side)
+            C.wait_event(main, ev[D + 1])                              # the decoder needs both halves of every fm[l]
         x, cx = b['fm'][D], 2 * cl[D]
         for j in range(U - 1):
             (da, dact_a), (db, dact_b) = q.layers[D + 1 + j].convs()
@@ -504,9 +552,9 @@ class RenderPlan:
                 events.append(torch.cuda.Event())
             ev = events[cur[0]]
             cur[0] += 1
-            ev.record(torch.cuda.current_stream())
+            C.record_event(ev, torch.cuda.current_stream())
             with torch.cuda.stream(side):
-                side.wait_event(ev)
+                C.wait_event(side, ev)
                 self._wgrad_now(label, layer, src0, c0, ld0, src1, c1, ld1, n, h, w, dpre, ldp)
             return
         self._wgrad_now(label, layer, src0, c0, ld0, src1, c1, ld1, n, h, w, dpre, ldp)
@@ -551,6 +599,32 @@ class RenderPlan:
         g = self._grad_buffers(b)
         q, o, D, U, cl = self.q, self.o, self.n_down, self.n_up, b['C']
         zb = g['zero_bias']
+        reg = getattr(self.q.layers[0], '_registry', None)
+        tkey = None
+        if self.use_tape and dpred.is_cuda and self.timer is None and reg is not None and obs_weights is None:
+            tkey = ('bwd', dpred.data_ptr(), base.data_ptr(), cvis.data_ptr(), lvis.data_ptr(), nn_rgb.data_ptr(),
+                    nn_base.data_ptr(), bool(b.get('train_fused')), self.bwd_streams, C._stream())
+            tapes = b.setdefault('tapes', {})
+            ent = tapes.get(tkey, 0)
+            if isinstance(ent, tuple):
+                if C.tape_valid(ent, reg.version):
+                    C.replay(ent)
+                    self.tape_replays += 1
+                    return
+                ent = 1
+            tapes[tkey] = 1
+            if ent == 1:
+                C.tape_begin()
+        try:
+            self._backward_streams(dpred, base, cvis, lvis, nn_rgb, nn_base, obs_weights, b, g, n, h, w, k)
+        except BaseException:
+            if tkey is not None and ent == 1:
+                C.tape_abort()
+            raise
+        if tkey is not None and ent == 1:
+            b['tapes'][tkey] = C.tape_end(reg.version) or 1
+
+    def _backward_streams(self, dpred, base, cvis, lvis, nn_rgb, nn_base, obs_weights, b, g, n, h, w, k):
         concurrent = self.bwd_streams and dpred.is_cuda and self.timer is None
         if concurrent:
             if self._bside is None:
@@ -564,8 +638,8 @@ class RenderPlan:
                 self._bside[2] = None
                 if cur[0] == len(events):
                     events.append(torch.cuda.Event())
-                events[cur[0]].record(side)
-                torch.cuda.current_stream().wait_event(events[cur[0]])   # the optimizer step needs every gradient
+                C.record_event(events[cur[0]], side)
+                C.wait_event(torch.cuda.current_stream(), events[cur[0]])   # the optimizer step needs every gradient
 
     def _backward_plan(self, dpred, base, cvis, lvis, nn_rgb, nn_base, obs_weights, b, g, n, h, w, k):
         q, o, D, U, cl = self.q, self.o, self.n_down, self.n_up, b['C']

@@ -185,7 +185,9 @@ class Model(BaseModel):
             d_pred_c = d_pred_c.contiguous()
             if (hc, wc) != (self.imh, self.imw):
                 d_pred_c = C.resize_bilinear_backward(d_pred_c, hc, wc)
-            dpred = torch.empty((n, self.uvh, self.uvw, 3), device=base.device, dtype=torch.float32)
+            dpred = getattr(self, '_dpred', None)            # persistent: the backward plan's launch tape points at it
+            if dpred is None or dpred.shape[0] != n or dpred.device != base.device:
+                dpred = self._dpred = torch.empty((n, self.uvh, self.uvw, 3), device=base.device, dtype=torch.float32)
             C.warp_backward(d_pred_c, warp, n, self.uvh, self.uvw, hc, wc, dpred)
             self.plan.backward(dpred, base, cvis, lvis, nn_rgb, nn_base, obs_weights)
 

@@ -170,6 +170,7 @@ class PackRegistry:
         self.table = None
         self.state_fn = state_fn     # () -> hashable that changes whenever any kernel of the model is rewritten
         self.state = None
+        self.version = 0             # bumped when the SET of buffers changes (recorded launch tapes point at them)
 
     def owns(self, layer, key):
         return (id(layer), key) in self.entries
@@ -177,10 +178,12 @@ class PackRegistry:
     def add(self, layer, key, buf, desc):
         self.entries[(id(layer), key)] = (layer, key, buf, desc)
         self.table = None
+        self.version += 1
 
     def drop(self, layer):
         self.entries = {k: v for k, v in self.entries.items() if v[0] is not layer}
         self.table = None
+        self.version += 1
 
     def prepare(self):
         """Builds the device descriptor table (a host-to-device copy: must not happen inside a graph capture)."""

@@ -87,7 +87,8 @@ class GraphedTrainStep:
                 if reg is not None:                      # the refresh of the packed weights must be IN the graph, its
                     reg.prepare()                        # descriptor upload must not
                     reg.state = None
-                self.model.plan._front_blob = None       # ... and so must the folded front-kernel weights
+                if self.model.plan._front_blob is not None:
+                    self.model.plan._front_blob[0] = None    # ... and so must the folded front-kernel weights
                 torch.cuda.synchronize()
                 graph = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(graph):

@@ -271,7 +271,7 @@ _BUFFERS = ('cosine_map', 'albedo', 'diffuse_base', 'remap_bilinear', 'uv_index_
 
 
 # ------------------------------------------------------------------ fused inference ends (TEST-ONLY emulation)
-def front_pack_weights(wq0, bq0, wo0, bo0, wqa, bqa, wqb, bqb, woa, boa, wob, bob, wh, bh):
+def front_pack_weights(wq0, bq0, wo0, bo0, wqa, bqa, wqb, bqb, woa, boa, wob, bob, wh, bh, out=None):
     return dict(wq0=wq0, bq0=bq0, wo0=wo0, bo0=bo0, wqa=wqa, bqa=bqa, wqb=wqb, bqb=bqb, woa=woa, boa=boa,
                 wob=wob, bob=bob, wh=wh, bh=bh)
 
@@ -399,7 +399,7 @@ def conv_backward_weights_narrow(mode, src0, c0, ld0, src1, c1, ld1, n, h, w, dp
     conv_backward_weights(mode, src0, c0, ld0, src1, c1, ld1, n, h, w, dpre, ldp, cout, dw, db)
 
 
-def front_pack_l2_weights(wq, bq, wo, bo):
+def front_pack_l2_weights(wq, bq, wo, bo, out=None):
     return dict(wq=wq, bq=bq, wo=wo, bo=bo)
 
 

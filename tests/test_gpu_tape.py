@@ -1,0 +1,61 @@
+"""-m gpu: the launch tape (nlt_amd/_capi.py, engine.RenderPlan): replaying a step's recorded C calls gives the same
+results as issuing them through the Python adapters, follows in-place weight updates, and is dropped when it must be."""
+import numpy as np
+import pytest
+import torch
+
+import nlt_amd
+from nlt_amd import trainvali
+from oracle import nlt_oracle as O
+from gpu_util import make_pair, to_device_batch
+
+pytestmark = pytest.mark.gpu
+
+
+def _model(tape, seed=5, loss='l2'):
+    _, pm = make_pair(depth=256, uv=64, im=32, loss=loss, seed=seed)
+    pm.build('cuda')                       # (make_pair already registered the trainables; build() flattens them)
+    pm.plan.use_tape = tape
+    return pm
+
+
+def test_forward_replays_match_adapter_launches_and_follow_weight_updates():
+    batch = to_device_batch(*O.synth_batch(2, 64, 64, 32, 32, 32, 32, k=3, seed=70))
+    a, b = _model(True), _model(False)
+    outs = [[m.call(batch, 'test')[0].clone() for _ in range(4)] for m in (a, b)]
+    assert a.plan.tape_replays >= 2 and b.plan.tape_replays == 0      # sights 3 and 4 are replays
+    for x in outs[0][1:]:
+        assert torch.equal(x, outs[0][0])                              # a replay = the same launches, bit for bit
+    close = lambda x, y: float((x - y).norm() / y.norm()) < 1e-5        # (the two models autotune separately: other tiles,
+    assert close(outs[0][0], outs[1][0])                               #  other split-K factors -> fp32 re-association only)
+    # model b's plan-time autotune grew the shared split-K workspace: every tape recorded before that is invalid and the
+    # next sight re-records instead of replaying a dangling pointer
+    r = a.plan.tape_replays
+    a.call(batch, 'test')
+    assert a.plan.tape_replays in (r, r + 1)
+    a.call(batch, 'test')
+    with torch.no_grad():                                              # an optimizer-style in-place update of the flat bucket
+        for m in (a, b):
+            m.flat_params.mul_(1.01)
+            m.mark_weights_updated()
+    before = a.plan.tape_replays
+    x, y = a.call(batch, 'test')[0], b.call(batch, 'test')[0]
+    assert a.plan.tape_replays == before + 1                          # same tape, refreshed weights
+    assert close(x, y) and not close(x, outs[0][0])
+    other = to_device_batch(*O.synth_batch(2, 64, 64, 32, 32, 32, 32, k=3, seed=71))     # new tensors: no replay of the old tape
+    assert close(a.call(other, 'test')[0], b.call(other, 'test')[0])
+    assert a.plan.tape_replays == before + 1
+
+
+def test_train_steps_with_and_without_the_tape_agree():
+    batch = to_device_batch(*O.synth_batch(2, 64, 64, 32, 32, 32, 32, k=2, seed=72))
+    res = []
+    for tape in (True, False):
+        pm = _model(tape, seed=6, loss='barron')
+        opt = nlt_amd.optim.AdamAMSGrad(pm, 1e-3)
+        losses = [float(trainvali.distributed_train_step(pm, batch, opt, 2)[0]) for _ in range(6)]
+        res.append((losses, pm.flat_params.detach().clone(), pm.plan.tape_replays))
+    (l0, p0, r0), (l1, p1, r1) = res
+    assert r0 >= 6 and r1 == 0                                         # forward + backward tapes from step 3 on
+    np.testing.assert_allclose(l0, l1, rtol=2e-5)
+    assert float((p0 - p1).abs().max()) < 2e-5                        # float atomics in the warp scatter: not bit-exact
