@@ -345,6 +345,8 @@ class RenderPlan:
             tkey = ('fwd', base.data_ptr(), cvis.data_ptr(), lvis.data_ptr(), nn_rgb.data_ptr(), nn_base.data_ptr(),
                     bool(skip_connect_base), algo, inference, fused, C._stream())
             tapes = b.setdefault('tapes', {})
+            if len(tapes) > 16:                     # ever-changing input addresses (a loader that allocates per step): forget
+                tapes.clear()
             ent = tapes.get(tkey, 0)
             if isinstance(ent, tuple):
                 if C.tape_valid(ent, reg.version):
@@ -605,6 +607,8 @@ class RenderPlan:
             tkey = ('bwd', dpred.data_ptr(), base.data_ptr(), cvis.data_ptr(), lvis.data_ptr(), nn_rgb.data_ptr(),
                     nn_base.data_ptr(), bool(b.get('train_fused')), self.bwd_streams, C._stream())
             tapes = b.setdefault('tapes', {})
+            if len(tapes) > 16:                     # ever-changing input addresses (a loader that allocates per step): forget
+                tapes.clear()
             ent = tapes.get(tkey, 0)
             if isinstance(ent, tuple):
                 if C.tape_valid(ent, reg.version):
