@@ -459,7 +459,8 @@ int nlt_front_backward(const float* base, const float* cvis, const float* lvis, 
  *             rows), nlt_lrelu_backward, 2x nlt_conv_backward_weights and 3x backward-data nlt_conv_forward.
  * x [n,h2,w2,8], fm1 [n,h2,w2,32] (the block's two inputs), u / v [n,2h2,2w2,4] (its two LeakyReLU outputs), dpred
  * [n,2h2,2w2,3] (texel (0,0) ignored).  Keras weights w_s2 (2,2,4,40), w_s1 (2,2,4,4), w_head (1,1,36,3) (rows 0..3 used).
- * Writes dx [n,h2,w2,8] and dfm1 [n,h2,w2,32] (gradients w.r.t. the two inputs; dx is w.r.t. the POST-activation x).
+ * Writes dx [n,h2,w2,8] and dfm1 [n,h2,w2,32]: gradients w.r.t. the two inputs; x is the previous block's LeakyReLU(alpha)
+ * output and dx is handed back w.r.t. that block's PRE-activation (times 1 or alpha by the sign of x); dfm1 is plain.
  * ACCUMULATES (+=) dw_s2, db_s2, dw_s1, db_s1, rows 0..3 of dw_head, db_head.
  * workspace: nlt_back_backward_workspace_floats(n, h2, w2) floats.
  */

@@ -8,7 +8,7 @@
 //   phase 2 (VALU)  du = lrelu'(u) . sum_{a,b} W_s1[a,b]^T dv(y + a, x + b) -> LDS; sums for dW_s1 (u at (y - a, x - b)), db_s2
 //   phase 3 (MFMA)  dW_s2^T[(a,b,o), c] += sum_texels du[2i+a,2j+b,o] in[i,j,c]   (K = 4 half-resolution texels per step)
 //                   d_in[i,j,c] = sum_{a,b,o} W_s2[a,b,o,c] du[2i+a,2j+b,o]         (permuted K: lane group = tap, one
-//                   16-byte LDS read feeds the four k-steps) -> dx (8 channels) | dfm1 (32 channels)
+//                   16-byte LDS read feeds the four k-steps) -> dx (8 channels, times lrelu'(x)) | dfm1 (32 channels)
 // Replaces, of the unfused backward plan (engine.py): bwd.head, bwd.L12.q.s1.{act,wgrad,dgrad} and
 // bwd.L12.q.s2.{wgrad,dgrad.x,dgrad.skip}: seven launches over 4-channel full-resolution tensors (the weight-gradient
 // kernel alone took 0.43 ms on the 4 -> 4 layer at 4 x 1024^2).  Deterministic: per-workgroup partial sums, then a
@@ -176,8 +176,14 @@ __global__ __launch_bounds__(256) void back_bwd_kernel(
         for (int ks = 0; ks < 4; ++ks) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[mt][ks], bvec[ks], acc, 0, 0, 0);
         const int c0 = 16 * mt + 4 * kk;
         if (inside) {
-          if (c0 < 8) *reinterpret_cast<f32x4*>(dx + tex2 * 8 + c0) = acc;
-          else if (c0 < 40) *reinterpret_cast<f32x4*>(dfm1 + tex2 * 32 + c0 - 8) = acc;
+          if (c0 < 8) {                                                // x is the previous block's LeakyReLU output: hand back the
+            const f32x4 xv = *reinterpret_cast<const f32x4*>(x + tex2 * 8 + c0);   // gradient w.r.t. its PRE-activation
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[e] = xv[e] > 0.f ? acc[e] : alpha * acc[e];
+            *reinterpret_cast<f32x4*>(dx + tex2 * 8 + c0) = acc;
+          } else if (c0 < 40) {
+            *reinterpret_cast<f32x4*>(dfm1 + tex2 * 32 + c0 - 8) = acc;
+          }
         }
       }
     }

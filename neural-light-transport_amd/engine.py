@@ -670,13 +670,15 @@ class RenderPlan:
         hh, ww = h, w
         if fused:
             hh, ww = h // 2, w // 2
+        masked = fused      # g['dec'][j] already holds the gradient w.r.t. the PRE-activation (mask fused into its producer)
         for j in range(U - 2 if fused else U - 1, -1, -1):
             (da, act_a), (db, act_b) = q.layers[D + 1 + j].convs()
             nl = db.n_ch_out
             lab = 'bwd.L%d.q' % (D + 1 + j)
             # s1:  dec[j] = act(deconv_s1(dtmp[j]))
-            self._launch(lab + '.s1.act', 12 * n * hh * ww * nl, C.lrelu_backward, g['dec'][j], nl, b['dec'][j], nl, nl,
-                         n * hh * ww, act_b.alpha, g['dec'][j], nl)
+            if not masked:
+                self._launch(lab + '.s1.act', 12 * n * hh * ww * nl, C.lrelu_backward, g['dec'][j], nl, b['dec'][j], nl, nl,
+                             n * hh * ww, act_b.alpha, g['dec'][j], nl)
             self._wgrad(lab + '.s1.wgrad', db, b['dtmp'][j], nl, nl, None, 0, 0, n, hh, ww, g['dec'][j], nl)
             self._dgrad(lab + '.s1.dgrad', db, 0, nl, g['dec'][j], nl, n, hh, ww, g['dtmp'][j], nl,
                         mask_src=b['dtmp'][j], ldm=nl, mask_alpha=act_a.alpha, zero_bias=zb)
@@ -689,7 +691,14 @@ class RenderPlan:
                 dx = g['fm'][D]
             skip, csj, dskip = b['fm'][D - j], 2 * cl[D - j], g['fm'][D - j]
             self._wgrad(lab + '.s2.wgrad', da, x, cxj, cxj, skip, csj, csj, n, hh // 2, ww // 2, g['dtmp'][j], nl)
-            self._dgrad(lab + '.s2.dgrad.x', da, 0, cxj, g['dtmp'][j], nl, n, hh, ww, dx, cxj, zero_bias=zb)
+            if j > 0:
+                # dx = gradient w.r.t. dec[j-1], whose own LeakyReLU derivative is applied in this launch's epilogue
+                prev_act = q.layers[D + j].convs()[1][1]
+                self._dgrad(lab + '.s2.dgrad.x', da, 0, cxj, g['dtmp'][j], nl, n, hh, ww, dx, cxj, mask_src=x, ldm=cxj,
+                            mask_alpha=prev_act.alpha, zero_bias=zb)
+                masked = True
+            else:
+                self._dgrad(lab + '.s2.dgrad.x', da, 0, cxj, g['dtmp'][j], nl, n, hh, ww, dx, cxj, zero_bias=zb)
             self._dgrad(lab + '.s2.dgrad.skip', da, cxj, cxj + csj, g['dtmp'][j], nl, n, hh, ww, dskip, csj,
                         accumulate=(j == 0), zero_bias=zb)
             hh, ww = hh // 2, ww // 2

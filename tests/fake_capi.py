@@ -354,7 +354,7 @@ def back_backward(x, fm1, u, v, dpred, n, h2, w2, w_s2, w_s1, w_head, alpha, dx,
         vv = v.detach() + (zv - zv.detach())
         s = ((vv @ wh[0, 0, :4]) * g).sum()
         gr = torch.autograd.grad(s, (xin, ws2, b2, ws1, b1, wh))
-    dx.copy_(gr[0][..., :8]); dfm1.copy_(gr[0][..., 8:])
+    dx.copy_(gr[0][..., :8] * slope(x)); dfm1.copy_(gr[0][..., 8:])          # dx: w.r.t. the producer's pre-activation
     dw_s2 += gr[1]; db_s2 += gr[2]; dw_s1 += gr[3]; db_s1 += gr[4]; dw_head += gr[5]
     db_head += g.reshape(-1, 3).sum(0)
 
