@@ -102,23 +102,27 @@ def init_weights(layers, in_channels, rng, bias_range=0.1, contracting_only=None
     return ws
 
 
-def apply_layer(L, w, x):
-    """One entry of Network.layers (convnet.py:44,50-59,67-76,85)."""
+ACT_ALPHA = {'leakyrelu': T.LRELU_ALPHA, 'relu': 0.0}     # elements.py:69-73: LeakyReLU(alpha=0.3) / ReLU(negative_slope=0)
+
+
+def apply_layer(L, w, x, alpha=T.LRELU_ALPHA):
+    """One entry of Network.layers (convnet.py:44,50-59,67-76,85); alpha = negative slope of the block's activation."""
     if L['kind'] == 'conv1x1':
         return T.conv2d_same(x, w[0][0], w[0][1], 1)
     if L['kind'] == 'down':
-        y = T.leaky_relu(T.conv2d_same(x, w[0][0], w[0][1], L['s']))
-        return T.leaky_relu(T.conv2d_same(y, w[1][0], w[1][1], 1))
-    y = T.leaky_relu(T.conv2d_transpose_same(x, w[0][0], w[0][1], L['s']))
-    return T.leaky_relu(T.conv2d_transpose_same(y, w[1][0], w[1][1], 1))
+        y = T.leaky_relu(T.conv2d_same(x, w[0][0], w[0][1], L['s']), alpha)
+        return T.leaky_relu(T.conv2d_same(y, w[1][0], w[1][1], 1), alpha)
+    y = T.leaky_relu(T.conv2d_transpose_same(x, w[0][0], w[0][1], L['s']), alpha)
+    return T.leaky_relu(T.conv2d_transpose_same(y, w[1][0], w[1][1], 1), alpha)
 
 
 class OracleModel:
     """nlt/models/nlt.py Model, restated.  Weights are torch-CPU leaf tensors."""
 
     def __init__(self, depth0=16, depth=256, kernel=2, stride=2, uvh=512, uvw=512, imh=512,
-                 imw=512, use_obs=True, skip_connect_base=True, loss='l2', seed=0, dtype=torch.float32):
+                 imw=512, use_obs=True, skip_connect_base=True, loss='l2', seed=0, dtype=torch.float32, act='leakyrelu'):
         self.layers, self.is_contracting, _ = build_layers(depth0, depth, kernel, stride)
+        self.alpha = ACT_ALPHA[act]                              # config key `act` (dragon_specular.ini:61)
         self.uvh, self.uvw, self.imh, self.imw = uvh, uvw, imh, imw
         self.use_obs, self.skip_connect_base = use_obs, skip_connect_base
         self.loss_spec = loss
@@ -152,13 +156,13 @@ class OracleModel:
         query_y = None
         for i, (L, c) in enumerate(zip(self.layers, self.is_contracting)):
             if c:
-                obs_ys = [apply_layer(L, self.wo[i], x) for x in obs_xs]       # :154-155
+                obs_ys = [apply_layer(L, self.wo[i], x, self.alpha) for x in obs_xs]       # :154-155
                 obs_agg = torch.stack(obs_ys, -1)                               # :161
                 if obs_weights is not None:
                     obs_agg = obs_weights * obs_agg                             # :162-163
                 obs_agg = obs_agg.mean(-1)                                      # :164
                 obs_xs = obs_ys                                                 # :166
-                query_y = apply_layer(L, self.wq[i], query_x)                   # :168
+                query_y = apply_layer(L, self.wq[i], query_x, self.alpha)               # :168
                 if self.use_obs:
                     if obs_override is not None:
                         obs_agg = obs_override[i]                               # :172-173
@@ -170,7 +174,7 @@ class OracleModel:
             else:
                 if stack:
                     query_x = torch.cat((query_x, stack.pop()), -1)             # :184-190
-                query_y = apply_layer(L, self.wq[i], query_x)                   # :195
+                query_y = apply_layer(L, self.wq[i], query_x, self.alpha)               # :195
                 query_x = query_y
         return (query_y, feats) if return_feats else query_y
 

@@ -72,6 +72,33 @@ def test_no_obs_and_no_skip_base():
     _compare(om, pm, batch, nn)
 
 
+def test_relu_activation_branch_forward_and_train_step():
+    """Config branch act = relu (negative slope 0): fused plan vs oracle, and one train step's gradients."""
+    om, pm = make_pair(depth=256, uv=64, im=32, seed=13, act='relu')
+    pm.build('cuda')
+    batch, nn = O.synth_batch(2, 64, 64, 32, 32, 32, 32, k=2, seed=14)
+    db = to_device_batch(batch, nn)
+    with torch.no_grad():
+        ref = om.call(batch, 'vali', nn_list=nn)
+        got = pm.call(db, 'vali')
+    assert rel_l2(got[3]['pred'].cpu(), ref[3]['pred']) <= TOL and rel_l2(got[0].cpu(), ref[0]) <= TOL
+    pred, gt, kw, _ = pm(db, mode='train')
+    loss = pm.compute_loss(pred, gt, keep_batch=True).sum() / 2
+    pm.flat_params.grad = None
+    loss.backward()
+    po, go, _, _ = om.call(batch, 'train', nn_list=nn)
+    lo = om.compute_loss(po, go, keep_batch=True).sum() / 2
+    grads = torch.autograd.grad(lo, om.parameters())
+    assert abs(float(loss.detach()) - float(lo)) <= 1e-5 * abs(float(lo))
+    it = iter(grads)
+    worst = 0.0
+    for c in pm._conv_layers():
+        for name in ('dkernel', 'dbias'):
+            g = next(it)
+            worst = max(worst, float((getattr(c, name).cpu() - g).norm() / (g.norm() + 1e-12)))
+    assert worst < 2e-3, worst
+
+
 def test_layerwise_call_matches_fused_plan_and_oracle():
     """Model._call (reference structure, materialised concats, generic layer objects) ==
     fused plan == oracle."""

@@ -82,6 +82,21 @@ def test_no_obs_no_skip(monkeypatch):
     assert rel_l2(pm.call(cpu_batch(batch, nn), 'vali')[3]['pred'], ref) < 1e-5
 
 
+def test_relu_activation_config_branch(monkeypatch):
+    """act = relu (elements.py:69-70, ReLU(negative_slope=0)) runs through the same fused epilogues with slope 0,
+    forward (fused and layer-by-layer plans) and in the train step's derivative masks."""
+    fake_capi.install(monkeypatch)
+    om, pm = make(256, 64, 32, act='relu')
+    batch, nn = O.synth_batch(2, 64, 64, 32, 32, 32, 32, k=2, seed=12)
+    with torch.no_grad():
+        ref = om.call(batch, 'vali', nn_list=nn)[3]['pred']
+    assert rel_l2(pm.call(cpu_batch(batch, nn), 'vali')[3]['pred'], ref) < 1e-5
+    pm.plan.fuse_ends = False
+    assert rel_l2(pm.call(cpu_batch(batch, nn), 'vali')[3]['pred'], ref) < 1e-5
+    with pytest.raises(NotImplementedError):              # elu (elements.py:73-74) is not built
+        get_model_class('nlt')(nlt_amd.make_config(depth=256, uvh=64, uvw=64, imh=32, imw=32, act='elu'))
+
+
 def test_op_labels_and_algorithmic_bytes(monkeypatch):
     """Per-launch algorithmic bytes sum to SURVEY 8d's per-texel figure (961.5 B k=1; 1755.75 B k=4)."""
     fake_capi.install(monkeypatch)
