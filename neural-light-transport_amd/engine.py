@@ -341,7 +341,8 @@ class RenderPlan:
             self._front_weights(dev)        # folded front-kernel weights, refreshed in place OUTSIDE any tape
         tkey = None
         if (self.use_tape and base.is_cuda and self.timer is None and not self._tuning and reg is not None
-                and obs_weights is None and obs_override is None):
+                and obs_weights is None and obs_override is None
+                and all(t.is_contiguous() for t in (base, cvis, lvis, nn_rgb, nn_base))):    # (a replay skips the adapters' layout checks)
             tkey = ('fwd', base.data_ptr(), cvis.data_ptr(), lvis.data_ptr(), nn_rgb.data_ptr(), nn_base.data_ptr(),
                     bool(skip_connect_base), algo, inference, fused, C._stream())
             tapes = b.setdefault('tapes', {})
@@ -603,7 +604,8 @@ class RenderPlan:
         zb = g['zero_bias']
         reg = getattr(self.q.layers[0], '_registry', None)
         tkey = None
-        if self.use_tape and dpred.is_cuda and self.timer is None and reg is not None and obs_weights is None:
+        if (self.use_tape and dpred.is_cuda and self.timer is None and reg is not None and obs_weights is None
+                and all(t.is_contiguous() for t in (dpred, base, cvis, lvis, nn_rgb, nn_base))):
             tkey = ('bwd', dpred.data_ptr(), base.data_ptr(), cvis.data_ptr(), lvis.data_ptr(), nn_rgb.data_ptr(),
                     nn_base.data_ptr(), bool(b.get('train_fused')), self.bwd_streams, C._stream())
             tapes = b.setdefault('tapes', {})
