@@ -183,6 +183,177 @@ __global__ __launch_bounds__(256) void wgrad_narrow_kernel(WN w) {
     for (int nt = 0; nt < NT; ++nt) dst[KN + nt * 16 + i] = bsum[nt];
 }
 
+// Quad-A form (channel counts and leading dimensions multiples of 4, 16-byte aligned sources): ONE 16-byte load per lane
+// brings the four K values of a channel quad, so a 64-entry slice of K (= all four taps of a 16-channel layer) costs one
+// load + one address computation instead of four; tile e of the four MFMA row tiles it feeds holds K indices
+// 4 * quad + e, i.e. the same [K][N] workspace layout as the scalar form above.  B stays one 4-byte load per 16 columns.
+template <int MODE, int MQ, int NT>
+__global__ __launch_bounds__(256) void wgrad_narrowq_kernel(WN w) {
+  extern __shared__ float xch[];
+  const ConvP& p = w.c;
+  constexpr int TAPS = MODE == NLT_DECONV_K2S2 ? 1 : 4;
+  constexpr int S = MODE == NLT_CONV_K2S2 ? 2 : 1;
+  constexpr int MT = 4 * MQ;
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int i = lane & 15, kk = lane >> 4;
+  const int ms = blockIdx.x;
+  const int q0 = p.c0 >> 2, qpt = (p.c0 + p.c1) >> 2, nquads = w.K >> 2;
+
+  const float* ap[MQ]; int ald[MQ], oy[MQ], ox[MQ], tdelta[MQ]; bool aok[MQ];
+#pragma unroll
+  for (int mq = 0; mq < MQ; ++mq) {
+    const int q = mq * 16 + i;
+    aok[mq] = q < nquads;
+    const int tap = aok[mq] ? q / qpt : 0;
+    const int cq = aok[mq] ? q - tap * qpt : 0;
+    const bool from1 = cq >= q0;
+    ap[mq] = from1 ? p.src1 + 4 * (cq - q0) : p.src0 + 4 * cq;
+    ald[mq] = from1 ? p.ld1 : p.ld0;
+    const int a = TAPS == 4 ? tap >> 1 : 0, b = TAPS == 4 ? tap & 1 : 0;
+    oy[mq] = MODE == NLT_DECONV_K2S1 ? -a : a;
+    ox[mq] = MODE == NLT_DECONV_K2S1 ? -b : b;
+    tdelta[mq] = oy[mq] * p.w + ox[mq];
+  }
+  int boff[NT], bdelta[NT]; bool bok[NT];
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) {
+    const int n = nt * 16 + i;
+    bok[nt] = n < w.N;
+    const int nn = bok[nt] ? n : 0;
+    if (MODE == NLT_DECONV_K2S2) {
+      const int ab = nn / p.cout;
+      boff[nt] = nn - ab * p.cout;
+      bdelta[nt] = (ab >> 1) * p.ow + (ab & 1);
+    } else {
+      boff[nt] = nn;
+      bdelta[nt] = 0;
+    }
+  }
+
+  f32x4 acc[MQ][4][NT];
+  float bsum[NT];
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) {
+    bsum[nt] = 0.f;
+#pragma unroll
+    for (int mq = 0; mq < MQ; ++mq)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) acc[mq][e][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  }
+
+  const int m_begin = ms * w.rows_per_split;
+  int m_end = m_begin + w.rows_per_split;
+  if (m_end > p.M) m_end = p.M;
+  int m = m_begin + 4 * wv + kk;
+  int rx, ry, rf;
+  {
+    const int mc = m < p.M ? m : p.M - 1;
+    rx = mc % p.gw; ry = (mc / p.gw) % p.gh; rf = mc / (p.gw * p.gh);
+  }
+  auto issue = [&](f32x4 (&av)[MQ], float (&bv)[NT]) {
+    const bool rv = m < m_end;
+    const int ys = S * ry, xs = S * rx;
+    const int rowtex = (rf * p.h + ys) * p.w + xs;
+#pragma unroll
+    for (int mq = 0; mq < MQ; ++mq) {
+      const bool ok = rv && aok[mq] && (unsigned)(ys + oy[mq]) < (unsigned)p.h && (unsigned)(xs + ox[mq]) < (unsigned)p.w;
+      const int tex = ok ? rowtex + tdelta[mq] : 0;
+      const f32x4 v = *reinterpret_cast<const f32x4*>(ap[mq] + (size_t)tex * ald[mq]);   // unconditional, clamped address
+      av[mq] = ok ? v : (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+    const int rowo = MODE == NLT_DECONV_K2S2 ? (rf * p.oh + 2 * ry) * p.ow + 2 * rx : m;
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      const bool ok = rv && bok[nt];
+      const int otex = ok ? rowo + bdelta[nt] : 0;
+      const float v = w.dp[(size_t)otex * w.ldp + boff[nt]];
+      bv[nt] = ok ? v : 0.f;
+    }
+    m += 16; rx += 16;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const bool wx = rx >= p.gw;
+      rx -= wx ? p.gw : 0;
+      ry += wx ? 1 : 0;
+      const bool wy = ry >= p.gh;
+      ry = wy ? 0 : ry;
+      rf += wy ? 1 : 0;
+    }
+  };
+  auto compute = [&](const f32x4 (&av)[MQ], const float (&bv)[NT]) {
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      bsum[nt] += bv[nt];
+#pragma unroll
+      for (int mq = 0; mq < MQ; ++mq)
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          acc[mq][e][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[mq][e], bv[nt], acc[mq][e][nt], 0, 0, 0);
+    }
+  };
+  const int first = m_begin + 4 * wv;
+  const int nsteps = first < m_end ? (m_end - first + 15) / 16 : 0;
+  f32x4 a0[MQ], a1[MQ], a2[MQ];
+  float b0[NT], b1[NT], b2[NT];
+  issue(a0, b0);
+  issue(a1, b1);
+  for (int s3 = 0; s3 < nsteps; s3 += 3) {
+    issue(a2, b2); compute(a0, b0);
+    issue(a0, b0); compute(a1, b1);
+    issue(a1, b1); compute(a2, b2);
+  }
+
+  constexpr int NC = NT * 16, KN = MT * 16 * NC;
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) {
+    bsum[nt] += __shfl_xor(bsum[nt], 16);
+    bsum[nt] += __shfl_xor(bsum[nt], 32);
+  }
+  // K index of accumulator (mq, e), D row 4 kk + r:  4 * (16 mq + 4 kk + r) + e
+  for (int src = 1; src < 4; ++src) {
+    if (wv == src) {
+#pragma unroll
+      for (int mq = 0; mq < MQ; ++mq)
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) xch[(4 * (16 * mq + 4 * kk + r) + e) * NC + nt * 16 + i] = acc[mq][e][nt][r];
+      if (kk == 0)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) xch[KN + nt * 16 + i] = bsum[nt];
+    }
+    __syncthreads();
+    if (wv == 0) {
+#pragma unroll
+      for (int mq = 0; mq < MQ; ++mq)
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[mq][e][nt][r] += xch[(4 * (16 * mq + 4 * kk + r) + e) * NC + nt * 16 + i];
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) bsum[nt] += xch[KN + nt * 16 + i];
+    }
+    __syncthreads();
+  }
+  if (wv) return;
+  float* dst = w.ws + (size_t)ms * (KN + NC);
+#pragma unroll
+  for (int mq = 0; mq < MQ; ++mq)
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) dst[(4 * (16 * mq + 4 * kk + r) + e) * NC + nt * 16 + i] = acc[mq][e][nt][r];
+  if (kk == 0)
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) dst[KN + nt * 16 + i] = bsum[nt];
+}
+
 // Pass 2: 16 entries of the [K pad][N pad] block (+ the column sums) per workgroup, the slices dealt to 16 thread groups x 4
 // running sums (64 independent load streams per entry; a serial walk over ~500 slices is pure latency), fixed order.
 template <int MODE, int MT, int NT>
@@ -241,6 +412,22 @@ int run_narrow(WN& w, hipStream_t s) {
   return NLT_OK;
 }
 
+template <int MODE, int MQ, int NT>
+int run_narrowq(WN& w, hipStream_t s) {
+  constexpr int MT = 4 * MQ, PER = MT * 16 * NT * 16 + NT * 16;
+  hipLaunchKernelGGL((wgrad_narrowq_kernel<MODE, MQ, NT>), dim3((unsigned)w.msplits), dim3(256), PER * sizeof(float), s, w);
+  hipLaunchKernelGGL((wgrad_narrow_reduce_kernel<MODE, MT, NT>), dim3(PER / 16), dim3(256), 0, s, w);
+  if (MODE == NLT_DECONV_K2S2 && w.db) hipLaunchKernelGGL((wgrad_narrow_bias_k2s2_kernel<MT, NT>), dim3(1), dim3(64), 0, s, w);
+  NLT_CHECK_LAUNCH();
+  return NLT_OK;
+}
+
+template <int MODE>
+int dispatchq(WN& w, int mq, int nt, hipStream_t s) {
+  if (mq == 1) return nt == 1 ? run_narrowq<MODE, 1, 1>(w, s) : run_narrowq<MODE, 1, 2>(w, s);
+  return nt == 1 ? run_narrowq<MODE, 2, 1>(w, s) : run_narrowq<MODE, 2, 2>(w, s);
+}
+
 template <int MODE>
 int dispatch(WN& w, int mt, int nt, hipStream_t s) {
 #define NLT_WN(M_, N_) if (mt == M_ && nt == N_) return run_narrow<MODE, M_, N_>(w, s);
@@ -271,7 +458,7 @@ int prepare_narrow(WN& w, int mode, const float* src0, int ld0, int c0, const fl
   rows = (rows + 15) & ~15L;
   w.msplits = (int)((w.c.M + rows - 1) / rows);
   w.rows_per_split = (int)rows;
-  const int mt = tiles_m(w.K), nt = w.N <= 16 ? 1 : 2;
+  const int mt = w.K <= 64 ? 4 : 8, nt = w.N <= 16 ? 1 : 2;               // (the quad-A form pads K to 64 / 128)
   *ws_floats = ((long)w.msplits + 1) * (mt * 16 * nt * 16 + nt * 16);
   return NLT_OK;
 }
@@ -301,6 +488,17 @@ extern "C" int nlt_conv_backward_weights_narrow(int mode,
   t.ws = workspace;
   hipStream_t s = static_cast<hipStream_t>(stream);
   const int mt = tiles_m(t.K), nt = t.N <= 16 ? 1 : 2;
+  const bool quads = !(c0 & 3) && !(c1 & 3) && !(ld0 & 3) && (c1 == 0 || !(ld1 & 3)) && nlt_aligned16(src0) &&
+                     (c1 == 0 || nlt_aligned16(src1));
+  if (quads && t.K > 32) {                                           // (K <= 32: two scalar row tiles beat four half-empty quad tiles)
+    const int mq = t.K <= 64 ? 1 : 2;
+    switch (mode) {
+      case NLT_CONV_K2S2: return dispatchq<NLT_CONV_K2S2>(t, mq, nt, s);
+      case NLT_CONV_K2S1: return dispatchq<NLT_CONV_K2S1>(t, mq, nt, s);
+      case NLT_DECONV_K2S2: return dispatchq<NLT_DECONV_K2S2>(t, mq, nt, s);
+      case NLT_DECONV_K2S1: return dispatchq<NLT_DECONV_K2S1>(t, mq, nt, s);
+    }
+  }
   switch (mode) {
     case NLT_CONV_K2S2: return dispatch<NLT_CONV_K2S2>(t, mt, nt, s);
     case NLT_CONV_K2S1: return dispatch<NLT_CONV_K2S1>(t, mt, nt, s);
