@@ -89,6 +89,7 @@ def test_relu_activation_branch_forward_and_train_step():
     po, go, _, _ = om.call(batch, 'train', nn_list=nn)
     lo = om.compute_loss(po, go, keep_batch=True).sum() / 2
     grads = torch.autograd.grad(lo, om.parameters())
+    lo = lo.detach()
     assert abs(float(loss.detach()) - float(lo)) <= 1e-5 * abs(float(lo))
     it = iter(grads)
     worst = 0.0
