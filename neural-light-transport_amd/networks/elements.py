@@ -179,6 +179,8 @@ class PackRegistry:
         self.entries[(id(layer), key)] = (layer, key, buf, desc)
         self.table = None
         self.version += 1
+        if self.state is None and self.state_fn is not None:
+            self.state = self.state_fn()     # the first buffers were packed from the current weights
 
     def drop(self, layer):
         self.entries = {k: v for k, v in self.entries.items() if v[0] is not layer}
