@@ -233,3 +233,130 @@ def test_wgrad_tiled_kernel_index_math(mode, n, h, w, c0, c1, cout, rows):
                                  dp.reshape(-1), cout + padp, cout, rows)
     np.testing.assert_allclose(dw.reshape(wshape), gw.numpy(), atol=1e-4)
     np.testing.assert_allclose(db, gb.numpy(), atol=1e-4)
+
+
+# ---------------------------------------------------------------------------------------------------------
+# narrow layers: csrc/wgrad_narrow.hip (MFMA tile = [K index 16] x [output channel 16]; scalar and quad-A operand forms,
+# the wave-strided row walk, 4 waves -> one block per row slice -> workspace -> fixed-order reduction)
+# ---------------------------------------------------------------------------------------------------------
+def emulate_wgrad_narrow(mode, src0, ld0, c0, src1, ld1, c1, n, h, w, dp, ldp, cout, rows_per_split, quad):
+    gh, gw, oh, ow, N = h, w, h, w, cout
+    S = 1
+    if mode == CONV_K2S2:
+        gh = oh = h // 2; gw = ow = w // 2; S = 2
+    if mode == DECONV_K2S2:
+        oh, ow, N = 2 * h, 2 * w, 4 * cout
+    M = n * gh * gw
+    cin = c0 + c1
+    taps = 1 if mode == DECONV_K2S2 else 4
+    K = taps * cin
+    NT = 1 if N <= 16 else 2
+    if quad:
+        MQ = 1 if K <= 64 else 2
+        MT = 4 * MQ
+    else:
+        MT = 2 if K <= 32 else (4 if K <= 64 else 8)
+    NC, KN = NT * 16, MT * 16 * NT * 16
+    PER = KN + NC
+    msplits = -(-M // rows_per_split)
+    ws = np.zeros((msplits + 1) * PER, np.float32)
+    lane = np.arange(64); I, KKl = lane & 15, lane >> 4
+    sign = -1 if mode == DECONV_K2S1 else 1
+
+    def a_value(kidx, m_row):                                        # X[row][k index] with the kernel's validity rules
+        if kidx >= K:
+            return 0.0
+        tap, c = kidx // cin, kidx % cin
+        a, b = (tap >> 1, tap & 1) if taps == 4 else (0, 0)
+        x, y, f = m_row % gw, (m_row // gw) % gh, m_row // (gw * gh)
+        iy, ix = S * y + sign * a, S * x + sign * b
+        if not (0 <= iy < h and 0 <= ix < w):
+            return 0.0
+        tex = (f * h + iy) * w + ix
+        return src1[tex * ld1 + c - c0] if c >= c0 else src0[tex * ld0 + c]
+
+    for ms in range(msplits):
+        m_begin = ms * rows_per_split
+        m_end = min(m_begin + rows_per_split, M)
+        block = np.zeros(PER, np.float32)
+        for wv in range(4):
+            acc = np.zeros((MT, NT, 64, 4), np.float32)              # [row tile][col tile][lane][r]
+            bsum = np.zeros((NT, 64), np.float32)
+            first = m_begin + 4 * wv
+            nsteps = (m_end - first + 15) // 16 if first < m_end else 0
+            for s in range(nsteps):
+                m = first + 16 * s + KKl                             # the wave's steps are 16 rows apart
+                rv = m < m_end
+                av = np.zeros((MT, 64), np.float32); bv = np.zeros((NT, 64), np.float32)
+                for l in range(64):
+                    if not rv[l]:
+                        continue
+                    for mt in range(MT):
+                        if quad:                                     # tile e of quad block mq holds K index 4 * (16 mq + i) + e
+                            mq, e = mt >> 2, mt & 3
+                            kidx = 4 * (16 * mq + I[l]) + e
+                        else:
+                            kidx = 16 * mt + I[l]
+                        av[mt, l] = a_value(kidx, m[l])
+                    x, y, f = m[l] % gw, (m[l] // gw) % gh, m[l] // (gw * gh)
+                    for nt in range(NT):
+                        col = nt * 16 + I[l]
+                        if col >= N:
+                            continue
+                        ab, oc = (col // cout, col % cout) if mode == DECONV_K2S2 else (0, col)
+                        otex = m[l] if mode != DECONV_K2S2 else (f * oh + 2 * y + (ab >> 1)) * ow + 2 * x + (ab & 1)
+                        bv[nt, l] = dp[otex * ldp + oc]
+                for nt in range(NT):
+                    bsum[nt] += bv[nt]
+                    for mt in range(MT):
+                        mfma(av[mt], bv[nt], acc[mt, nt])
+            for mt in range(MT):                                     # accumulator (mt, D row 4 kk + r) -> K index
+                for nt in range(NT):
+                    for l in range(64):
+                        for r in range(4):
+                            row = 4 * KKl[l] + r
+                            kidx = 4 * (16 * (mt >> 2) + row) + (mt & 3) if quad else 16 * mt + row
+                            block[kidx * NC + nt * 16 + I[l]] += acc[mt, nt, l, r]
+            for nt in range(NT):
+                for i in range(16):
+                    block[KN + nt * 16 + i] += bsum[nt, i] + bsum[nt, i + 16] + bsum[nt, i + 32] + bsum[nt, i + 48]
+        ws[ms * PER:(ms + 1) * PER] = block
+    # pass 2
+    tot = ws[:msplits * PER].reshape(msplits, PER).astype(np.float64).sum(0)
+    dw = np.zeros(taps * cin * N, np.float64)
+    db = np.zeros(cout, np.float64)
+    for idx in range(KN):
+        kidx, ncol = idx // NC, idx % NC
+        if kidx < K and ncol < N:
+            dw[keras_widx(mode, kidx // cin, kidx % cin, ncol, cin, cout)] += tot[idx]
+    for ncol in range(N):
+        db[ncol % cout if mode == DECONV_K2S2 else ncol] += tot[KN + ncol]
+    return dw, db
+
+
+@pytest.mark.parametrize('mode,n,h,w,c0,c1,cout,rows,quad', [
+    (CONV_K2S1, 1, 5, 6, 16, 0, 16, 16, False), (CONV_K2S1, 1, 5, 6, 16, 0, 16, 16, True),
+    (CONV_K2S2, 1, 4, 8, 32, 0, 32, 32, True), (CONV_K2S2, 1, 4, 8, 16, 0, 32, 16, False),
+    (DECONV_K2S2, 1, 3, 4, 16, 64, 8, 16, True), (DECONV_K2S2, 1, 3, 4, 8, 32, 4, 32, False),
+    (DECONV_K2S1, 2, 3, 4, 8, 0, 8, 16, False), (DECONV_K2S1, 1, 4, 4, 16, 0, 16, 16, True),
+    (CONV_K2S1, 1, 3, 5, 5, 0, 7, 16, False), (CONV_K2S2, 1, 4, 4, 3, 6, 12, 16, False),
+])
+def test_wgrad_narrow_kernel_index_math(mode, n, h, w, c0, c1, cout, rows, quad):
+    rng = np.random.default_rng(mode * 7 + cout + int(quad))
+    tr = mode in (DECONV_K2S2, DECONV_K2S1)
+    s = 2 if mode in (CONV_K2S2, DECONV_K2S2) else 1
+    cin = c0 + c1
+    pad0, pad1, padp = 4, 8, 4
+    x0 = rng.standard_normal((n, h, w, c0 + pad0)).astype(np.float32)
+    x1 = rng.standard_normal((n, h, w, c1 + pad1)).astype(np.float32)
+    x = np.concatenate((x0[..., :c0], x1[..., :c1]), -1) if c1 else x0[..., :c0]
+    wshape = (2, 2, cout, cin) if tr else (2, 2, cin, cout)
+    wz = torch.zeros(wshape, requires_grad=True); bz = torch.zeros(cout, requires_grad=True)
+    f = T.conv2d_transpose_same if tr else T.conv2d_same
+    y = f(torch.tensor(x), wz, bz, s)
+    dp = rng.standard_normal(tuple(y.shape[:3]) + (cout + padp,)).astype(np.float32)
+    gw, gb = torch.autograd.grad(y, (wz, bz), torch.tensor(dp[..., :cout]))
+    dw, db = emulate_wgrad_narrow(mode, x0.reshape(-1), c0 + pad0, c0, x1.reshape(-1), c1 + pad1, c1, n, h, w,
+                                  dp.reshape(-1), cout + padp, cout, rows, quad)
+    np.testing.assert_allclose(dw.reshape(wshape), gw.numpy(), atol=1e-4)
+    np.testing.assert_allclose(db, gb.numpy(), atol=1e-4)
