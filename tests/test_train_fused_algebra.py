@@ -55,3 +55,49 @@ def test_texel_sum_identities_reproduce_autograd(n, h, w, k):
     close(dwq0, ref['wq0'][0, 0]); close(dbq0, ref['bq0'])
     close(dwo0, ref['wo0'][0, 0]); close(dbo0, ref['bo0'])
     close(dwh, ref['wh'][0, 0])
+
+
+@pytest.mark.parametrize('n,h2,w2', [(1, 3, 4), (2, 2, 5)])
+def test_last_block_backward_formulas_reproduce_autograd(n, h2, w2):
+    """The per-texel formulas of csrc/train_back.hip (phases 1-3), written out with explicit index shifts:
+    dv = lrelu'(v) . Wh dpred;  du[y,x] = lrelu'(u) . sum_{a,b} W1[a,b]^T dv[y+a, x+b];  dW1[a,b,o,c] = sum u[y-a,x-b,c] dv[y,x,o];
+    dW2[a,b,o,c] = sum in[i,j,c] du[2i+a,2j+b,o];  d_in[i,j,c] = sum_{a,b,o} W2[a,b,o,c] du[2i+a,2j+b,o]."""
+    rng = np.random.default_rng(h2 * 3 + w2)
+    R = lambda *s: torch.from_numpy(rng.standard_normal(s))
+    alpha = 0.3
+    xin, dpred = R(n, h2, w2, 40), R(n, 2 * h2, 2 * w2, 3)
+    W2, b2, W1, b1, Wh = R(2, 2, 4, 40), R(4), R(2, 2, 4, 4), R(4), R(36, 3)
+    dpred[:, 0, 0, :] = 0                                                         # set_left_top_corner: that texel carries no gradient
+    leaves = [t.clone().requires_grad_(True) for t in (xin, W2, b2, W1, b1, Wh)]
+    u = T.leaky_relu(T.conv2d_transpose_same(leaves[0], leaves[1], leaves[2], 2), alpha)
+    v = T.leaky_relu(T.conv2d_transpose_same(u, leaves[3], leaves[4], 1), alpha)
+    ref = torch.autograd.grad(((v @ leaves[5][:4]) * dpred).sum(), leaves)
+    u, v = u.detach(), v.detach()
+    slope = lambda a: torch.where(a > 0, torch.ones_like(a), torch.full_like(a, alpha))
+    h, w = 2 * h2, 2 * w2
+
+    dv = slope(v) * (dpred @ Wh[:4].t())                                          # phase 1
+    pad_br = lambda t: torch.nn.functional.pad(t, (0, 0, 0, 1, 0, 1))             # zero beyond bottom / right
+    pad_tl = lambda t: torch.nn.functional.pad(t, (0, 0, 1, 0, 1, 0))             # zero above / left
+    dvp, up = pad_br(dv), pad_tl(u)
+    du = torch.zeros_like(u)
+    dW1 = torch.zeros(2, 2, 4, 4, dtype=torch.float64)
+    for a in (0, 1):
+        for b in (0, 1):
+            du += dvp[:, a:a + h, b:b + w] @ W1[a, b]                             # [.., o] @ [o, c]: sum_o W1[a,b,o,c] dv[y+a,x+b,o]
+            ush = up[:, 1 - a:1 - a + h, 1 - b:1 - b + w]                         # u[y - a, x - b]
+            dW1[a, b] = torch.einsum('nyxo,nyxc->oc', dv, ush)
+    du = slope(u) * du                                                            # phase 2
+    dW2 = torch.zeros(2, 2, 4, 40, dtype=torch.float64)
+    d_in = torch.zeros_like(xin)
+    for a in (0, 1):
+        for b in (0, 1):
+            sub = du[:, a::2, b::2]                                               # du[2i + a, 2j + b]
+            dW2[a, b] = torch.einsum('nijo,nijc->oc', sub, xin)                   # phase 3a
+            d_in += sub @ W2[a, b]                                                # phase 3b
+    dWh = torch.zeros(36, 3, dtype=torch.float64)
+    dWh[:4] = torch.einsum('nyxc,nyxo->co', v, dpred)
+
+    close = lambda a, b: np.testing.assert_allclose(a.numpy(), b.numpy(), rtol=1e-9, atol=1e-9)
+    close(d_in, ref[0]); close(dW2, ref[1]); close(du.sum((0, 1, 2)), ref[2])
+    close(dW1, ref[3]); close(dv.sum((0, 1, 2)), ref[4]); close(dWh, ref[5])
