@@ -104,3 +104,34 @@ def test_barron_loss_runs_and_is_per_example():
     # zero residual -> every coefficient 0 -> rho=0 -> loss = log(c)+logZ(1)
     z = B.barron_loss(gt, gt).item()
     assert abs(z - (np.log(0.01) + B.LOG_Z_ALPHA1)) < 1e-6
+
+
+def test_log_partition_fractions_match_numerical_integration():    # distribution_test.py:95-106, 156-166
+    """The reference checks the spline against a Meijer-G closed form (mpmath) at alpha = n/11, n = 0..22; here the same
+    grid is checked against the DEFINITION  Z(alpha) = integral exp(-rho(x, alpha, 1)) dx  by quadrature -- i.e. the
+    restated spline interpolation + the shipped partition_spline.npz give a pdf that integrates to one."""
+    import scipy.integrate
+    s = np.load(os.path.join(G, 'partition_spline.npz'))
+    for n in range(0, 23):
+        alpha = n / 11.0
+        z, _ = scipy.integrate.quad(lambda x: np.exp(-float(B.lossfun(x, alpha, 1.0))), -np.inf, np.inf, epsabs=1e-12, epsrel=1e-12,
+                                    limit=400)
+        assert abs(float(B.log_base_partition_function(alpha, s)) - np.log(z)) < 2e-6, (alpha, np.log(z))
+
+
+def test_lossfun_general_properties():          # general_test.py:104-131, 184-195
+    rng = np.random.default_rng(0)
+    x = rng.normal(size=4000) * 4
+    alpha = rng.uniform(-4, 6, size=4000)
+    scale = np.exp(rng.normal(size=4000))
+    loss = B.lossfun(x, alpha, scale)
+    assert np.all(np.isfinite(loss)) and np.all(loss >= 0)
+    small = B.lossfun(rng.normal(size=4000) * 1e-6, alpha, scale)
+    assert np.all(np.abs(small) < 1e-5)                                             # near zero at the origin
+    mask = np.abs(x) < 0.5 * scale
+    np.testing.assert_allclose(loss[mask], 0.5 * (x[mask] / scale[mask]) ** 2, rtol=1e-5, atol=1e-2)   # quadratic bowl near 0
+    mult = np.maximum(0.2, np.exp(rng.normal(size=4000)))
+    np.testing.assert_allclose(B.lossfun(mult * x, alpha, mult * scale), loss, rtol=1e-9, atol=1e-12)  # scale invariance
+    # monotone in |x|: the derivative has the sign of x
+    d = (B.lossfun(x + 1e-6, alpha, scale) - B.lossfun(x - 1e-6, alpha, scale)) / 2e-6
+    assert np.all(d[np.abs(x) > 1e-3] * np.sign(x[np.abs(x) > 1e-3]) > 0)
