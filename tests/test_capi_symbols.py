@@ -72,3 +72,26 @@ def test_bad_arguments_return_status_codes_without_a_gpu():
     # sizes the kernels do not implement are "unsupported", not "bad"
     assert L.nlt_conv_tile_packed_floats(C.CONV_K2S1, 24, 32, 32) == -1 and L.nlt_chmix_bf16_packed_elems(48, 64) == -1
     assert L.nlt_wgrad_workspace_floats(C.CONV1X1, 5, 0, 1, 8, 8, 16) == -1
+
+
+def test_binding_table_matches_the_header_prototypes_argument_for_argument():
+    """Every prototype of include/nlt_hip.h against nlt_amd._capi.SIGNATURES: same number of parameters, pointers bound as
+    c_void_p, float / double / long / int as themselves -- an ABI drift between the header and the ctypes table would
+    otherwise only show up as garbage arguments on the GPU."""
+    hdr = open(os.path.join(ROOT, 'include', 'nlt_hip.h')).read()
+    hdr = re.sub(r'/\*.*?\*/', '', hdr, flags=re.S)
+    protos = re.findall(r'\b(?:const\s+)?(int|long|const char\s*\*)\s+(nlt_[a-z0-9_]+)\s*\(([^;{]*?)\)\s*;', hdr, flags=re.S)
+    assert len(protos) >= 60
+    kinds = {ctypes.c_void_p: 'ptr', ctypes.c_int: 'int', ctypes.c_long: 'long', ctypes.c_float: 'float',
+             ctypes.c_double: 'double', ctypes.c_char_p: 'ptr'}
+    for ret, name, params in protos:
+        res, args = C.SIGNATURES[name]
+        params = params.strip()
+        plist = [] if params in ('', 'void') else [p.strip() for p in params.split(',')]
+        assert len(plist) == len(args), (name, len(plist), len(args))
+        for p, a in zip(plist, args):
+            want = 'ptr' if '*' in p else re.sub(r'\bconst\b', '', p).split()[0]
+            want = {'nlt_map_dtype': 'int', 'unsigned': 'int'}.get(want, want)
+            assert kinds[a] == want, (name, p, a)
+        want_ret = 'ptr' if '*' in ret else ret
+        assert kinds[res] == want_ret, (name, ret, res)
