@@ -23,6 +23,27 @@ def flat_oracle_grads(pm, grads):
     return out
 
 
+def per_tensor_worst(pm, grads):
+    """(largest rel-L2 error over every kernel / bias gradient, its index) -- a flat-bucket norm is dominated by the big
+    deep kernels and cannot see a wrong 16-float bias gradient."""
+    it = iter(grads)
+    worst = (0.0, None)
+    for i, c in enumerate(pm._conv_layers()):
+        for name in ('dkernel', 'dbias'):
+            g = next(it)
+            e = float((getattr(c, name).detach().cpu() - g).norm() / (g.norm() + 1e-30))
+            worst = max(worst, (e, '%d.%s' % (i, name)))
+    return worst
+
+
+# fp32 HIP gradients vs the fp32 torch-CPU oracle: both sides carry fp32 accumulation error (different summation
+# orders); the float64 comparison at BASELINE config 4's size is in tests/test_gpu_baseline_sizes.py
+# (single tensors: LeakyReLU-derivative flips of texels whose pre-activation is within fp32 rounding of zero move a small
+# deep-layer gradient by up to ~2e-3 between ANY two fp32 evaluation orders -- the fp32 and float64 torch-CPU oracles
+# differ by 1e-3 among themselves; the kink-free alpha = 1 comparison there holds every tensor to 5e-5)
+FLAT_TOL, TENSOR_TOL = 1e-4, 5e-3
+
+
 @pytest.mark.parametrize('loss,k,uv,cam,im', [('l2', 1, 64, 64, 64), ('l2', 4, 128, 64, 64), ('barron', 2, 64, 32, 32),
                                               ('barron,5e-1l2', 1, 64, 32, 48)])
 def test_train_step_matches_oracle(loss, k, uv, cam, im):
@@ -39,7 +60,9 @@ def test_train_step_matches_oracle(loss, k, uv, cam, im):
         assert abs(float(lp) - float(lo)) <= 2e-5 * max(1.0, abs(float(lo))), (step, float(lp), float(lo))
         ref = flat_oracle_grads(pm, go)
         rel = float((pm.flat_params.grad - ref).norm() / ref.norm())
-        assert rel < 1e-3, (step, rel)
+        assert rel < FLAT_TOL, (step, rel)
+        worst = per_tensor_worst(pm, go)
+        assert worst[0] < TENSOR_TOL, (step, worst)
     # three Adam steps later the weights still track the oracle (lr 1e-3: each step moves ~1e-3)
     worst = max(float((po.detach() - c.kernel.cpu()).abs().max()) for po, c in zip(om.parameters()[::2], pm._conv_layers()))
     assert worst < 2e-4, worst
@@ -106,10 +129,11 @@ def test_rccl_single_rank_group_runs_the_gradient_all_reduce():
 
 @pytest.mark.parametrize('loss', ['l2', 'barron'])
 def test_full_size_gradient_agrees_with_directional_finite_differences(loss):
-    """BASELINE config 4's per-GPU shape (1024^2 UV, 512^2 camera; 2 frames here): the oracle cannot run this size in
-    seconds, so the whole fused training path (front/back forward with kept activations, warp adjoint, fused backward
-    ends, narrow / tiled weight gradients, flat bucket) is checked through a size-independent property instead:
-    (L(w + e d) - L(w - e d)) / 2e = <grad L, d> along the gradient and along its parts owned by each fused backward end."""
+    """BASELINE config 4's per-GPU shape (1024^2 UV, 512^2 camera; 2 frames here), a size-independent property check
+    BESIDE the direct oracle comparison of tests/test_gpu_baseline_sizes.py: the whole fused training path (front/back
+    forward with kept activations, warp adjoint, fused backward ends, narrow / tiled weight gradients, flat bucket)
+    must satisfy (L(w + e d) - L(w - e d)) / 2e = <grad L, d> along the gradient and along its parts owned by each
+    fused backward end."""
     _, pm = make_pair(depth=256, uv=1024, im=512, loss=loss, seed=21)
     pm.build('cuda')
     db = to_device_batch(*O.synth_batch(2, 1024, 1024, 512, 512, 512, 512, k=1, seed=77))
