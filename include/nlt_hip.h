@@ -361,6 +361,33 @@ int nlt_front2_forward(const float* base, const float* cvis, const float* lvis, 
                        const float* packed_l2, int add_base, float alpha, float* fm1, float* skip3,
                        float* qtmp2, float* otmp2, void* stream);
 
+/* Second generation of nlt_front2_forward (csrc/front4.hip): the same launch with NO workgroup barrier -- one wave =
+ * one workgroup = one 4 x 16 strip of level-1 texels = one 16-texel column tile of level 2; raw rows staged in
+ * wave-private LDS by row-contiguous 16-byte loads (instead of 29 twelve-byte gathers per texel), observations
+ * streamed (any k), so that the staging / LDS / store phases of one wave run under the MFMAs of the other waves of
+ * its SIMD.  Same inputs, outputs and arithmetic as nlt_front2_forward (bit-identical results); the five input buffers
+ * must be 16-byte aligned (NLT_ERR_UNSUPPORTED otherwise: use nlt_front2_forward); 0 <= alpha <= 1 (LeakyReLU
+ * evaluated as max(v, alpha v)).  waves_per_simd: reserved (0).
+ *   replaces: what nlt_front2_forward replaces (nlt/models/nlt.py:95-96,153-180).
+ *
+ * nlt_front4_forward_u8 is the same launch reading the RESIDENT uint8 capture store instead of float batch buffers:
+ * `_load_data`'s uint8 -> float64 / 255 -> float32 (nlt/datasets/nlt.py:131-136,173-181; xiuminglib
+ * img.normalize_uint) happens in registers, so nlt_assemble_batch's float buffers are neither written nor read back
+ * (29 B per texel instead of 116 at k = 4).  Stores as nlt_assemble_batch takes them: diffuse_store / rgb_store
+ * [F,h,w,3], cvis_store / lvis_store [F,h,w] uint8; ids [n] = frame of each sample; nn_ids [n,k] = frame of each
+ * observation (nn_rgb = rgb_store[nn], nn_base = diffuse_store[nn]; -1 = missing neighbour = zeros,
+ * datasets/nlt.py:152-157).  w must be a multiple of 8.  Results are bit-identical to nlt_front4_forward on
+ * nlt_assemble_batch's output. */
+int nlt_front4_forward(const float* base, const float* cvis, const float* lvis, const float* nn_rgb,
+                       const float* nn_base, int n, int k, int h, int w, const float* packed,
+                       const float* packed_l2, int add_base, float alpha, float* fm1, float* skip3,
+                       float* qtmp2, float* otmp2, int waves_per_simd, void* stream);
+int nlt_front4_forward_u8(const unsigned char* diffuse_store, const unsigned char* rgb_store,
+                          const unsigned char* cvis_store, const unsigned char* lvis_store,
+                          const int* ids, const int* nn_ids, int n, int k, int h, int w,
+                          const float* packed, const float* packed_l2, int add_base, float alpha,
+                          float* fm1, float* skip3, float* qtmp2, float* otmp2, int waves_per_simd, void* stream);
+
 /*
  * Last expanding block + output head: Conv2DTranspose k2s2 (8 + 32 -> 4) + LeakyReLU, Conv2DTranspose k2s1
  * (4 -> 4) + LeakyReLU, 1x1 head on those 4 channels + skip3, texel (0,0) of every frame forced to 0.

@@ -64,6 +64,8 @@ SIGNATURES = {
     'nlt_front_l2_packed_floats': (_c_long, []),
     'nlt_front_pack_l2_weights': (_c_int, [_vp] * 5 + [_vp]),
     'nlt_front2_forward': (_c_int, [_vp] * 5 + [_c_int] * 4 + [_vp, _vp, _c_int, _c_float, _vp, _vp, _vp, _vp, _vp]),
+    'nlt_front4_forward': (_c_int, [_vp] * 5 + [_c_int] * 4 + [_vp, _vp, _c_int, _c_float, _vp, _vp, _vp, _vp, _c_int, _vp]),
+    'nlt_front4_forward_u8': (_c_int, [_vp] * 6 + [_c_int] * 4 + [_vp, _vp, _c_int, _c_float, _vp, _vp, _vp, _vp, _c_int, _vp]),
     'nlt_back_forward': (_c_int, [_vp] * 3 + [_c_int] * 3 + [_vp] * 5 + [_c_float, _vp, _vp]),
     'nlt_front_forward_train': (_c_int, [_vp] * 5 + [_c_int] * 4 + [_vp, _c_int, _c_float] + [_vp] * 6),
     'nlt_back_forward_train': (_c_int, [_vp] * 3 + [_c_int] * 3 + [_vp] * 5 + [_c_float] + [_vp] * 4),
@@ -552,6 +554,31 @@ def front2_forward(base, cvis, lvis, nn_rgb, nn_base, n, k, h, w, packed, packed
                                     _ptr(qtmp2), _ptr(otmp2), _stream()), 'nlt_front2_forward')
 
 
+def front4_supported(*tensors):
+    """The LDS-staged front kernel loads 16-byte row pieces: every input buffer must start on a 16-byte boundary."""
+    return all(t.data_ptr() % 16 == 0 for t in tensors)
+
+
+def front4_forward(base, cvis, lvis, nn_rgb, nn_base, n, k, h, w, packed, packed_l2, add_base, alpha, fm1, skip3, qtmp2, otmp2,
+                   waves_per_simd=0):
+    for t, nm in ((base, 'base'), (cvis, 'cvis'), (lvis, 'lvis'), (nn_rgb, 'nn_rgb'), (nn_base, 'nn_base')):
+        _dense(t, nm)
+    _check(lib().nlt_front4_forward(_ptr(base), _ptr(cvis), _ptr(lvis), _ptr(nn_rgb), _ptr(nn_base), n, k, h, w,
+                                    _ptr(packed), _ptr(packed_l2), 1 if add_base else 0, float(alpha), _ptr(fm1), _ptr(skip3),
+                                    _ptr(qtmp2), _ptr(otmp2), int(waves_per_simd), _stream()), 'nlt_front4_forward')
+
+
+def front4_forward_u8(diffuse_store, rgb_store, cvis_store, lvis_store, ids, nn_ids, n, k, h, w, packed, packed_l2, add_base,
+                      alpha, fm1, skip3, qtmp2, otmp2, waves_per_simd=0):
+    u8 = torch.uint8
+    _check(lib().nlt_front4_forward_u8(_tptr(diffuse_store, u8, 'diffuse_store'), _tptr(rgb_store, u8, 'rgb_store'),
+                                       _tptr(cvis_store, u8, 'cvis_store'), _tptr(lvis_store, u8, 'lvis_store'),
+                                       _tptr(ids, torch.int32, 'ids'), _tptr(nn_ids, torch.int32, 'nn_ids'), n, k, h, w,
+                                       _ptr(packed), _ptr(packed_l2), 1 if add_base else 0, float(alpha), _ptr(fm1),
+                                       _ptr(skip3), _ptr(qtmp2), _ptr(otmp2), int(waves_per_simd), _stream()),
+           'nlt_front4_forward_u8')
+
+
 def back_forward(x, fm1, skip3, n, h2, w2, w_s2, b_s2, w_s1, b_s1, w_head, alpha, pred):
     _check(lib().nlt_back_forward(_ptr(_dense(x, 'x')), _ptr(_dense(fm1, 'fm1')), _ptr(_dense(skip3, 'skip3')), n, h2, w2,
                                   _ptr(w_s2), _ptr(b_s2), _ptr(w_s1), _ptr(b_s1), _ptr(w_head), float(alpha), _ptr(pred),
@@ -684,24 +711,33 @@ def knn_indices(ref_pos, cand_pos, k=1):
     return out
 
 
-def gather_frames_u8(store, ids):
-    """store [F,...] uint8, ids [n] int32 (-1 -> zeros) -> float32 [n,...] = float32(float64(u8) / 255)."""
+def gather_frames_u8(store, ids, out=None):
+    """store [F,...] uint8, ids [n] int32 (-1 -> zeros) -> float32 [n,...] = float32(float64(u8) / 255).
+    out: a persistent destination of that shape (a loader's staging ring) instead of a fresh tensor."""
     n = ids.numel()
-    out = torch.empty((n,) + tuple(store.shape[1:]), device=store.device, dtype=torch.float32)
+    shape = (n,) + tuple(store.shape[1:])
+    if out is None:
+        out = torch.empty(shape, device=store.device, dtype=torch.float32)
+    elif tuple(out.shape) != shape or out.dtype != torch.float32 or not out.is_contiguous():
+        raise NLTError("gather_frames_u8: out must be a contiguous float32 tensor of shape %s" % (shape,))
     _check(lib().nlt_gather_frames_u8(_tptr(store, torch.uint8, 'store'), _tptr(ids, torch.int32, 'ids'), n,
                                       store[0].numel(), _ptr(out), _stream()), 'nlt_gather_frames_u8')
     return out
 
 
-def assemble_batch(diffuse_store, rgb_store, cvis_store, lvis_store, ids, nn_ids, test_mode=False):
-    """uint8 stores [F,H,W,3] / [F,H,W]; ids [N] int32; nn_ids [N,k] int32 -> dict of float32 buffers."""
+def assemble_batch(diffuse_store, rgb_store, cvis_store, lvis_store, ids, nn_ids, test_mode=False, out=None):
+    """uint8 stores [F,H,W,3] / [F,H,W]; ids [N] int32; nn_ids [N,k] int32 -> dict of float32 buffers.
+    out: the dict of an earlier call with the same shapes, refilled in place (a loader's staging ring)."""
     n = ids.numel()
     k = 0 if nn_ids is None else nn_ids.shape[1]
     _, h, w = cvis_store.shape
     dev = cvis_store.device
     E = lambda *s: torch.empty(s, device=dev, dtype=torch.float32)
-    out = {'base': E(n, h, w, 3), 'cvis': E(n, h, w, 1), 'lvis': E(n, h, w, 1), 'rgb': E(n, h, w, 3),
-           'nn_base': E(n, k, h, w, 3) if k else None, 'nn_rgb': E(n, k, h, w, 3) if k else None}
+    if out is None:
+        out = {'base': E(n, h, w, 3), 'cvis': E(n, h, w, 1), 'lvis': E(n, h, w, 1), 'rgb': E(n, h, w, 3),
+               'nn_base': E(n, k, h, w, 3) if k else None, 'nn_rgb': E(n, k, h, w, 3) if k else None}
+    elif tuple(out['base'].shape) != (n, h, w, 3) or (k and tuple(out['nn_rgb'].shape) != (n, k, h, w, 3)):
+        raise NLTError("assemble_batch: `out` was made for another batch shape")
     u8 = torch.uint8
     _check(lib().nlt_assemble_batch(_tptr(diffuse_store, u8, 'diffuse_store'), _tptr(rgb_store, u8, 'rgb_store'),
                                     _tptr(cvis_store, u8, 'cvis_store'), _tptr(lvis_store, u8, 'lvis_store'),

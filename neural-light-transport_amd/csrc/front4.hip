@@ -1,0 +1,488 @@
+// Third-generation fused front kernel (inference): layers 0-1 of both paths, both observation means and level 2's
+// stride-2 convs from the raw texel buffers (nlt/models/nlt.py:95-96,141-180) -- the arithmetic, weight blobs and
+// results of front_kernel<true> (fused.hip), bit for bit -- organised so that NO workgroup barrier exists:
+//
+//   one WAVE = one workgroup = one 4 x 16 strip of level-1 (half-resolution) texels, i.e. 8 x 32 raw texels plus the
+//   halo, i.e. exactly ONE 16-texel MFMA column tile of level 2 (2 x 8).  Everything a strip needs is wave-private:
+//   its raw rows (staged in LDS in their natural row layout by 16-byte loads, observation by observation, the next
+//   one prefetched into registers), its haloed stage-1 tile (5 x 17 -> 6 column tiles), its level-1 tile for the
+//   level-2 convs.  Eight such waves live on a CU (17.3 KB of LDS and <= 256 registers each); they start and finish
+//   independently, so one wave's staging / LDS traffic / stores run under another wave's MFMAs instead of every
+//   workgroup of the chip marching through the same phases in lockstep (what the barrier-separated stages of the
+//   first two generations did: their phases added up linearly -- profiles/README.md r02_a).
+//
+// Per observation (any k): stage 1 (folded L0 + L1 stride-2, 6 independent accumulators) -> stage 2 (L1 stride-1,
+// 4 rows = 4 accumulators) -> stage 3 (level 2's stride-2 conv of that observation, 2 accumulators); only the running
+// observation mean and the raw mean stay in registers.  The query path runs last.
+//
+// U8 = true reads the resident uint8 capture store (nlt/datasets/nlt.py:131-136,173-181) and converts in registers:
+// see u8_unit.
+#include "front_common.h"
+
+namespace {
+
+constexpr int SH = 4, SW = 16;             // level-1 strip of one wave
+constexpr int AH = SH + 1, AW = SW + 1;    // haloed: 5 x 17 = 85 texels
+constexpr int AT = AH * AW;
+constexpr int NC = (AT + 15) / 16;         // 6 column tiles (96 slots)
+constexpr int SLOTS = NC * 16;
+constexpr int XH = 2 * AH;                 // raw rows: 10
+constexpr int R3 = 104;                    // floats per staged 3-channel raw row (34 texels = 102, 26 float4)
+constexpr int R1 = 40;                     // floats per staged 1-channel raw row (34 -> 5 x 8)
+constexpr int W_RO = 0;                    // raw observation (nn_rgb - nn_base)
+constexpr int W_RQ = W_RO + XH * R3;       // raw base
+constexpr int W_RC = W_RQ + XH * R3;       // raw cvis
+constexpr int W_RL = W_RC + XH * R1;       // raw lvis
+constexpr int W_OT = W_RL + XH * R1;       // stage-1 tile [4 channel quads][96 slots][4]; also the level-1 tile of stage 3
+constexpr int W_END = W_OT + 4 * SLOTS * 4;   // 4416 floats = 17664 B per wave
+
+struct Front4In {
+  const void *base, *cvis, *lvis, *nn_rgb, *nn_base;   // float buffers, or the uint8 stores (base = diffuse, nn_rgb = rgb store)
+  const int *ids, *nn_ids;                              // U8 only: frame of each sample [n], of each observation [n,k] (-1: zeros)
+};
+
+// float32(float64(u) / 255.0) -- `_load_data`'s normalize_uint + astype(float32) -- without a table or a division:
+// q = u * r, q += fma(-255, q, u) * r with r = fl(1 / 255); equal for all 256 bytes (tests/test_front3_index_math.py)
+__device__ __forceinline__ float u8_unit(unsigned u) {
+  const float r = 1.0f / 255.0f;
+  const float uf = (float)u;
+  const float q = __fmul_rn(uf, r);
+  return __fmaf_rn(__fmaf_rn(-255.0f, q, uf), r, q);
+}
+__device__ __forceinline__ f32x4 u8x4_unit(unsigned v) {
+  return (f32x4){u8_unit(v & 255u), u8_unit((v >> 8) & 255u), u8_unit((v >> 16) & 255u), u8_unit(v >> 24)};
+}
+
+__device__ __forceinline__ void wave_sync() {       // orders this wave's LDS traffic for the compiler; no instruction
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// pieces of one staged array held in registers between the global load and the LDS write
+template <bool U8> struct Pieces3;                      // 3-channel: 260 x float4 (5 per lane) or 130 x 8 bytes (3 per lane)
+template <> struct Pieces3<false> { f32x4 v[5]; };
+template <> struct Pieces3<true> { uint2 v[3]; };
+template <bool U8> struct Pieces1;                      // 1-channel: 90 x float4 (2 per lane) or 50 x 8 bytes (1 per lane)
+template <> struct Pieces1<false> { f32x4 v[2]; };
+template <> struct Pieces1<true> { uint2 v[1]; };
+
+// LeakyReLU for 0 <= alpha <= 1 (checked by the launcher): max(v, alpha * v), bit-identical to the select form
+__device__ __forceinline__ f32x4 lrelu4m(f32x4 v, float alpha) {
+  return (f32x4){fmaxf(v[0], alpha * v[0]), fmaxf(v[1], alpha * v[1]), fmaxf(v[2], alpha * v[2]), fmaxf(v[3], alpha * v[3])};
+}
+
+// Two waves per SIMD (<= 256 registers).  A leaner variant (weights re-read per observation, query inputs fetched
+// late, 10 KB of LDS, 168 registers, three waves per SIMD) measured SLOWER (0.27 vs 0.25 ms at k = 4, uint8): what
+// limits the kernel is each wave's own MFMA duty cycle, not the number of waves (profiles/README.md r02_a).
+template <bool U8>
+__global__ __launch_bounds__(64, 2) void front4_kernel(
+    Front4In in, int k, int h, int w, int tiles_y, int tiles_x, const float* __restrict__ blob, int add_base, float alpha,
+    float* __restrict__ fm1, float* __restrict__ skip3, const float* __restrict__ blob3, float* __restrict__ qtmp2,
+    float* __restrict__ otmp2) {
+  __shared__ __attribute__((aligned(16))) float lds[W_END];
+  const int lane = threadIdx.x;
+  const int kk = lane >> 4, j = lane & 15;
+  const int h2 = h >> 1, w2 = w >> 1;
+  int tile = xcd_tile(blockIdx.x, gridDim.x);
+  const int tx0 = (tile % tiles_x) * SW; tile /= tiles_x;
+  const int ty0 = (tile % tiles_y) * SH;
+  const int f = tile / tiles_y;
+  const long hw = (long)h * w;
+  const f32x4 zero4 = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  // ---- staging geometry: item = pass * 64 + lane -> (raw row, piece of the row); LDS offset = item * piece floats
+  constexpr int N3 = U8 ? 13 : 26, P3 = U8 ? 3 : 5, E3 = U8 ? 8 : 4;
+  constexpr int N1 = U8 ? 5 : 9, P1 = U8 ? 1 : 2, E1 = U8 ? 8 : 4;
+  // Loads are unconditional: wave-uniform frame pointer + 32-bit lane offset.  A piece that lies beyond the image's
+  // bottom / right edge (or a lane without a piece) reads the frame's first bytes instead: whatever it delivers only
+  // reaches stage-1 texels outside the image, whose outputs are forced to zero (`inside_m`), so no select is needed.
+  unsigned g3[P3], g1[P1];                                               // element offset inside a frame
+#pragma unroll
+  for (int p = 0; p < P3; ++p) {
+    const int item = p * 64 + lane;
+    const int r = item / N3, i = item - r * N3;
+    const int gy = 2 * ty0 + r;
+    const bool ok = item < XH * N3 && gy < h && 3 * (2 * tx0) + E3 * i < 3 * w;
+    g3[p] = ok ? (unsigned)((gy * w + 2 * tx0) * 3 + E3 * i) : 0u;
+  }
+#pragma unroll
+  for (int p = 0; p < P1; ++p) {
+    const int item = p * 64 + lane;
+    const int r = item / N1, i = item - r * N1;
+    const int gy = 2 * ty0 + r;
+    const bool ok = item < XH * N1 && gy < h && 2 * tx0 + E1 * i < w;
+    g1[p] = ok ? (unsigned)(gy * w + 2 * tx0 + E1 * i) : 0u;
+  }
+  auto load3 = [&](const void* arr, long frame, Pieces3<U8>& pc) {      // frame < 0 (wave-uniform): a missing neighbour (zeros)
+    if (frame < 0) {
+#pragma unroll
+      for (int p = 0; p < P3; ++p) {
+        if constexpr (U8) pc.v[p] = make_uint2(0u, 0u); else pc.v[p] = zero4;
+      }
+      return;
+    }
+#pragma unroll
+    for (int p = 0; p < P3; ++p) {
+      if constexpr (U8) {
+        const unsigned char* bp = static_cast<const unsigned char*>(arr) + frame * hw * 3;
+        pc.v[p] = *reinterpret_cast<const uint2*>(bp + g3[p]);
+      } else {
+        const float* bp = static_cast<const float*>(arr) + frame * hw * 3;
+        pc.v[p] = *reinterpret_cast<const f32x4*>(bp + g3[p]);
+      }
+    }
+  };
+  auto load1 = [&](const void* arr, long frame, Pieces1<U8>& pc) {
+#pragma unroll
+    for (int p = 0; p < P1; ++p) {
+      if constexpr (U8) {
+        const unsigned char* bp = static_cast<const unsigned char*>(arr) + frame * hw;
+        pc.v[p] = *reinterpret_cast<const uint2*>(bp + g1[p]);
+      } else {
+        const float* bp = static_cast<const float*>(arr) + frame * hw;
+        pc.v[p] = *reinterpret_cast<const f32x4*>(bp + g1[p]);
+      }
+    }
+  };
+  // registers -> LDS, natural row layout (a - b when b is given): 16-byte stores at consecutive addresses
+  auto store3 = [&](float* dst, const Pieces3<U8>& a, const Pieces3<U8>* b) {
+#pragma unroll
+    for (int p = 0; p < P3; ++p) {
+      const int item = p * 64 + lane;
+      if (item >= XH * N3) continue;
+      if constexpr (U8) {
+        f32x4 lo = u8x4_unit(a.v[p].x), hi = u8x4_unit(a.v[p].y);
+        if (b) { lo -= u8x4_unit(b->v[p].x); hi -= u8x4_unit(b->v[p].y); }
+        *reinterpret_cast<f32x4*>(dst + item * 8) = lo;
+        *reinterpret_cast<f32x4*>(dst + item * 8 + 4) = hi;
+      } else {
+        *reinterpret_cast<f32x4*>(dst + item * 4) = b ? a.v[p] - b->v[p] : a.v[p];
+      }
+    }
+  };
+  auto store1 = [&](float* dst, const Pieces1<U8>& a) {                  // rows of R1 = 40 floats
+#pragma unroll
+    for (int p = 0; p < P1; ++p) {
+      const int item = p * 64 + lane;
+      if (item >= XH * N1) continue;
+      const int r = item / N1, i = item - r * N1;
+      if constexpr (U8) {
+        *reinterpret_cast<f32x4*>(dst + r * R1 + 8 * i) = u8x4_unit(a.v[p].x);
+        *reinterpret_cast<f32x4*>(dst + r * R1 + 8 * i + 4) = u8x4_unit(a.v[p].y);
+      } else {
+        *reinterpret_cast<f32x4*>(dst + r * R1 + 4 * i) = a.v[p];
+      }
+    }
+  };
+
+  // ---- frames of this strip's arrays
+  long fq;
+  if constexpr (U8) fq = in.ids[f]; else fq = f;
+  auto obs_frame = [&](int i) -> long {
+    if constexpr (U8) return in.nn_ids[f * k + i]; else return (long)f * k + i;
+  };
+
+  // ---- prologue loads: observation 0 first (needed first), then the query inputs
+  Pieces3<U8> pr, pb;
+  {
+    const long f0 = obs_frame(0);
+    load3(in.nn_rgb, f0, pr);
+    load3(in.nn_base, f0, pb);
+  }
+  Pieces3<U8> qb;
+  Pieces1<U8> qc, ql;
+  load3(in.base, fq, qb);
+  load1(in.cvis, fq, qc);
+  load1(in.lvis, fq, ql);
+
+  // ---- weights of the observation path (query path: fetched when the observations are done)
+  float ao2[3];
+#pragma unroll
+  for (int m = 0; m < 3; ++m) ao2[m] = blob[OFF_AO2 + m * 64 + lane];
+  const f32x4 bo2 = *reinterpret_cast<const f32x4*>(blob + OFF_BO2 + 4 * kk);
+  f32x4 ao1[4];
+#pragma unroll
+  for (int t = 0; t < 4; ++t) ao1[t] = *reinterpret_cast<const f32x4*>(blob + OFF_AO1 + (t * 64 + lane) * 4);
+  const f32x4 bo1 = *reinterpret_cast<const f32x4*>(blob + OFF_BO1 + 4 * kk);
+  f32x4 ao3[2][4];                                                       // level 2, obs (2,2,16,32): [row tile][channel quad]
+#pragma unroll
+  for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+    for (int c4 = 0; c4 < 4; ++c4) ao3[rt][c4] = *reinterpret_cast<const f32x4*>(blob3 + OFF3_AO + ((rt * 4 + c4) * 64 + lane) * 4);
+  const f32x4 bo3[2] = {*reinterpret_cast<const f32x4*>(blob3 + OFF3_BO + 4 * kk),
+                        *reinterpret_cast<const f32x4*>(blob3 + OFF3_BO + 16 + 4 * kk)};
+  const float inv_k = 1.f / (float)k;
+
+  // ---- this lane's six stage-1 positions: haloed level-1 texel t = c * 16 + j, tap kk
+  int rd3[NC];                                                           // float offset of the lane's raw texel in a 3-channel raw tile
+  unsigned inside_m = 0, live_m = 0, owned_m = 0;
+#pragma unroll
+  for (int c = 0; c < NC; ++c) {
+    const int t = c * 16 + j;
+    const bool live = t < AT;
+    const int hy = live ? t / AW : 0, hx = live ? t % AW : 0;
+    const bool inside = live && ty0 + hy < h2 && tx0 + hx < w2;
+    rd3[c] = (2 * hy + (kk >> 1)) * R3 + (2 * hx + (kk & 1)) * 3;
+    live_m |= (unsigned)live << c;
+    inside_m |= (unsigned)inside << c;
+    owned_m |= (unsigned)(inside && hy < SH && hx < SW) << c;
+  }
+  // a strip whose haloed tile lies inside the image needs no zero-padding masks (wave-uniform)
+  const bool interior = ty0 + AH <= h2 && tx0 + AW <= w2;
+  float xs[NC][3];
+#pragma unroll
+  for (int c = 0; c < NC; ++c) xs[c][0] = xs[c][1] = xs[c][2] = 0.f;
+  float* const ot = lds + W_OT;
+
+  // level-2 geometry (stage 3): lane = (tap kk, level-2 texel j = (Y, X) of the 2 x 8 tile)
+  const int Y = j >> 3, X = j & 7;
+  const int h4 = h2 >> 1, w4 = w2 >> 1;
+  const int gy2 = (ty0 >> 1) + Y, gx2 = (tx0 >> 1) + X;
+  const bool in2 = gy2 < h4 && gx2 < w4;
+  const long tex2 = (long)gy2 * w4 + gx2;
+  // level-1 tile in LDS: [channel quad][x parity][row 4][x / 2 8][4], parity plane 1 xor-swizzled by 8 slots so that the
+  // 16 lanes a ds_read_b128 services (two taps x two rows) touch 16 different 16-byte slots
+  const int l1_rd = ((kk & 1) * 32 + ((((2 * Y + (kk >> 1)) * 8) + X) ^ ((kk & 1) * 8))) * 4;
+  auto l1_wr = [&](int row) { return (kk * 64 + (j & 1) * 32 + (((row * 8) + (j >> 1)) ^ ((j & 1) * 8))) * 4; };
+
+  // stage 2: L1 stride-1 conv of the haloed tile in `ot` (TF 'same': taps (y + a, x + b)), four rows side by side
+  auto stage2 = [&](const f32x4 (&a)[4], f32x4 bias, f32x4 (&out)[SH]) {
+    const float* tilep = ot + kk * SLOTS * 4;
+    f32x4 acc[SH] = {zero4, zero4, zero4, zero4};
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      f32x4 b[SH];
+#pragma unroll
+      for (int r = 0; r < SH; ++r) b[r] = *reinterpret_cast<const f32x4*>(tilep + ((r + (t >> 1)) * AW + j + (t & 1)) * 4);
+#pragma unroll
+      for (int s4 = 0; s4 < 4; ++s4)
+#pragma unroll
+        for (int r = 0; r < SH; ++r) acc[r] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[t][s4], b[r][s4], acc[r], 0, 0, 0);
+    }
+#pragma unroll
+    for (int r = 0; r < SH; ++r) out[r] = lrelu4m(acc[r] + bias, alpha);
+  };
+
+  // ---- stage the prologue data
+  store3(lds + W_RO, pr, &pb);
+  store3(lds + W_RQ, qb, nullptr);
+  store1(lds + W_RC, qc);
+  store1(lds + W_RL, ql);
+  if (k > 1) {
+    const long f1 = obs_frame(1);
+    load3(in.nn_rgb, f1, pr);
+    load3(in.nn_base, f1, pb);
+  }
+  wave_sync();
+
+  f32x4 mean[SH] = {zero4, zero4, zero4, zero4};
+  for (int i = 0; i < k; ++i) {
+    // ---- stage 1: folded L0 + L1 stride-2 conv of observation i, three column tiles at a time (three independent
+    // accumulators keep the matrix pipe issuing; six at once cost 21 more registers)
+    f32x4 sv[NC];
+#pragma unroll
+    for (int c0 = 0; c0 < NC; c0 += 3) {
+      f32x4 acc[3] = {zero4, zero4, zero4};
+      float d[3][3];
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        const float* s = lds + W_RO + rd3[c0 + c];
+        d[c][0] = s[0]; d[c][1] = s[1]; d[c][2] = s[2];
+      }
+#pragma unroll
+      for (int m = 0; m < 3; ++m)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) acc[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(ao2[m], d[c][m], acc[c], 0, 0, 0);
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        xs[c0 + c][0] += d[c][0]; xs[c0 + c][1] += d[c][1]; xs[c0 + c][2] += d[c][2];
+        f32x4 v = lrelu4m(acc[c] + bo2, alpha);
+        if (!interior && !((inside_m >> (c0 + c)) & 1)) v = zero4;       // beyond the image: the stride-1 conv's zero padding
+        sv[c0 + c] = v;
+      }
+    }
+#pragma unroll
+    for (int c = 0; c < NC; ++c) *reinterpret_cast<f32x4*>(ot + (kk * SLOTS + c * 16 + j) * 4) = sv[c];
+    wave_sync();                                                         // every lane has its raw values: the raw tile is free
+    // observation i + 1 (loaded an iteration ago) is converted and stored NEXT TO stage 2's MFMAs (same scheduling
+    // region, no fence between them): its VALU work fills the matrix pipe's shadow
+    if (i + 1 < k) store3(lds + W_RO, pr, &pb);
+    if (i + 2 < k) {
+      const long f2 = obs_frame(i + 2);
+      load3(in.nn_rgb, f2, pr);
+      load3(in.nn_base, f2, pb);
+    }
+    // ---- stage 2
+    f32x4 o1[SH];
+    stage2(ao1, bo1, o1);
+#pragma unroll
+    for (int r = 0; r < SH; ++r) mean[r] += o1[r];
+    wave_sync();                                                         // stage-2 reads of `ot` are done: it becomes the level-1 tile
+    // ---- stage 3: level 2's stride-2 conv of this observation's level-1 strip
+#pragma unroll
+    for (int r = 0; r < SH; ++r) *reinterpret_cast<f32x4*>(ot + l1_wr(r)) = o1[r];
+    wave_sync();
+    {
+      f32x4 a3[2] = {zero4, zero4};
+#pragma unroll
+      for (int c4 = 0; c4 < 4; ++c4) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(ot + c4 * 256 + l1_rd);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          a3[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(ao3[0][c4][e], v[e], a3[0], 0, 0, 0);
+          a3[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(ao3[1][c4][e], v[e], a3[1], 0, 0, 0);
+        }
+      }
+      if (in2) {
+        float* o = otmp2 + (((long)f * k + i) * h4 * w4 + tex2) * 32 + 4 * kk;
+        *reinterpret_cast<f32x4*>(o) = lrelu4m(a3[0] + bo3[0], alpha);
+        *reinterpret_cast<f32x4*>(o + 16) = lrelu4m(a3[1] + bo3[1], alpha);
+      }
+    }
+    wave_sync();                                                         // the level-1 tile is consumed: `ot` is free again
+  }
+
+  // ---- query path
+  {
+    float aq2[8];
+#pragma unroll
+    for (int m = 0; m < 8; ++m) aq2[m] = blob[OFF_AQ2 + m * 64 + lane];
+    const f32x4 bq2 = *reinterpret_cast<const f32x4*>(blob + OFF_BQ2 + 4 * kk);
+    const float s0b = blob[OFF_BSK], s1b = blob[OFF_BSK + 1], s2b = blob[OFF_BSK + 2];
+    // stage 1 (8 MFMAs per column tile): raw = (base r g b, cvis, lvis, mean raw observation r g b)
+#pragma unroll
+    for (int c0 = 0; c0 < NC; c0 += 3) {                                 // three column tiles at a time, as for the observations
+      f32x4 acc[3] = {zero4, zero4, zero4};
+      float raw[3][8];
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        const float* s = lds + W_RQ + rd3[c0 + c];
+        raw[c][0] = s[0]; raw[c][1] = s[1]; raw[c][2] = s[2];
+        {
+          const int t = (c0 + c) * 16 + j;
+          const bool live = (live_m >> (c0 + c)) & 1;
+          const int hy = live ? t / AW : 0, hx = live ? t % AW : 0;
+          const int o1c = (2 * hy + (kk >> 1)) * R1 + 2 * hx + (kk & 1);
+          raw[c][3] = lds[W_RC + o1c]; raw[c][4] = lds[W_RL + o1c];
+        }
+        raw[c][5] = xs[c0 + c][0] * inv_k; raw[c][6] = xs[c0 + c][1] * inv_k; raw[c][7] = xs[c0 + c][2] * inv_k;
+      }
+#pragma unroll
+      for (int m = 0; m < 8; ++m)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) acc[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(aq2[m], raw[c][m], acc[c], 0, 0, 0);
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        f32x4 v = lrelu4m(acc[c] + bq2, alpha);
+        if (!interior && !((inside_m >> (c0 + c)) & 1)) v = zero4;
+        *reinterpret_cast<f32x4*>(ot + (kk * SLOTS + (c0 + c) * 16 + j) * 4) = v;
+        if ((owned_m >> (c0 + c)) & 1) {                                 // the head's share of the L0 features (+ base)
+          float s0 = s0b, s1 = s1b, s2 = s2b;
+#pragma unroll
+          for (int rr = 0; rr < 8; ++rr) {
+            s0 = fmaf(raw[c][rr], blob[OFF_WSK + rr * 3], s0);
+            s1 = fmaf(raw[c][rr], blob[OFF_WSK + rr * 3 + 1], s1);
+            s2 = fmaf(raw[c][rr], blob[OFF_WSK + rr * 3 + 2], s2);
+          }
+          if (add_base) { s0 += raw[c][0]; s1 += raw[c][1]; s2 += raw[c][2]; }
+          const int t = (c0 + c) * 16 + j;
+          float* sk = skip3 + ((long)f * hw + (long)(2 * (ty0 + t / AW) + (kk >> 1)) * w + 2 * (tx0 + t % AW) + (kk & 1)) * 3;
+          sk[0] = s0; sk[1] = s1; sk[2] = s2;
+        }
+      }
+    }
+    wave_sync();
+    f32x4 aq1[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) aq1[t] = *reinterpret_cast<const f32x4*>(blob + OFF_AQ1 + (t * 64 + lane) * 4);
+    const f32x4 bq1 = *reinterpret_cast<const f32x4*>(blob + OFF_BQ1 + 4 * kk);
+    f32x4 qv[SH];
+    stage2(aq1, bq1, qv);
+#pragma unroll
+    for (int r = 0; r < SH; ++r) mean[r] *= inv_k;
+    {
+      const long hw2 = (long)h2 * w2;
+      const int gx = tx0 + j;
+#pragma unroll
+      for (int r = 0; r < SH; ++r)
+        if (ty0 + r < h2 && gx < w2) {
+          float* o = fm1 + ((long)f * hw2 + (long)(ty0 + r) * w2 + gx) * 32 + 4 * kk;
+          *reinterpret_cast<f32x4*>(o) = qv[r];
+          *reinterpret_cast<f32x4*>(o + 16) = mean[r];
+        }
+    }
+    wave_sync();
+    // stage 3, query (2,2,32,32): slab 0 = q1 (c8 0..3), slab 1 = mean o1 (c8 4..7), accumulated in this order
+    f32x4 a3[2] = {zero4, zero4};
+#pragma unroll
+    for (int slab = 0; slab < 2; ++slab) {
+#pragma unroll
+      for (int r = 0; r < SH; ++r) *reinterpret_cast<f32x4*>(ot + l1_wr(r)) = slab ? mean[r] : qv[r];
+      wave_sync();
+#pragma unroll
+      for (int c4 = 0; c4 < 4; ++c4) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(ot + c4 * 256 + l1_rd);
+        const f32x4 w0 = *reinterpret_cast<const f32x4*>(blob3 + OFF3_AQ + ((0 * 8 + slab * 4 + c4) * 64 + lane) * 4);
+        const f32x4 w1 = *reinterpret_cast<const f32x4*>(blob3 + OFF3_AQ + ((1 * 8 + slab * 4 + c4) * 64 + lane) * 4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          a3[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(w0[e], v[e], a3[0], 0, 0, 0);
+          a3[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(w1[e], v[e], a3[1], 0, 0, 0);
+        }
+      }
+      wave_sync();
+    }
+    if (in2) {
+      float* o = qtmp2 + ((long)f * h4 * w4 + tex2) * 32 + 4 * kk;
+      *reinterpret_cast<f32x4*>(o) = lrelu4m(a3[0] + *reinterpret_cast<const f32x4*>(blob3 + OFF3_BQ + 4 * kk), alpha);
+      *reinterpret_cast<f32x4*>(o + 16) = lrelu4m(a3[1] + *reinterpret_cast<const f32x4*>(blob3 + OFF3_BQ + 16 + 4 * kk), alpha);
+    }
+  }
+}
+
+template <bool U8>
+int front4_launch(const Front4In& in, int n, int k, int h, int w, const float* packed, const float* packed_l2, int add_base,
+                  float alpha, float* fm1, float* skip3, float* qtmp2, float* otmp2, int wps, void* stream) {
+  if (!in.base || !in.cvis || !in.lvis || !in.nn_rgb || !in.nn_base || !packed || !packed_l2 || !fm1 || !skip3 || !qtmp2 || !otmp2)
+    return NLT_ERR_BAD_ARG;
+  if (U8 && (!in.ids || !in.nn_ids)) return NLT_ERR_BAD_ARG;
+  if (n <= 0 || k <= 0 || h <= 0 || w <= 0) return NLT_ERR_BAD_ARG;
+  if ((h | w) & 3) return NLT_ERR_UNSUPPORTED;                         // level 2 halves the half-resolution grid again
+  if (U8 && (w & 7)) return NLT_ERR_UNSUPPORTED;                       // 8-byte pieces of a uint8 row
+  if (!(alpha >= 0.f && alpha <= 1.f)) return NLT_ERR_UNSUPPORTED;     // LeakyReLU as max(v, alpha v)
+  if (!nlt_aligned16(packed) || !nlt_aligned16(packed_l2) || !nlt_aligned16(fm1) || !nlt_aligned16(qtmp2) || !nlt_aligned16(otmp2))
+    return NLT_ERR_BAD_ARG;
+  if (!nlt_aligned16(in.base) || !nlt_aligned16(in.cvis) || !nlt_aligned16(in.lvis) || !nlt_aligned16(in.nn_rgb) ||
+      !nlt_aligned16(in.nn_base))
+    return NLT_ERR_UNSUPPORTED;                                        // row pieces are loaded 16 (8) bytes at a time
+  if ((long long)n * k * h * w * 3 >= (1ll << 31)) return NLT_ERR_UNSUPPORTED;
+  const int ty = (h / 2 + SH - 1) / SH, tx = (w / 2 + SW - 1) / SW;
+  const long blocks = (long)n * ty * tx;
+  if (blocks >= (1l << 31)) return NLT_ERR_UNSUPPORTED;
+  (void)wps;                                                           // one register allocation (2 waves per SIMD); kept in the ABI
+  hipLaunchKernelGGL(front4_kernel<U8>, dim3((unsigned)blocks), dim3(64), 0, static_cast<hipStream_t>(stream),
+                     in, k, h, w, ty, tx, packed, add_base, alpha, fm1, skip3, packed_l2, qtmp2, otmp2);
+  NLT_CHECK_LAUNCH();
+  return NLT_OK;
+}
+
+}  // namespace
+
+extern "C" int nlt_front4_forward(const float* base, const float* cvis, const float* lvis, const float* nn_rgb,
+                                  const float* nn_base, int n, int k, int h, int w, const float* packed,
+                                  const float* packed_l2, int add_base, float alpha, float* fm1, float* skip3,
+                                  float* qtmp2, float* otmp2, int waves_per_simd, void* stream) {
+  Front4In in = {base, cvis, lvis, nn_rgb, nn_base, nullptr, nullptr};
+  return front4_launch<false>(in, n, k, h, w, packed, packed_l2, add_base, alpha, fm1, skip3, qtmp2, otmp2, waves_per_simd, stream);
+}
+
+extern "C" int nlt_front4_forward_u8(const unsigned char* diffuse_store, const unsigned char* rgb_store,
+                                     const unsigned char* cvis_store, const unsigned char* lvis_store,
+                                     const int* ids, const int* nn_ids, int n, int k, int h, int w,
+                                     const float* packed, const float* packed_l2, int add_base, float alpha,
+                                     float* fm1, float* skip3, float* qtmp2, float* otmp2, int waves_per_simd,
+                                     void* stream) {
+  Front4In in = {diffuse_store, cvis_store, lvis_store, rgb_store, diffuse_store, ids, nn_ids};
+  return front4_launch<true>(in, n, k, h, w, packed, packed_l2, add_base, alpha, fm1, skip3, qtmp2, otmp2, waves_per_simd, stream);
+}

@@ -79,12 +79,44 @@ def load_store(data_root, device='cuda', ids=None):
     return store
 
 
+class ResidentTexels:
+    """The UV-space texel buffers of a batch (base, cvis, lvis, rgb, nn_base, nn_rgb of the model's 11-tuple) still in
+    the resident uint8 store: frame ids instead of float tensors.  `Model.call` hands this to the fused front kernel,
+    which converts uint8 -> float64 / 255 -> float32 (`_load_data`, nlt/datasets/nlt.py:131-136,173-181) in registers;
+    any consumer that needs the float tensors asks for them (`materialize`, bit-identical to the eager batch)."""
+
+    def __init__(self, store, ids, nn_ids, test_mode=False):
+        self.diffuse, self.rgb, self.cvis, self.lvis = store['diffuse'], store['rgb'], store['cvis'], store['lvis']
+        self.ids, self.nn_ids, self.test_mode = ids, nn_ids, test_mode
+        self.n, self.k = ids.numel(), nn_ids.shape[1]
+        self.h, self.w = self.cvis.shape[1:3]
+        self._float, self._base = None, None
+
+    def key(self):
+        return tuple(t.data_ptr() for t in (self.diffuse, self.rgb, self.cvis, self.lvis, self.ids, self.nn_ids)) + (self.n, self.k)
+
+    def base_float(self, out=None):
+        """base [n,h,w,3] float32 alone (the UV -> camera warp of Model.call needs it)."""
+        if self._float is not None:
+            return self._float['base']
+        if self._base is None:
+            self._base = C.gather_frames_u8(self.diffuse, self.ids, out=out)
+        return self._base
+
+    def materialize(self):
+        """All six float buffers, as Dataset.load_batch(resident=False) returns them."""
+        if self._float is None:
+            self._float = C.assemble_batch(self.diffuse, self.rgb, self.cvis, self.lvis, self.ids, self.nn_ids,
+                                           test_mode=self.test_mode)
+        return self._float
+
+
 class Dataset:
     """store: {'ids': [str], 'nn': {id: {'cam','light'}}, 'diffuse','rgb' [F,H,W,3] uint8 CUDA,
     'cvis','lvis' [F,H,W] uint8, 'uv2cam' [F,imh,imw,2] fp16, 'rgb_camspc' [F,imh,imw,3] uint8,
     'complete': [bool]}.  ids follow the reference's '{trainvali|test}_{i:09d}_{cam}_{light}'."""
 
-    def __init__(self, config, mode, store=None, k=1, device='cuda'):
+    def __init__(self, config, mode, store=None, k=1, device='cuda', ring=3):
         if mode not in ('train', 'vali', 'test'):
             raise ValueError("Invalid mode: {provided}. Allowed modes: {allowed}".format(
                 provided=mode, allowed=('train', 'vali', 'test')))
@@ -95,6 +127,16 @@ class Dataset:
                 raise NotImplementedError("stored UV resolution %d != uvh %d (the reference resizes with cv2)"
                                           % (store['cvis'].shape[1], uvh))
         self.config, self.mode, self.store, self.k = config, mode, store, k
+        # Staging ring: load_batch fills one of `ring` persistent buffer sets instead of allocating ~20 fresh tensors per
+        # step, so the addresses a batch arrives at repeat every `ring` steps and the model's recorded launch tape (keyed
+        # by input addresses) keeps replaying in a real data loop.  A returned batch stays valid for `ring - 1` further
+        # load_batch calls (ring = 0: fresh tensors every call, as the reference's tf.data pipeline hands out).
+        self.ring, self._slots, self._turn = int(ring), {}, 0
+        imh, imw = (config.getint('DEFAULT', k_, fallback=0) for k_ in ('imh', 'imw'))
+        cam = tuple(store['rgb_camspc'].shape[1:3])
+        if imh and imw and cam != (imh, imw):                        # the reference resizes rgb_camspc with cv2 (nlt.py:143)
+            raise NotImplementedError("stored camera-space resolution %s != (imh, imw) = %s (the reference resizes with cv2)"
+                                      % (cam, (imh, imw)))
         self.index = {id_: i for i, id_ in enumerate(store['ids'])}
         self.bs = 1 if mode == 'test' else config.getint('DEFAULT', 'bs')     # datasets/base.py
         self.files = self._glob()
@@ -135,21 +177,61 @@ class Dataset:
             out.append(-1 if nn_id is None else self.index[nn_id])       # missing neighbour -> zeros (:152-157)
         return out + [-1] * (self.k - len(out))
 
-    def load_batch(self, ids):
-        """`_load_data` (nlt.py:115-184) for a list of sample ids, as the model's 11-tuple."""
+    def _slot(self, n):
+        """The staging buffers the next batch of n samples goes into (None: allocate fresh ones)."""
+        if self.ring <= 0:
+            return None
+        slots = self._slots.setdefault(n, [])
+        i = self._turn % self.ring
+        self._turn += 1
+        while len(slots) <= i:
+            slots.append({})
+        return slots[i]
+
+    def load_batch(self, ids, resident=False):
+        """`_load_data` (nlt.py:115-184) for a list of sample ids, as the model's 11-tuple.
+        resident=True leaves the six UV-space texel buffers in the uint8 store: entry 1 (base) is a ResidentTexels and
+        entries 2, 3, 5, 8, 9 are None -- `Model.call` feeds the store to the fused front kernel (29 B per texel read
+        instead of 116 written + 116 read at k = 4) and materialises floats only where something asks for them."""
         s = self.store
         dev = s['cvis'].device
-        fid = torch.tensor([self.index[i] for i in ids], dtype=torch.int32, device=dev)
-        nnid = torch.tensor([self._nn_indices(i) for i in ids], dtype=torch.int32, device=dev)
-        b = C.assemble_batch(s['diffuse'], s['rgb'], s['cvis'], s['lvis'], fid, nnid, test_mode=self.mode == 'test')
-        li = fid.long()
-        warp = s['uv2cam'][li].float()                                           # never resized (nlt.py:147-148)
-        if self.mode == 'test':
-            rgb_c = torch.zeros((len(ids),) + tuple(s['rgb_camspc'].shape[1:]), device=dev)     # nlt.py:126-128
+        n = len(ids)
+        slot = self._slot(n)
+        fid_h = torch.tensor([self.index[i] for i in ids], dtype=torch.int32)
+        nn_h = torch.tensor([self._nn_indices(i) for i in ids], dtype=torch.int32)
+        if slot is None or 'fid' not in slot:
+            fid, nnid = fid_h.to(dev), nn_h.to(dev)
+            if slot is not None:
+                slot['fid'], slot['nnid'] = fid, nnid
         else:
-            rgb_c = C.gather_frames_u8(s['rgb_camspc'], fid)
-        nn_rgb_c = C.gather_frames_u8(s['rgb_camspc'], nnid[:, 0].contiguous())
-        nn_names = [s['ids'][j] if j >= 0 else 'incomplete-data' for j in nnid[:, 0].tolist()]
+            fid, nnid = slot['fid'], slot['nnid']
+            fid.copy_(fid_h); nnid.copy_(nn_h)
+        test = self.mode == 'test'
+        li = fid.long()
+        cam_shape = (n,) + tuple(s['rgb_camspc'].shape[1:])
+        if slot is None:
+            warp = s['uv2cam'][li].float()                                       # never resized (nlt.py:147-148)
+            rgb_c = torch.zeros(cam_shape, device=dev) if test else C.gather_frames_u8(s['rgb_camspc'], fid)   # nlt.py:126-128
+            nn_rgb_c = C.gather_frames_u8(s['rgb_camspc'], nnid[:, 0].contiguous())
+        else:
+            if 'warp' not in slot:
+                slot['warp'] = torch.empty((n,) + tuple(s['uv2cam'].shape[1:]), device=dev, dtype=torch.float32)
+                slot['rgb_c'] = torch.zeros(cam_shape, device=dev)
+                slot['nn_rgb_c'] = torch.empty(cam_shape, device=dev)
+                slot['nn0'] = torch.empty(n, device=dev, dtype=torch.int32)
+            warp, rgb_c, nn_rgb_c = slot['warp'], slot['rgb_c'], slot['nn_rgb_c']
+            warp.copy_(s['uv2cam'][li])                                          # fp16 -> fp32 on the way in
+            if not test:
+                C.gather_frames_u8(s['rgb_camspc'], fid, out=rgb_c)
+            slot['nn0'].copy_(nnid[:, 0])
+            C.gather_frames_u8(s['rgb_camspc'], slot['nn0'], out=nn_rgb_c)
+        nn_names = [s['ids'][j] if j >= 0 else 'incomplete-data' for j in nn_h[:, 0].tolist()]
+        if resident:
+            res = ResidentTexels(s, fid, nnid, test_mode=test)
+            return (list(ids), res, None, None, warp, None, rgb_c, nn_names, None, None, nn_rgb_c)
+        b = C.assemble_batch(s['diffuse'], s['rgb'], s['cvis'], s['lvis'], fid, nnid, test_mode=test,
+                             out=slot.get('texels') if slot is not None else None)
+        if slot is not None:
+            slot['texels'] = b
         return (list(ids), b['base'], b['cvis'], b['lvis'], warp, b['rgb'], rgb_c, nn_names,
                 b['nn_base'], b['nn_rgb'], nn_rgb_c)
-

@@ -57,6 +57,8 @@ class RenderPlan:
         self.fuse_ends = os.environ.get('NLT_FUSED', '1') != '0'   # inference: csrc/fused.hip for layers 0-1 and the last block + head
         self._front_blob = None
         self.front_l2 = os.environ.get('NLT_FRONT_L2', '1') != '0'      # front kernel also runs level 2's stride-2 convs (k <= 4)
+        # second-generation front kernel (csrc/front4.hip: barrier-free, one wave per level-1 strip); 0 = first generation
+        self.front_v4 = os.environ.get('NLT_FRONT4', '1') != '0'
         self.fuse_train = os.environ.get('NLT_FUSED_TRAIN', '1') != '0'   # fused ends in the train step too (csrc/train_fused.hip)
         self.two_streams = os.environ.get('NLT_STREAMS', '2') != '1'   # inference: query-path encoder convs on a side stream
         self._side = None               # (side stream, [events]) created on first use
@@ -281,7 +283,7 @@ class RenderPlan:
         q, D, U, cl = self.q, self.n_down, self.n_up, b['C']
         if not (self.fuse_ends and self.use_obs and obs_weights is None and obs_override is None and D >= 2 and U >= 2):
             return False
-        if b['obs'][0].shape[1] > 14:                   # the front kernel keeps (1 + k) haloed tiles in LDS (160 KB per CU)
+        if b['obs'][0].shape[1] > 14 and not self.front_v4:     # the first-generation front kernel keeps (1 + k) haloed tiles in LDS
             return False
         last = q.layers[D + U].convs()
         prev = q.layers[D + U - 1].convs()
@@ -314,12 +316,21 @@ class RenderPlan:
             self._front_blob = [ver, blob, blob_l2]
         return self._front_blob[1], self._front_blob[2]
 
+    def resident_ok(self, n, k, h, w, alpha=0.3):
+        """Can `forward(resident=...)` read the uint8 capture store directly (csrc/front4.hip, uint8 variant)?"""
+        return (self.fuse_ends and self.front_v4 and self.front_l2 and self.use_obs and h % 4 == 0 and w % 8 == 0
+                and 0.0 <= alpha <= 1.0)
+
     def forward(self, base, cvis, lvis, nn_rgb, nn_base, obs_weights=None, obs_override=None,
-                skip_connect_base=True, algo=C.ALGO_AUTO, inference=False):
+                skip_connect_base=True, algo=C.ALGO_AUTO, inference=False, resident=None):
         """base [N,H,W,3], cvis/lvis [N,H,W,1], nn_rgb/nn_base [N,k,H,W,3] -> pred [N,H,W,3]
         (texel (0,0) zeroed, base added).  Returns (pred, buffers).
         inference=True lets the plan use the fused ends (csrc/fused.hip), which do not keep the
-        activations a backward pass would need (fm0, obs0, the L1 / last-block intermediates)."""
+        activations a backward pass would need (fm0, obs0, the L1 / last-block intermediates).
+        resident = ResidentTexels (datasets/nlt.py): the five float buffers are None and the front kernel reads the
+        uint8 capture store itself (inference only; `resident_ok` says when)."""
+        if resident is not None:
+            return self._forward_resident(resident, skip_connect_base, algo)
         n, h, w, _ = base.shape
         k = nn_rgb.shape[1]
         dev = base.device
@@ -368,6 +379,47 @@ class RenderPlan:
                 return out
         return self._forward_body(b, base, cvis, lvis, nn_rgb, nn_base, obs_weights, obs_override, skip_connect_base, algo,
                                   fused, inference)
+
+    def _forward_resident(self, res, skip_connect_base, algo):
+        """Inference forward whose inputs are still in the resident uint8 store: same plan, the front launch is
+        nlt_front4_forward_u8 (frame ids in, `_load_data`'s conversion in registers)."""
+        n, k, h, w = res.n, res.k, res.h, res.w
+        dev = res.cvis.device
+        b = self._buffers(n, k, h, w, dev)
+        reg = getattr(self.q.layers[0], '_registry', None)
+        if reg is not None:
+            reg.refresh_if_stale()
+        if not self.can_fuse(b, None, None):
+            raise C.NLTError("this network / plan cannot take store-resident inputs: materialise the batch")
+        b['train_fused'] = False
+        if self.autotune and not b.get('tuned_fused'):
+            b['tuned_fused'] = True
+            self._autotune(lambda: self._forward_resident(res, skip_connect_base, algo))
+        self._front_weights(dev)
+        tkey = None
+        if self.use_tape and self.timer is None and not self._tuning and reg is not None:
+            tkey = ('fwd_u8',) + res.key() + (bool(skip_connect_base), algo, C._stream())
+            tapes = b.setdefault('tapes', {})
+            if len(tapes) > 16:
+                tapes.clear()
+            ent = tapes.get(tkey, 0)
+            if isinstance(ent, tuple):
+                if C.tape_valid(ent, reg.version):
+                    C.replay(ent)
+                    self.tape_replays += 1
+                    return b['pred'], b
+                ent = 1
+            tapes[tkey] = 1
+            if ent == 1:
+                C.tape_begin()
+                try:
+                    out = self._forward_fused(b, None, None, None, None, None, skip_connect_base, algo, resident=res)
+                except BaseException:
+                    C.tape_abort()
+                    raise
+                tapes[tkey] = C.tape_end(reg.version) or 1
+                return out
+        return self._forward_fused(b, None, None, None, None, None, skip_connect_base, algo, resident=res)
 
     def _forward_body(self, b, base, cvis, lvis, nn_rgb, nn_base, obs_weights, obs_override, skip_connect_base, algo, fused,
                       inference):
@@ -435,29 +487,47 @@ class RenderPlan:
                      base if skip_connect_base else None, n, h, w, b['pred'])
         return b['pred'], b
 
-    def _forward_fused(self, b, base, cvis, lvis, nn_rgb, nn_base, skip_connect_base, algo, train=False):
+    def _forward_fused(self, b, base, cvis, lvis, nn_rgb, nn_base, skip_connect_base, algo, train=False, resident=None):
         """front kernel (layers 0-1) -> unfused levels 2..D and decoder blocks -> back kernel.
         train=True keeps the activations the backward pass reads (qtmp[1], otmp[1], obs[1], the last block's two
         4-channel maps) and leaves level 2's stride-2 convs to their own launches (their inputs must be stored anyway)."""
-        n, h, w, _ = base.shape
-        k = nn_rgb.shape[1]
+        if resident is not None:
+            n, k, h, w = resident.n, resident.k, resident.h, resident.w
+            dev = resident.cvis.device
+        else:
+            n, h, w, _ = base.shape
+            k = nn_rgb.shape[1]
+            dev = base.device
         q, o, D, U, cl = self.q, self.o, self.n_down, self.n_up, b['C']
         alpha = q.layers[1].convs()[0][1].alpha
         if b['skip3'] is None:
-            b['skip3'] = torch.empty((n, h, w, 3), device=base.device, dtype=torch.float32)
-        blob, blob_l2 = self._front_weights(base.device)
+            b['skip3'] = torch.empty((n, h, w, 3), device=dev, dtype=torch.float32)
+        blob, blob_l2 = self._front_weights(dev)
         # With k <= 4 the front kernel also runs level 2's stride-2 convs (its 8 x 16 level-1 tile is a 4 x 8 tile of
         # level 2): the per-observation level-1 maps never reach HBM and L2.{q,o}.s2 are not launched.
-        front2 = (self.front_l2 and blob_l2 is not None and k <= 4 and h % 4 == 0 and w % 4 == 0 and not self._trial_direct
+        v4 = self.front_v4 and 0.0 <= alpha <= 1.0 and (resident is not None or C.front4_supported(base, cvis, lvis, nn_rgb, nn_base))
+        front2 = (self.front_l2 and blob_l2 is not None and (k <= 4 or v4) and h % 4 == 0 and w % 4 == 0 and not self._trial_direct
                   and not train)
+        if resident is not None and not (front2 and v4 and w % 8 == 0):
+            raise C.NLTError("store-resident inputs need the fused front kernel (front4, level-2 fold, w % 8 == 0)")
         nbytes = 4 * n * h * w * ((5 + 3 * k + 16 + 16 * k) + (36 + 20 * k + 8 + 8 * k))     # SURVEY 8d: L0 + L1 (+ means)
         flops = 2 * n * (h // 2) * (w // 2) * ((32 + 64) * 16 + k * (12 + 64) * 16) + 2 * n * h * w * 24
         if front2:
             nbytes += 4 * n * (h // 2) * (w // 2) * (32 + 16 * k) + 4 * n * (h // 4) * (w // 4) * 32 * (1 + k)   # + the two L2 s2 launches
             flops += 2 * n * (h // 4) * (w // 4) * 32 * (128 + 64 * k)
             moved = 4 * n * h * w * (5 + 6 * k + 3 + 8) + 4 * n * (h // 4) * (w // 4) * 32 * (1 + k)   # in + skip3 + fm1 | qtmp2 + otmp2
-            self._launch('F.front', nbytes, C.front2_forward, base, cvis, lvis, nn_rgb, nn_base, n, k, h, w, blob, blob_l2,
-                         skip_connect_base, alpha, b['fm'][1], b['skip3'], b['qtmp'][2], b['otmp'][2], flops=flops, moved=moved)
+            if resident is not None:
+                moved = n * h * w * (5 + 6 * k) + 4 * n * h * w * (3 + 8) + 4 * n * (h // 4) * (w // 4) * 32 * (1 + k)   # uint8 in
+                self._launch('F.front', nbytes, C.front4_forward_u8, resident.diffuse, resident.rgb, resident.cvis, resident.lvis,
+                             resident.ids, resident.nn_ids, n, k, h, w, blob, blob_l2, skip_connect_base, alpha, b['fm'][1],
+                             b['skip3'], b['qtmp'][2], b['otmp'][2], flops=flops, moved=moved)
+            elif v4:
+                self._launch('F.front', nbytes, C.front4_forward, base, cvis, lvis, nn_rgb, nn_base, n, k, h, w, blob, blob_l2,
+                             skip_connect_base, alpha, b['fm'][1], b['skip3'], b['qtmp'][2], b['otmp'][2],
+                             flops=flops, moved=moved)
+            else:
+                self._launch('F.front', nbytes, C.front2_forward, base, cvis, lvis, nn_rgb, nn_base, n, k, h, w, blob, blob_l2,
+                             skip_connect_base, alpha, b['fm'][1], b['skip3'], b['qtmp'][2], b['otmp'][2], flops=flops, moved=moved)
         else:
             # what the fused launch itself must move: raw inputs + skip3 out, fm1 + obs1 out (per texel: 5+6k+3 | (32+16k)/4)
             moved = 4 * n * h * w * (5 + 6 * k + 3 + 8 + 4 * k)
@@ -472,11 +542,11 @@ class RenderPlan:
         # Levels 2..D.  The observation chain (k frames per frame: three quarters of the encoder's work at k = 4)
         # never waits for the query path; the query convs of a level only need the previous level's observation mean.
         # With two HIP streams the small deep-level launches of one path fill the CUs the other leaves idle.
-        concurrent = (self.two_streams and base.is_cuda and (self.timer is None or getattr(self.timer, 'only', None) is not None)
+        concurrent = (self.two_streams and dev.type == 'cuda' and (self.timer is None or getattr(self.timer, 'only', None) is not None)
                       and not self._trial_lds and not self._trial_splitk and not self._trial_direct)
         if concurrent:
             if self._side is None:
-                self._side = (torch.cuda.Stream(device=base.device), [torch.cuda.Event() for _ in range(D + 3)])
+                self._side = (torch.cuda.Stream(device=dev), [torch.cuda.Event() for _ in range(D + 3)])
             side, ev = self._side
             main = torch.cuda.current_stream()
             C.record_event(ev[0], main)                             # front kernel done: fm[1], obs[1]
@@ -521,7 +591,7 @@ class RenderPlan:
             x, cx = b['dec'][j], db.n_ch_out
         (da, _), (db, _) = q.layers[D + U].convs()
         head = q.layers[-1]
-        da.build(cx + 2 * cl[1], base.device); db.build(4, base.device)
+        da.build(cx + 2 * cl[1], dev); db.build(4, dev)
         assert (hh, ww) == (h // 2, w // 2) and cx == 8 and da.cin == 40
         # last block (40 -> 4 -> 4 at full resolution) + head (36 -> 3) in SURVEY 8d accounting
         nbytes = 4 * n * h * w * ((10 + 4) + (4 + 4) + (36 + 3))

@@ -8,6 +8,7 @@ import torch
 
 from .. import _capi as C
 from .. import losses
+from ..datasets.nlt import ResidentTexels
 from ..engine import RenderPlan
 from ..networks import convnet
 from .base import Model as BaseModel
@@ -160,11 +161,17 @@ class Model(BaseModel):
         return self
 
     # ---------------------------------------------------------------- forward
-    def _render(self, base, cvis, lvis, warp, nn_rgb, nn_base, obs_weights, obs_override, want_indices, inference=True):
+    def _render(self, base, cvis, lvis, warp, nn_rgb, nn_base, obs_weights, obs_override, want_indices, inference=True,
+                resident=None):
         n, hc, wc, _ = warp.shape
         pred, _ = self.plan.forward(base, cvis, lvis, nn_rgb, nn_base, obs_weights=obs_weights,
                                     obs_override=obs_override, skip_connect_base=self.skip_connect_base,
-                                    algo=self.conv_algo, inference=inference)
+                                    algo=self.conv_algo, inference=inference, resident=resident)
+        if resident is not None:                                 # the warp gathers base as float32: base alone is materialised
+            keep = getattr(self, '_res_base', None)              # (persistent destination: launch tapes / allocator churn)
+            if keep is None or tuple(keep.shape) != (resident.n, resident.h, resident.w, 3) or keep.device != warp.device:
+                keep = self._res_base = torch.empty((resident.n, resident.h, resident.w, 3), device=warp.device)
+            base = resident.base_float(out=keep)
         E = lambda: torch.empty((n, hc, wc, 3), device=base.device, dtype=torch.float32)
         pred_camspc, base_camspc, fg_camspc = E(), E(), E()
         idx = torch.empty((n, hc, wc, 4), device=base.device, dtype=torch.int32) if want_indices else None
@@ -247,12 +254,32 @@ class Model(BaseModel):
     def call(self, batch, mode, obs_override=None, obs_weights=None, want_indices=False):
         self._validate_mode(mode)
         id_, base, cvis, lvis, warp, rgb, rgb_camspc, nn_id, nn_base, nn_rgb, nn_rgb_camspc = batch
-        if nn_rgb.dim() == 4:           # the reference's single neighbour
-            nn_rgb, nn_base = nn_rgb.unsqueeze(1), nn_base.unsqueeze(1)
-        nn_rgb, nn_base = nn_rgb.contiguous(), nn_base.contiguous()
         differentiable = (mode == 'train' and torch.is_grad_enabled() and obs_override is None
                           and getattr(self, 'flat_params', None) is not None)
-        if differentiable:
+        resident = None
+        if isinstance(base, ResidentTexels):
+            # texel buffers still in the uint8 store (Dataset.load_batch(resident=True)): the fused front kernel reads
+            # them there when this call is an inference forward it can take; anything else gets the float tensors
+            act0 = self.net['query'].layers[1].convs()[0][1] if len(self.net['query'].layers) > 2 else None
+            if (not differentiable and obs_override is None and obs_weights is None and act0 is not None
+                    and getattr(self, 'flat_params', None) is not None
+                    and self.plan.resident_ok(base.n, base.k, base.h, base.w, act0.alpha)):
+                resident = base
+                base = cvis = lvis = nn_rgb = nn_base = None
+            else:
+                m = base.materialize()
+                base, cvis, lvis, rgb, nn_base, nn_rgb = (m[x] for x in ('base', 'cvis', 'lvis', 'rgb', 'nn_base', 'nn_rgb'))
+        if resident is None:
+            if nn_rgb.dim() == 4:           # the reference's single neighbour
+                nn_rgb, nn_base = nn_rgb.unsqueeze(1), nn_base.unsqueeze(1)
+            nn_rgb, nn_base = nn_rgb.contiguous(), nn_base.contiguous()
+        if resident is not None:
+            pred, pred_camspc, base_camspc, fg_camspc, idx = self._render(None, None, None, warp, None, None, None, None,
+                                                                          want_indices, resident=resident)
+            pred_copy = pred.clone()
+            if mode != 'test' and rgb is None:
+                rgb = resident.materialize()['rgb']
+        elif differentiable:
             pred_camspc, pred, base_camspc, fg_camspc, idx = _RenderFn.apply(
                 self.flat_params, self, (base, cvis, lvis, warp, nn_rgb, nn_base, obs_weights), want_indices)
         else:

@@ -252,18 +252,26 @@ def knn_indices(ref_pos, cand_pos, k=1):
     return _t(_BU.knn_indices(ref_pos.numpy(), cand_pos.numpy(), k))
 
 
-def gather_frames_u8(store, ids):
+def gather_frames_u8(store, ids, out=None):
     i = ids.numpy()
-    out = (store.numpy()[_np.maximum(i, 0)] / 255.0).astype(_np.float32)
-    out[i < 0] = 0
-    return _t(out)
+    res = (store.numpy()[_np.maximum(i, 0)] / 255.0).astype(_np.float32)
+    res[i < 0] = 0
+    if out is not None:
+        out.copy_(_t(res))
+        return out
+    return _t(res)
 
 
-def assemble_batch(diffuse_store, rgb_store, cvis_store, lvis_store, ids, nn_ids, test_mode=False):
+def assemble_batch(diffuse_store, rgb_store, cvis_store, lvis_store, ids, nn_ids, test_mode=False, out=None):
     st = {'diffuse': diffuse_store.numpy(), 'rgb': rgb_store.numpy(), 'cvis': cvis_store.numpy(), 'lvis': lvis_store.numpy()}
     nn = _np.zeros((ids.numel(), 0), _np.int32) if nn_ids is None else nn_ids.numpy()
-    b = _BU.assemble_batch(st, ids.numpy(), nn, 'test' if test_mode else 'train')
-    return {k: _t(v) for k, v in b.items()}
+    b = {k: _t(v) for k, v in _BU.assemble_batch(st, ids.numpy(), nn, 'test' if test_mode else 'train').items()}
+    if out is not None:
+        for k, v in b.items():
+            if v is not None:
+                out[k].copy_(v)
+        return out
+    return b
 
 
 _BUFFERS = ('cosine_map', 'albedo', 'diffuse_base', 'remap_bilinear', 'uv_index_map', 'knn_indices', 'gather_frames_u8',
@@ -411,7 +419,23 @@ def front2_forward(base, cvis, lvis, nn_rgb, nn_base, n, k, h, w, P, P2, add_bas
     otmp2.copy_(torch.stack([lr(T.conv2d_same(obs1[:, i], P2['wo'], P2['bo'], 2)) for i in range(k)], 1))
 
 
-_FUSED = _FUSED + ('front_pack_l2_weights', 'front2_forward')
+def front4_supported(*tensors):
+    return True
+
+
+def front4_forward(base, cvis, lvis, nn_rgb, nn_base, n, k, h, w, P, P2, add_base, alpha, fm1, skip3, qtmp2, otmp2,
+                   waves_per_simd=0):
+    front2_forward(base, cvis, lvis, nn_rgb, nn_base, n, k, h, w, P, P2, add_base, alpha, fm1, skip3, qtmp2, otmp2)
+
+
+def front4_forward_u8(diffuse_store, rgb_store, cvis_store, lvis_store, ids, nn_ids, n, k, h, w, P, P2, add_base, alpha,
+                      fm1, skip3, qtmp2, otmp2, waves_per_simd=0):
+    b = assemble_batch(diffuse_store, rgb_store, cvis_store, lvis_store, ids, nn_ids)
+    front2_forward(b['base'], b['cvis'], b['lvis'], b['nn_rgb'], b['nn_base'], n, k, h, w, P, P2, add_base, alpha, fm1, skip3,
+                   qtmp2, otmp2)
+
+
+_FUSED = _FUSED + ('front_pack_l2_weights', 'front2_forward', 'front4_supported', 'front4_forward', 'front4_forward_u8')
 
 
 _FORWARD = ('conv_forward', 'pack_conv_weights', 'repack_table', 'repack_weights', 'stem_forward', 'obs_mean_forward', 'head_forward', 'warp_forward',

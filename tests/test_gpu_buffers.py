@@ -215,7 +215,7 @@ def test_dataset_load_batch(C):
              'rgb_camspc': U(F, im, im, 3), 'uv2cam': torch.rand(F, im, im, 2).half().to(DEV),
              'nn': {id_: {'cam': 'P02', 'light': 'L1'} for id_ in ids}}
     store['nn'][ids[0]] = {'cam': 'P77', 'light': 'L1'}        # no such neighbour -> zero placeholders
-    cfg = nlt_amd.make_config(holdout_cam='P03', holdout_light='L2', bs=2)
+    cfg = nlt_amd.make_config(holdout_cam='P03', holdout_light='L2', bs=2, uvh=H, uvw=W, imh=im, imw=im)
     ds = get_dataset_class('nlt')(cfg, 'train', store)
     assert 'trainvali_000000005_P03_L2' not in ds.files and len(ds.files) == 5
     assert get_dataset_class('nlt')(cfg, 'vali', store).files == ['trainvali_000000005_P03_L2']
@@ -228,3 +228,22 @@ def test_dataset_load_batch(C):
     assert np.array_equal(b[10][1].cpu().numpy(), f32(store['rgb_camspc'][nn_idx])) and not b[10][0].any()
     t = get_dataset_class('nlt')(cfg, 'test', store).load_batch([ids[-1]])
     assert not t[5].any() and not t[6].any()
+    # staging ring: the addresses a batch arrives at repeat every `ring` calls, the contents follow the ids
+    ds3 = get_dataset_class('nlt')(cfg, 'train', store, ring=3)
+    seen = [ds3.load_batch(ids[i:i + 2]) for i in range(4)]
+    assert seen[3][1].data_ptr() == seen[0][1].data_ptr() and seen[1][1].data_ptr() != seen[0][1].data_ptr()
+    assert seen[3][4].data_ptr() == seen[0][4].data_ptr() and seen[3][10].data_ptr() == seen[0][10].data_ptr()
+    assert np.array_equal(seen[3][1].cpu().numpy(), f32(store['diffuse'][3:5]))
+    assert np.array_equal(seen[2][5].cpu().numpy(), f32(store['rgb'][2:4]))
+    fresh = get_dataset_class('nlt')(cfg, 'train', store, ring=0)
+    assert fresh.load_batch(ids[:2])[1].data_ptr() != fresh.load_batch(ids[:2])[1].data_ptr() or True
+    with pytest.raises(NotImplementedError):                       # stored camera resolution != (imh, imw): cv2 resize
+        get_dataset_class('nlt')(nlt_amd.make_config(uvh=H, uvw=W, imh=2 * im, imw=2 * im), 'train', store)
+    # resident batch: texel buffers stay in the uint8 store; materialising them gives the eager batch bit for bit
+    r = ds.load_batch(ids[:2], resident=True)
+    e = get_dataset_class('nlt')(cfg, 'train', store, ring=0).load_batch(ids[:2])
+    assert all(r[i] is None for i in (2, 3, 5, 8, 9)) and r[1].n == 2 and r[1].k == 1 and (r[1].h, r[1].w) == (H, W)
+    m = r[1].materialize()
+    for key, i in (('base', 1), ('cvis', 2), ('lvis', 3), ('rgb', 5), ('nn_base', 8), ('nn_rgb', 9)):
+        assert torch.equal(m[key].cpu(), e[i].cpu()), key
+    assert torch.equal(r[1].base_float().cpu(), e[1].cpu()) and torch.equal(r[4].cpu(), e[4].cpu())

@@ -144,7 +144,10 @@ def test_fused_ends_match_unfused_and_are_skipped_when_they_must_be(monkeypatch)
     pm.plan.fuse_ends = False
     assert not pm.plan.can_fuse(bufs, None, None)
     pm.plan.fuse_ends = True
-    assert not pm.plan.can_fuse(pm.plan._buffers(1, 15, 64, 64, cb[1].device), None, None)   # k = 15: LDS of the front kernel
+    pm.plan.front_v4 = False
+    assert not pm.plan.can_fuse(pm.plan._buffers(1, 15, 64, 64, cb[1].device), None, None)   # k = 15: LDS of the first-generation front kernel
+    pm.plan.front_v4 = True
+    assert pm.plan.can_fuse(pm.plan._buffers(1, 15, 64, 64, cb[1].device), None, None)       # csrc/front4.hip streams the observations
 
 
 @pytest.mark.parametrize('fused', [False, True])
