@@ -2,7 +2,9 @@
 """bench.py -- rendered Mtexels/s of the NLT hot path on MI355X (BASELINE.json metric).
 
 One "step" = one full `Model.call` forward (buffers -> two-path U-Net -> pred -> UV->camera warp)
-over one batch of synthetic frames already resident in HBM.  Workload at every N: BASELINE
+over one batch of synthetic frames already resident in HBM; the batches come out of `Dataset.load_batch`
+on a synthetic uint8 capture store and at least three DIFFERENT batches (different frames, different
+addresses) are rotated through the timed steps.  Workload at every N: BASELINE
 config 3 per GPU -- depth0 16 / depth 256, 4 frames, 1024^2 UV, k = 4 neighbour observation
 maps, 512^2 camera-space warp (70 % foreground via fp16, 30 % background = (0,0)); frames shard
 data-parallel across ranks with no data-path collective in the forward (weak scaling).
@@ -27,7 +29,8 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E peak (MI355X_MICROARCH.md)
 MFMA_F32_PEAK_TFLOPS = 157.3   # dense fp32-input MFMA peak = the fp32 vector peak (MI355X_MICROARCH.md)
 # launch label -> kernel-name fragment in the rocprofv3 output (profiles/*_pmc_traffic.json)
-KERNEL_OF_LABEL = {'F.front': 'front_kernel', 'F.back': 'back_kernel', 'L0.stem': 'stem_kernel', 'L13.head': 'head_kernel'}
+KERNEL_OF_LABEL = {'F.front': ('front4_kernel', 'front_kernel'), 'F.back': ('back_kernel',), 'L0.stem': ('stem_kernel',),
+                   'L13.head': ('head_kernel',)}
 
 
 def pmc_traffic(label):
@@ -35,7 +38,7 @@ def pmc_traffic(label):
     (FETCH_SIZE / WRITE_SIZE collected in separate --pmc passes, tools/pmc_summary.py applies the
     gfx950 corrections of MI355X_MICROARCH.md).  None when no summary covers this kernel."""
     import glob
-    frag = KERNEL_OF_LABEL.get(label)
+    frags = KERNEL_OF_LABEL.get(label, ())
     for path in sorted(glob.glob(os.path.join(ROOT, 'profiles', '*_pmc_traffic.json')), reverse=True):
         try:
             with open(path) as f:
@@ -43,11 +46,41 @@ def pmc_traffic(label):
         except (OSError, ValueError):
             continue
         for name, rec in d.get('kernels', {}).items():
-            if frag and frag in name and rec.get('hbm_bytes') is not None:
+            if any(fr in name for fr in frags) and rec.get('hbm_bytes') is not None:
                 return int(rec['hbm_bytes'])
     return None
 
 BYTES_PER_TEXEL = {1: 961.5, 4: 1755.75}   # SURVEY.md 8d, fp32 layer-wise algorithmic bytes
+
+
+def pmc_step_bytes():
+    """HBM bytes one forward step moves, summed over every kernel of the step, from the newest committed PMC summary
+    that carries it (tools/pmc_summary.py: sum of calls x (2 x FETCH_SIZE + WRITE_SIZE) / forward steps profiled)."""
+    import glob
+    for path in sorted(glob.glob(os.path.join(ROOT, 'profiles', '*_pmc_traffic.json')), reverse=True):
+        try:
+            with open(path) as f:
+                d = json.load(f)
+        except (OSError, ValueError):
+            continue
+        if d.get('hbm_bytes_per_forward_step'):
+            return int(d['hbm_bytes_per_forward_step']), os.path.basename(path)
+    return None, None
+
+
+def whole_pass(args, timer, sec_per_step, layerwise_bpt):
+    """Two utilisation figures for the whole forward (per GPU): useful FLOP/s against the fp32 MFMA peak, and the HBM
+    bytes the step really moves (PMC) against the HBM peak.  SURVEY 8d's layer-wise bytes are what an unfused
+    implementation would move -- kept as a reference figure, NOT as a utilisation."""
+    flops = sum(timer.flops.get(l, 0) for l in timer.records)            # 2 x MACs of the plan's launches (L0 folded)
+    tf = flops / sec_per_step / 1e12
+    hbm, src = pmc_step_bytes()
+    out = {"useful_flops_per_step": int(flops), "tflops": round(tf, 2), "frac_of_fp32_mfma_peak": round(tf / MFMA_F32_PEAK_TFLOPS, 4),
+           "hbm_bytes_per_step_pmc": hbm, "pmc_source": src,
+           "frac_of_hbm_peak": round(hbm / sec_per_step / 1e9 / HBM_PEAK_GBS, 4) if hbm else None,
+           "layerwise_equivalent_bytes_per_texel": layerwise_bpt,
+           "layerwise_equivalent_GBps": round(args.frames * args.uv * args.uv * layerwise_bpt / sec_per_step / 1e9, 1)}
+    return out
 
 
 def algorithmic_bytes_per_texel(k):
@@ -57,8 +90,8 @@ def algorithmic_bytes_per_texel(k):
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=20)
-    ap.add_argument('--warmup', type=int, default=5)
+    ap.add_argument('--steps', type=int, default=100)
+    ap.add_argument('--warmup', type=int, default=10)
     ap.add_argument('--uv', type=int, default=1024)
     ap.add_argument('--cam', type=int, default=512)
     ap.add_argument('--frames', type=int, default=4, help='frames (light x view pairs) per GPU')
@@ -71,19 +104,23 @@ def parse():
     ap.add_argument('--no-fused', action='store_true', help='layer-by-layer plan (disable csrc/fused.hip) for A/B runs')
     ap.add_argument('--tune-cache', type=str, default=None, help='JSON of tile choices: loaded if present, else written')
     ap.add_argument('--cpu-baseline-worker', action='store_true', help=argparse.SUPPRESS)
-    ap.add_argument('--cpu-threads', type=int, default=32, help='host threads for the CPU oracle leg (0 = all)')
+    ap.add_argument('--cpu-threads', type=int, default=0, help='host threads for the CPU oracle leg (0 = all)')
+    ap.add_argument('--batches', type=int, default=3, help='distinct batches rotated through the timed steps (>= 3)')
+    ap.add_argument('--store-frames', type=int, default=16, help='frames of the synthetic uint8 capture store')
     ap.add_argument('--per-op', action='store_true', help='print a per-launch timing table to stderr')
     ap.add_argument('--dominant', type=str, default=None, help='label of the kernel to time in the timed region')
-    ap.add_argument('--train-steps', type=int, default=-1, help='train steps to time for the train_step field (-1: steps//2, 0: skip)')
-    ap.add_argument('--train-loss', type=str, default='l2')
+    ap.add_argument('--train-steps', type=int, default=-1, help='train steps to time per loss for the train_step field (-1: max(50, steps//2), 0: skip)')
+    ap.add_argument('--train-loss', type=str, default='l2,barron', help='comma-separated losses, one train_step line each')
     ap.add_argument('--train-graph', action='store_true',
                     help='train step: replay forward + loss + backward as one hipGraph (trainvali.GraphedTrainStep); measured '
                          'slower than eager launches on ROCm 7.0 (5.15 vs 4.75 ms), so off by default')
+    ap.add_argument('--headline-only', action='store_true', help='only the timed forward (profiling runs): no loader-inclusive legs, train steps or CPU leg')
     ap.add_argument('--per-op-train', action='store_true', help='per-launch timing table of one train step (stderr)')
     return ap.parse_args()
 
 
 def synth_device_batch(n, uv, cam, k, device, seed):
+    """A float32 11-tuple of uniform random buffers (tests / tools; the bench itself loads through `make_loader`)."""
     import torch
     g = torch.Generator(device=device).manual_seed(seed)
     U = lambda *s: torch.rand(s, device=device, generator=g)
@@ -93,6 +130,21 @@ def synth_device_batch(n, uv, cam, k, device, seed):
     nn_base, nn_rgb = U(n, k, uv, uv, 3), U(n, k, uv, uv, 3)
     rgb_c, nn_rgb_c = U(n, cam, cam, 3), U(n, cam, cam, 3)
     return (None, base, cvis, lvis, warp, rgb, rgb_c, None, nn_base, nn_rgb, nn_rgb_c)
+
+
+def make_loader(args, device, k, mode, seed, loss='l2'):
+    """(config, Dataset on a seeded synthetic uint8 capture store, list of `--batches` disjoint id lists)."""
+    import nlt_amd
+    from nlt_amd.datasets import get_dataset_class
+    from nlt_amd.datasets.synth import synthetic_store
+    nb = max(3, args.batches)
+    frames = max(args.store_frames, nb * args.frames)
+    cfg = nlt_amd.make_config(depth=args.depth, uvh=args.uv, uvw=args.uv, imh=args.cam, imw=args.cam, bs=args.frames,
+                              loss=loss, lr=1e-3)
+    store = synthetic_store(frames, args.uv, args.cam, device=device, seed=seed, k=k)
+    ds = get_dataset_class('nlt')(cfg, mode, store, k=k, device=device, ring=nb)
+    id_lists = [store['ids'][i * args.frames:(i + 1) * args.frames] for i in range(nb)]
+    return cfg, ds, id_lists
 
 
 def cpu_baseline_worker(args):
@@ -115,7 +167,7 @@ def cpu_baseline_worker(args):
         with torch.no_grad():
             om.call(batch, 'test', nn_list=nn)                     # warm-up
             times, t_start = [], time.perf_counter()
-            while len(times) < 9 and (not times or time.perf_counter() - t_start < 12.0):
+            while len(times) < 9 and (not times or time.perf_counter() - t_start < 8.0):
                 t0 = time.perf_counter()
                 om.call(batch, 'test', nn_list=nn)
                 times.append(time.perf_counter() - t0)
@@ -131,31 +183,44 @@ def cpu_baseline_worker(args):
 
 
 def cpu_baseline(args):
-    """The CPU leg, isolated in a child process with a hard timeout so that a slow or wedged host
-    run can never take the GPU line with it."""
+    """The CPU leg, isolated in child processes with a hard timeout so that a slow or wedged host run can never take the
+    GPU line with it.  ALL host cores are used the way a CPU deployment of this data-parallel
+    path would use them: one oracle process per 32 hardware threads, each rendering its own frame concurrently, texels/s
+    summed.  (One process across 256 threads collapses -- torch-CPU convs of this size stop scaling near 32 threads:
+    0.001 Mtexels/s measured -- so that figure would say nothing about the host.)"""
     import subprocess
+    cores = os.cpu_count() or 1
+    per = 32 if args.cpu_threads == 0 else args.cpu_threads
+    procs = max(1, cores // per) if args.cpu_threads == 0 else 1
     cmd = [sys.executable, os.path.abspath(__file__), '--cpu-baseline-worker', '--uv', str(args.uv), '--k', str(args.k),
-           '--depth', str(args.depth), '--cpu-threads', str(args.cpu_threads)]
+           '--depth', str(args.depth), '--cpu-threads', str(per)]
     env = dict(os.environ, HIP_VISIBLE_DEVICES='', CUDA_VISIBLE_DEVICES='')
-    try:
-        r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=150, env=env, cwd=ROOT)
-        lines = [l for l in r.stdout.decode().splitlines() if l.startswith('{')]
-        return json.loads(lines[-1])
-    except Exception as e:                                         # timeout / crash: report it, keep the GPU line
-        return {"value": None, "unit": "Mtexels/s", "cores": 0, "kind": "port",
-                "sample": "CPU oracle leg did not finish: %s" % type(e).__name__}
+    ps = [subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, env=env, cwd=ROOT) for _ in range(procs)]
+    recs = []
+    deadline = time.time() + 170
+    for p_ in ps:
+        try:
+            out, _ = p_.communicate(timeout=max(1.0, deadline - time.time()))
+            lines = [l for l in out.decode().splitlines() if l.startswith('{')]
+            recs.append(json.loads(lines[-1]))
+        except Exception:                                          # timeout / crash of one worker: drop it, keep the rest
+            p_.kill()
+    if not recs:
+        return {"value": None, "unit": "Mtexels/s", "cores": 0, "kind": "port", "sample": "CPU oracle leg did not finish"}
+    return {"value": round(sum(r["value"] for r in recs), 3), "unit": "Mtexels/s", "cores": per * len(recs), "kind": "port",
+            "processes": len(recs), "threads_per_process": per, "value_one_process": recs[0]["value"],
+            "sample": recs[0]["sample"] + "; %d such processes ran concurrently (one frame each), texels/s summed" % len(recs)}
 
 
-def bench_train(args, device, world, rank, n_steps):
-    """BASELINE config 4 per GPU: 4 frames, 1024^2 UV, k=1, loss l2, Keras Adam-AMSGrad, ONE RCCL
-    all-reduce(sum) of the flat fp32 gradient bucket per step.  Reported beside the headline."""
+def bench_train(args, device, world, rank, n_steps, loss):
+    """BASELINE config 4 per GPU: 4 frames, 1024^2 UV, k=1, Keras Adam-AMSGrad, ONE RCCL all-reduce(sum) of the flat
+    fp32 gradient bucket per step; batches rotate through `Dataset.load_batch`'s staging ring.  Reported beside the
+    headline, one line per loss (the released configs train with `barron`)."""
     import torch
     import torch.distributed as dist
-    import nlt_amd
     from nlt_amd import trainvali
     from nlt_amd.models import get_model_class
-    cfg = nlt_amd.make_config(depth=args.depth, uvh=args.uv, uvw=args.uv, imh=args.cam, imw=args.cam,
-                              loss=args.train_loss, lr=1e-3)
+    cfg, ds, id_lists = make_loader(args, device, 1, 'train', seed=200 + rank, loss=loss)
     model = get_model_class('nlt')(cfg).build(device)
     model.register_trainable()
     g = torch.Generator(device=device).manual_seed(4321)
@@ -163,57 +228,66 @@ def bench_train(args, device, world, rank, n_steps):
         for c in model._conv_layers():
             c.bias.uniform_(-0.1, 0.1, generator=g)
     opt = trainvali.make_optimizer(model, cfg)
-    batch = synth_device_batch(args.frames, args.uv, args.cam, 1, device, seed=200 + rank)
+    batches = [ds.load_batch(ids) for ids in id_lists]                 # one ring slot each: resident, distinct addresses
     gbs = world * args.frames
     tune_train = args.tune_cache + '.train' if args.tune_cache else None
     if tune_train and os.path.exists(tune_train):
         model.plan.load_tuning(tune_train)                           # the train plan's own tile choices (k = 1, keeps activations)
     step = trainvali.GraphedTrainStep(model, opt, gbs) if args.train_graph else trainvali.distributed_train_step
-    run = (lambda: step(batch)) if args.train_graph else (lambda: step(model, batch, opt, gbs))
-    for _ in range(4):                                               # eager warm-ups (autotune), then the graph capture
-        run()
+    run = (lambda b: step(b)) if args.train_graph else (lambda b: step(model, b, opt, gbs))
+    for i in range(4 * len(batches)):                                # eager warm-ups (autotune, tapes of every batch), graph capture
+        run(batches[i % len(batches)])
     if tune_train and not os.path.exists(tune_train) and rank == 0:
         model.plan.save_tuning(tune_train)
-    if args.train_graph and step.static_batch() is not None:
-        batch = step.static_batch()                                  # synthetic data resident in the graph's input buffers
     if args.per_op_train and rank == 0:
         from nlt_amd.engine import OpTimer
         timer = OpTimer()
         model.plan.timer = timer
-        for _ in range(3):
-            trainvali.distributed_train_step(model, batch, opt, gbs)
+        for i in range(3):
+            trainvali.distributed_train_step(model, batches[i % len(batches)], opt, gbs)
         rec = timer.collect()
         model.plan.timer = None
-        table = sorted(((r[1] / r[0], l, r[2]) for l, r in rec.items()), reverse=True)
+        table = sorted(((r[1] / r[0], l, timer.moved.get(l, r[2])) for l, r in rec.items()), reverse=True)
         tot = sum(t for t, _, _ in table)
-        sys.stderr.write("train step, plan launches only (loss / warp backward / Adam / all-reduce are outside the plan)\n")
+        sys.stderr.write("train step (%s), plan launches only (loss / warp backward / Adam / all-reduce are outside the plan); "
+                         "GB/s = bytes the launch itself moves\n" % loss)
         for t, l, nb in table[:60]:
             sys.stderr.write("%-22s %10.4f %6.1f%% %10.1f GB/s\n" % (l, t, 100 * t / tot, nb / t / 1e6))
         sys.stderr.write("sum of plan launches %.3f ms (%d launches)\n" % (tot, len(table)))
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(n_steps):
-        loss, _ = run()
-    enq = time.perf_counter() - t0                                   # host enqueue time (the GPU may still be running)
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    el = time.perf_counter() - t0
-    if world > 1:
-        te = torch.tensor([el], device=device, dtype=torch.float64)
-        dist.all_reduce(te, op=dist.ReduceOp.MAX)
-        el = float(te.item())
-    return {"value": round(world * args.frames * args.uv * args.uv * n_steps / el / 1e6, 2), "unit": "Mtexels/s",
-            "ms_per_step": round(1e3 * el / n_steps, 3), "host_enqueue_ms_per_step": round(1e3 * enq / n_steps, 3),
-            "steps": n_steps, "global_batch": gbs,
+    replays0 = model.plan.tape_replays
+
+    def timed(same_batch):
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(n_steps):
+            loss_v, _ = run(batches[0 if same_batch else i % len(batches)])
+        enq = time.perf_counter() - t0                               # host enqueue time (the GPU may still be running)
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        el = time.perf_counter() - t0
+        if world > 1:
+            te = torch.tensor([el], device=device, dtype=torch.float64)
+            dist.all_reduce(te, op=dist.ReduceOp.MAX)
+            el = float(te.item())
+        return el, enq, float(loss_v)
+    el, enq, last = timed(False)
+    replays = model.plan.tape_replays - replays0
+    el_same, _, _ = timed(True)
+    return {"loss": loss, "value": round(world * args.frames * args.uv * args.uv * n_steps / el / 1e6, 2), "unit": "Mtexels/s",
+            "ms_per_step": round(1e3 * el / n_steps, 3), "ms_per_step_same_batch_every_step": round(1e3 * el_same / n_steps, 3),
+            "host_enqueue_ms_per_step": round(1e3 * enq / n_steps, 3),
+            "steps": n_steps, "global_batch": gbs, "distinct_batches_rotated": len(batches),
+            "launch_tape_replays": int(replays), "plan_passes": 2 * n_steps,
             "launch": ("eager" if not args.train_graph or step.graph is None else
                        "hipGraph replay of forward + loss + backward; all-reduce and Adam-AMSGrad eager"),
             "graph_error": step.failed if args.train_graph else None,
             "workload": "BASELINE config 4: %d frames/GPU, %d^2 UV, k=1, loss %s, Adam-AMSGrad, flat %d-float "
-                        "gradient bucket all-reduce" % (args.frames, args.uv, args.train_loss, model.flat_params.numel()),
-            "final_loss": float(loss)}
+                        "gradient bucket all-reduce; batches from Dataset.load_batch (uint8 store, staging ring)"
+                        % (args.frames, args.uv, loss, model.flat_params.numel()),
+            "final_loss": last}
 
 
 def main():
@@ -237,7 +311,7 @@ def main():
     from nlt_amd import capi
     from nlt_amd.engine import OpTimer
     from nlt_amd.models import get_model_class
-    cfg = nlt_amd.make_config(depth=args.depth, uvh=args.uv, uvw=args.uv, imh=args.cam, imw=args.cam)
+    cfg, ds, id_lists = make_loader(args, device, args.k, 'train', seed=100 + rank)
     model = get_model_class('nlt')(cfg).build(device)
     # random-init weights of the released architecture; non-zero biases so the bias path is live
     g = torch.Generator(device=device).manual_seed(1234)          # same weights on every rank
@@ -251,10 +325,14 @@ def main():
     model.use_graphs = bool(args.graph)
     if args.tune_cache and os.path.exists(args.tune_cache):
         model.plan.load_tuning(args.tune_cache)
-    batch = synth_device_batch(args.frames, args.uv, args.cam, args.k, device, seed=100 + rank)
+    # `--batches` different batches, assembled by Dataset.load_batch into its staging ring (one slot each): inputs are
+    # resident in HBM as the float32 11-tuple the reference's `_load_data` hands to Model.call
+    batches = [ds.load_batch(ids) for ids in id_lists]
+    calls = [0]
 
     def step():
-        return model.call(batch, 'test')
+        calls[0] += 1
+        return model.call(batches[calls[0] % len(batches)], 'test')
 
     # per-launch survey (outside the timed region) -> dominant kernel
     for _ in range(2):
@@ -309,10 +387,29 @@ def main():
     dom_bytes = timer.moved.get(dominant, dom_layerwise)      # a fused launch: the bytes it must itself move
     dom_flops = timer.flops.get(dominant, 0)
 
-    train = None
-    n_train = args.steps // 2 if args.train_steps < 0 else args.train_steps
-    if n_train > 0:
-        train = bench_train(args, device, world, rank, n_train)
+    # beside the headline: the same forward INCLUDING the loader, fed (a) the way the reference is (float32 batch assembled
+    # per step) and (b) store-resident (uint8 frame ids; the front kernel converts in registers)
+    with_loader = {}
+    if not args.graph and not args.headline_only:
+        n_l = max(10, min(args.steps, 50))
+        for name, resident in (("float32_batch_assembled_per_step", False), ("uint8_store_resident", True)):
+            for i in range(2 * len(id_lists)):
+                model.call(ds.load_batch(id_lists[i % len(id_lists)], resident=resident), 'test')
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for i in range(n_l):
+                model.call(ds.load_batch(id_lists[i % len(id_lists)], resident=resident), 'test')
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t1
+            with_loader[name] = {"ms_per_step": round(1e3 * dt / n_l, 4),
+                                 "Mtexels_per_s_per_gpu": round(args.frames * args.uv * args.uv * n_l / dt / 1e6, 1)}
+    fwd_replays = int(model.plan.tape_replays)
+
+    train = []
+    n_train = max(50, args.steps // 2) if args.train_steps < 0 else args.train_steps
+    if n_train > 0 and not args.headline_only:
+        for loss in args.train_loss.split(','):
+            train.append(bench_train(args, device, world, rank, n_train, loss))
 
     if rank == 0:
         texels = world * args.frames * args.uv * args.uv * args.steps
@@ -343,15 +440,19 @@ def main():
                        "frames_per_gpu": args.frames, "uv": args.uv, "k": args.k, "cam": args.cam,
                        "conv_algo": args.algo, "plan": "layer-by-layer" if args.no_fused else "fused ends",
                        "launch": "hipGraph replay" if args.graph else "eager, two HIP streams",
-                       "launch_tape_replays": int(model.plan.tape_replays), "parallelism": "dp%d (frames sharded, no forward collective)" % world},
+                       "distinct_batches_rotated": len(batches), "batch_source": "Dataset.load_batch (uint8 store -> float32 11-tuple, staging ring)",
+                       "launch_tape_replays": fwd_replays, "parallelism": "dp%d (frames sharded, no forward collective)" % world,
+                       "world": world, "dist_world_size": dist.get_world_size() if world > 1 else 1, "device": str(device)},
             "roofline": roof,
-            "roofline_whole_pass": {"algorithmic_bytes_per_texel": bpt,
-                                    "achieved": round(value / world * 1e6 * bpt / 1e9, 1), "unit": "GB/s per GPU",
-                                    "frac": round(value / world * 1e6 * bpt / 1e9 / HBM_PEAK_GBS, 4)},
+            "whole_pass": whole_pass(args, timer, elapsed / args.steps, bpt),
         }
-        if train is not None:
-            out["train_step"] = train
-        if world == 1 and not args.no_cpu_baseline:
+        if with_loader:
+            out["forward_including_loader"] = with_loader
+        if train:
+            out["train_step"] = train[0]
+            if len(train) > 1:
+                out["train_step_other_losses"] = train[1:]
+        if world == 1 and not args.no_cpu_baseline and not args.headline_only:
             out["cpu_baseline"] = cpu_baseline(args)
         print(json.dumps(out), flush=True)
     if world > 1:

@@ -148,5 +148,5 @@ def test_model_call_on_a_store_resident_batch_equals_the_eager_float_batch():
         loss.backward()
         torch.cuda.synchronize()
         grads.append((float(loss.detach()), pm.flat_params.grad.clone()))
-    assert grads[0][0] == grads[1][0]
+    assert abs(grads[0][0] - grads[1][0]) <= 1e-6 * abs(grads[0][0])          # (the loss reductions use float atomics)
     assert float((grads[0][1] - grads[1][1]).abs().max()) <= 1e-6 * float(grads[0][1].abs().max())   # (atomics in the warp adjoint)

@@ -97,7 +97,8 @@ def _labels(pm, db, mode):
 @pytest.mark.parametrize('depth,uv,k,n', [(256, 64, 1, 2), (256, 64, 2, 2), (256, 64, 4, 1), (256, 128, 3, 1), (1024, 256, 1, 1),
                                           (256, 64, 5, 1)])
 def test_model_call_with_fused_ends_vs_oracle(depth, uv, k, n):
-    # k <= 4: the front kernel also runs level 2's stride-2 convs; the (256, 64, 5, 1) case below takes the plain front
+    # the front kernel (csrc/front4.hip, any k) also runs level 2's stride-2 convs; with the first-generation kernel
+    # (plan.front_v4 = False) k = 5 takes the plain front and launches them separately -- both are checked for k = 5
     om, pm = make_pair(depth=depth, uv=uv, im=uv // 2, seed=depth + k)
     batch, nn = O.synth_batch(n, uv, uv, uv // 2, uv // 2, uv // 2, uv // 2, k=k, seed=20 + k)
     with torch.no_grad():
@@ -106,9 +107,16 @@ def test_model_call_with_fused_ends_vs_oracle(depth, uv, k, n):
     (p_pred_c, p_gt_c, _, p_vis), labels = _labels(pm, db, 'vali')
     torch.cuda.synchronize()
     assert 'F.front' in labels and 'F.back' in labels and 'L0.stem' not in labels
-    assert ('L2.o.s2' in labels) == (k > 4) and ('L2.q.s2' in labels) == (k > 4) and 'L2.o.s1' in labels
+    assert 'L2.o.s2' not in labels and 'L2.q.s2' not in labels and 'L2.o.s1' in labels
     assert rel_l2(p_vis['pred'].cpu(), o_vis['pred']) <= TOL
     assert rel_l2(p_pred_c.cpu(), o_pred_c) <= TOL and rel_l2(p_gt_c.cpu(), o_gt_c) <= 1e-6
+    if k > 4:
+        pm.plan.front_v4 = False
+        pm.plan._drop_tapes()
+        (g1_pred_c, _, _, g1_vis), labels = _labels(pm, db, 'vali')
+        assert 'L2.o.s2' in labels and 'L2.q.s2' in labels and 'F.front' in labels
+        assert rel_l2(g1_vis['pred'].cpu(), o_vis['pred']) <= TOL
+        pm.plan.front_v4 = True
     pm.plan.fuse_ends = False
     (u_pred_c, _, _, u_vis), labels = _labels(pm, db, 'vali')
     assert 'L0.stem' in labels and 'F.front' not in labels

@@ -48,8 +48,14 @@ def main():
             rec['write_bytes_reported'] = c['WRITE_SIZE']['avg'] * 1024
             rec['hbm_bytes'] = rec['fetch_bytes_corrected'] + rec['write_bytes_reported']
         kernels[name[:200]] = rec
+    # whole forward step: every kernel of the profiled command, per forward step (= launches of the front kernel; the
+    # profiled command loads its tile choices from a cache, so no plan-time trial launches are in the trace)
+    steps = max([rec['counters']['FETCH_SIZE']['calls'] for name, rec in kernels.items()
+                 if ('front4_kernel' in name or 'front_kernel' in name) and 'FETCH_SIZE' in rec['counters']] or [0])
+    total = sum(rec['hbm_bytes'] * rec['counters']['FETCH_SIZE']['calls'] for rec in kernels.values() if 'hbm_bytes' in rec)
     with open(out_path, 'w') as f:
-        json.dump({'note': 'FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 reports 1/2 of wide coalesced reads); '
+        json.dump({'forward_steps_profiled': steps, 'hbm_bytes_per_forward_step': total / steps if steps else None,
+                   'note': 'FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 reports 1/2 of wide coalesced reads); '
                            'WRITE_SIZE as reported (uncalibrated); KiB -> bytes', 'kernels': kernels}, f, indent=1)
     for name, rec in sorted(kernels.items(), key=lambda kv: -kv[1].get('hbm_bytes', 0))[:12]:
         print('%-60s %s' % (name[:60], {k: round(v / 1e6, 2) for k, v in rec.items() if k.endswith('bytes') or k.endswith('corrected') or k.endswith('reported')}))
