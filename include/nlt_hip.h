@@ -224,6 +224,12 @@ int nlt_barron_loss(const float* pred, const float* gt, int n, int h, int w, flo
 /* out[f,:] = x[f,:] * scale[f] */
 int nlt_scale_rows(const float* x, const float* scale, int n, long per_row, float* out, void* stream);
 
+/* Keras `clipnorm` (config key mgm > 0): every variable's gradient g -> g * clip / max(||g||_2, clip)
+ * (tf.clip_by_norm, multiply then divide), in place, over the slots of the flat gradient bucket.
+ * slots: device int64 [n_slots][2] = (first element, element count) of each kernel / bias.
+ *   replaces: tf.keras.optimizers.Adam(clipnorm=mgm) (nlt/trainvali.py:122-127). */
+int nlt_clip_by_norm_slots(float* grad, const long* slots, int n_slots, float clipnorm, void* stream);
+
 /* One fused Keras Adam(amsgrad=True) step over a flat parameter bucket (TF 2.2 OptimizerV2:
  * p -= lr_t * m / (sqrt(vhat) + eps), lr_t = lr*sqrt(1-b2^t)/(1-b1^t) computed by the caller).
  *   replaces: optimizer.apply_gradients (nlt/trainvali.py:124-127,280). */

@@ -57,6 +57,7 @@ SIGNATURES = {
     'nlt_barron_workspace_floats': (_c_long, [_c_int] * 3),
     'nlt_barron_loss': (_c_int, [_vp, _vp, _c_int, _c_int, _c_int, _vp, _vp, _vp, _vp]),
     'nlt_scale_rows': (_c_int, [_vp, _vp, _c_int, _c_long, _vp, _vp]),
+    'nlt_clip_by_norm_slots': (_c_int, [_vp, _vp, _c_int, _c_float, _vp]),
     'nlt_adam_amsgrad_step': (_c_int, [_vp] * 5 + [_c_long] + [_c_float] * 4 + [_vp]),
     'nlt_front_packed_floats': (_c_long, []),
     'nlt_front_pack_weights': (_c_int, [_vp] * 15 + [_vp]),
@@ -294,7 +295,13 @@ def resize_bilinear_forward(x, oh, ow):
     return out
 
 
+def _same_shape(a, b, what):
+    if tuple(a.shape) != tuple(b.shape):
+        raise NLTError("%s: shapes differ, %s vs %s" % (what, tuple(a.shape), tuple(b.shape)))
+
+
 def mul_forward(a, b):
+    _same_shape(a, b, 'mul_forward')
     out = torch.empty_like(a)
     _check(lib().nlt_mul_forward(_ptr(_dense(a, 'a')), _ptr(_dense(b, 'b')), a.numel(), _ptr(out), _stream()),
            'nlt_mul_forward')
@@ -390,6 +397,7 @@ def resize_bilinear_backward(dout, h, w):
 
 
 def l2_loss_forward(pred, gt):
+    _same_shape(pred, gt, 'l2_loss_forward')
     n = pred.shape[0]
     loss = torch.empty(n, device=pred.device, dtype=torch.float32)
     _check(lib().nlt_l2_loss_forward(_ptr(_dense(pred, 'pred')), _ptr(_dense(gt, 'gt')), n, pred[0].numel(),
@@ -398,6 +406,9 @@ def l2_loss_forward(pred, gt):
 
 
 def l2_loss_backward(pred, gt, gloss):
+    _same_shape(pred, gt, 'l2_loss_backward')
+    if gloss.numel() != pred.shape[0]:
+        raise NLTError("l2_loss_backward: %d loss gradients for %d examples" % (gloss.numel(), pred.shape[0]))
     dpred = torch.empty_like(pred)
     _check(lib().nlt_l2_loss_backward(_ptr(pred), _ptr(gt), _ptr(_dense(gloss, 'gloss')), pred.shape[0],
                                       pred[0].numel(), _ptr(dpred), _stream()), 'nlt_l2_loss_backward')
@@ -405,6 +416,7 @@ def l2_loss_backward(pred, gt, gloss):
 
 
 def barron_loss(pred, gt, want_grad):
+    _same_shape(pred, gt, 'barron_loss')
     n, h, w, c = pred.shape
     assert c == 3
     nws = lib().nlt_barron_workspace_floats(n, h, w)
@@ -419,10 +431,18 @@ def barron_loss(pred, gt, want_grad):
 
 
 def scale_rows(x, scale):
+    if scale.numel() != x.shape[0]:
+        raise NLTError("scale_rows: %d scales for %d rows" % (scale.numel(), x.shape[0]))
     out = torch.empty_like(x)
     _check(lib().nlt_scale_rows(_ptr(_dense(x, 'x')), _ptr(_dense(scale, 'scale')), x.shape[0], x[0].numel(),
                                 _ptr(out), _stream()), 'nlt_scale_rows')
     return out
+
+
+def clip_by_norm_slots(grad, slots, clipnorm):
+    """grad: flat fp32 bucket; slots: int64 [n,2] (offset, count) on the same device; in place."""
+    _check(lib().nlt_clip_by_norm_slots(_ptr(grad), _tptr(slots, torch.int64, 'slots'), slots.shape[0], float(clipnorm),
+                                        _stream()), 'nlt_clip_by_norm_slots')
 
 
 def adam_amsgrad_step(param, grad, m, v, vhat, lr_t, beta1, beta2, eps):

@@ -213,12 +213,18 @@ _KEY = re.compile(r'^net/net_(query|obs)_layer(\d+)/(?:layer_with_weights-(\d+)/
 def reference_weights(prefix, verify=True):
     """Checkpoint -> {'query': [[(kernel, bias), ...] per layer], 'obs': [...]} as `Model.load_weights` takes it
     (Keras layouts: Conv2D (kh,kw,Cin,Cout), Conv2DTranspose (kh,kw,Cout,Cin))."""
-    found = {}
+    found, other = {}, []
     for key, arr in read_bundle(prefix, verify).items():
         m = _KEY.match(key)
         if m:
             net, layer, conv, what = m.group(1), int(m.group(2)), int(m.group(3) or 0), m.group(4)
             found.setdefault(net, {}).setdefault(layer, {}).setdefault(conv, {})[what] = arr
+        elif key.startswith('net/') and key.endswith('/.ATTRIBUTES/VARIABLE_VALUE') and '/.OPTIMIZER_SLOT/' not in key:
+            other.append(key)
+    if other:
+        # norm layers (gamma / beta / moving_*) would shift the layer_with_weights-N numbering: refuse instead of misaligning
+        raise NotImplementedError("%s: the checkpoint holds network variables that are not conv kernels / biases (%s%s); only "
+                                  "the norm = None branch can be imported" % (prefix, other[0], ', ...' if len(other) > 1 else ''))
     if 'query' not in found:
         raise ValueError("%s: no net/net_query_layer*/... variables (is this an NLT checkpoint?)" % prefix)
     out = {}
@@ -228,6 +234,10 @@ def reference_weights(prefix, verify=True):
             convs = layers.get(li)
             if convs is None:
                 raise ValueError("%s: %s layer %d has no variables" % (prefix, net, li))
+            for c in sorted(convs):
+                missing = [w for w in ('kernel', 'bias') if w not in convs[c]]
+                if missing:
+                    raise ValueError("%s: net_%s_layer%d (conv %d) has no %s variable" % (prefix, net, li, c, ' / '.join(missing)))
             out[net].append([(convs[c]['kernel'], convs[c]['bias']) for c in sorted(convs)])
     out.setdefault('obs', [])
     return out

@@ -259,7 +259,34 @@ __global__ __launch_bounds__(256) void adam_amsgrad_kernel(float* __restrict__ p
   p[i] -= lr_t * mi / (sqrtf(vh) + eps);
 }
 
+// Keras `clipnorm` = tf.clip_by_norm per variable: t * clip / max(||t||_2, clip), evaluated in that order (multiply, then
+// divide -- also when nothing is clipped).  One workgroup per slot of the flat gradient bucket; the sum of squares is
+// reduced in a fixed order (lane-strided partial sums, then a tree), so the result is deterministic.
+__global__ __launch_bounds__(256) void clip_slots_kernel(float* __restrict__ g, const long* __restrict__ slots, float clip) {
+  __shared__ float part[256];
+  const long off = slots[2 * blockIdx.x], cnt = slots[2 * blockIdx.x + 1];
+  float s = 0.f;
+  for (long i = threadIdx.x; i < cnt; i += 256) { const float v = g[off + i]; s = fmaf(v, v, s); }
+  part[threadIdx.x] = s;
+  __syncthreads();
+  for (int w = 128; w > 0; w >>= 1) {
+    if ((int)threadIdx.x < w) part[threadIdx.x] += part[threadIdx.x + w];
+    __syncthreads();
+  }
+  const float l2 = part[0];
+  const float norm = l2 > 0.f ? sqrtf(l2) : l2;
+  const float den = fmaxf(norm, clip);
+  for (long i = threadIdx.x; i < cnt; i += 256) g[off + i] = (g[off + i] * clip) / den;
+}
+
 }  // namespace
+
+extern "C" int nlt_clip_by_norm_slots(float* grad, const long* slots, int n_slots, float clipnorm, void* stream) {
+  if (!grad || !slots || n_slots <= 0 || !(clipnorm > 0.f)) return NLT_ERR_BAD_ARG;
+  hipLaunchKernelGGL(clip_slots_kernel, dim3(n_slots), dim3(256), 0, static_cast<hipStream_t>(stream), grad, slots, clipnorm);
+  NLT_CHECK_LAUNCH();
+  return NLT_OK;
+}
 
 extern "C" int nlt_lrelu_backward(const float* g, int ldg, const float* y, int ldy, int c, long texels, float alpha,
                                   float* out, int ldo, void* stream) {

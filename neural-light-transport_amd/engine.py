@@ -70,6 +70,7 @@ class RenderPlan:
         # launch tape: replay a step's C calls with their resolved arguments instead of re-deriving them (see _capi.py)
         self.use_tape = os.environ.get('NLT_TAPE', '1') != '0'
         self._tuning = False
+        self.generation = 0             # bumped by every forward: the activations in the plan's buffers belong to that pass
         self.tape_replays = 0
         self._trial_direct = False
         self._ran_direct = set()
@@ -335,6 +336,8 @@ class RenderPlan:
         k = nn_rgb.shape[1]
         dev = base.device
         b = self._buffers(n, k, h, w, dev)
+        if not self._tuning:
+            self.generation += 1
         reg = getattr(self.q.layers[0], '_registry', None)
         if reg is not None:
             reg.refresh_if_stale()          # all packed fragments, one launch, before any stream is forked
@@ -386,6 +389,8 @@ class RenderPlan:
         n, k, h, w = res.n, res.k, res.h, res.w
         dev = res.cvis.device
         b = self._buffers(n, k, h, w, dev)
+        if not self._tuning:
+            self.generation += 1
         reg = getattr(self.q.layers[0], '_registry', None)
         if reg is not None:
             reg.refresh_if_stale()
@@ -442,7 +447,7 @@ class RenderPlan:
                          o0.bias.detach(), b['fm'][0], b['obs'][0])
         else:
             # no observation path to run (use_obs = False, or its features are given): query L0 alone
-            x5 = torch.cat((base, cvis, lvis), 3)
+            x5 = b['x5'] = torch.cat((base, cvis, lvis), 3)              # (kept: the L0 weight gradient reads it)
             self._conv('L0.q', q0, None, x5, 5, 5, None, 0, 0, n, h, w, b['fm'][0], mult * cl[0], algo)
             if self.use_obs:
                 b['fm'][0][..., cl[0]:].copy_(obs_override[0].expand(n, -1, -1, -1))
@@ -660,12 +665,17 @@ class RenderPlan:
                      zero_bias, hi - lo, out, ldo, act=False, alpha=mask_alpha, algo=C.ALGO_MFMA,
                      mask_src=mask_src, ldm=ldm, accumulate=accumulate)
 
-    def backward(self, dpred, base, cvis, lvis, nn_rgb, nn_base, obs_weights=None):
+    def backward(self, dpred, base, cvis, lvis, nn_rgb, nn_base, obs_weights=None, generation=None):
         """Gradient of everything `forward` computed, given dpred = dL/d(pred) [N,H,W,3]; uses the
         activations the last forward left in the plan's buffers.  Weight gradients are ACCUMULATED
-        into each layer's dkernel / dbias (views of the model's flat gradient bucket: zero it first)."""
-        if not self.use_obs:
-            raise NotImplementedError("training with use_obs = False")
+        into each layer's dkernel / dbias (views of the model's flat gradient bucket: zero it first).
+        generation: `plan.generation` right after the forward this backward belongs to -- the plan keeps ONE set of
+        activations, so a backward after any other forward (a second micro-batch, a vali / test call) would silently
+        pair this pass's inputs with that pass's activations; it raises instead."""
+        if generation is not None and generation != self.generation:
+            raise RuntimeError("backward() of a forward pass whose activations have been overwritten by a later forward "
+                               "(pass %d, the plan now holds pass %d): run each backward before the next forward"
+                               % (generation, self.generation))
         n, h, w, _ = base.shape
         k = nn_rgb.shape[1]
         b = self._buffers(n, k, h, w, base.device)
@@ -720,12 +730,13 @@ class RenderPlan:
     def _backward_plan(self, dpred, base, cvis, lvis, nn_rgb, nn_base, obs_weights, b, g, n, h, w, k):
         q, o, D, U, cl = self.q, self.o, self.n_down, self.n_up, b['C']
         zb = g['zero_bias']
+        mult = 2 if self.use_obs else 1         # use_obs = False (nlt.py:176-177): no observation half in any fm[l]
 
         # ---- head
         head = q.layers[-1]
         x_last = b['dec'][U - 1]
         cx = x_last.shape[-1]
-        cs = 2 * cl[0]
+        cs = mult * cl[0]
         fused = bool(b.get('train_fused'))
         if fused:
             # last expanding block + head in one launch (csrc/train_back.hip); the head's skip rows are F.front.bwd's
@@ -759,9 +770,9 @@ class RenderPlan:
                 x, cxj = b['dec'][j - 1], b['dec'][j - 1].shape[-1]
                 dx = g['dec'][j - 1]
             else:
-                x, cxj = b['fm'][D], 2 * cl[D]
+                x, cxj = b['fm'][D], mult * cl[D]
                 dx = g['fm'][D]
-            skip, csj, dskip = b['fm'][D - j], 2 * cl[D - j], g['fm'][D - j]
+            skip, csj, dskip = b['fm'][D - j], mult * cl[D - j], g['fm'][D - j]
             self._wgrad(lab + '.s2.wgrad', da, x, cxj, cxj, skip, csj, csj, n, hh // 2, ww // 2, g['dtmp'][j], nl)
             if j > 0:
                 # dx = gradient w.r.t. dec[j-1], whose own LeakyReLU derivative is applied in this launch's epilogue
@@ -782,29 +793,31 @@ class RenderPlan:
             c, cp = cl[l], cl[l - 1]
             lab = 'bwd.L%d' % l
             # query half of dfm[l] -> gradient w.r.t. the pre-activation of q.s1
-            self._launch(lab + '.q.s1.act', 12 * n * hh * ww * c, C.lrelu_backward, g['fm'][l], 2 * c, b['fm'][l], 2 * c,
-                         c, n * hh * ww, qact_b.alpha, g['fm'][l], 2 * c)
-            # observation half: distribute the mean's gradient, add the obs path's own, activation backward
-            self._launch(lab + '.o.mean', 4 * n * hh * ww * c * (1 + 3 * k), C.obs_mean_backward,
-                         g['fm'][l].view(-1)[c:], 2 * c, b['obs'][l], obs_weights, g['obs'][l] if l < D else None,
-                         n, k, hh * ww, c, oact_b.alpha, g['obs'][l])
+            self._launch(lab + '.q.s1.act', 12 * n * hh * ww * c, C.lrelu_backward, g['fm'][l], mult * c, b['fm'][l], mult * c,
+                         c, n * hh * ww, qact_b.alpha, g['fm'][l], mult * c)
+            if self.use_obs:
+                # observation half: distribute the mean's gradient, add the obs path's own, activation backward
+                self._launch(lab + '.o.mean', 4 * n * hh * ww * c * (1 + 3 * k), C.obs_mean_backward,
+                             g['fm'][l].view(-1)[c:], 2 * c, b['obs'][l], obs_weights, g['obs'][l] if l < D else None,
+                             n, k, hh * ww, c, oact_b.alpha, g['obs'][l])
             # q.s1 / q.s2
-            self._wgrad(lab + '.q.s1.wgrad', qb, b['qtmp'][l], c, c, None, 0, 0, n, hh, ww, g['fm'][l], 2 * c)
-            self._dgrad(lab + '.q.s1.dgrad', qb, 0, c, g['fm'][l], 2 * c, n, hh, ww, g['qtmp'][l], c,
+            self._wgrad(lab + '.q.s1.wgrad', qb, b['qtmp'][l], c, c, None, 0, 0, n, hh, ww, g['fm'][l], mult * c)
+            self._dgrad(lab + '.q.s1.dgrad', qb, 0, c, g['fm'][l], mult * c, n, hh, ww, g['qtmp'][l], c,
                         mask_src=b['qtmp'][l], ldm=c, mask_alpha=qact_a.alpha, zero_bias=zb)
             if not (fused and l == 1):
-                self._wgrad(lab + '.q.s2.wgrad', qa, b['fm'][l - 1], 2 * cp, 2 * cp, None, 0, 0, n, 2 * hh, 2 * ww,
+                self._wgrad(lab + '.q.s2.wgrad', qa, b['fm'][l - 1], mult * cp, mult * cp, None, 0, 0, n, 2 * hh, 2 * ww,
                             g['qtmp'][l], c)
-                self._dgrad(lab + '.q.s2.dgrad', qa, 0, 2 * cp, g['qtmp'][l], c, n, hh, ww, g['fm'][l - 1], 2 * cp,
+                self._dgrad(lab + '.q.s2.dgrad', qa, 0, mult * cp, g['qtmp'][l], c, n, hh, ww, g['fm'][l - 1], mult * cp,
                             accumulate=True, zero_bias=zb)
-            # o.s1 / o.s2 (n*k observation frames)
-            self._wgrad(lab + '.o.s1.wgrad', ob, b['otmp'][l], c, c, None, 0, 0, n * k, hh, ww, g['obs'][l], c)
-            self._dgrad(lab + '.o.s1.dgrad', ob, 0, c, g['obs'][l], c, n * k, hh, ww, g['otmp'][l], c,
-                        mask_src=b['otmp'][l], ldm=c, mask_alpha=oact_a.alpha, zero_bias=zb)
-            if not (fused and l == 1):
-                self._wgrad(lab + '.o.s2.wgrad', oa, b['obs'][l - 1], cp, cp, None, 0, 0, n * k, 2 * hh, 2 * ww,
-                            g['otmp'][l], c)
-                self._dgrad(lab + '.o.s2.dgrad', oa, 0, cp, g['otmp'][l], c, n * k, hh, ww, g['obs'][l - 1], cp, zero_bias=zb)
+            if self.use_obs:
+                # o.s1 / o.s2 (n*k observation frames)
+                self._wgrad(lab + '.o.s1.wgrad', ob, b['otmp'][l], c, c, None, 0, 0, n * k, hh, ww, g['obs'][l], c)
+                self._dgrad(lab + '.o.s1.dgrad', ob, 0, c, g['obs'][l], c, n * k, hh, ww, g['otmp'][l], c,
+                            mask_src=b['otmp'][l], ldm=c, mask_alpha=oact_a.alpha, zero_bias=zb)
+                if not (fused and l == 1):
+                    self._wgrad(lab + '.o.s2.wgrad', oa, b['obs'][l - 1], cp, cp, None, 0, 0, n * k, 2 * hh, 2 * ww,
+                                g['otmp'][l], c)
+                    self._dgrad(lab + '.o.s2.dgrad', oa, 0, cp, g['otmp'][l], c, n * k, hh, ww, g['obs'][l - 1], cp, zero_bias=zb)
             hh, ww = hh * 2, ww * 2
 
         # ---- L0 (both paths)
@@ -817,6 +830,11 @@ class RenderPlan:
                          C.front_backward, base, cvis, lvis, nn_rgb, nn_base, n, k, h, w, g['qtmp'][1], g['otmp'][1], dpred,
                          (D_(q0.kernel), D_(q0.bias), D_(o0.kernel), D_(o0.bias), D_(qa.kernel), D_(oa.kernel), D_(head.kernel)),
                          (q0.dkernel, q0.dbias, o0.dkernel, o0.dbias, qa.dkernel, qa.dbias, oa.dkernel, oa.dbias, head.dkernel))
+            return
+        if not self.use_obs:
+            # query L0 alone (the observation net is evaluated by the reference but feeds nothing: its gradients stay zero)
+            self._launch('bwd.L0.q', 4 * n * h * w * (5 + cl[0]), C.conv_backward_weights, C.CONV1X1, b['x5'], 5, 5, None, 0, 0,
+                         n, h, w, g['fm'][0], cl[0], cl[0], q0.dkernel, q0.dbias)
             return
         self._launch('bwd.L0.stem', 4 * n * h * w * (5 + 6 * k + 2 * cl[0] + k * cl[0]), C.stem_backward,
                      base, cvis, lvis, nn_rgb, nn_base, obs_weights, n, k, h, w, cl[0], g['fm'][0], g['obs'][0],

@@ -23,7 +23,7 @@ class _RenderFn(torch.autograd.Function):
     def forward(ctx, flat_params, model, inputs, want_indices):
         base, cvis, lvis, warp, nn_rgb, nn_base, obs_weights = inputs
         out = model._render(base, cvis, lvis, warp, nn_rgb, nn_base, obs_weights, None, want_indices, inference=False)
-        ctx.model, ctx.inputs = model, inputs
+        ctx.model, ctx.inputs, ctx.generation = model, inputs, model.plan.generation
         pred, pred_c, base_c, fg_c, idx = out
         nd = [t for t in (pred, base_c, fg_c) if t is not None]
         ctx.mark_non_differentiable(*nd)
@@ -35,7 +35,7 @@ class _RenderFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, d_pred_c, *unused):
-        ctx.model._render_backward(d_pred_c, ctx.inputs)
+        ctx.model._render_backward(d_pred_c, ctx.inputs, ctx.generation)
         return ctx.model.flat_grads, None, None, None
 
 
@@ -156,8 +156,39 @@ class Model(BaseModel):
             for layer, lw in zip(layers, weights[name]):
                 convs = [layer] if hasattr(layer, 'set_weights') else [c for c, _ in layer.convs()]
                 assert len(convs) == len(lw)
-                for c, (k, b) in zip(convs, lw):
+                for ci, (c, (k, b)) in enumerate(zip(convs, lw)):
+                    if c.built and (tuple(k.shape) != tuple(c.kernel.shape) or tuple(b.shape) != tuple(c.bias.shape)):
+                        raise ValueError("net_%s: layer %d conv %d expects kernel %s / bias %s, got %s / %s"
+                                         % (name, layers.index(layer), ci, tuple(c.kernel.shape), tuple(c.bias.shape),
+                                            tuple(k.shape), tuple(b.shape)))
                     c.set_weights(k, b)
+        return self
+
+    def get_weights(self):
+        """The inverse of `load_weights`: {'query': [[(kernel, bias), ...] per layer], 'obs': [...]} as NumPy arrays in
+        Keras layouts (what a TF checkpoint of the reference holds under net/net_<name>_layer<i>)."""
+        out = {}
+        for name in ('query', 'obs'):
+            out[name] = []
+            for layer in self.net[name].layers:
+                convs = [layer] if hasattr(layer, 'set_weights') else [c for c, _ in layer.convs()]
+                out[name].append([(c.kernel.detach().cpu().numpy().copy(), c.bias.detach().cpu().numpy().copy()) for c in convs])
+        return out
+
+    def state_dict(self):
+        """Everything `tf.train.Checkpoint(net=...)` tracks for this model (nlt/trainvali.py:134-141): the flat parameter
+        bucket and the slot table that maps it onto the layers (so a mismatching architecture is refused on load)."""
+        assert getattr(self, 'flat_params', None) is not None, "build() the model first"
+        slots = [(tuple(c.kernel.shape), tuple(c.bias.shape)) for c in self._conv_layers()]
+        return {'flat_params': self.flat_params.detach().clone(), 'slots': slots}
+
+    def load_state_dict(self, sd):
+        slots = [(tuple(c.kernel.shape), tuple(c.bias.shape)) for c in self._conv_layers()]
+        if [tuple(map(tuple, x)) for x in sd['slots']] != slots or sd['flat_params'].numel() != self.flat_params.numel():
+            raise ValueError("checkpoint was written by a different architecture (layer shapes differ)")
+        with torch.no_grad():
+            self.flat_params.copy_(sd['flat_params'])
+        self.mark_weights_updated()
         return self
 
     # ---------------------------------------------------------------- forward
@@ -182,7 +213,7 @@ class Model(BaseModel):
             pred_camspc = C.resize_bilinear_forward(pred_camspc, self.imh, self.imw)
         return pred, pred_camspc, base_camspc, fg_camspc, idx
 
-    def _render_backward(self, d_pred_c, inputs):
+    def _render_backward(self, d_pred_c, inputs, generation=None):
         """Fills the flat gradient bucket from dL/d(pred_camspc): resize / warp (TFA resampler) adjoints, then the
         hand-ordered backward plan over the activations the last inference=False forward left behind."""
         base, cvis, lvis, warp, nn_rgb, nn_base, obs_weights = inputs
@@ -196,7 +227,7 @@ class Model(BaseModel):
             if dpred is None or dpred.shape[0] != n or dpred.device != base.device:
                 dpred = self._dpred = torch.empty((n, self.uvh, self.uvw, 3), device=base.device, dtype=torch.float32)
             C.warp_backward(d_pred_c, warp, n, self.uvh, self.uvw, hc, wc, dpred)
-            self.plan.backward(dpred, base, cvis, lvis, nn_rgb, nn_base, obs_weights)
+            self.plan.backward(dpred, base, cvis, lvis, nn_rgb, nn_base, obs_weights, generation=generation)
 
     def train_forward_backward(self, batch, global_bs):
         """One train step's forward + loss + backward WITHOUT the torch.autograd tape around the network (only the loss
@@ -210,13 +241,14 @@ class Model(BaseModel):
         with torch.no_grad():
             pred, pred_camspc, base_camspc, fg_camspc, _ = self._render(base, cvis, lvis, warp, nn_rgb, nn_base, None, None,
                                                                         False, inference=False)
+            gen = self.plan.generation
             gt_camspc = C.mul_forward(rgb_camspc, fg_camspc)
         leaf = pred_camspc.detach().requires_grad_(True)
         with torch.enable_grad():
             loss = self.compute_loss(leaf, gt_camspc, keep_batch=True).sum() / global_bs
             (d_pred_c,) = torch.autograd.grad(loss, leaf)
         with torch.no_grad():
-            self._render_backward(d_pred_c, (base, cvis, lvis, warp, nn_rgb, nn_base, None))
+            self._render_backward(d_pred_c, (base, cvis, lvis, warp, nn_rgb, nn_base, None), gen)
             to_vis = {'id': id_, 'nn_id': nn_id, 'base_camspc': base_camspc, 'pred': pred.clone(), 'pred_camspc': pred_camspc,
                       'nn_camspc': nn_rgb_camspc, 'gt': rgb, 'gt_camspc': gt_camspc}
         return loss.detach(), to_vis

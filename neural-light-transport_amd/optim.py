@@ -9,8 +9,10 @@ from . import _capi as C
 
 class AdamAMSGrad:
     def __init__(self, model, lr, beta1=0.9, beta2=0.999, eps=1e-7, clipnorm=None):
-        if clipnorm is not None and clipnorm > 0:
-            raise NotImplementedError("clipnorm (mgm > 0); the released configs use mgm = -1")
+        # clipnorm (config key mgm > 0, nlt/trainvali.py:122-127): Keras' per-variable tf.clip_by_norm, applied here to the
+        # (all-reduced) gradient of every kernel / bias right before the Adam update.  The released configs use mgm = -1.
+        self.clipnorm = float(clipnorm) if clipnorm is not None and clipnorm > 0 else None
+        self._slots = None
         self.model, self.lr, self.b1, self.b2, self.eps = model, lr, beta1, beta2, eps
         self.t = 0
         z = lambda: torch.zeros_like(model.flat_params, requires_grad=False)
@@ -20,6 +22,12 @@ class AdamAMSGrad:
         """grad: flat gradient bucket (defaults to model.flat_params.grad, i.e. what backward() left)."""
         if grad is None:
             grad = self.model.flat_params.grad
+        if self.clipnorm is not None:
+            if self._slots is None:                      # (offset, count) of every variable inside the flat bucket
+                base = self.model.flat_grads.data_ptr()
+                rows = [((v.data_ptr() - base) // 4, v.numel()) for c in self.model._conv_layers() for v in (c.dkernel, c.dbias)]
+                self._slots = torch.tensor(rows, dtype=torch.int64, device=grad.device)
+            C.clip_by_norm_slots(grad, self._slots, self.clipnorm)
         self.t += 1
         lr_t = self.lr * math.sqrt(1.0 - self.b2 ** self.t) / (1.0 - self.b1 ** self.t)
         C.adam_amsgrad_step(self.model.flat_params.detach(), grad, self.m, self.v, self.vhat, lr_t, self.b1, self.b2,

@@ -15,6 +15,30 @@ def make_optimizer(model, config):
     return optim.AdamAMSGrad(model, lr, clipnorm=mgm if mgm > 0 else None)
 
 
+def save_checkpoint(path, model, optimizer, step):
+    """`tf.train.Checkpoint(step=, optimizer=, net=)` + `CheckpointManager.save` of the reference train loop
+    (nlt/trainvali.py:134-141,197): weights, Adam-AMSGrad slots (m, v, vhat) and iteration count, global step -- enough to
+    resume training bit for bit, and what `nlt_test`-style inference restores.  One torch.save file (tensors on CPU)."""
+    cpu = lambda d: {k: (v.detach().cpu() if torch.is_tensor(v) else v) for k, v in d.items()}
+    torch.save({'format': 'nlt_amd-ckpt-1', 'step': int(step), 'net': cpu(model.state_dict()),
+                'optimizer': cpu(optimizer.state_dict()) if optimizer is not None else None}, path)
+    return path
+
+
+def restore_checkpoint(path, model, optimizer=None):
+    """Loads what `save_checkpoint` wrote into a built model (and optimizer); returns the global step.  The optimizer may be
+    omitted (inference: nlt/nlt_test.py:92-97 restores the net alone)."""
+    ck = torch.load(path, map_location='cpu', weights_only=False)
+    if ck.get('format') != 'nlt_amd-ckpt-1':
+        raise ValueError("%s is not an nlt_amd checkpoint" % path)
+    model.load_state_dict(ck['net'])
+    if optimizer is not None:
+        if ck['optimizer'] is None:
+            raise ValueError("%s holds no optimizer state" % path)
+        optimizer.load_state_dict(ck['optimizer'])
+    return ck['step']
+
+
 def _world(group):
     return dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
 

@@ -265,14 +265,24 @@ class KerasAdamAMSGrad:
                 p.sub_(lr_t * m / (vh.sqrt() + self.eps))
 
 
-def train_step(model, opt, batch, global_bs, nn_list=None):
+def clip_by_norm(t, clip):
+    """tf.clip_by_norm (what Keras `clipnorm` applies per variable, nlt/trainvali.py:122-127): t * clip / max(||t||, clip),
+    multiply first, then divide; the norm of an all-zero tensor is taken as 0."""
+    l2 = (t * t).sum()
+    norm = torch.sqrt(l2) if float(l2) > 0 else l2
+    return (t * clip) / torch.maximum(norm, torch.as_tensor(clip, dtype=t.dtype))
+
+
+def train_step(model, opt, batch, global_bs, nn_list=None, clipnorm=None):
     """nlt/trainvali.py:272-281 on one replica: per-example loss -> sum/global_bs ->
-    grads -> Adam-AMSGrad.  Returns (weighted_loss, grads)."""
+    grads (-> per-variable clipnorm when mgm > 0) -> Adam-AMSGrad.  Returns (weighted_loss, grads as applied)."""
     pred, gt, kw, _ = model.call(batch, 'train', nn_list=nn_list)
     per_example = model.compute_loss(pred, gt, keep_batch=True)
     weighted = per_example.sum() / global_bs                 # tf.nn.compute_average_loss
     params = model.parameters()
     grads = torch.autograd.grad(weighted, params)
+    if clipnorm is not None and clipnorm > 0:
+        grads = tuple(clip_by_norm(g, clipnorm) for g in grads)
     opt.step(grads)
     return weighted.detach(), grads
 

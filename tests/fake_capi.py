@@ -6,6 +6,7 @@ import torch
 
 from nlt_amd import _capi as C
 from oracle import tf_ops as T
+from oracle import nlt_oracle as O
 
 _MODES = {C.CONV1X1: (1, False), C.CONV_K2S2: (2, False), C.CONV_K2S1: (1, False),
           C.DECONV_K2S2: (2, True), C.DECONV_K2S1: (1, True)}
@@ -201,6 +202,12 @@ def scale_rows(x, scale):
     return x * scale.view(-1, *([1] * (x.dim() - 1)))
 
 
+def clip_by_norm_slots(grad, slots, clipnorm):
+    for off, cnt in slots.tolist():
+        g = grad[off:off + cnt]
+        g.copy_(O.clip_by_norm(g.clone(), clipnorm))
+
+
 def adam_amsgrad_step(param, grad, m, v, vhat, lr_t, beta1, beta2, eps):
     with torch.no_grad():
         m.mul_(beta1).add_(grad, alpha=1 - beta1)
@@ -211,7 +218,7 @@ def adam_amsgrad_step(param, grad, m, v, vhat, lr_t, beta1, beta2, eps):
 
 _TRAIN = ('conv_backward_weights', 'lrelu_backward', 'obs_mean_backward', 'stem_backward', 'head_backward',
           'warp_backward', 'resize_bilinear_backward', 'l2_loss_forward', 'l2_loss_backward', 'barron_loss',
-          'scale_rows', 'adam_amsgrad_step')
+          'scale_rows', 'adam_amsgrad_step', 'clip_by_norm_slots')
 
 
 # ------------------------------------------------------------------ texel-buffer assembly (TEST-ONLY emulation)

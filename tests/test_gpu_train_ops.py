@@ -291,3 +291,32 @@ def test_adam_amsgrad_matches_keras_form():
         lr_t = 1e-2 * math.sqrt(1 - 0.999 ** t) / (1 - 0.9 ** t)
         C.adam_amsgrad_step(pd, d(g), m, v, vh, lr_t, 0.9, 0.999, 1e-7)
         np.testing.assert_allclose(pd.cpu().numpy(), p.detach().numpy(), atol=2e-6)
+
+
+def test_clip_by_norm_slots_matches_tf_clip_by_norm():
+    """Keras clipnorm (mgm > 0): per-slot t * clip / max(||t||, clip) over the flat gradient bucket, in place; slots that are
+    below the norm come back multiplied-then-divided (tf.clip_by_norm's op order), an all-zero slot stays zero."""
+    from oracle import nlt_oracle as O
+    g = torch.Generator(device='cuda').manual_seed(5)
+    sizes = [16, 5 * 16, 2 * 2 * 32 * 16, 3, 1024 * 1024 + 7, 64, 8]
+    offs, off = [], 0
+    for n in sizes:
+        offs.append((off, n)); off += (n + 3) // 4 * 4
+    flat = torch.randn(off, device='cuda', generator=g) * 1e-3
+    flat[offs[5][0]:offs[5][0] + 64] = 0                         # an all-zero tensor
+    flat[offs[2][0]:offs[2][0] + sizes[2]] *= 50                 # one far above the threshold
+    ref = flat.clone().cpu()
+    clip = 0.02
+    for o, n in offs:
+        ref[o:o + n] = O.clip_by_norm(ref[o:o + n].clone(), clip)
+    slots = torch.tensor(offs, dtype=torch.int64, device='cuda')
+    C.clip_by_norm_slots(flat, slots, clip)
+    torch.cuda.synchronize()
+    got = flat.cpu()
+    assert float((got - ref).abs().max()) <= 2e-6 * float(ref.abs().max())
+    for o, n in offs:
+        assert float(got[o:o + n].norm()) <= clip * (1 + 1e-5)
+    pad = torch.ones(off, dtype=torch.bool)
+    for o, n in offs:
+        pad[o:o + n] = False
+    assert torch.equal(got[pad], ref[pad])                       # padding between slots untouched

@@ -178,3 +178,48 @@ def test_full_size_gradient_agrees_with_directional_finite_differences(loss):
     with torch.no_grad():
         pm.flat_params.copy_(w0)
     pm.mark_weights_updated()
+
+
+def test_train_step_without_observation_path():
+    """use_obs = False (nlt/models/nlt.py:176-177) on the GPU: loss and every query-net gradient vs the oracle; the
+    observation net's gradients stay zero."""
+    om, pm = make_pair(depth=256, uv=64, im=32, loss='l2', seed=6, use_obs=False)
+    pm.build('cuda')
+    batch, nn = O.synth_batch(2, 64, 64, 32, 32, 32, 32, k=1, seed=51)
+    po, go_, _, _ = om.call(batch, 'train', nn_list=nn)
+    lo = om.compute_loss(po, go_, keep_batch=True).sum() / 2
+    grads = torch.autograd.grad(lo, om.parameters(), allow_unused=True)
+    pred, gt, kw, _ = pm(to_device_batch(batch, nn), mode='train')
+    lp = pm.compute_loss(pred, gt, keep_batch=True).sum() / 2
+    pm.flat_params.grad = None
+    lp.backward()
+    torch.cuda.synchronize()
+    assert abs(float(lp.detach()) - float(lo.detach())) <= 1e-5 * abs(float(lo.detach()))
+    it = iter(grads)
+    n_q = sum(len(lw) for lw in om.wq)
+    for i, c in enumerate(pm._conv_layers()):
+        for name in ('dkernel', 'dbias'):
+            g = next(it)
+            got = getattr(c, name).cpu()
+            if i < n_q:
+                assert float((got - g).norm()) <= TENSOR_TOL * float(g.norm()), (i, name)
+            else:
+                assert g is None and not got.any(), (i, name)
+
+
+def test_clipnorm_train_step_on_the_gpu():
+    """mgm > 0: three steps with Keras clipnorm against the oracle (tf.clip_by_norm per variable before Adam)."""
+    om, pm = make_pair(depth=256, uv=64, im=32, loss='l2', seed=8)
+    pm.build('cuda')
+    batch, nn = O.synth_batch(2, 64, 64, 32, 32, 32, 32, k=2, seed=52)
+    db = to_device_batch(batch, nn)
+    opt_o = O.KerasAdamAMSGrad(om.parameters(), 1e-3)
+    opt_p = nlt_amd.optim.AdamAMSGrad(pm, 1e-3, clipnorm=1e-3)
+    for step in range(3):
+        lo, go = O.train_step(om, opt_o, batch, global_bs=2, nn_list=nn, clipnorm=1e-3)
+        lp, _ = trainvali.distributed_train_step(pm, db, opt_p, global_bs=2)
+        torch.cuda.synchronize()
+        ref = flat_oracle_grads(pm, go)
+        assert float((pm.flat_params.grad - ref).norm() / ref.norm()) < 5e-4, step
+    worst = max(float((po.detach() - c.kernel.cpu()).abs().max()) for po, c in zip(om.parameters()[::2], pm._conv_layers()))
+    assert worst < 2e-4, worst

@@ -145,3 +145,21 @@ def test_corruption_and_foreign_files_are_rejected(tmp_path):
     open(prefix + '.index', 'wb').write(b'not a table' * 10)
     with pytest.raises(ValueError):
         ckpt.read_bundle(prefix)
+
+
+def test_import_refuses_norm_layer_variables_and_half_written_convs(tmp_path):
+    """A checkpoint with norm layers (gamma / beta) would shift the layer_with_weights-N numbering: refused, not misaligned;
+    a conv without its bias is named in the error."""
+    from nlt_amd import ckpt
+    base = {'net/net_query_layer0/kernel/.ATTRIBUTES/VARIABLE_VALUE': np.zeros((1, 1, 5, 16), np.float32),
+            'net/net_query_layer0/bias/.ATTRIBUTES/VARIABLE_VALUE': np.zeros(16, np.float32)}
+    t = dict(base)
+    t['net/net_query_layer1/layer_with_weights-1/gamma/.ATTRIBUTES/VARIABLE_VALUE'] = np.ones(16, np.float32)
+    write_bundle(str(tmp_path / 'norm'), t)
+    with pytest.raises(NotImplementedError, match='gamma'):
+        ckpt.reference_weights(str(tmp_path / 'norm'))
+    t = dict(base)
+    t['net/net_query_layer1/layer_with_weights-0/kernel/.ATTRIBUTES/VARIABLE_VALUE'] = np.zeros((2, 2, 32, 16), np.float32)
+    write_bundle(str(tmp_path / 'half'), t)
+    with pytest.raises(ValueError, match='net_query_layer1.*bias'):
+        ckpt.reference_weights(str(tmp_path / 'half'))

@@ -87,3 +87,124 @@ def test_tape_free_train_forward_backward_equals_the_autograd_path(monkeypatch):
     step = trainvali.GraphedTrainStep(pm, nlt_amd.optim.AdamAMSGrad(pm, 1e-3), 4, warmup=0)
     l3, _ = step(b)
     assert step.graph is None and abs(float(l3) - float(loss)) <= 1e-6 * abs(float(loss))
+
+
+def test_checkpoint_save_restore_resumes_training_bit_for_bit(monkeypatch, tmp_path):
+    """trainvali.save_checkpoint / restore_checkpoint (nlt/trainvali.py:134-141,197): weights + Adam-AMSGrad slots +
+    iteration count + global step.  Train 2 steps, save, train 2 more; a FRESH model + optimizer restored from the file and
+    trained 2 steps must land on exactly the same weights; inference can restore the net alone; get_weights round-trips
+    through load_weights; a different architecture is refused."""
+    fake_capi.install(monkeypatch)
+    batch, nn = O.synth_batch(2, 64, 64, 32, 32, 32, 32, k=1, seed=21)
+    b = cpu_batch(batch, nn)
+
+    def fresh(seed):
+        _, pm = make(256, 64, 32, loss='l2')
+        pm.build('cpu'); pm.register_trainable()
+        with torch.no_grad():
+            pm.flat_params.mul_(1.0 + 0.01 * seed)               # different initial weights per instance
+        pm.mark_weights_updated()
+        return pm, nlt_amd.optim.AdamAMSGrad(pm, 1e-3)
+    pm, opt = fresh(1)
+    for _ in range(2):
+        trainvali.distributed_train_step(pm, b, opt, 2)
+    path = trainvali.save_checkpoint(str(tmp_path / 'ckpt-2.pt'), pm, opt, step=2)
+    for _ in range(2):
+        trainvali.distributed_train_step(pm, b, opt, 2)
+    want = pm.flat_params.detach().clone()
+
+    pm2, opt2 = fresh(2)                                        # other initial weights: everything must come from the file
+    assert trainvali.restore_checkpoint(path, pm2, opt2) == 2 and opt2.t == 2
+    for _ in range(2):
+        trainvali.distributed_train_step(pm2, b, opt2, 2)
+    assert torch.equal(pm2.flat_params.detach(), want)
+
+    pm3, _ = fresh(3)
+    assert trainvali.restore_checkpoint(path, pm3) == 2         # net alone (nlt_test.py:92-97)
+    pm4, _ = fresh(4)
+    pm4.load_weights(pm3.get_weights())
+    assert torch.equal(pm4.flat_params.detach(), pm3.flat_params.detach())
+    w = pm3.get_weights()
+    w['query'][1][0] = (w['query'][1][0][0][..., :8], w['query'][1][0][1][:8])
+    with pytest.raises(ValueError, match='expects kernel'):
+        pm4.load_weights(w)
+    _, deep = make(1024, 64, 32, loss='l2')
+    deep.build('cpu')
+    with pytest.raises(ValueError, match='different architecture'):
+        trainvali.restore_checkpoint(path, deep)
+
+
+def test_backward_after_a_later_forward_raises(monkeypatch):
+    """The plan keeps ONE set of activations: a backward whose forward has been overwritten (second micro-batch, a vali
+    call in between) must not silently pair its inputs with the other pass's activations."""
+    fake_capi.install(monkeypatch)
+    _, pm = make(256, 64, 32, loss='l2')
+    pm.build('cpu'); pm.register_trainable()
+    b1 = cpu_batch(*O.synth_batch(2, 64, 64, 32, 32, 32, 32, k=1, seed=31))
+    b2 = cpu_batch(*O.synth_batch(2, 64, 64, 32, 32, 32, 32, k=1, seed=32))
+    p1, g1, _, _ = pm(b1, mode='train')
+    l1 = pm.compute_loss(p1, g1, keep_batch=True).sum()
+    pm(b2, mode='vali')                                          # overwrites the activations l1's backward needs
+    with pytest.raises(RuntimeError, match='overwritten by a later forward'):
+        l1.backward()
+    p1, g1, _, _ = pm(b1, mode='train')                         # the normal order still works
+    pm.compute_loss(p1, g1, keep_batch=True).sum().backward()
+
+
+def test_adapters_refuse_mismatched_shapes(monkeypatch):
+    """Raw kernels take element counts: the adapters compare shapes first (rgb_camspc vs fg_camspc)."""
+    from nlt_amd import capi as C
+    a, b = torch.zeros(2, 8, 8, 3), torch.zeros(2, 4, 4, 3)
+    for fn, args in ((C.mul_forward, (a, b)), (C.l2_loss_forward, (a, b)), (C.l2_loss_backward, (a, b, torch.zeros(2))),
+                     (C.barron_loss, (a, b, False)), (C.scale_rows, (a, torch.zeros(3)))):
+        with pytest.raises(C.NLTError):
+            fn(*args)
+
+
+def test_clipnorm_train_step_matches_oracle(monkeypatch):
+    """mgm > 0 (nlt/trainvali.py:122-127): Keras clipnorm = tf.clip_by_norm per variable, before the Adam update."""
+    fake_capi.install(monkeypatch)
+    om, pm = make(256, 64, 32, loss='l2')
+    pm.build('cpu'); pm.register_trainable()
+    pm.config.set('DEFAULT', 'mgm', '1e-3')
+    batch, nn = O.synth_batch(2, 64, 64, 32, 32, 32, 32, k=1, seed=41)
+    opt_o = O.KerasAdamAMSGrad(om.parameters(), 1e-3)
+    opt_p = trainvali.make_optimizer(pm, pm.config)
+    assert opt_p.clipnorm == 1e-3
+    clipped = 0
+    for step in range(2):
+        lo, go = O.train_step(om, opt_o, batch, global_bs=2, nn_list=nn, clipnorm=1e-3)
+        lp, _ = trainvali.distributed_train_step(pm, cpu_batch(batch, nn), opt_p, global_bs=2)
+        ref = flat_oracle_grads(om, pm, go)
+        assert float((pm.flat_params.grad - ref).norm() / ref.norm()) < 2e-4
+        clipped += sum(float(g.norm()) > 0.99e-3 for g in go)
+        for po, c in zip(om.parameters()[::2], pm._conv_layers()):
+            assert float((po.detach() - c.kernel).abs().max()) < 2e-5
+    assert clipped > 0                                           # the clip was active on some tensors
+
+
+def test_train_step_without_observation_path(monkeypatch):
+    """use_obs = False (nlt/models/nlt.py:176-177): the query net alone carries the gradient; the observation net's
+    gradients stay zero (TF: `None`, skipped by apply_gradients)."""
+    fake_capi.install(monkeypatch)
+    om, pm = make(256, 64, 32, loss='l2', use_obs=False)
+    pm.build('cpu'); pm.register_trainable()
+    batch, nn = O.synth_batch(2, 64, 64, 32, 32, 32, 32, k=1, seed=51)
+    po, go_, _, _ = om.call(batch, 'train', nn_list=nn)
+    lo = om.compute_loss(po, go_, keep_batch=True).sum() / 2
+    grads = torch.autograd.grad(lo, om.parameters(), allow_unused=True)
+    pred, gt, kw, _ = pm(cpu_batch(batch, nn), mode='train')
+    lp = pm.compute_loss(pred, gt, keep_batch=True).sum() / 2
+    pm.flat_params.grad = None
+    lp.backward()
+    assert abs(float(lp.detach()) - float(lo.detach())) <= 1e-5 * abs(float(lo.detach()))
+    it = iter(grads)
+    n_q = sum(len(lw) for lw in om.wq)
+    for i, c in enumerate(pm._conv_layers()):
+        for name in ('dkernel', 'dbias'):
+            g = next(it)
+            got = getattr(c, name)
+            if i < n_q:
+                assert g is not None and float((got - g).norm()) <= 2e-4 * float(g.norm()), (i, name)
+            else:
+                assert g is None and not got.any(), (i, name)
