@@ -304,6 +304,14 @@ int nlt_uv_index_map(const double* uvs, const double* values, long samples, int 
  */
 int nlt_knn_indices(const double* ref_pos, int np, const double* cand_pos, int nq, int k, int* out, void* stream);
 
+/* The two sums behind PSNR on luma (xiuminglib/metric.py:105-151; luma = 0.2126 r + 0.7152 g + 0.0722 b, img.py:600-611), in
+ * float64 like the reference's `im.astype(float)`: out2[0] = sum over masked pixels of (lum(im1) - lum(im2))^2,
+ * out2[1] = number of masked pixels (mask NULL = all).  im1 / im2 [pixels, channels] float32, channels 1 or 3;
+ * workspace: 512 doubles.  PSNR = 10 log10(drange^2 / (out2[0] / out2[1])).
+ *   replaces: xm.metric.PSNR(np.float32)(gt, pred) of Model.vis_batch (nlt/models/nlt.py:64,259-269). */
+int nlt_psnr_sums(const float* im1, const float* im2, const unsigned char* mask, long pixels, int channels,
+                  double* workspace, double* out2, void* stream);
+
 /* out[i] = float32(float64(store[ids[i]]) / 255) for whole frames of per_frame bytes (per_frame % 4 == 0);
  * ids == NULL means frames 0..n-1, id -1 a frame of zeros.  The primitive behind nlt_assemble_batch; also serves
  * the camera-space images (rgb_camspc, nn_rgb_camspc; nlt/datasets/nlt.py:129-136,162-171). */

@@ -5,7 +5,7 @@ Mirrors the reference's plugin surface: `models.get_model_class('nlt')(config)`,
 libnlt_hip.so (include/nlt_hip.h), reached through `_capi`.
 """
 from . import _capi as capi          # noqa: F401
-from . import networks, models, losses, optim, trainvali, nlt_test   # noqa: F401
+from . import networks, models, losses, optim, trainvali, nlt_test, metric   # noqa: F401
 from .util import net as netutil     # noqa: F401
 
 

@@ -93,6 +93,7 @@ SIGNATURES = {
     'nlt_uv_index_map_workspace_bytes': (_c_long, [_c_int, _c_int, _c_long]),
     'nlt_uv_index_map': (_c_int, [_vp, _vp, _c_long, _c_int, _c_int, _c_int, _c_int, _c_double, _vp, _vp, _vp, _vp]),
     'nlt_knn_indices': (_c_int, [_vp, _c_int, _vp, _c_int, _c_int, _vp, _vp]),
+    'nlt_psnr_sums': (_c_int, [_vp, _vp, _vp, _c_long, _c_int, _vp, _vp, _vp]),
     'nlt_gather_frames_u8': (_c_int, [_vp, _vp, _c_int, _c_long, _vp, _vp]),
     'nlt_assemble_batch': (_c_int, [_vp] * 6 + [_c_int, _c_int, _c_long, _c_int] + [_vp] * 6 + [_vp]),
 }
@@ -728,6 +729,21 @@ def knn_indices(ref_pos, cand_pos, k=1):
     out = torch.empty((p, k), device=ref_pos.device, dtype=torch.int32)
     _check(lib().nlt_knn_indices(_tptr(ref_pos, torch.float64, 'ref_pos'), p, _tptr(cand_pos, torch.float64, 'cand_pos'),
                                  q, k, out.data_ptr(), _stream()), 'nlt_knn_indices')
+    return out
+
+
+def psnr_sums(im1, im2, mask=None):
+    """im1 / im2 [H,W] or [H,W,C] float32 (C = 1 or 3), mask [H,W] uint8 or None -> (sum of squared luma differences,
+    number of pixels counted) as a float64 CUDA tensor [2]."""
+    _same_shape(im1, im2, 'psnr_sums')
+    c = 1 if im1.dim() == 2 else im1.shape[2]
+    pixels = im1.numel() // c
+    if mask is not None and mask.numel() != pixels:
+        raise NLTError("psnr_sums: mask has %d pixels, the images %d" % (mask.numel(), pixels))
+    ws = torch.empty(512, device=im1.device, dtype=torch.float64)
+    out = torch.empty(2, device=im1.device, dtype=torch.float64)
+    _check(lib().nlt_psnr_sums(_ptr(_dense(im1, 'im1')), _ptr(_dense(im2, 'im2')), _tptr(mask, torch.uint8, 'mask'), pixels, c,
+                               ws.data_ptr(), out.data_ptr(), _stream()), 'nlt_psnr_sums')
     return out
 
 

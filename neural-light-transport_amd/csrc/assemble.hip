@@ -286,6 +286,45 @@ __global__ __launch_bounds__(256) void u8_gather_kernel(const u8* __restrict__ s
   }
 }
 
+// ---------------------------------------------------------------------------------------
+// PSNR on luma (xiuminglib/metric.py:105-151, img.py:600-611): float64 throughout, as the reference's
+// `im.astype(float)`.  Pass 1: every workgroup adds its pixels' masked squared luma differences in a fixed order
+// (thread-strided partial sums, then a tree) and writes (sum, count) to its slot; pass 2: one workgroup adds the slots in
+// order.  Deterministic; differs from NumPy's pairwise sum by float64 rounding only.
+// ---------------------------------------------------------------------------------------
+constexpr int PSNR_BLOCKS = 256;
+
+__device__ __forceinline__ double lum_of(const float* p, int c) {
+  if (c == 1) return (double)p[0];
+  return 0.2126 * (double)p[0] + 0.7152 * (double)p[1] + 0.0722 * (double)p[2];
+}
+
+__global__ __launch_bounds__(256) void psnr_partial_kernel(const float* __restrict__ a, const float* __restrict__ b,
+                                                           const u8* __restrict__ mask, long pixels, int c,
+                                                           double* __restrict__ part) {
+  __shared__ double s_se[256], s_n[256];
+  double se = 0.0, cnt = 0.0;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < pixels; i += (long)PSNR_BLOCKS * 256) {
+    if (mask && !mask[i]) continue;
+    const double d = lum_of(a + i * c, c) - lum_of(b + i * c, c);
+    se = se + d * d;
+    cnt = cnt + 1.0;
+  }
+  s_se[threadIdx.x] = se; s_n[threadIdx.x] = cnt;
+  __syncthreads();
+  for (int w = 128; w > 0; w >>= 1) {
+    if ((int)threadIdx.x < w) { s_se[threadIdx.x] += s_se[threadIdx.x + w]; s_n[threadIdx.x] += s_n[threadIdx.x + w]; }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) { part[2 * blockIdx.x] = s_se[0]; part[2 * blockIdx.x + 1] = s_n[0]; }
+}
+
+__global__ void psnr_final_kernel(const double* __restrict__ part, double* __restrict__ out) {
+  double se = 0.0, cnt = 0.0;
+  for (int i = 0; i < PSNR_BLOCKS; ++i) { se = se + part[2 * i]; cnt = cnt + part[2 * i + 1]; }
+  out[0] = se; out[1] = cnt;
+}
+
 int launch_gather(const u8* store, const int* ids, int nframes_out, long per_frame, float* out, hipStream_t s) {
   if (per_frame & 3) return NLT_ERR_UNSUPPORTED;
   if ((reinterpret_cast<uintptr_t>(store) & 3u) || !nlt_aligned16(out)) return NLT_ERR_BAD_ARG;
@@ -298,6 +337,17 @@ int launch_gather(const u8* store, const int* ids, int nframes_out, long per_fra
 }
 
 }  // namespace
+
+extern "C" int nlt_psnr_sums(const float* im1, const float* im2, const unsigned char* mask, long pixels, int channels,
+                             double* workspace, double* out2, void* stream) {
+  if (!im1 || !im2 || !workspace || !out2 || pixels <= 0) return NLT_ERR_BAD_ARG;
+  if (channels != 1 && channels != 3) return NLT_ERR_UNSUPPORTED;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  hipLaunchKernelGGL(psnr_partial_kernel, dim3(PSNR_BLOCKS), dim3(256), 0, s, im1, im2, mask, pixels, channels, workspace);
+  hipLaunchKernelGGL(psnr_final_kernel, dim3(1), dim3(1), 0, s, workspace, out2);
+  NLT_CHECK_LAUNCH();
+  return NLT_OK;
+}
 
 extern "C" int nlt_cosine_map(const double* locs, const double* normals, const unsigned char* valid,
                               const unsigned char* occluded, double sx, double sy, double sz, long pixels,

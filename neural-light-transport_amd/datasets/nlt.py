@@ -17,11 +17,19 @@ import torch
 from .. import _capi as C
 
 
+def read_png(path):
+    """xm.io.img.load(path, as_array=True) (xiuminglib/io/img.py:12-33): the decoded PIL image as it is, any mode / depth."""
+    from PIL import Image
+    with open(path, 'rb') as h:
+        img = Image.open(h)
+        img.load()
+    return np.array(img)
+
+
 def load_store(data_root, device='cuda', ids=None):
     """Decodes a capture laid out as the reference writes it (data_gen/render.py:196-206, postproc.py:66-122) into
     the resident uint8 store.  Paths in `<data_root>.json` are relative to data_root (nlt/datasets/nlt.py:36-45).
     Test samples have no rgb / rgb_camspc (postproc.py:104-107): their slots stay zero."""
-    from PIL import Image
     status = data_root.rstrip('/') + '.json'
     if not exists(status):
         raise FileNotFoundError(("Data status JSON not found at \n\t%s\nRun "
@@ -31,7 +39,7 @@ def load_store(data_root, device='cuda', ids=None):
     ids = sorted(paths) if ids is None else list(ids)
 
     def png(path, channels):
-        a = np.asarray(Image.open(path))
+        a = read_png(path)
         if a.dtype != np.uint8:
             raise NotImplementedError("%s: %s PNGs (the resident store is uint8)" % (path, a.dtype))
         if channels == 3:

@@ -4,10 +4,12 @@
 """
 import os
 
+import numpy as np
 import torch
 
 from .. import _capi as C
 from .. import losses
+from .. import metric
 from ..datasets.nlt import ResidentTexels
 from ..engine import RenderPlan
 from ..networks import convnet
@@ -58,6 +60,7 @@ class Model(BaseModel):
         self.uvw = config.getint('DEFAULT', 'uvw')
         self.use_obs = config.getboolean('DEFAULT', 'use_obs')
         self.skip_connect_base = config.getboolean('DEFAULT', 'skip_connect_base')
+        self.psnr = metric.PSNR(np.float32)                      # nlt/models/nlt.py:64
         self.plan = RenderPlan(self.net['query'], self.net['obs'], self.use_obs)
         self.conv_algo = C.ALGO_AUTO
         # hipGraph replay of the inference forward (opt-in: NLT_GRAPH=1 or model.use_graphs = True).  The ~36 launches

@@ -247,3 +247,24 @@ def test_dataset_load_batch(C):
     for key, i in (('base', 1), ('cvis', 2), ('lvis', 3), ('rgb', 5), ('nn_base', 8), ('nn_rgb', 9)):
         assert torch.equal(m[key].cpu(), e[i].cpu()), key
     assert torch.equal(r[1].base_float().cpu(), e[1].cpu()) and torch.equal(r[4].cpu(), e[4].cpu())
+
+
+def test_psnr_on_luma_matches_the_reference_values():
+    """nlt_psnr_sums + nlt_amd.metric.PSNR against the values xm.metric.PSNR(np.float32) returned (golden, reference imported
+    and run) and against the oracle on a 1024^2 image."""
+    from nlt_amd.metric import PSNR
+    from oracle import metric as M
+    D = np.load(os.path.join(os.path.dirname(__file__), 'golden', 'io_metric.npz'))
+    psnr = PSNR(np.float32)
+    for i, (plain, masked) in enumerate(D['psnr_values']):
+        a, b = torch.from_numpy(D['psnr_a%d' % i]).to(DEV), torch.from_numpy(D['psnr_b%d' % i]).to(DEV)
+        m = torch.from_numpy(D['psnr_m%d' % i]).to(DEV)
+        assert abs(psnr(a, b) - plain) <= 1e-10 * abs(plain)
+        assert abs(psnr(a, b, mask=m) - masked) <= 1e-10 * abs(masked)
+    rng = np.random.default_rng(3)
+    a = rng.random((1024, 1024, 3), dtype=np.float32)
+    b = np.clip(a + 0.02 * rng.standard_normal(a.shape).astype(np.float32), 0, 1).astype(np.float32)
+    got = psnr(torch.from_numpy(a).to(DEV), torch.from_numpy(b).to(DEV))
+    assert abs(got - M.psnr(a, b)) <= 1e-10 * abs(got)
+    with pytest.raises(AssertionError):
+        psnr(torch.zeros(4, 4, 3, device=DEV), torch.zeros(4, 5, 3, device=DEV))
