@@ -24,12 +24,15 @@ pytestmark = pytest.mark.gpu
 TOL = 1e-4
 # Bounds on train-step gradients vs the FLOAT64 oracle:
 #   flat gradient bucket (what the all-reduce and Adam see)          <= 1e-5 rel-L2 (measured 1e-7)
-#   every single kernel / bias, kink-free network (alpha = 1)        <= GRAD_TOL_SMOOTH
+#   every single kernel / bias, kink-free network (alpha = 1)        <= GRAD_TOL_SMOOTH (measured 1e-6; the fp32 torch-CPU
+#       oracle itself sits at 1.4e-5 .. 1.9e-5 from float64 on its worst tensor)
 #   every single kernel / bias, released LeakyReLU(0.3)              <= max(GRAD_TOL_KINK, 3 x what the fp32 torch-CPU
-#       oracle itself is away from float64 on its worst tensor): mask flips at |pre-activation| ~ 1e-7, see the test
+#       oracle itself is away from float64 on its worst tensor): derivative-mask flips of the few texels whose
+#       pre-activation is within fp32 rounding of zero.  Whether a flip lands on a tensor is chance; at a 32^2-texel deep
+#       layer under the Barron loss ONE flipped texel moved a 256-channel kernel gradient by 2.4e-3 (measured, r02).
 GRAD_TOL_FLAT = 1e-5
-GRAD_TOL_SMOOTH = 5e-5
-GRAD_TOL_KINK = 2e-3
+GRAD_TOL_SMOOTH = 1e-5
+GRAD_TOL_KINK = 5e-3
 DUMP = os.environ.get('NLT_PARITY_DUMP')
 
 
