@@ -194,6 +194,13 @@ def replay(tape):
             raise NLTError("replayed launch failed: %s" % lib().nlt_status_string(rc).decode())
 
 
+def tape_call(fn, *args):
+    """A host-side step that belongs to the plan (a hook): run it now and, while a tape is open, on every replay."""
+    fn(*args)
+    if _tape is not None:
+        _tape.append((fn, args))
+
+
 def record_event(ev, stream):
     ev.record(stream)
     if _tape is not None:

@@ -70,6 +70,7 @@ class RenderPlan:
         # launch tape: replay a step's C calls with their resolved arguments instead of re-deriving them (see _capi.py)
         self.use_tape = os.environ.get('NLT_TAPE', '1') != '0'
         self._tuning = False
+        self.grad_hook = None           # callable fired by backward() once the expanding blocks' weight gradients are queued
         self.generation = 0             # bumped by every forward: the activations in the plan's buffers belong to that pass
         self.tape_replays = 0
         self._trial_direct = False
@@ -637,6 +638,17 @@ class RenderPlan:
             return
         self._wgrad_now(label, layer, src0, c0, ld0, src1, c1, ld1, n, h, w, dpre, ldp)
 
+    def _decoder_grads_queued(self):
+        hook = self.grad_hook
+        if hook is None:
+            return
+        bs = self._bside
+        if bs is not None and bs[2] is not None:                     # the weight gradients are on the side stream: so is the hook
+            with torch.cuda.stream(bs[0]):
+                hook()
+        else:
+            hook()
+
     def _wgrad_now(self, label, layer, src0, c0, ld0, src1, c1, ld1, n, h, w, dpre, ldp):
         oh, ow = layer.out_hw(h, w)
         nbytes = 4 * (n * h * w * (c0 + c1) + n * oh * ow * layer.n_ch_out)
@@ -785,6 +797,10 @@ class RenderPlan:
             self._dgrad(lab + '.s2.dgrad.skip', da, cxj, cxj + csj, g['dtmp'][j], nl, n, hh, ww, dskip, csj,
                         accumulate=(j == 0), zero_bias=zb)
             hh, ww = hh // 2, ww // 2
+
+        # every weight gradient of the expanding blocks is queued now: the leading range of the flat gradient
+        # bucket (models/nlt.py:_flatten) can start its all-reduce while the encoder's backward runs
+        C.tape_call(self._decoder_grads_queued)
 
         # ---- encoder (contracting blocks), deepest first; hh, ww = dims of level D
         for l in range(D, 0, -1):

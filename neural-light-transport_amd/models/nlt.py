@@ -118,11 +118,26 @@ class Model(BaseModel):
         with a matching flat gradient bucket; layers keep views.  One bucket = one RCCL all-reduce
         and one fused Adam launch per step."""
         convs = self._conv_layers()
-        slots, off = [], 0
-        for c in convs:
-            for t in (c.kernel, c.bias):
-                slots.append((off, t.numel(), tuple(t.shape)))
+        # Slot ORDER inside the bucket: the query net's expanding blocks first, everything else after them.  The backward
+        # pass finishes those weight gradients first (it walks head -> decoder -> encoder), so the bucket's leading
+        # `bucket_split` floats can be all-reduced while the encoder's backward is still running
+        # (trainvali.distributed_train_step); the second collective covers the rest.  Two fixed, contiguous ranges.
+        # (The 1x1 head stays in the second range: the fused training path adds its skip rows at the very end.)
+        q = self.net['query']
+        late = set()
+        for layer, is_c in zip(q.layers, q.is_contracting):
+            if not is_c and not hasattr(layer, 'set_weights'):
+                late.update(id(c) for c, _ in layer.convs())
+        order = [c for c in convs if id(c) in late] + [c for c in convs if id(c) not in late]
+        where, off = {}, 0
+        for c in order:
+            for name in ('kernel', 'bias'):
+                t = getattr(c, name)
+                where[(id(c), name)] = (off, t.numel(), tuple(t.shape))
                 off += (t.numel() + 3) // 4 * 4
+            if id(c) in late:
+                self.bucket_split = off
+        slots = [where[(id(c), name)] for c in convs for name in ('kernel', 'bias')]
         flat = torch.zeros(off, device=device, dtype=torch.float32)
         it = iter(slots)
         for c in convs:

@@ -43,20 +43,43 @@ def _world(group):
     return dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
 
 
-def distributed_train_step(model, batch, optimizer, global_bs, group=None):
-    """batch = this rank's shard of the global batch.  Returns (loss summed over ranks, to_vis)."""
+def distributed_train_step(model, batch, optimizer, global_bs, group=None, overlap=True):
+    """batch = this rank's shard of the global batch.  Returns (loss summed over ranks, to_vis).
+
+    One rank: per-example loss -> sum / global batch -> autograd backward -> fused Adam.
+    Several ranks: the gradient sum is TWO all-reduces of fixed contiguous ranges of the flat bucket (so every rank adds the
+    same numbers in the same order: bit-identical weights).  The first -- the expanding blocks, whose gradients the
+    backward pass finishes first -- is issued from inside the backward plan as soon as those weight-gradient launches are
+    queued (on their stream), and runs over xGMI while the encoder's backward occupies the CUs; the second follows the
+    backward.  overlap=False issues both after the backward (same result)."""
     assert model.trainable_registered, "Register the trainable layers before using `trainable_variables`"
-    pred, gt, loss_kwargs, to_vis = model(batch, mode='train')
-    loss_kwargs['keep_batch'] = True
-    per_example_loss = model.compute_loss(pred, gt, **loss_kwargs)
-    weighted_loss = per_example_loss.sum() / global_bs             # tf.nn.compute_average_loss
-    model.flat_params.grad = None
-    weighted_loss.backward()
-    grad = model.flat_params.grad
-    loss = weighted_loss.detach().clone()
-    if _world(group) > 1:
-        dist.all_reduce(grad, op=dist.ReduceOp.SUM, group=group)  # the one data-path collective
-        dist.all_reduce(loss, op=dist.ReduceOp.SUM, group=group)
+    world = _world(group)
+    if world == 1:
+        pred, gt, loss_kwargs, to_vis = model(batch, mode='train')
+        loss_kwargs['keep_batch'] = True
+        per_example_loss = model.compute_loss(pred, gt, **loss_kwargs)
+        weighted_loss = per_example_loss.sum() / global_bs         # tf.nn.compute_average_loss
+        model.flat_params.grad = None
+        weighted_loss.backward()
+        grad = model.flat_params.grad
+        optimizer.step(grad)
+        return weighted_loss.detach().clone(), to_vis
+    grad, split = model.flat_grads, model.bucket_split
+    works = []
+    if overlap:
+        model.plan.grad_hook = lambda: works.append(dist.all_reduce(grad[:split], op=dist.ReduceOp.SUM, group=group, async_op=True))
+    try:
+        loss, to_vis = model.train_forward_backward(batch, global_bs)    # gradients land in the flat bucket (no autograd copy)
+    finally:
+        model.plan.grad_hook = None
+    if not works:
+        works.append(dist.all_reduce(grad[:split], op=dist.ReduceOp.SUM, group=group, async_op=True))
+    works.append(dist.all_reduce(grad[split:], op=dist.ReduceOp.SUM, group=group, async_op=True))
+    loss = loss.clone()
+    works.append(dist.all_reduce(loss, op=dist.ReduceOp.SUM, group=group, async_op=True))
+    for w in works:
+        w.wait()                                                    # (CUDA: the current stream waits; the host does not block)
+    model.flat_params.grad = grad
     optimizer.step(grad)
     return loss, to_vis
 

@@ -1,7 +1,8 @@
-"""CPU, world_size 2 over gloo: the data-parallel train step (frames sharded across ranks, ONE
-all-reduce(sum) of the flat gradient bucket, identical Adam step on every rank, scalar loss
-all-reduce) reproduces the single-process oracle on the full batch (nlt/trainvali.py:267-325).
-Device kernels are replaced by the TEST-ONLY C-ABI emulation; the collective path is the real one."""
+"""CPU, world_size 2 and 4 over gloo: the data-parallel train step (frames sharded across ranks, the gradient sum as TWO
+all-reduces of fixed ranges of the flat bucket -- the first issued from inside the backward plan --, identical Adam step
+on every rank, scalar loss all-reduce) reproduces the single-process oracle on the full batch
+(nlt/trainvali.py:267-325).  Device kernels are replaced by the TEST-ONLY C-ABI emulation; the collective path is the
+real one."""
 import os
 import sys
 import tempfile
@@ -13,9 +14,15 @@ import torch.distributed as dist
 import torch.multiprocessing as mp
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GLOBAL = {2: 4, 4: 7}                          # global batch per world size (7 over 4 ranks: shards 2, 2, 2, 1)
 
 
-def _worker(rank, world, port, outdir):
+def _shard(world, rank):
+    per = -(-GLOBAL[world] // world)
+    return slice(per * rank, min(per * (rank + 1), GLOBAL[world]))
+
+
+def _worker(rank, world, port, outdir, mode):
     sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'tests'))
     os.environ['MASTER_ADDR'] = '127.0.0.1'; os.environ['MASTER_PORT'] = str(port)
     torch.set_num_threads(2)
@@ -32,42 +39,65 @@ def _worker(rank, world, port, outdir):
     fake_capi.install(MP())
     om, pm = make(256, 64, 32, loss='l2')
     pm.build('cpu'); pm.register_trainable()
-    batch, nn = O.synth_batch(4, 64, 64, 32, 32, 32, 32, k=2, seed=5)     # GLOBAL batch of 4 frames
-    sl = slice(2 * rank, 2 * rank + 2)                                      # contiguous shard per rank
+    gbs = GLOBAL[world]
+    batch, nn = O.synth_batch(gbs, 64, 64, 32, 32, 32, 32, k=2, seed=5)   # the GLOBAL batch
+    sl = _shard(world, rank)                                                # contiguous shard per rank
     shard = tuple(t[sl] if torch.is_tensor(t) else t for t in batch)
     nn_s = [(b[sl], r[sl]) for b, r in nn]
     opt = nlt_amd.optim.AdamAMSGrad(pm, 1e-3)
+    fired = []
+    if mode == 'graphed':
+        step = trainvali.GraphedTrainStep(pm, opt, gbs, warmup=0)         # off the GPU: degrades to the eager step
+        run = lambda: step(cpu_batch(shard, nn_s))
+    else:
+        def run():
+            real = dist.all_reduce
+
+            def spy(t, *a, **kw):                                         # order and sizes of the collectives
+                fired.append(t.numel())
+                return real(t, *a, **kw)
+            dist.all_reduce = spy
+            try:
+                return trainvali.distributed_train_step(pm, cpu_batch(shard, nn_s), opt, global_bs=gbs, overlap=(mode == 'overlap'))
+            finally:
+                dist.all_reduce = real
     losses = []
     for _ in range(2):
-        loss, _ = trainvali.distributed_train_step(pm, cpu_batch(shard, nn_s), opt, global_bs=4)
+        loss, _ = run()
         losses.append(float(loss))
-    lv, _ = trainvali.distributed_vali_step(pm, cpu_batch(shard, nn_s), 4)
+    lv, _ = trainvali.distributed_vali_step(pm, cpu_batch(shard, nn_s), gbs)
+    base = pm.flat_params.data_ptr()
+    offs = [((v.data_ptr() - base) // 4, v.numel()) for c in pm._conv_layers() for v in (c.kernel, c.bias)]
     torch.save({'losses': losses, 'vali': float(lv), 'params': pm.flat_params.detach().clone(),
-                'grad': pm.flat_params.grad.clone()}, os.path.join(outdir, 'r%d.pt' % rank))
+                'grad': pm.flat_params.grad.clone(), 'offs': offs, 'fired': fired, 'split': pm.bucket_split},
+               os.path.join(outdir, 'r%d.pt' % rank))
     dist.destroy_process_group()
 
 
-def test_data_parallel_train_step_world2():
+@pytest.mark.parametrize('world,mode', [(2, 'overlap'), (2, 'after'), (4, 'overlap'), (2, 'graphed')])
+def test_data_parallel_train_step(world, mode):
     sys.path.insert(0, os.path.join(ROOT, 'tests'))
     from oracle import nlt_oracle as O
     with tempfile.TemporaryDirectory() as td:
-        port = 29500 + os.getpid() % 2000
-        mp.spawn(_worker, args=(2, port, td), nprocs=2, join=True)
-        r0, r1 = torch.load(os.path.join(td, 'r0.pt')), torch.load(os.path.join(td, 'r1.pt'))
-    # every rank holds bit-identical weights and gradients after the all-reduce + Adam step
-    assert torch.equal(r0['params'], r1['params']) and torch.equal(r0['grad'], r1['grad'])
-    assert r0['losses'] == r1['losses'] and r0['vali'] == r1['vali']
-    # ... and they equal the single-process oracle on the full batch of 4
+        port = 29500 + (os.getpid() * 7 + world * 13 + len(mode)) % 2000
+        mp.spawn(_worker, args=(world, port, td, mode), nprocs=world, join=True)
+        r = [torch.load(os.path.join(td, 'r%d.pt' % i)) for i in range(world)]
+    # every rank holds bit-identical weights and gradients after the all-reduces + Adam step
+    for x in r[1:]:
+        assert torch.equal(r[0]['params'], x['params']) and torch.equal(r[0]['grad'], x['grad'])
+        assert r[0]['losses'] == x['losses'] and r[0]['vali'] == x['vali']
+    if mode != 'graphed':
+        # per step: the bucket's leading range (expanding blocks), the rest, the scalar loss -- in this order
+        n, split = r[0]['params'].numel(), r[0]['split']
+        assert 0 < split < n and r[0]['fired'] == [split, n - split, 1] * 2
+    # ... and they equal the single-process oracle on the full batch
+    gbs = GLOBAL[world]
     om = O.OracleModel(depth=256, uvh=64, uvw=64, imh=32, imw=32, seed=1, loss='l2')
-    batch, nn = O.synth_batch(4, 64, 64, 32, 32, 32, 32, k=2, seed=5)
+    batch, nn = O.synth_batch(gbs, 64, 64, 32, 32, 32, 32, k=2, seed=5)
     opt = O.KerasAdamAMSGrad(om.parameters(), 1e-3)
-    ref_losses = [float(O.train_step(om, opt, batch, global_bs=4, nn_list=nn)[0]) for _ in range(2)]
-    np.testing.assert_allclose(r0['losses'], ref_losses, rtol=1e-5)
-    flat_ref = torch.cat([p.detach().reshape(-1) for p in om.parameters()])
-    got = r0['params']
-    # compare through the product's slot layout: every oracle tensor appears contiguously, in order
-    off = 0
-    for p in om.parameters():
-        n = p.numel()
-        assert float((got[off:off + n] - p.detach().reshape(-1)).abs().max()) < 2e-5
-        off += (n + 3) // 4 * 4
+    ref_losses = [float(O.train_step(om, opt, batch, global_bs=gbs, nn_list=nn)[0]) for _ in range(2)]
+    np.testing.assert_allclose(r[0]['losses'], ref_losses, rtol=1e-5)
+    got = r[0]['params']
+    for p, (off, cnt) in zip(om.parameters(), r[0]['offs']):       # through the product's slot table
+        assert cnt == p.numel()
+        assert float((got[off:off + cnt] - p.detach().reshape(-1)).abs().max()) < 2e-5

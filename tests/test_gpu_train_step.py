@@ -127,6 +127,38 @@ def test_rccl_single_rank_group_runs_the_gradient_all_reduce():
         dist.destroy_process_group()
 
 
+def test_rccl_two_bucket_overlapped_step_equals_the_single_rank_step(monkeypatch):
+    """The multi-rank code path of trainvali.distributed_train_step (gradient all-reduce in two ranges, the first issued
+    as an async RCCL collective from inside the backward plan on the weight-gradient stream, launch tape replays included)
+    on a ONE-rank `nccl` group with the world size patched to 2: the collectives are identities, so weights and losses must
+    track the plain single-rank step exactly (up to the float atomics of the warp adjoint)."""
+    import os
+    import torch.distributed as dist
+    os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+    os.environ.setdefault('MASTER_PORT', '29537')
+    try:
+        dist.init_process_group('nccl', rank=0, world_size=1, device_id=torch.device('cuda', 0))
+    except Exception as e:
+        pytest.skip("RCCL process group could not be created: %r" % (e,))
+    try:
+        batches = [to_device_batch(*O.synth_batch(2, 128, 128, 64, 64, 64, 64, k=1, seed=80 + i)) for i in range(2)]
+        res = []
+        for multi in (False, True):
+            _, pm = make_pair(depth=256, uv=128, im=64, loss='l2', seed=12)
+            pm.build('cuda')
+            opt = nlt_amd.optim.AdamAMSGrad(pm, 1e-3)
+            monkeypatch.setattr(trainvali, '_world', (lambda g: 2) if multi else (lambda g: 1))
+            losses = [float(trainvali.distributed_train_step(pm, batches[i % 2], opt, 2)[0]) for i in range(6)]
+            torch.cuda.synchronize()
+            res.append((losses, pm.flat_params.detach().clone(), pm.plan.tape_replays))
+        (l0, p0, _), (l1, p1, replays) = res
+        np.testing.assert_allclose(l1, l0, rtol=2e-5)
+        assert float((p0 - p1).abs().max()) < 2e-5
+        assert replays > 0                                       # the hook also fires from replayed tapes
+    finally:
+        dist.destroy_process_group()
+
+
 @pytest.mark.parametrize('loss', ['l2', 'barron'])
 def test_full_size_gradient_agrees_with_directional_finite_differences(loss):
     """BASELINE config 4's per-GPU shape (1024^2 UV, 512^2 camera; 2 frames here), a size-independent property check
