@@ -224,6 +224,23 @@ int nlt_barron_loss(const float* pred, const float* gt, int n, int h, int w, flo
 /* out[f,:] = x[f,:] * scale[f] */
 int nlt_scale_rows(const float* x, const float* scale, int n, long per_row, float* out, void* stream);
 
+/* Layers of the config branches the released .ini files leave off (executed layer by layer, nlt_amd/generic.py):
+ *   nlt_act_forward / _backward       kind 0: LeakyReLU(alpha) / ReLU (alpha = 0), kind 1: tf.keras.layers.ELU(alpha)
+ *                                     (nlt/networks/elements.py:69-78); backward takes the layer's OUTPUT y
+ *   nlt_pixelnorm_forward / _backward y = x * rsqrt(mean_c(x^2) + eps), per texel over c channels (elements.py:103-121)
+ *   nlt_pool2x2_forward / _backward   MaxPooling2D / AveragePooling2D(pool 2, strides 2, 'same') on even sizes, kind 0 max /
+ *                                     1 average (elements.py:81-94); max backward: the first maximal tap gets the gradient
+ * All NHWC fp32, any channel count. */
+int nlt_sub_forward(const float* a, const float* b, long count, float* out, void* stream);      /* y_obs = nn_rgb - nn_base (nlt.py:96) */
+/* pred = y (+ base when base != NULL), texel (0,0) of every frame zeroed (nlt/models/nlt.py:99-110); y, base, pred [n,h,w,3] */
+int nlt_finish_pred(const float* y, const float* base, int n, int h, int w, float* pred, void* stream);
+int nlt_act_forward(const float* x, long count, int kind, float alpha, float* y, void* stream);
+int nlt_act_backward(const float* g, const float* y, long count, int kind, float alpha, float* dx, void* stream);
+int nlt_pixelnorm_forward(const float* x, long texels, int c, float eps, float* y, void* stream);
+int nlt_pixelnorm_backward(const float* g, const float* x, long texels, int c, float eps, float* dx, void* stream);
+int nlt_pool2x2_forward(const float* x, int n, int h, int w, int c, int kind, float* y, void* stream);
+int nlt_pool2x2_backward(const float* g, const float* x, int n, int h, int w, int c, int kind, float* dx, void* stream);
+
 /* Keras `clipnorm` (config key mgm > 0): every variable's gradient g -> g * clip / max(||g||_2, clip)
  * (tf.clip_by_norm, multiply then divide), in place, over the slots of the flat gradient bucket.
  * slots: device int64 [n_slots][2] = (first element, element count) of each kernel / bias.
@@ -401,6 +418,19 @@ int nlt_front4_forward_u8(const unsigned char* diffuse_store, const unsigned cha
                           const int* ids, const int* nn_ids, int n, int k, int h, int w,
                           const float* packed, const float* packed_l2, int add_base, float alpha,
                           float* fm1, float* skip3, float* qtmp2, float* otmp2, int waves_per_simd, void* stream);
+
+/*
+ * One expanding block in one launch (inference): Conv2DTranspose k2s2 (cx + cs -> c) + LeakyReLU on the virtual concat
+ * [x | skip], Conv2DTranspose k2s1 (c -> c) + LeakyReLU; the intermediate map stays in LDS.  c = 8 or 16 (the blocks at
+ * 1/2 and 1/4 resolution, where the intermediate's HBM round trip costs more than the block's output), cx and cs
+ * multiples of 4.
+ *   replaces: one `Sequential[iden, deconv(2,n,s2), iden, lrelu, deconv(2,n,s1), iden, lrelu]` entry of
+ *             net['query'].layers (convnet.py:67-76) as Model._call runs it (nlt.py:182-195), i.e. 2x nlt_conv_forward.
+ * x [n,h,w,cx], skip [n,h,w,cs]; Keras weights w_s2 (2,2,c,cx+cs), w_s1 (2,2,c,c); out [n,2h,2w,c].
+ */
+int nlt_dec_block_forward(const float* x, int cx, const float* skip, int cs, int n, int h, int w,
+                          const float* w_s2, const float* b_s2, const float* w_s1, const float* b_s1,
+                          int c, float alpha, float* out, void* stream);
 
 /*
  * Last expanding block + output head: Conv2DTranspose k2s2 (8 + 32 -> 4) + LeakyReLU, Conv2DTranspose k2s1

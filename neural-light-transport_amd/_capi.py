@@ -57,6 +57,14 @@ SIGNATURES = {
     'nlt_barron_workspace_floats': (_c_long, [_c_int] * 3),
     'nlt_barron_loss': (_c_int, [_vp, _vp, _c_int, _c_int, _c_int, _vp, _vp, _vp, _vp]),
     'nlt_scale_rows': (_c_int, [_vp, _vp, _c_int, _c_long, _vp, _vp]),
+    'nlt_sub_forward': (_c_int, [_vp, _vp, _c_long, _vp, _vp]),
+    'nlt_finish_pred': (_c_int, [_vp, _vp, _c_int, _c_int, _c_int, _vp, _vp]),
+    'nlt_act_forward': (_c_int, [_vp, _c_long, _c_int, _c_float, _vp, _vp]),
+    'nlt_act_backward': (_c_int, [_vp, _vp, _c_long, _c_int, _c_float, _vp, _vp]),
+    'nlt_pixelnorm_forward': (_c_int, [_vp, _c_long, _c_int, _c_float, _vp, _vp]),
+    'nlt_pixelnorm_backward': (_c_int, [_vp, _vp, _c_long, _c_int, _c_float, _vp, _vp]),
+    'nlt_pool2x2_forward': (_c_int, [_vp, _c_int, _c_int, _c_int, _c_int, _c_int, _vp, _vp]),
+    'nlt_pool2x2_backward': (_c_int, [_vp, _vp, _c_int, _c_int, _c_int, _c_int, _c_int, _vp, _vp]),
     'nlt_clip_by_norm_slots': (_c_int, [_vp, _vp, _c_int, _c_float, _vp]),
     'nlt_adam_amsgrad_step': (_c_int, [_vp] * 5 + [_c_long] + [_c_float] * 4 + [_vp]),
     'nlt_front_packed_floats': (_c_long, []),
@@ -67,6 +75,7 @@ SIGNATURES = {
     'nlt_front2_forward': (_c_int, [_vp] * 5 + [_c_int] * 4 + [_vp, _vp, _c_int, _c_float, _vp, _vp, _vp, _vp, _vp]),
     'nlt_front4_forward': (_c_int, [_vp] * 5 + [_c_int] * 4 + [_vp, _vp, _c_int, _c_float, _vp, _vp, _vp, _vp, _c_int, _vp]),
     'nlt_front4_forward_u8': (_c_int, [_vp] * 6 + [_c_int] * 4 + [_vp, _vp, _c_int, _c_float, _vp, _vp, _vp, _vp, _c_int, _vp]),
+    'nlt_dec_block_forward': (_c_int, [_vp, _c_int, _vp, _c_int, _c_int, _c_int, _c_int, _vp, _vp, _vp, _vp, _c_int, _c_float, _vp, _vp]),
     'nlt_back_forward': (_c_int, [_vp] * 3 + [_c_int] * 3 + [_vp] * 5 + [_c_float, _vp, _vp]),
     'nlt_front_forward_train': (_c_int, [_vp] * 5 + [_c_int] * 4 + [_vp, _c_int, _c_float] + [_vp] * 6),
     'nlt_back_forward_train': (_c_int, [_vp] * 3 + [_c_int] * 3 + [_vp] * 5 + [_c_float] + [_vp] * 4),
@@ -447,6 +456,72 @@ def scale_rows(x, scale):
     return out
 
 
+# ---------------------------------------------------------------- layers of the non-default config branches
+ACT_LRELU, ACT_ELU = 0, 1
+POOL_MAX, POOL_AVG = 0, 1
+
+
+def sub_forward(a, b):
+    _same_shape(a, b, 'sub_forward')
+    out = torch.empty_like(a)
+    _check(lib().nlt_sub_forward(_ptr(_dense(a, 'a')), _ptr(_dense(b, 'b')), a.numel(), _ptr(out), _stream()), 'nlt_sub_forward')
+    return out
+
+
+def finish_pred(y, base, pred):
+    n, h, w, c = y.shape
+    if c != 3 or (base is not None and tuple(base.shape) != tuple(y.shape)) or tuple(pred.shape) != tuple(y.shape):
+        raise NLTError("finish_pred: y / base / pred must be [n,h,w,3] of one shape")
+    _check(lib().nlt_finish_pred(_ptr(_dense(y, 'y')), _ptr(base), n, h, w, _ptr(pred), _stream()), 'nlt_finish_pred')
+
+
+def act_forward(x, kind, alpha):
+    y = torch.empty_like(x)
+    _check(lib().nlt_act_forward(_ptr(_dense(x, 'x')), x.numel(), kind, float(alpha), _ptr(y), _stream()), 'nlt_act_forward')
+    return y
+
+
+def act_backward(g, y, kind, alpha):
+    _same_shape(g, y, 'act_backward')
+    dx = torch.empty_like(y)
+    _check(lib().nlt_act_backward(_ptr(_dense(g, 'g')), _ptr(_dense(y, 'y')), y.numel(), kind, float(alpha), _ptr(dx), _stream()),
+           'nlt_act_backward')
+    return dx
+
+
+def pixelnorm_forward(x, eps=1e-8):
+    y = torch.empty_like(x)
+    c = x.shape[-1]
+    _check(lib().nlt_pixelnorm_forward(_ptr(_dense(x, 'x')), x.numel() // c, c, float(eps), _ptr(y), _stream()), 'nlt_pixelnorm_forward')
+    return y
+
+
+def pixelnorm_backward(g, x, eps=1e-8):
+    _same_shape(g, x, 'pixelnorm_backward')
+    dx = torch.empty_like(x)
+    c = x.shape[-1]
+    _check(lib().nlt_pixelnorm_backward(_ptr(_dense(g, 'g')), _ptr(_dense(x, 'x')), x.numel() // c, c, float(eps), _ptr(dx), _stream()),
+           'nlt_pixelnorm_backward')
+    return dx
+
+
+def pool2x2_forward(x, kind):
+    n, h, w, c = x.shape
+    y = torch.empty((n, h // 2, w // 2, c), device=x.device, dtype=torch.float32)
+    _check(lib().nlt_pool2x2_forward(_ptr(_dense(x, 'x')), n, h, w, c, kind, _ptr(y), _stream()), 'nlt_pool2x2_forward')
+    return y
+
+
+def pool2x2_backward(g, x, kind):
+    n, h, w, c = x.shape
+    if tuple(g.shape) != (n, h // 2, w // 2, c):
+        raise NLTError("pool2x2_backward: gradient %s for input %s" % (tuple(g.shape), tuple(x.shape)))
+    dx = torch.empty_like(x)
+    _check(lib().nlt_pool2x2_backward(_ptr(_dense(g, 'g')), _ptr(_dense(x, 'x')), n, h, w, c, kind, _ptr(dx), _stream()),
+           'nlt_pool2x2_backward')
+    return dx
+
+
 def clip_by_norm_slots(grad, slots, clipnorm):
     """grad: flat fp32 bucket; slots: int64 [n,2] (offset, count) on the same device; in place."""
     _check(lib().nlt_clip_by_norm_slots(_ptr(grad), _tptr(slots, torch.int64, 'slots'), slots.shape[0], float(clipnorm),
@@ -605,6 +680,12 @@ def front4_forward_u8(diffuse_store, rgb_store, cvis_store, lvis_store, ids, nn_
                                        _ptr(packed), _ptr(packed_l2), 1 if add_base else 0, float(alpha), _ptr(fm1),
                                        _ptr(skip3), _ptr(qtmp2), _ptr(otmp2), int(waves_per_simd), _stream()),
            'nlt_front4_forward_u8')
+
+
+def dec_block_forward(x, cx, skip, cs, n, h, w, w_s2, b_s2, w_s1, b_s1, c, alpha, out):
+    """One expanding block (deconv k2s2 + LeakyReLU + deconv k2s1 + LeakyReLU), c = 8 or 16, intermediate in LDS."""
+    _check(lib().nlt_dec_block_forward(_ptr(_dense(x, 'x')), cx, _ptr(_dense(skip, 'skip')), cs, n, h, w, _ptr(w_s2), _ptr(b_s2),
+                                       _ptr(w_s1), _ptr(b_s1), c, float(alpha), _ptr(out), _stream()), 'nlt_dec_block_forward')
 
 
 def back_forward(x, fm1, skip3, n, h2, w2, w_s2, b_s2, w_s1, b_s1, w_head, alpha, pred):

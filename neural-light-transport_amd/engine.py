@@ -57,6 +57,8 @@ class RenderPlan:
         self.fuse_ends = os.environ.get('NLT_FUSED', '1') != '0'   # inference: csrc/fused.hip for layers 0-1 and the last block + head
         self._front_blob = None
         self.front_l2 = os.environ.get('NLT_FRONT_L2', '1') != '0'      # front kernel also runs level 2's stride-2 convs (k <= 4)
+        # inference: expanding blocks with 8 / 16 output channels as ONE launch each (csrc/dec_block.hip: intermediate map in LDS)
+        self.fuse_dec = os.environ.get('NLT_FUSED_DEC', '1') != '0'
         # second-generation front kernel (csrc/front4.hip: barrier-free, one wave per level-1 strip); 0 = first generation
         self.front_v4 = os.environ.get('NLT_FRONT4', '1') != '0'
         self.fuse_train = os.environ.get('NLT_FUSED_TRAIN', '1') != '0'   # fused ends in the train step too (csrc/train_fused.hip)
@@ -590,6 +592,18 @@ class RenderPlan:
             (da, dact_a), (db, dact_b) = q.layers[D + 1 + j].convs()
             skip, cs = b['fm'][D - j], 2 * cl[D - j]
             lab = 'L%d.q' % (D + 1 + j)
+            nl = da.n_ch_out
+            if (self.fuse_dec and not train and nl in (8, 16) and db.n_ch_out == nl and cx % 4 == 0 and algo == C.ALGO_AUTO
+                    and dact_a is not None and dact_b is not None and dact_a.alpha == dact_b.alpha and not self._trial_direct):
+                da.build(cx + cs, dev); db.build(nl, dev)
+                nbytes = 4 * n * hh * ww * ((cx + cs) + 4 * nl) + 4 * n * 4 * hh * ww * 2 * nl      # both convs
+                self._launch(lab, nbytes, C.dec_block_forward, x, cx, skip, cs, n, hh, ww, da.kernel.detach(), da.bias.detach(),
+                             db.kernel.detach(), db.bias.detach(), nl, dact_a.alpha, b['dec'][j],
+                             flops=2 * n * hh * ww * (cx + cs) * 4 * nl + 2 * n * 4 * hh * ww * 4 * nl * nl,
+                             moved=4 * n * hh * ww * ((cx + cs) + 4 * nl))
+                hh, ww = hh * 2, ww * 2
+                x, cx = b['dec'][j], nl
+                continue
             self._conv(lab + '.s2', da, dact_a, x, cx, cx, skip, cs, cs, n, hh, ww, b['dtmp'][j], da.n_ch_out, algo)
             hh, ww = hh * 2, ww * 2
             self._conv(lab + '.s1', db, dact_b, b['dtmp'][j], da.n_ch_out, da.n_ch_out, None, 0, 0, n, hh, ww,

@@ -16,6 +16,43 @@ from ..networks import convnet
 from .base import Model as BaseModel
 
 
+def _convs_of(layer):
+    """The Conv2D objects of one Network.layers entry (a bare conv or a Sequential, nested ones included)."""
+    return [layer] if hasattr(layer, 'set_weights') else layer.all_convs()
+
+
+class _GenericFn(torch.autograd.Function):
+    """autograd glue for the layer-by-layer path (generic.py): same contract as _RenderFn."""
+
+    @staticmethod
+    def forward(ctx, flat_params, model, inputs, want_indices):
+        base, cvis, lvis, warp, nn_rgb, nn_base, obs_weights = inputs
+        out = model._render_generic(base, cvis, lvis, warp, nn_rgb, nn_base, obs_weights, None, want_indices, record=True)
+        pred, pred_c, base_c, fg_c, idx, ctx.tape, ctx.out_node = out
+        ctx.model, ctx.inputs = model, inputs
+        ctx.mark_non_differentiable(pred, base_c, fg_c)
+        ctx.set_materialize_grads(False)
+        if idx is None:
+            idx = torch.empty(0, dtype=torch.int32, device=pred.device)
+        ctx.mark_non_differentiable(idx)
+        return pred_c, pred, base_c, fg_c, idx
+
+    @staticmethod
+    def backward(ctx, d_pred_c, *unused):
+        m = ctx.model
+        base, cvis, lvis, warp, nn_rgb, nn_base, obs_weights = ctx.inputs
+        n, hc, wc, _ = warp.shape
+        m.flat_grads.zero_()
+        if d_pred_c is not None:
+            d_pred_c = d_pred_c.contiguous()
+            if (hc, wc) != (m.imh, m.imw):
+                d_pred_c = C.resize_bilinear_backward(d_pred_c, hc, wc)
+            dpred = torch.empty((n, m.uvh, m.uvw, 3), device=base.device, dtype=torch.float32)
+            C.warp_backward(d_pred_c, warp, n, m.uvh, m.uvw, hc, wc, dpred)
+            ctx.tape.backward(ctx.out_node, dpred)          # (+ base and the corner zero are constants / masks of pred's warp)
+        return m.flat_grads, None, None, None
+
+
 class _RenderFn(torch.autograd.Function):
     """torch-autograd glue around the hand-written forward/backward plans: `flat_params` is the
     model's single parameter bucket; its gradient is the flat gradient bucket the backward plan
@@ -60,6 +97,8 @@ class Model(BaseModel):
         self.uvw = config.getint('DEFAULT', 'uvw')
         self.use_obs = config.getboolean('DEFAULT', 'use_obs')
         self.skip_connect_base = config.getboolean('DEFAULT', 'skip_connect_base')
+        # config branches the fused plan does not execute (act = elu, a norm, pooling + upconv) run layer by layer (generic.py)
+        self.generic = not all(l.is_plain() for net in self.net.values() for l in net.layers if hasattr(l, 'is_plain'))
         self.psnr = metric.PSNR(np.float32)                      # nlt/models/nlt.py:64
         self.plan = RenderPlan(self.net['query'], self.net['obs'], self.use_obs)
         self.conv_algo = C.ALGO_AUTO
@@ -110,7 +149,7 @@ class Model(BaseModel):
         out = []
         for name in ('query', 'obs'):
             for layer in self.net[name].layers:
-                out += [layer] if hasattr(layer, 'set_weights') else [c for c, _ in layer.convs()]
+                out += _convs_of(layer)
         return out
 
     def _flatten(self, device):
@@ -127,7 +166,7 @@ class Model(BaseModel):
         late = set()
         for layer, is_c in zip(q.layers, q.is_contracting):
             if not is_c and not hasattr(layer, 'set_weights'):
-                late.update(id(c) for c, _ in layer.convs())
+                late.update(id(c) for c in _convs_of(layer))
         order = [c for c in convs if id(c) in late] + [c for c in convs if id(c) not in late]
         where, off = {}, 0
         for c in order:
@@ -172,7 +211,7 @@ class Model(BaseModel):
             layers = self.net[name].layers
             assert len(layers) == len(weights[name]), (name, len(layers), len(weights[name]))
             for layer, lw in zip(layers, weights[name]):
-                convs = [layer] if hasattr(layer, 'set_weights') else [c for c, _ in layer.convs()]
+                convs = _convs_of(layer)
                 assert len(convs) == len(lw)
                 for ci, (c, (k, b)) in enumerate(zip(convs, lw)):
                     if c.built and (tuple(k.shape) != tuple(c.kernel.shape) or tuple(b.shape) != tuple(c.bias.shape)):
@@ -189,8 +228,8 @@ class Model(BaseModel):
         for name in ('query', 'obs'):
             out[name] = []
             for layer in self.net[name].layers:
-                convs = [layer] if hasattr(layer, 'set_weights') else [c for c, _ in layer.convs()]
-                out[name].append([(c.kernel.detach().cpu().numpy().copy(), c.bias.detach().cpu().numpy().copy()) for c in convs])
+                out[name].append([(c.kernel.detach().cpu().numpy().copy(), c.bias.detach().cpu().numpy().copy())
+                                  for c in _convs_of(layer)])
         return out
 
     def state_dict(self):
@@ -230,6 +269,26 @@ class Model(BaseModel):
             base_camspc = C.resize_bilinear_forward(base_camspc, self.imh, self.imw)
             pred_camspc = C.resize_bilinear_forward(pred_camspc, self.imh, self.imw)
         return pred, pred_camspc, base_camspc, fg_camspc, idx
+
+    def _render_generic(self, base, cvis, lvis, warp, nn_rgb, nn_base, obs_weights, obs_override, want_indices, record=False):
+        """`_render` on the layer-by-layer path: Model._call on generic layers, then + base, corner zero, warp, resize."""
+        from .. import generic
+        n, hc, wc, _ = warp.shape
+        x = torch.cat((base, cvis, lvis), 3)                                    # nlt.py:95
+        k = nn_rgb.shape[1]
+        y_obs = [C.sub_forward(nn_rgb[:, i].contiguous(), nn_base[:, i].contiguous()) for i in range(k)]   # nlt.py:96
+        node, tape = generic.forward(self, x, y_obs, obs_weights=obs_weights, obs_override=obs_override, record=record)
+        pred = torch.empty_like(base)
+        C.finish_pred(node.value, base if self.skip_connect_base else None, pred)   # + base, texel (0,0) zeroed (nlt.py:99-110)
+        E = lambda: torch.empty((n, hc, wc, 3), device=base.device, dtype=torch.float32)
+        pred_camspc, base_camspc, fg_camspc = E(), E(), E()
+        idx = torch.empty((n, hc, wc, 4), device=base.device, dtype=torch.int32) if want_indices else None
+        C.warp_forward(pred, base, warp, n, self.uvh, self.uvw, hc, wc, pred_camspc, base_camspc, fg_camspc, idx)
+        if (hc, wc) != (self.imh, self.imw):
+            fg_camspc = C.resize_bilinear_forward(fg_camspc, self.imh, self.imw)
+            base_camspc = C.resize_bilinear_forward(base_camspc, self.imh, self.imw)
+            pred_camspc = C.resize_bilinear_forward(pred_camspc, self.imh, self.imw)
+        return (pred, pred_camspc, base_camspc, fg_camspc, idx, tape, node) if record else (pred, pred_camspc, base_camspc, fg_camspc, idx)
 
     def _render_backward(self, d_pred_c, inputs, generation=None):
         """Fills the flat gradient bucket from dL/d(pred_camspc): resize / warp (TFA resampler) adjoints, then the
@@ -310,8 +369,8 @@ class Model(BaseModel):
         if isinstance(base, ResidentTexels):
             # texel buffers still in the uint8 store (Dataset.load_batch(resident=True)): the fused front kernel reads
             # them there when this call is an inference forward it can take; anything else gets the float tensors
-            act0 = self.net['query'].layers[1].convs()[0][1] if len(self.net['query'].layers) > 2 else None
-            if (not differentiable and obs_override is None and obs_weights is None and act0 is not None
+            act0 = self.net['query'].layers[1].convs()[0][1] if (not self.generic and len(self.net['query'].layers) > 2) else None
+            if (not self.generic and not differentiable and obs_override is None and obs_weights is None and act0 is not None
                     and getattr(self, 'flat_params', None) is not None
                     and self.plan.resident_ok(base.n, base.k, base.h, base.w, act0.alpha)):
                 resident = base
@@ -323,7 +382,17 @@ class Model(BaseModel):
             if nn_rgb.dim() == 4:           # the reference's single neighbour
                 nn_rgb, nn_base = nn_rgb.unsqueeze(1), nn_base.unsqueeze(1)
             nn_rgb, nn_base = nn_rgb.contiguous(), nn_base.contiguous()
-        if resident is not None:
+        if self.generic:
+            if differentiable:
+                pred_camspc, pred, base_camspc, fg_camspc, idx = _GenericFn.apply(
+                    self.flat_params, self, (base, cvis, lvis, warp, nn_rgb, nn_base, obs_weights), want_indices)
+                pred_copy = pred
+            else:
+                pred, pred_camspc, base_camspc, fg_camspc, idx = self._render_generic(
+                    base, cvis, lvis, warp, nn_rgb, nn_base, obs_weights, obs_override, want_indices)
+                pred_copy = pred
+            differentiable = False                                   # (`pred` is a fresh tensor on this path: no clone below)
+        elif resident is not None:
             pred, pred_camspc, base_camspc, fg_camspc, idx = self._render(None, None, None, warp, None, None, None, None,
                                                                           want_indices, resident=resident)
             pred_copy = pred.clone()

@@ -2,8 +2,10 @@
 executed by libnlt_hip.so.  Weights live in Keras layouts (conv: (kh,kw,Cin,Cout); deconv:
 (kh,kw,Cout,Cin)) as torch CUDA tensors so checkpoints / oracles exchange arrays unchanged.
 
-Released-config branch only (conv, deconv, leakyrelu/relu, iden, norm/pool 'none'); the other
-norm / pool / act / upconv branches raise NotImplementedError.
+The released-config branch (conv, deconv, leakyrelu / relu, iden, norm / pool 'none') runs on the fused RenderPlan
+(engine.py).  act = elu, norm = pixel, pool = max / avg and `upconv` are stand-alone layers executed layer by layer
+(generic.py; csrc/branches.hip).  norm = batch / layer / instance raise NotImplementedError: they add trainable
+variables the flat bucket / checkpoint layout does not carry (and `instance` is tf.contrib, absent from TF 2.2).
 """
 import math
 
@@ -214,12 +216,51 @@ class PackRegistry:
 
 
 class Act(Layer):
-    def __init__(self, alpha):
-        self.alpha = alpha
+    """kind 'lrelu': LeakyReLU(alpha) / ReLU (alpha = 0), fused into the preceding conv's epilogue by the plan;
+    kind 'elu': tf.keras.layers.ELU(alpha), a stand-alone launch."""
+
+    def __init__(self, alpha, kind='lrelu'):
+        self.alpha, self.kind = alpha, kind
 
     def __call__(self, x):
-        raise NotImplementedError(
-            "activations run fused into the preceding conv kernel; call the enclosing Sequential")
+        return C.act_forward(x.contiguous(), C.ACT_ELU if self.kind == 'elu' else C.ACT_LRELU, self.alpha)
+
+    def backward(self, g, y):
+        return C.act_backward(g.contiguous(), y, C.ACT_ELU if self.kind == 'elu' else C.ACT_LRELU, self.alpha)
+
+
+class PixelNorm(Layer):
+    """elements.py:103-121: x * rsqrt(mean_c(x^2) + 1e-8)."""
+    eps = 1.0e-8
+
+    def __call__(self, x):
+        return C.pixelnorm_forward(x.contiguous(), self.eps)
+
+    def backward(self, g, x):
+        return C.pixelnorm_backward(g.contiguous(), x, self.eps)
+
+
+class Pool2D(Layer):
+    """MaxPooling2D / AveragePooling2D(pool_size=2, strides=2, padding='same') (elements.py:81-94)."""
+
+    def __init__(self, kind):
+        self.kind = C.POOL_MAX if kind == 'max' else C.POOL_AVG
+
+    def __call__(self, x):
+        return C.pool2x2_forward(x.contiguous(), self.kind)
+
+    def backward(self, g, x):
+        return C.pool2x2_backward(g.contiguous(), x, self.kind)
+
+
+class UpSample2D(Layer):
+    """tf.keras.layers.UpSampling2D(size=2, interpolation='bilinear') = tf.image.resize (half-pixel centres)."""
+
+    def __call__(self, x):
+        return C.resize_bilinear_forward(x.contiguous(), 2 * x.shape[1], 2 * x.shape[2])
+
+    def backward(self, g, x):
+        return C.resize_bilinear_backward(g.contiguous(), x.shape[1], x.shape[2])
 
 
 class Identity(Layer):
@@ -245,6 +286,20 @@ class Sequential(Layer):
 
     def variables(self):
         return [v for l in self.layers for v in l.variables()]
+
+    def all_convs(self):
+        """Every Conv2D inside, nested Sequentials (upconv) included, in execution order."""
+        out = []
+        for l in self.layers:
+            if isinstance(l, Conv2D):
+                out.append(l)
+            elif isinstance(l, Sequential):
+                out += l.all_convs()
+        return out
+
+    def is_plain(self):
+        """Only convs, identities and fused-able LeakyReLU / ReLU activations (what RenderPlan executes)?"""
+        return all(isinstance(l, (Conv2D, Identity)) or (isinstance(l, Act) and l.kind == 'lrelu') for l in self.layers)
 
     def convs(self):
         """[(Conv2D, Act or None)] in execution order."""
@@ -279,12 +334,18 @@ def deconv(kernel_size, n_ch_out, stride=1):
 
 
 def upconv(n_ch_out):
-    raise NotImplementedError("upconv (bilinear x2 + 2x2 conv) is only reached with pool != None")
+    """2x bilinear upsampling + Conv2D(n, 2, padding='same') (elements.py:42-48)."""
+    return Sequential([UpSample2D(), Conv2D(n_ch_out, 2, 1)])
 
 
 def norm(type_):
     if type_ is None or type_.lower() == 'none':
         return iden()
+    if type_ == 'pixel':
+        return PixelNorm()
+    if type_ in ('batch', 'layer', 'instance'):
+        raise NotImplementedError("norm = %s: trainable gamma / beta (and, for batch, moving statistics) are not carried by "
+                                  "the flat parameter bucket; `instance` is tf.contrib, which TF 2.2 does not have" % type_)
     raise NotImplementedError(type_)
 
 
@@ -293,12 +354,16 @@ def act(type_):
         return Act(0.0)                 # tf.keras.layers.ReLU(negative_slope=0)
     if type_ == 'leakyrelu':
         return Act(0.3)                 # tf.keras.layers.LeakyReLU(alpha=0.3)
+    if type_ == 'elu':
+        return Act(1.0, kind='elu')     # tf.keras.layers.ELU(alpha=1.0)
     raise NotImplementedError(type_)
 
 
 def pool(type_):
     if type_ is None or type_.lower() == 'none':
         return iden()
+    if type_ in ('max', 'avg'):
+        return Pool2D(type_)
     raise NotImplementedError(type_)
 
 

@@ -77,7 +77,7 @@ def _layer_in_channels(layers, is_c, cin_query, cin_obs, use_obs=True):
     return q_in, o_in
 
 
-def init_weights(layers, in_channels, rng, bias_range=0.1, contracting_only=None):
+def init_weights(layers, in_channels, rng, bias_range=0.1, contracting_only=None, pool=False):
     """Keras-layout weights.  conv: (kh,kw,Cin,Cout); deconv: (kh,kw,Cout,Cin).
     Kernels glorot-uniform (Keras default); biases U(-bias_range,bias_range) instead of
     Keras' zeros so the bias path is exercised."""
@@ -95,6 +95,11 @@ def init_weights(layers, in_channels, rng, bias_range=0.1, contracting_only=None
             k = L['k']
             ws.append([(T.glorot_uniform(rng, (k, k, cin, n)), bias()),
                        (T.glorot_uniform(rng, (k, k, n, n)), bias())])
+        elif pool:                                               # upconv's Conv2D(n, 2) first (elements.py:42-48), then the deconvs
+            k = L['k']
+            ws.append([(T.glorot_uniform(rng, (2, 2, cin, n)), bias()),
+                       (T.glorot_uniform(rng, (k, k, n, n)), bias()),
+                       (T.glorot_uniform(rng, (k, k, n, n)), bias())])
         else:
             k = L['k']
             ws.append([(T.glorot_uniform(rng, (k, k, n, cin)), bias()),
@@ -102,34 +107,54 @@ def init_weights(layers, in_channels, rng, bias_range=0.1, contracting_only=None
     return ws
 
 
-ACT_ALPHA = {'leakyrelu': T.LRELU_ALPHA, 'relu': 0.0}     # elements.py:69-73: LeakyReLU(alpha=0.3) / ReLU(negative_slope=0)
+ACT_ALPHA = {'leakyrelu': T.LRELU_ALPHA, 'relu': 0.0, 'elu': 1.0}     # elements.py:69-75: LeakyReLU(0.3) / ReLU(0) / ELU(alpha=1)
 
 
-def apply_layer(L, w, x, alpha=T.LRELU_ALPHA):
-    """One entry of Network.layers (convnet.py:44,50-59,67-76,85); alpha = negative slope of the block's activation."""
+def pixel_norm(x, eps=1.0e-8):
+    """elements.py:103-121."""
+    return x * torch.rsqrt((x * x).mean(-1, keepdim=True) + eps)
+
+
+def pool2x2(x, kind):
+    """tf.keras.layers.Max/AveragePooling2D(pool_size=2, strides=2, padding='same') on even sizes (elements.py:81-94)."""
+    f = torch.nn.functional.max_pool2d if kind == 'max' else torch.nn.functional.avg_pool2d
+    return f(x.permute(0, 3, 1, 2), 2, 2).permute(0, 2, 3, 1)
+
+
+def apply_layer(L, w, x, alpha=T.LRELU_ALPHA, norm=None, pool=None, act='leakyrelu'):
+    """One entry of Network.layers (convnet.py:44,50-59,67-76,85); alpha = negative slope (lrelu / relu) or ELU's alpha;
+    norm in (None, 'pixel'); pool in (None, 'max', 'avg') -- with pooling the expanding blocks start with `upconv`."""
+    nrm = (lambda v: pixel_norm(v)) if norm == 'pixel' else (lambda v: v)
+    a = (lambda v: torch.nn.functional.elu(v, alpha)) if act == 'elu' else (lambda v: T.leaky_relu(v, alpha))
     if L['kind'] == 'conv1x1':
         return T.conv2d_same(x, w[0][0], w[0][1], 1)
     if L['kind'] == 'down':
-        y = T.leaky_relu(T.conv2d_same(x, w[0][0], w[0][1], L['s']), alpha)
-        return T.leaky_relu(T.conv2d_same(y, w[1][0], w[1][1], 1), alpha)
-    y = T.leaky_relu(T.conv2d_transpose_same(x, w[0][0], w[0][1], L['s']), alpha)
-    return T.leaky_relu(T.conv2d_transpose_same(y, w[1][0], w[1][1], 1), alpha)
+        y = a(nrm(T.conv2d_same(x, w[0][0], w[0][1], L['s'])))
+        y = a(nrm(T.conv2d_same(y, w[1][0], w[1][1], 1)))
+        return pool2x2(y, pool) if pool else y
+    if pool:                                                     # upconv: bilinear x2 + Conv2D(n, 2, 'same')
+        x = T.conv2d_same(T.resize_bilinear(x, 2 * x.shape[1], 2 * x.shape[2]), w[0][0], w[0][1], 1)
+        w = w[1:]
+    y = a(nrm(T.conv2d_transpose_same(x, w[0][0], w[0][1], L['s'])))
+    return a(nrm(T.conv2d_transpose_same(y, w[1][0], w[1][1], 1)))
 
 
 class OracleModel:
     """nlt/models/nlt.py Model, restated.  Weights are torch-CPU leaf tensors."""
 
     def __init__(self, depth0=16, depth=256, kernel=2, stride=2, uvh=512, uvw=512, imh=512,
-                 imw=512, use_obs=True, skip_connect_base=True, loss='l2', seed=0, dtype=torch.float32, act='leakyrelu'):
+                 imw=512, use_obs=True, skip_connect_base=True, loss='l2', seed=0, dtype=torch.float32, act='leakyrelu',
+                 norm=None, pool=None):
         self.layers, self.is_contracting, _ = build_layers(depth0, depth, kernel, stride)
         self.alpha = ACT_ALPHA[act]                              # config key `act` (dragon_specular.ini:61)
+        self.act, self.norm, self.pool = act, norm, pool         # config keys `norm`, `pool` (dragon_specular.ini:60,62)
         self.uvh, self.uvw, self.imh, self.imw = uvh, uvw, imh, imw
         self.use_obs, self.skip_connect_base = use_obs, skip_connect_base
         self.loss_spec = loss
         q_in, o_in = _layer_in_channels(self.layers, self.is_contracting, 5, 3, use_obs)
         rng = np.random.default_rng(seed)
-        wq = init_weights(self.layers, q_in, rng)
-        wo = init_weights(self.layers, o_in, rng, contracting_only=self.is_contracting)
+        wq = init_weights(self.layers, q_in, rng, pool=bool(pool))
+        wo = init_weights(self.layers, o_in, rng, contracting_only=self.is_contracting, pool=bool(pool))
         tt = lambda a: torch.tensor(a, dtype=dtype, requires_grad=True)
         self.wq = [[(tt(k), tt(b)) for k, b in lw] for lw in wq]
         self.wo = [[(tt(k), tt(b)) for k, b in lw] for lw in wo]   # obs net keeps contracting layers only (nlt.py:57-59)
@@ -156,13 +181,13 @@ class OracleModel:
         query_y = None
         for i, (L, c) in enumerate(zip(self.layers, self.is_contracting)):
             if c:
-                obs_ys = [apply_layer(L, self.wo[i], x, self.alpha) for x in obs_xs]       # :154-155
+                obs_ys = [apply_layer(L, self.wo[i], x, self.alpha, self.norm, self.pool, self.act) for x in obs_xs]   # :154-155
                 obs_agg = torch.stack(obs_ys, -1)                               # :161
                 if obs_weights is not None:
                     obs_agg = obs_weights * obs_agg                             # :162-163
                 obs_agg = obs_agg.mean(-1)                                      # :164
                 obs_xs = obs_ys                                                 # :166
-                query_y = apply_layer(L, self.wq[i], query_x, self.alpha)               # :168
+                query_y = apply_layer(L, self.wq[i], query_x, self.alpha, self.norm, self.pool, self.act)              # :168
                 if self.use_obs:
                     if obs_override is not None:
                         obs_agg = obs_override[i]                               # :172-173
@@ -174,7 +199,7 @@ class OracleModel:
             else:
                 if stack:
                     query_x = torch.cat((query_x, stack.pop()), -1)             # :184-190
-                query_y = apply_layer(L, self.wq[i], query_x, self.alpha)               # :195
+                query_y = apply_layer(L, self.wq[i], query_x, self.alpha, self.norm, self.pool, self.act)              # :195
                 query_x = query_y
         return (query_y, feats) if return_feats else query_y
 

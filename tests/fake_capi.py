@@ -426,6 +426,53 @@ def front2_forward(base, cvis, lvis, nn_rgb, nn_base, n, k, h, w, P, P2, add_bas
     otmp2.copy_(torch.stack([lr(T.conv2d_same(obs1[:, i], P2['wo'], P2['bo'], 2)) for i in range(k)], 1))
 
 
+def act_forward(x, kind, alpha):
+    return torch.nn.functional.elu(x, alpha) if kind == 1 else T.leaky_relu(x, alpha)
+
+
+def act_backward(g, y, kind, alpha):
+    return g * torch.where(y > 0, torch.ones_like(y), (y + alpha) if kind == 1 else torch.full_like(y, alpha))
+
+
+def pixelnorm_forward(x, eps=1e-8):
+    return O.pixel_norm(x, eps)
+
+
+def pixelnorm_backward(g, x, eps=1e-8):
+    with torch.enable_grad():
+        xx = x.detach().clone().requires_grad_(True)
+        return torch.autograd.grad(O.pixel_norm(xx, eps), xx, g)[0]
+
+
+def pool2x2_forward(x, kind):
+    return O.pool2x2(x, 'max' if kind == 0 else 'avg').contiguous()
+
+
+def pool2x2_backward(g, x, kind):
+    with torch.enable_grad():
+        xx = x.detach().clone().requires_grad_(True)
+        return torch.autograd.grad(O.pool2x2(xx, 'max' if kind == 0 else 'avg'), xx, g)[0]
+
+
+def resize_bilinear_backward_(dout, h, w):
+    return resize_bilinear_backward(dout, h, w)
+
+
+def sub_forward(a, b):
+    return a - b
+
+
+def finish_pred(y, base, pred):
+    v = y + base if base is not None else y.clone()
+    pred.copy_(T.set_left_top_corner(v, 0))
+
+
+def dec_block_forward(x, cx, skip, cs, n, h, w, w_s2, b_s2, w_s1, b_s1, c, alpha, out):
+    lr = lambda v: T.leaky_relu(v, alpha)
+    u = lr(T.conv2d_transpose_same(torch.cat((x, skip), 3), w_s2, b_s2, 2))
+    out.copy_(lr(T.conv2d_transpose_same(u, w_s1, b_s1, 1)))
+
+
 def front4_supported(*tensors):
     return True
 
@@ -442,7 +489,8 @@ def front4_forward_u8(diffuse_store, rgb_store, cvis_store, lvis_store, ids, nn_
                    qtmp2, otmp2)
 
 
-_FUSED = _FUSED + ('front_pack_l2_weights', 'front2_forward', 'front4_supported', 'front4_forward', 'front4_forward_u8')
+_FUSED = _FUSED + ('front_pack_l2_weights', 'front2_forward', 'front4_supported', 'front4_forward', 'front4_forward_u8', 'dec_block_forward', 'act_forward', 'act_backward',
+                  'pixelnorm_forward', 'pixelnorm_backward', 'pool2x2_forward', 'pool2x2_backward', 'sub_forward', 'finish_pred')
 
 
 _FORWARD = ('conv_forward', 'pack_conv_weights', 'repack_table', 'repack_weights', 'stem_forward', 'obs_mean_forward', 'head_forward', 'warp_forward',

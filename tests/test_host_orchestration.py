@@ -120,8 +120,9 @@ def test_op_labels_and_algorithmic_bytes(monkeypatch):
             if not fused:
                 extra += 4 * 64 * 64 * (3 * k + 16) + 4 * 64 * 64 * 3
             assert abs((total - extra) / (64 * 64) - per_texel) < 1e-6, (k, fused, (total - extra) / 4096)
-            # fused: front (L0, L1 and, with k <= 4, level 2's two stride-2 convs) + 5 levels x 5 - 2 + 5 decoder blocks x 2 + back
-            assert len(pm.plan.timer.records) == (1 + 5 * 5 - 2 + 5 * 2 + 1 if fused else 1 + 6 * 5 + 6 * 2 + 1)
+            # fused: front (L0, L1 and level 2's two stride-2 convs) + 5 levels x 5 - 2 + 3 decoder blocks x 2 + the two
+            # single-launch blocks with 16 / 8 output channels (csrc/dec_block.hip) + back
+            assert len(pm.plan.timer.records) == (1 + 5 * 5 - 2 + 3 * 2 + 2 + 1 if fused else 1 + 6 * 5 + 6 * 2 + 1)
             assert ('F.front' in pm.plan.timer.records) == fused and ('L0.stem' in pm.plan.timer.records) != fused
 
 
