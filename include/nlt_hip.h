@@ -224,6 +224,27 @@ int nlt_barron_loss(const float* pred, const float* gt, int n, int h, int w, flo
 /* out[f,:] = x[f,:] * scale[f] */
 int nlt_scale_rows(const float* x, const float* scale, int n, long per_row, float* out, void* stream);
 
+/*
+ * bf16 middle of the network (BASELINE config 5): the conv family on v_mfma_f32_16x16x32_bf16 with fp32 accumulation,
+ * bf16-STORED activations between layers, fp32 bias + LeakyReLU on the accumulator.  Same modes, geometry, virtual
+ * concat (src0 | src1) and Keras weight layouts as nlt_conv_forward; each source and the output may independently be
+ * fp32 (the region's boundaries: rounded to bf16, nearest even, on load / kept fp32 on store) or bf16.
+ * c0, c1 multiples of 8, cout multiple of 4, ld* multiples of 8 (bf16) / 8 (fp32 source), 16-byte aligned pointers.
+ *   replaces: Conv2D / Conv2DTranspose + LeakyReLU of the encoder levels >= 3 and the expanding blocks mirroring them
+ *             (nlt/networks/convnet.py:50-59,67-76) when the model's `precision` is bf16.
+ * nlt_conv_bf16_pack: Keras fp32 kernel -> bf16 MFMA fragments (nlt_conv_bf16_packed_elems uint16 elements).
+ * nlt_obs_mean_bf16: mean over the k stored-bf16 observation maps of a level into a channel slice of the bf16 fm[l]
+ *   (tf.reduce_mean, nlt/models/nlt.py:161-164): fp32 sum in observation order, * (1/k), rounded to bf16.
+ */
+long nlt_conv_bf16_packed_elems(int mode, int c0, int c1, int cout);
+int nlt_conv_bf16_pack(int mode, const float* w_keras, int c0, int c1, int cout, unsigned short* packed, void* stream);
+int nlt_conv_bf16_forward(int mode, int tile_hint,
+                          const void* src0, int ld0, int c0, int src0_is_f32,
+                          const void* src1, int ld1, int c1, int src1_is_f32,
+                          int n, int h, int w, const unsigned short* w_packed, const float* bias,
+                          int cout, void* out, int ldo, int out_is_f32, int act, float alpha, void* stream);
+int nlt_obs_mean_bf16(const unsigned short* obs, int n, int k, long hw, int c, unsigned short* out, int ldo, void* stream);
+
 /* Layers of the config branches the released .ini files leave off (executed layer by layer, nlt_amd/generic.py):
  *   nlt_act_forward / _backward       kind 0: LeakyReLU(alpha) / ReLU (alpha = 0), kind 1: tf.keras.layers.ELU(alpha)
  *                                     (nlt/networks/elements.py:69-78); backward takes the layer's OUTPUT y

@@ -91,6 +91,11 @@ SIGNATURES = {
     'nlt_pack_conv_tile_weights': (_c_int, [_c_int, _vp, _c_int, _c_int, _c_int, _vp, _vp]),
     'nlt_conv_tile_forward': (_c_int, [_c_int, _vp, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _vp, _vp, _c_int, _c_int,
                                        _vp, _c_int, _vp, _c_int, _c_int, _c_float, _vp]),
+    'nlt_conv_bf16_packed_elems': (_c_long, [_c_int] * 4),
+    'nlt_conv_bf16_pack': (_c_int, [_c_int, _vp, _c_int, _c_int, _c_int, _vp, _vp]),
+    'nlt_conv_bf16_forward': (_c_int, [_c_int, _c_int, _vp, _c_int, _c_int, _c_int, _vp, _c_int, _c_int, _c_int,
+                                       _c_int, _c_int, _c_int, _vp, _vp, _c_int, _vp, _c_int, _c_int, _c_int, _c_float, _vp]),
+    'nlt_obs_mean_bf16': (_c_int, [_vp, _c_int, _c_int, _c_long, _c_int, _vp, _c_int, _vp]),
     'nlt_chmix_bf16_packed_elems': (_c_long, [_c_int, _c_int]),
     'nlt_chmix_bf16_pack': (_c_int, [_vp, _c_int, _c_int, _vp, _vp]),
     'nlt_chmix_bf16_forward': (_c_int, [_vp, _c_long, _c_int, _vp, _vp, _c_int, _c_int, _c_float, _vp, _vp]),
@@ -599,6 +604,41 @@ def conv_tile_forward(mode, src, ld, cin, frames, kobs, h, w, packed, bias, cout
     _check(lib().nlt_conv_tile_forward(mode, _ptr(src), ld, cin, frames, kobs, h, w, _ptr(packed), _ptr(bias), cout, tn,
                                        _ptr(out), ldo, _ptr(mean_out), ldm, 1 if act else 0, float(alpha), _stream()),
            'nlt_conv_tile_forward')
+
+
+# ---------------------------------------------------------------- bf16 middle of the network
+def conv_bf16_pack(mode, w_keras, c0, c1, cout):
+    n = lib().nlt_conv_bf16_packed_elems(mode, c0, c1, cout)
+    if n <= 0:
+        raise NLTError("conv_bf16: unsupported (mode %d, c0 %d, c1 %d, cout %d)" % (mode, c0, c1, cout))
+    out = torch.empty(n, device=w_keras.device, dtype=torch.bfloat16)
+    _check(lib().nlt_conv_bf16_pack(mode, _ptr(_dense(w_keras, 'w_keras')), c0, c1, cout, out.data_ptr(), _stream()), 'nlt_conv_bf16_pack')
+    return out
+
+
+def _any_ptr(t, what):
+    """(device pointer, is_fp32) of a float32 or bfloat16 CUDA tensor (or an already offset view of one)."""
+    if t is None:
+        return None, 0
+    if not (t.is_cuda and t.dtype in (torch.float32, torch.bfloat16)):
+        raise NLTError("%s: expected a float32 / bfloat16 CUDA tensor, got %s on %s" % (what, t.dtype, t.device))
+    return t.data_ptr(), 1 if t.dtype == torch.float32 else 0
+
+
+def conv_bf16_forward(mode, src0, c0, ld0, src1, c1, ld1, n, h, w, w_packed, bias, cout, out, ldo, act=True, alpha=0.3, tile_hint=0):
+    """src* / out: float32 or bfloat16 tensors (views into wider NHWC tensors allowed: pass the per-texel stride ld*)."""
+    p0, f0 = _any_ptr(src0, 'src0')
+    p1, f1 = _any_ptr(src1, 'src1')
+    po, fo = _any_ptr(out, 'out')
+    _check(lib().nlt_conv_bf16_forward(mode, tile_hint, p0, ld0, c0, f0, p1, ld1, c1, f1, n, h, w,
+                                       _tptr(w_packed, torch.bfloat16, 'w_packed'), _ptr(bias), cout, po, ldo, fo,
+                                       1 if act else 0, float(alpha), _stream()), 'nlt_conv_bf16_forward')
+
+
+def obs_mean_bf16(obs, n, k, hw, c, out, ldo):
+    if obs.dtype != torch.bfloat16 or out.dtype != torch.bfloat16:
+        raise NLTError("obs_mean_bf16: bfloat16 tensors expected")
+    _check(lib().nlt_obs_mean_bf16(obs.data_ptr(), n, k, hw, c, out.data_ptr(), ldo, _stream()), 'nlt_obs_mean_bf16')
 
 
 # ---------------------------------------------------------------- bf16 channel mix

@@ -72,6 +72,9 @@ class RenderPlan:
         # launch tape: replay a step's C calls with their resolved arguments instead of re-deriving them (see _capi.py)
         self.use_tape = os.environ.get('NLT_TAPE', '1') != '0'
         self._tuning = False
+        # 'bf16' (BASELINE config 5): encoder levels >= 3 and the expanding blocks mirroring them run on csrc/conv_bf16.hip with
+        # bf16-stored activations (inference, fused plan); everything at full / half / quarter resolution stays fp32
+        self.precision = os.environ.get('NLT_PRECISION', 'fp32')
         self.grad_hook = None           # callable fired by backward() once the expanding blocks' weight gradients are queued
         self.generation = 0             # bumped by every forward: the activations in the plan's buffers belong to that pass
         self.tape_replays = 0
@@ -91,11 +94,13 @@ class RenderPlan:
 
     # ------------------------------------------------------------------ buffers
     def _buffers(self, n, k, h, w, device):
-        key = (n, k, h, w, str(device))
+        key = (n, k, h, w, str(device), self.precision)
         b = self._bufs.get(key)
         if b is not None:
             return b
-        E = lambda *s: torch.empty(s, device=device, dtype=torch.float32)
+        bf = self.precision == 'bf16'
+        # bf16 region: levels >= 3, expanding blocks j <= D - 3 (the last of them, 16 output channels, hands fp32 on)
+        E = lambda *s, lo=False: torch.empty(s, device=device, dtype=torch.bfloat16 if (bf and lo) else torch.float32)
         q, D = self.q, self.n_down
         mult = 2 if self.use_obs else 1
         cl = [q.layers[0].n_ch_out] + [q.layers[l].convs()[0][0].n_ch_out for l in range(1, D + 1)]
@@ -106,15 +111,15 @@ class RenderPlan:
                 if (hh | ww) & 1:
                     raise ValueError("UV size %dx%d is not divisible by 2^%d" % (h, w, D))
                 hh, ww = hh // 2, ww // 2
-                b['qtmp'].append(E(n, hh, ww, cl[l]))
-                b['otmp'].append(E(n, k, hh, ww, cl[l]))
-            b['fm'].append(E(n, hh, ww, mult * cl[l]))
-            b['obs'].append(E(n, k, hh, ww, cl[l]))
+                b['qtmp'].append(E(n, hh, ww, cl[l], lo=l >= 3))
+                b['otmp'].append(E(n, k, hh, ww, cl[l], lo=l >= 3))
+            b['fm'].append(E(n, hh, ww, mult * cl[l], lo=l >= 3))
+            b['obs'].append(E(n, k, hh, ww, cl[l], lo=l >= 3))
         for j in range(self.n_up):
             nl = q.layers[D + 1 + j].convs()[0][0].n_ch_out
             hh, ww = hh * 2, ww * 2
-            b['dtmp'].append(E(n, hh, ww, nl))
-            b['dec'].append(E(n, hh, ww, nl))
+            b['dtmp'].append(E(n, hh, ww, nl, lo=j <= D - 3))
+            b['dec'].append(E(n, hh, ww, nl, lo=j < D - 3))
         b['pred'] = E(n, h, w, 3)
         b['skip3'] = None               # allocated by the fused inference path on first use
         self._bufs = {key: b}           # keep one shape resident
@@ -165,6 +170,21 @@ class RenderPlan:
                        layer.packed(c0, c1) if ok else None, layer.bias.detach(), layer.n_ch_out, out, ldo,
                        act=act is not None, alpha=act.alpha if act is not None else 0.0,
                        algo=algo if ok else C.ALGO_DIRECT, tile_hint=tile_hint if ok else 0, flops=flops)
+
+    def _conv_bf(self, label, layer, act, src0, c0, ld0, src1, c1, ld1, n, h, w, out, ldo):
+        """One conv of the bf16 region (csrc/conv_bf16.hip); sources / output fp32 or bf16 as their tensors are."""
+        layer.build(c0 + c1, src0.device)
+        assert layer.cin == c0 + c1, (layer.cin, c0, c1)
+        oh, ow = layer.out_hw(h, w)
+        bpe = lambda t: 4 if t.dtype == torch.float32 else 2
+        moved = n * h * w * (c0 * bpe(src0) + (c1 * bpe(src1) if c1 else 0)) + n * oh * ow * layer.n_ch_out * bpe(out)
+        ncols = layer.n_ch_out * (4 if layer.mode == C.DECONV_K2S2 else 1)
+        taps = 4 if layer.mode in (C.CONV_K2S2, C.CONV_K2S1, C.DECONV_K2S1) else 1
+        rows = n * h * w // (4 if layer.mode == C.CONV_K2S2 else 1)
+        self._launch(label, 4 * (n * h * w * (c0 + c1) + n * oh * ow * layer.n_ch_out), C.conv_bf16_forward, layer.mode,
+                     src0, c0, ld0, src1, c1, ld1, n, h, w, layer.packed_bf16(c0, c1), layer.bias.detach(), layer.n_ch_out, out, ldo,
+                     act=act is not None, alpha=act.alpha if act is not None else 0.0,
+                     tile_hint=self.tile_hints.get('bf.' + label, 0), flops=2 * rows * taps * (c0 + c1) * ncols, moved=moved)
 
     def _conv_enc(self, label, layer, act, src, cin, ld, frames, kobs, h, w, out, ldo, algo, mean_out=None, ldm=0,
                   obs_weights=None):
@@ -437,6 +457,9 @@ class RenderPlan:
         q, o, D, cl = self.q, self.o, self.n_down, b['C']
         mult = 2 if self.use_obs else 1
         run_obs = self.use_obs and obs_override is None
+        if self.precision == 'bf16' and not (fused and inference):
+            raise C.NLTError("precision = bf16 is an inference mode of the fused plan (training, obs_override / obs_weights and the "
+                             "layer-by-layer plan run fp32)")
         if fused:
             return self._forward_fused(b, base, cvis, lvis, nn_rgb, nn_base, skip_connect_base, algo, train=not inference)
 
@@ -560,29 +583,46 @@ class RenderPlan:
             C.record_event(ev[0], main)                             # front kernel done: fm[1], obs[1]
             C.wait_event(side, ev[0])
         hh, ww = h // 2, w // 2
+        bf = self.precision == 'bf16' and not train
         for l in range(2, D + 1):
             (qa, qact_a), (qb, qact_b) = q.layers[l].convs()
             (oa, oact_a), (ob, oact_b) = o.layers[l].convs()
             cin = 2 * cl[l - 1]
             s2_done = front2 and l == 2                             # the front kernel already wrote qtmp[2] / otmp[2]
-            if not s2_done:
-                self._conv_enc('L%d.o.s2' % l, oa, oact_a, b['obs'][l - 1], cl[l - 1], cl[l - 1], n, k, hh, ww, b['otmp'][l], cl[l], algo)
-            self._conv_enc('L%d.o.s1' % l, ob, oact_b, b['otmp'][l], cl[l], cl[l], n, k, hh // 2, ww // 2, b['obs'][l], cl[l], algo,
-                           mean_out=b['fm'][l].view(-1)[cl[l]:], ldm=2 * cl[l])
+            c = cl[l]
+            h2_, w2_ = hh // 2, ww // 2
+
+            def obs_path():
+                if bf and l >= 3:                                   # bf16 region: stored-bf16 maps, mean in its own launch
+                    self._conv_bf('L%d.o.s2' % l, oa, oact_a, b['obs'][l - 1], cl[l - 1], cl[l - 1], None, 0, 0, n * k, hh, ww,
+                                  b['otmp'][l], c)
+                    self._conv_bf('L%d.o.s1' % l, ob, oact_b, b['otmp'][l], c, c, None, 0, 0, n * k, h2_, w2_, b['obs'][l], c)
+                    self._launch('L%d.o.mean' % l, 4 * n * h2_ * w2_ * c * (k + 1), C.obs_mean_bf16, b['obs'][l], n, k, h2_ * w2_, c,
+                                 b['fm'][l].view(-1)[c:], 2 * c, moved=2 * n * h2_ * w2_ * c * (k + 1))
+                    return
+                if not s2_done:
+                    self._conv_enc('L%d.o.s2' % l, oa, oact_a, b['obs'][l - 1], cl[l - 1], cl[l - 1], n, k, hh, ww, b['otmp'][l], c, algo)
+                self._conv_enc('L%d.o.s1' % l, ob, oact_b, b['otmp'][l], c, c, n, k, h2_, w2_, b['obs'][l], c, algo,
+                               mean_out=b['fm'][l].view(-1)[c:], ldm=2 * c)
+
+            def query_path():
+                if bf and l >= 3:
+                    self._conv_bf('L%d.q.s2' % l, qa, qact_a, b['fm'][l - 1], cin, cin, None, 0, 0, n, hh, ww, b['qtmp'][l], c)
+                    self._conv_bf('L%d.q.s1' % l, qb, qact_b, b['qtmp'][l], c, c, None, 0, 0, n, h2_, w2_, b['fm'][l], 2 * c)
+                    return
+                if not s2_done:
+                    self._conv_enc('L%d.q.s2' % l, qa, qact_a, b['fm'][l - 1], cin, cin, n, 1, hh, ww, b['qtmp'][l], c, algo)
+                self._conv_enc('L%d.q.s1' % l, qb, qact_b, b['qtmp'][l], c, c, n, 1, h2_, w2_, b['fm'][l], 2 * c, algo)
+
+            obs_path()
             if concurrent:
                 C.record_event(ev[l], main)                         # fm[l]'s observation half is complete
                 with torch.cuda.stream(side):
                     if l > 2:
                         C.wait_event(side, ev[l - 1])
-                    if not s2_done:
-                        self._conv_enc('L%d.q.s2' % l, qa, qact_a, b['fm'][l - 1], cin, cin, n, 1, hh, ww, b['qtmp'][l], cl[l], algo)
-                    self._conv_enc('L%d.q.s1' % l, qb, qact_b, b['qtmp'][l], cl[l], cl[l], n, 1, hh // 2, ww // 2, b['fm'][l],
-                                   2 * cl[l], algo)
+                    query_path()
             else:
-                if not s2_done:
-                    self._conv_enc('L%d.q.s2' % l, qa, qact_a, b['fm'][l - 1], cin, cin, n, 1, hh, ww, b['qtmp'][l], cl[l], algo)
-                self._conv_enc('L%d.q.s1' % l, qb, qact_b, b['qtmp'][l], cl[l], cl[l], n, 1, hh // 2, ww // 2, b['fm'][l],
-                               2 * cl[l], algo)
+                query_path()
             hh, ww = hh // 2, ww // 2
         if concurrent:
             C.record_event(ev[D + 1], side)
@@ -593,6 +633,12 @@ class RenderPlan:
             skip, cs = b['fm'][D - j], 2 * cl[D - j]
             lab = 'L%d.q' % (D + 1 + j)
             nl = da.n_ch_out
+            if bf and j <= D - 3:                                   # bf16 region (the block with 16 outputs hands fp32 on)
+                self._conv_bf(lab + '.s2', da, dact_a, x, cx, cx, skip, cs, cs, n, hh, ww, b['dtmp'][j], nl)
+                hh, ww = hh * 2, ww * 2
+                self._conv_bf(lab + '.s1', db, dact_b, b['dtmp'][j], nl, nl, None, 0, 0, n, hh, ww, b['dec'][j], db.n_ch_out)
+                x, cx = b['dec'][j], db.n_ch_out
+                continue
             if (self.fuse_dec and not train and nl in (8, 16) and db.n_ch_out == nl and cx % 4 == 0 and algo == C.ALGO_AUTO
                     and dact_a is not None and dact_b is not None and dact_a.alpha == dact_b.alpha and not self._trial_direct):
                 da.build(cx + cs, dev); db.build(nl, dev)

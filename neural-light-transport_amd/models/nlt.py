@@ -101,6 +101,10 @@ class Model(BaseModel):
         self.generic = not all(l.is_plain() for net in self.net.values() for l in net.layers if hasattr(l, 'is_plain'))
         self.psnr = metric.PSNR(np.float32)                      # nlt/models/nlt.py:64
         self.plan = RenderPlan(self.net['query'], self.net['obs'], self.use_obs)
+        # `precision = bf16` (not a reference key; BASELINE config 5): the middle of the network on bf16 MFMA / bf16 storage
+        self.plan.precision = config.get('DEFAULT', 'precision', fallback=self.plan.precision)
+        if self.plan.precision not in ('fp32', 'bf16'):
+            raise NotImplementedError("precision = %s" % self.plan.precision)
         self.conv_algo = C.ALGO_AUTO
         # hipGraph replay of the inference forward (opt-in: NLT_GRAPH=1 or model.use_graphs = True).  The ~36 launches
         # of a step cost ~0.6 ms of host time; for small workloads (512^2, k = 1) that is the whole step.

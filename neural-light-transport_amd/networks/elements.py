@@ -125,6 +125,15 @@ class Conv2D(Layer):
                                  dict(kind=C.REPACK_TILE, mode=self.mode, c0=self.cin, c1=0, cout=self.n_ch_out, tn=tn, lo=0,
                                       full=self.n_ch_out))
 
+    def packed_bf16(self, c0, c1):
+        """bf16 MFMA fragments (csrc/conv_bf16.hip) for a (c0 | c1) input split; re-packed when the kernel was rewritten.
+        (Inference path: not part of the one-launch PackRegistry refresh.)"""
+        cache = self.__dict__.setdefault('_packed_bf', {})
+        ent, ver = cache.get((c0, c1)), self._version()
+        if ent is None or ent[0] != ver:
+            ent = cache[(c0, c1)] = (ver, C.conv_bf16_pack(self.mode, self.kernel.detach(), c0, c1, self.n_ch_out))
+        return ent[1]
+
     ADJOINT = {C.CONV_K2S2: C.DECONV_K2S2, C.CONV_K2S1: C.DECONV_K2S1,
                C.DECONV_K2S2: C.CONV_K2S2, C.DECONV_K2S1: C.CONV_K2S1}
 

@@ -121,6 +121,24 @@ def pool2x2(x, kind):
     return f(x.permute(0, 3, 1, 2), 2, 2).permute(0, 2, 3, 1)
 
 
+def round_bf16(t):
+    """Round to bfloat16 (nearest even) and back: the value a bf16-STORED tensor holds."""
+    return t.to(torch.bfloat16).to(t.dtype)
+
+
+def apply_layer_bf16(L, w, x, alpha, keep_fp32_out=False):
+    """A down / up block of the bf16 region (BASELINE config 5): operands rounded to bf16 (inputs as stored, weights as
+    packed), fp32 accumulation, fp32 bias + LeakyReLU, the result stored as bf16 -- except the region's last conv, whose
+    output stays fp32 (keep_fp32_out).  Mirrors csrc/conv_bf16.hip layer for layer."""
+    rb = round_bf16
+    if L['kind'] == 'down':
+        y = rb(T.leaky_relu(T.conv2d_same(rb(x), rb(w[0][0]), w[0][1], L['s']), alpha))
+        return rb(T.leaky_relu(T.conv2d_same(y, rb(w[1][0]), w[1][1], 1), alpha))
+    y = rb(T.leaky_relu(T.conv2d_transpose_same(rb(x), rb(w[0][0]), w[0][1], L['s']), alpha))
+    z = T.leaky_relu(T.conv2d_transpose_same(y, rb(w[1][0]), w[1][1], 1), alpha)
+    return z if keep_fp32_out else rb(z)
+
+
 def apply_layer(L, w, x, alpha=T.LRELU_ALPHA, norm=None, pool=None, act='leakyrelu'):
     """One entry of Network.layers (convnet.py:44,50-59,67-76,85); alpha = negative slope (lrelu / relu) or ELU's alpha;
     norm in (None, 'pixel'); pool in (None, 'max', 'avg') -- with pooling the expanding blocks start with `upconv`."""
@@ -148,6 +166,9 @@ class OracleModel:
         self.layers, self.is_contracting, _ = build_layers(depth0, depth, kernel, stride)
         self.alpha = ACT_ALPHA[act]                              # config key `act` (dragon_specular.ini:61)
         self.act, self.norm, self.pool = act, norm, pool         # config keys `norm`, `pool` (dragon_specular.ini:60,62)
+        # precision = 'bf16' (BASELINE config 5): layers [3, n_layers - 4] -- encoder levels >= 3 and the expanding blocks
+        # with >= 64 input channels -- on bf16 operands / bf16 storage, fp32 accumulation (csrc/conv_bf16.hip)
+        self.bf16_layers = None
         self.uvh, self.uvw, self.imh, self.imw = uvh, uvw, imh, imw
         self.use_obs, self.skip_connect_base = use_obs, skip_connect_base
         self.loss_spec = loss
@@ -173,7 +194,19 @@ class OracleModel:
         return {'query': conv(self.wq), 'obs': conv(self.wo)}
 
     # -- nlt/models/nlt.py:141-199
-    def _call(self, query_x, obs_xs, obs_weights=None, obs_override=None, return_feats=False):
+    def set_precision(self, precision):
+        n = len(self.layers)
+        self.bf16_layers = (3, n - 4) if precision == 'bf16' else None     # depth 256: layers 3 .. 10 of 14
+        return self
+
+    def _layer(self, i, L, w, x):
+        r = self.bf16_layers
+        if r is not None and r[0] <= i <= r[1]:
+            return apply_layer_bf16(L, w, x, self.alpha, keep_fp32_out=(i == r[1]))
+        return apply_layer(L, w, x, self.alpha, self.norm, self.pool, self.act)
+
+    def _call(self, query_x, obs_xs, obs_weights=None, obs_override=None, return_feats=False, layer_outputs=None):
+        """layer_outputs: a list that receives the query path's output of every layer (tests of intermediate maps)."""
         feats = []
         if obs_weights is not None:
             obs_weights = obs_weights.reshape(obs_weights.shape[0], 1, 1, 1, -1)
@@ -181,13 +214,17 @@ class OracleModel:
         query_y = None
         for i, (L, c) in enumerate(zip(self.layers, self.is_contracting)):
             if c:
-                obs_ys = [apply_layer(L, self.wo[i], x, self.alpha, self.norm, self.pool, self.act) for x in obs_xs]   # :154-155
+                obs_ys = [self._layer(i, L, self.wo[i], x) for x in obs_xs]              # :154-155
                 obs_agg = torch.stack(obs_ys, -1)                               # :161
                 if obs_weights is not None:
                     obs_agg = obs_weights * obs_agg                             # :162-163
                 obs_agg = obs_agg.mean(-1)                                      # :164
+                if self.bf16_layers is not None and self.bf16_layers[0] <= i <= self.bf16_layers[1]:
+                    obs_agg = round_bf16(obs_agg)                               # the mean is stored in the bf16 fm[l]
                 obs_xs = obs_ys                                                 # :166
-                query_y = apply_layer(L, self.wq[i], query_x, self.alpha, self.norm, self.pool, self.act)              # :168
+                query_y = self._layer(i, L, self.wq[i], query_x)                # :168
+                if layer_outputs is not None:
+                    layer_outputs.append(query_y)
                 if self.use_obs:
                     if obs_override is not None:
                         obs_agg = obs_override[i]                               # :172-173
@@ -199,7 +236,9 @@ class OracleModel:
             else:
                 if stack:
                     query_x = torch.cat((query_x, stack.pop()), -1)             # :184-190
-                query_y = apply_layer(L, self.wq[i], query_x, self.alpha, self.norm, self.pool, self.act)              # :195
+                query_y = self._layer(i, L, self.wq[i], query_x)                # :195
+                if layer_outputs is not None:
+                    layer_outputs.append(query_y)
                 query_x = query_y
         return (query_y, feats) if return_feats else query_y
 

@@ -34,9 +34,17 @@ def test_convnet_structure():
     assert convnet.Network(16, 1024, 2, 2, act_type='relu').layers[1].convs()[0][1].alpha == 0.0
     with pytest.raises(AssertionError):
         convnet.Network(8, 64, 2, 2)                       # depth0 must be 16
-    for bad in (dict(norm_type='batch'), dict(pool_type='max'), dict(act_type='elu')):
+    for bad in (dict(norm_type='batch'), dict(norm_type='layer'), dict(norm_type='instance'), dict(act_type='gelu'), dict(pool_type='l2')):
         with pytest.raises(NotImplementedError):
             convnet.Network(16, 256, 2, 2, **bad)
+    # the branches that ARE built: stand-alone layers, executed by nlt_amd/generic.py
+    from nlt_amd.networks import elements as E
+    pooled = convnet.Network(16, 32, 2, 2, norm_type='pixel', act_type='elu', pool_type='max')
+    down, up = pooled.layers[1], pooled.layers[4]
+    assert [type(l).__name__ for l in down.layers] == ['Conv2D', 'PixelNorm', 'Act', 'Conv2D', 'PixelNorm', 'Act', 'Pool2D']
+    assert isinstance(up.layers[0], E.Sequential) and [type(l).__name__ for l in up.layers[0].layers] == ['UpSample2D', 'Conv2D']
+    assert down.layers[2].kind == 'elu' and not down.is_plain() and len(up.all_convs()) == 3
+    assert pooled.spatsize_changes[1] == 0.25 and pooled.spatsize_changes[4] == 4
     assert convnet.Network.str2none('None') is None and convnet.Network.str2none('x') == 'x'
 
 
