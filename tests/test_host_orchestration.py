@@ -93,8 +93,9 @@ def test_relu_activation_config_branch(monkeypatch):
     assert rel_l2(pm.call(cpu_batch(batch, nn), 'vali')[3]['pred'], ref) < 1e-5
     pm.plan.fuse_ends = False
     assert rel_l2(pm.call(cpu_batch(batch, nn), 'vali')[3]['pred'], ref) < 1e-5
-    with pytest.raises(NotImplementedError):              # elu (elements.py:73-74) is not built
-        get_model_class('nlt')(nlt_amd.make_config(depth=256, uvh=64, uvw=64, imh=32, imw=32, act='elu'))
+    # elu (elements.py:74-75) is a stand-alone layer: the model takes the layer-by-layer path (tests/test_host_generic.py)
+    assert get_model_class('nlt')(nlt_amd.make_config(depth=256, uvh=64, uvw=64, imh=32, imw=32, act='elu')).generic
+    assert not pm.generic
 
 
 def test_op_labels_and_algorithmic_bytes(monkeypatch):
