@@ -98,6 +98,7 @@ def parse():
     ap.add_argument('--k', type=int, default=4, help='neighbour observation maps per frame')
     ap.add_argument('--depth', type=int, default=256)
     ap.add_argument('--algo', type=str, default='auto', choices=['auto', 'direct'])
+    ap.add_argument('--precision', type=str, default='fp32', choices=['fp32', 'bf16'], help='bf16: the middle of the network on bf16 MFMA / bf16 storage (reported as such in dtype)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--graph', action='store_true', help='replay the forward as one hipGraph (model.use_graphs); the dominant '
                     'kernel is then timed in an eager pass of the same steps right after the timed region')
@@ -290,6 +291,41 @@ def bench_train(args, device, world, rank, n_steps, loss):
             "final_loss": last}
 
 
+def bench_config5(args, device):
+    """BASELINE config 5 beside the headline (never instead of it): 2048^2 UV, 2 frames, k = 1, the SAME forward with the
+    middle of the network fp32 (MFMA f32) and bf16 (v_mfma_f32_16x16x32_bf16, bf16-stored maps, fp32 accumulate)."""
+    import copy
+    import torch
+    from nlt_amd.models import get_model_class
+    a5 = copy.copy(args)
+    a5.uv, a5.frames, a5.k, a5.batches, a5.store_frames = 2048, 2, 1, 3, 6
+    out = {"workload": "BASELINE config 5: depth0 16/depth %d, 2 frames, 2048^2 UV, k=1, %d^2 camera warp" % (args.depth, args.cam)}
+    for prec in ('fp32', 'bf16'):
+        cfg, ds, id_lists = make_loader(a5, device, 1, 'train', seed=500)
+        cfg.set('DEFAULT', 'precision', prec)
+        model = get_model_class('nlt')(cfg).build(device)
+        g = torch.Generator(device=device).manual_seed(1234)
+        for v in model.register_trainable() or model.trainable_variables:
+            if v.dim() == 1:
+                v.data.uniform_(-0.1, 0.1, generator=g)
+        batches = [ds.load_batch(ids) for ids in id_lists]
+        for i in range(9):
+            model.call(batches[i % 3], 'test')
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        n = 30
+        for i in range(n):
+            model.call(batches[i % 3], 'test')
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / n
+        out[prec] = {"ms_per_step": round(1e3 * dt, 4), "Mtexels_per_s": round(a5.frames * a5.uv * a5.uv / dt / 1e6, 1),
+                     "dtype": "f32" if prec == 'fp32' else "bf16 storage + bf16 MFMA (fp32 accumulate) for levels >= 3 and the "
+                              "expanding blocks mirroring them; fp32 ends"}
+        del model, batches, ds
+        torch.cuda.empty_cache()
+    return out
+
+
 def main():
     args = parse()
     if args.cpu_baseline_worker:
@@ -312,6 +348,7 @@ def main():
     from nlt_amd.engine import OpTimer
     from nlt_amd.models import get_model_class
     cfg, ds, id_lists = make_loader(args, device, args.k, 'train', seed=100 + rank)
+    cfg.set('DEFAULT', 'precision', args.precision)
     model = get_model_class('nlt')(cfg).build(device)
     # random-init weights of the released architecture; non-zero biases so the bias path is live
     g = torch.Generator(device=device).manual_seed(1234)          # same weights on every rank
@@ -432,7 +469,8 @@ def main():
             "metric": "rendered Mtexels/s at %d^2 UV (full Model.call forward: U-Net + UV->camera warp)" % args.uv,
             "value": round(value, 2), "unit": "Mtexels/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 4),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32" if args.precision == 'fp32' else "bf16 (fp32 accumulate) for the middle of the network, f32 ends",
             "data": "synthetic (seeded random texel buffers, random-init weights of the released architecture)",
             "config": {"workload": "BASELINE config 3: dragon_specular relight+view-synth, depth0 16/depth %d, "
                                    "%d frames/GPU, %d^2 UV, k=%d obs maps, %d^2 camera warp"
@@ -448,6 +486,8 @@ def main():
         }
         if with_loader:
             out["forward_including_loader"] = with_loader
+        if world == 1 and not args.headline_only and args.uv == 1024:
+            out["config5_2048_bf16"] = bench_config5(args, device)
         if train:
             out["train_step"] = train[0]
             if len(train) > 1:
