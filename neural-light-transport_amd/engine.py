@@ -237,7 +237,9 @@ class RenderPlan:
         if not self.fuse_ends:
             trials.append(('direct', 0))    # only the 4/8-channel full-resolution layers ever preferred it
         trials += [('lds', 32), ('lds', 64), ('lds', 256 + 32), ('lds', 256 + 64)]
-        trials += [('splitk', (16 * r + c, ks)) for (r, c) in ((1, 1), (1, 2), (2, 2)) for ks in (4, 8, 16)]
+        # split-K: launches with few GEMM rows and a long K (the deep levels; at depth 1024 a 1 x 1-texel level streams 33 MB of
+        # weights through 4 rows) need thousands of waves each walking a short K slice to keep HBM busy: up to 128 slices
+        trials += [('splitk', (16 * r + c, ks)) for (r, c) in ((1, 1), (1, 2), (2, 2), (1, 4)) for ks in (4, 8, 16, 32, 64, 128)]
         saved_lds, saved_sk = dict(self.lds_hints), dict(self.splitk_hints)
         for kind, hint in trials:
             self.tile_hints = {'*': hint} if kind == 'tile' else ({'*': hint[0]} if kind == 'splitk' else {})

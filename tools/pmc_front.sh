@@ -1,11 +1,11 @@
 # PMC pass over the bench forward: SQ counters of the front kernel (and everything else in the step)
 cd "$GRAFT_REPO_ROOT"; mkdir -p gpurun_out; export TMPDIR=/tmp; R="$GRAFT_REPO_ROOT"
-python bench.py --steps 5 --warmup 2 --no-cpu-baseline --train-steps 0 --tune-cache gpurun_out/tune_fused.json > /dev/null 2>&1
+python bench.py --steps 5 --warmup 2 --headline-only --tune-cache gpurun_out/tune_fused.json > /dev/null 2>&1
 cd /tmp
-rocprofv3 --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_BANK_CONFLICT --kernel-trace --output-format csv -d $R/gpurun_out/pmc_sq -- python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --train-steps 0 --tune-cache $R/gpurun_out/tune_fused.json > /dev/null 2>&1
-rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_LDS_IDX_ACTIVE SQ_INST_CYCLES_VMEM GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $R/gpurun_out/pmc_sq2 -- python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --train-steps 0 --tune-cache $R/gpurun_out/tune_fused.json > /dev/null 2>&1
-rocprofv3 --pmc SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_SCA SQ_INST_CYCLES_VALU SQ_VALU_MFMA_COEXEC_CYCLES SQ_WAIT_INST_LDS SQ_INST_LEVEL_VMEM --kernel-trace --output-format csv -d $R/gpurun_out/pmc_sq3 -- python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --train-steps 0 --tune-cache $R/gpurun_out/tune_fused.json > /dev/null 2>&1
-rocprofv3 --pmc TA_TA_BUSY_sum TCP_PENDING_STALL_CYCLES_sum SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_INST_CYCLES_VMEM_RD SQ_WAIT_ANY --kernel-trace --output-format csv -d $R/gpurun_out/pmc_sq4 -- python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --train-steps 0 --tune-cache $R/gpurun_out/tune_fused.json > /dev/null 2>&1
+rocprofv3 --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_BANK_CONFLICT --kernel-trace --output-format csv -d $R/gpurun_out/pmc_sq -- python $R/bench.py --steps 3 --warmup 1 --headline-only --tune-cache $R/gpurun_out/tune_fused.json > /dev/null 2>&1
+rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_LDS_IDX_ACTIVE SQ_INST_CYCLES_VMEM GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $R/gpurun_out/pmc_sq2 -- python $R/bench.py --steps 3 --warmup 1 --headline-only --tune-cache $R/gpurun_out/tune_fused.json > /dev/null 2>&1
+rocprofv3 --pmc SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_SCA SQ_INST_CYCLES_VALU SQ_VALU_MFMA_COEXEC_CYCLES SQ_WAIT_INST_LDS SQ_INST_LEVEL_VMEM --kernel-trace --output-format csv -d $R/gpurun_out/pmc_sq3 -- python $R/bench.py --steps 3 --warmup 1 --headline-only --tune-cache $R/gpurun_out/tune_fused.json > /dev/null 2>&1
+rocprofv3 --pmc TA_TA_BUSY_sum TCP_PENDING_STALL_CYCLES_sum SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_INST_CYCLES_VMEM_RD SQ_WAIT_ANY --kernel-trace --output-format csv -d $R/gpurun_out/pmc_sq4 -- python $R/bench.py --steps 3 --warmup 1 --headline-only --tune-cache $R/gpurun_out/tune_fused.json > /dev/null 2>&1
 cd $R
 python - <<'PY'
 import csv, glob, collections, json
@@ -15,7 +15,7 @@ for d in ('pmc_sq', 'pmc_sq2', 'pmc_sq3', 'pmc_sq4'):
     for p in glob.glob('gpurun_out/%s/**/*counter_collection*.csv' % d, recursive=True):
         for r in csv.DictReader(open(p)):
             n = r['Kernel_Name']
-            if 'front_kernel' in n or 'back_kernel' in n or 'conv_tile' in n or 'warp_kernel' in n:
+            if "front4_kernel" in n or "front_kernel" in n or "back_kernel" in n or "conv_tile" in n or "warp_kernel" in n or "dec_block" in n:
                 acc[n[:48]][r['Counter_Name']].append(float(r['Counter_Value']))
     for k, dd in acc.items():
         row = {c: round(sum(x)/len(x)) for c, x in dd.items()}
