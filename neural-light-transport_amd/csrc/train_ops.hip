@@ -157,10 +157,21 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(const float* __restrict__
 // Resampler backward w.r.t. data: 4-corner scatter-add with the forward weights.  Texel (0,0)
 // is skipped: every background pixel maps there and its gradient is discarded by the corner
 // mask anyway (nlt/models/nlt.py:110), so the one hot atomic address never exists.
+//
+// Device-scope float atomics are resolved behind the XCDs' L2s, one read-modify-write per touched line and instruction,
+// so the cost is the number of (instruction, line) pairs.  Lane = (camera pixel, one of the 6 contiguous floats of the
+// texel pair [fx, cx] x rgb): a wave covers 10 consecutive pixels, and ONE atomic instruction per texel row carries both
+// corners and all three channels of all of them (neighbouring pixels of a chart: one or two lines), instead of one
+// channel of one corner of 64 pixels.
+constexpr int WARPB_PX = 10;
 __global__ __launch_bounds__(256) void warp_bwd_kernel(const float* __restrict__ dcam, const float* __restrict__ warp,
                                                        int uvh, int uvw, int hcwc, long total, float* dpred) {
-  const long p = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (p >= total) return;
+  const int lane = threadIdx.x & 63;
+  const int j = lane / 6, sub = lane - 6 * j;
+  const int right = sub >= 3 ? 1 : 0, ch = sub - 3 * right;
+  const long wave = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const long p = wave * WARPB_PX + j;
+  if (j >= WARPB_PX || p >= total) return;
   const int f = p / hcwc;
   const float x = warp[p * 2 + 0] * (float)uvw;
   const float y = warp[p * 2 + 1] * (float)uvh;
@@ -168,16 +179,17 @@ __global__ __launch_bounds__(256) void warp_bwd_kernel(const float* __restrict__
   const int fx = (int)floorf(x), fy = (int)floorf(y);
   const int cx = fx + 1, cy = fy + 1;
   const float dx = (float)cx - x, dy = (float)cy - y;
-  const float wts[4] = {dx * dy, (1.f - dx) * (1.f - dy), dx * (1.f - dy), (1.f - dx) * dy};
-  const int xs[4] = {fx, cx, fx, cx};
-  const int ys[4] = {fy, cy, cy, fy};
-  const float g[3] = {dcam[p * 3 + 0], dcam[p * 3 + 1], dcam[p * 3 + 2]};
+  const float wx = right ? 1.f - dx : dx;
+  const float g = dcam[p * 3 + ch];
+  const int xi = fx + right;
+  if (xi < 0 || xi > uvw - 1) return;
 #pragma unroll
-  for (int t = 0; t < 4; ++t) {
-    const int xi = xs[t], yi = ys[t];
-    if (xi < 0 || yi < 0 || xi > uvw - 1 || yi > uvh - 1 || (xi == 0 && yi == 0) || wts[t] == 0.f) continue;
-    float* d = dpred + (((long)f * uvh + yi) * uvw + xi) * 3;
-    atomicAdd(d + 0, wts[t] * g[0]); atomicAdd(d + 1, wts[t] * g[1]); atomicAdd(d + 2, wts[t] * g[2]);
+  for (int r = 0; r < 2; ++r) {
+    const int yi = r ? cy : fy;
+    // the forward's weights, formed the same way: (fx,fy) dx*dy, (cx,fy) (1-dx)*dy, (fx,cy) dx*(1-dy), (cx,cy) (1-dx)*(1-dy)
+    const float wt = wx * (r ? 1.f - dy : dy);
+    if (yi < 0 || yi > uvh - 1 || (xi == 0 && yi == 0) || wt == 0.f) continue;
+    atomicAdd(dpred + (((long)f * uvh + yi) * uvw + xi) * 3 + ch, wt * g);
   }
 }
 
@@ -357,7 +369,7 @@ extern "C" int nlt_warp_backward(const float* dpred_cam, const float* warp, int 
   hipStream_t s = static_cast<hipStream_t>(stream);
   if (hipMemsetAsync(dpred, 0, (size_t)n * uvh * uvw * 3 * sizeof(float), s) != hipSuccess) return NLT_ERR_LAUNCH;
   const long total = (long)n * hc * wc;
-  hipLaunchKernelGGL(warp_bwd_kernel, dim3(blocks_for(total)), dim3(256), 0, s, dpred_cam, warp, uvh, uvw, hc * wc,
+  hipLaunchKernelGGL(warp_bwd_kernel, dim3((unsigned)((total + 4 * WARPB_PX - 1) / (4 * WARPB_PX))), dim3(256), 0, s, dpred_cam, warp, uvh, uvw, hc * wc,
                      total, dpred);
   NLT_CHECK_LAUNCH();
   return NLT_OK;

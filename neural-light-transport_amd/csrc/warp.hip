@@ -1,9 +1,15 @@
 // UV -> camera bilinear gather (tfa.image.resampler semantics) for pred/base/fg in one pass,
-// and the TF2 half-pixel bilinear resize.  Gather kernels: one thread per camera pixel; the
-// UV taps are served by L2 (neighbouring camera pixels hit neighbouring texels).
+// and the TF2 half-pixel bilinear resize.
+//
+// Gather kernel: one LANE per (camera pixel, colour channel) -- a wave covers 21 consecutive pixels x rgb = 63 lanes.
+// A tap instruction then reads 12 contiguous bytes per pixel (neighbouring pixels of a chart hit neighbouring texels:
+// ~0.5 KB per instruction) instead of one channel of 64 pixels spread over 1.5 KB, the 63 results of a wave are one
+// contiguous store, and every lane still adds its four taps in the resampler's order.
 #include "nlt_common.h"
 
 namespace {
+
+constexpr int WARP_PX = 21;      // camera pixels per wave pass (3 lanes each; lane 63 idles)
 
 // Arithmetic is kept un-contracted (no FMA fusion) and in the TFA kernel's order so that the
 // fp32 result equals the oracle's NumPy float32 restatement operation for operation.
@@ -13,45 +19,47 @@ __global__ __launch_bounds__(256) void warp_kernel(const float* __restrict__ pre
                                                    long total, float* __restrict__ pred_cam,
                                                    float* __restrict__ base_cam, float* __restrict__ fg_cam,
                                                    int* __restrict__ idx_out) {
-  const long p = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (p >= total) return;
+  const int lane = threadIdx.x & 63;
+  const int j = lane / 3, c = lane - 3 * j;
+  const long wave = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const long p = wave * WARP_PX + j;
+  if (j >= WARP_PX || p >= total) return;
   const int f = p / hcwc;
   const float x = warp[p * 2 + 0] * (float)uvw;     // nlt/models/nlt.py:104-106
   const float y = warp[p * 2 + 1] * (float)uvh;
   const bool inside = x > -1.f && y > -1.f && x < (float)uvw && y < (float)uvh;
   const int fx = (int)floorf(x), fy = (int)floorf(y);
-  if (idx_out) {
+  if (idx_out && c == 0) {
     idx_out[p * 4 + 0] = fx; idx_out[p * 4 + 1] = fy; idx_out[p * 4 + 2] = inside ? 1 : 0; idx_out[p * 4 + 3] = 0;
   }
-  float op[3] = {0.f, 0.f, 0.f}, ob[3] = {0.f, 0.f, 0.f}, og = 0.f;
+  float op = 0.f, ob = 0.f, og = 0.f;
   if (inside) {
     const int cx = fx + 1, cy = fy + 1;
     const float dx = (float)cx - x, dy = (float)cy - y;
     const float wts[4] = {dx * dy, (1.f - dx) * (1.f - dy), dx * (1.f - dy), (1.f - dx) * dy};
     const int xs[4] = {fx, cx, fx, cx};
     const int ys[4] = {fy, cy, cy, fy};
+    float vp[4], vb[4], vg[4];
 #pragma unroll
-    for (int t = 0; t < 4; ++t) {
+    for (int t = 0; t < 4; ++t) {                    // all taps in flight before the first add
       const int xi = xs[t], yi = ys[t];
       const bool ok = xi >= 0 && yi >= 0 && xi <= uvw - 1 && yi <= uvh - 1;
       const bool corner = (xi == 0 && yi == 0);      // set_left_top_corner(., 0): nlt.py:108-110
       const long tex = ((long)f * uvh + (ok ? yi : 0)) * uvw + (ok ? xi : 0);
+      vp[t] = (ok && pred) ? pred[tex * 3 + c] : 0.f;
+      vb[t] = (ok && !corner && base) ? base[tex * 3 + c] : 0.f;
+      vg[t] = (ok && !corner) ? 1.f : 0.f;
+    }
 #pragma unroll
-      for (int c = 0; c < 3; ++c) {
-        const float vp = (ok && pred) ? pred[tex * 3 + c] : 0.f;
-        const float vb = (ok && !corner && base) ? base[tex * 3 + c] : 0.f;
-        op[c] = op[c] + wts[t] * vp;
-        ob[c] = ob[c] + wts[t] * vb;
-      }
-      og = og + wts[t] * ((ok && !corner) ? 1.f : 0.f);
+    for (int t = 0; t < 4; ++t) {
+      op = op + wts[t] * vp[t];
+      ob = ob + wts[t] * vb[t];
+      og = og + wts[t] * vg[t];
     }
   }
-#pragma unroll
-  for (int c = 0; c < 3; ++c) {
-    if (pred_cam) pred_cam[p * 3 + c] = op[c];
-    if (base_cam) base_cam[p * 3 + c] = ob[c];
-    if (fg_cam) fg_cam[p * 3 + c] = og;
-  }
+  if (pred_cam) pred_cam[p * 3 + c] = op;
+  if (base_cam) base_cam[p * 3 + c] = ob;
+  if (fg_cam) fg_cam[p * 3 + c] = og;
 }
 
 __global__ __launch_bounds__(256) void resize_kernel(const float* __restrict__ x, int n, int h, int w, int c,
@@ -88,7 +96,7 @@ extern "C" int nlt_warp_forward(const float* pred, const float* base, const floa
   if (pred_cam && !pred) return NLT_ERR_BAD_ARG;
   if (!pred_cam && !base_cam && !fg_cam && !idx_out) return NLT_ERR_BAD_ARG;
   const long total = (long)n * hc * wc;
-  hipLaunchKernelGGL(warp_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0,
+  hipLaunchKernelGGL(warp_kernel, dim3((unsigned)((total + 4 * WARP_PX - 1) / (4 * WARP_PX))), dim3(256), 0,
                      static_cast<hipStream_t>(stream), pred, base, warp, uvh, uvw, hc * wc, total,
                      pred_cam, base_cam, fg_cam, idx_out);
   NLT_CHECK_LAUNCH();

@@ -72,6 +72,7 @@ class RenderPlan:
         # launch tape: replay a step's C calls with their resolved arguments instead of re-deriving them (see _capi.py)
         self.use_tape = os.environ.get('NLT_TAPE', '1') != '0'
         self._tuning = False
+        self.tune_backward = os.environ.get('NLT_TUNE_BWD', '1') != '0'   # plan-time trials for the backward-data launches too
         # 'bf16' (BASELINE config 5): encoder levels >= 3 and the expanding blocks mirroring them run on csrc/conv_bf16.hip with
         # bf16-stored activations (inference, fused plan); everything at full / half / quarter resolution stays fp32
         self.precision = os.environ.get('NLT_PRECISION', 'fp32')
@@ -225,7 +226,7 @@ class RenderPlan:
                          out, obs_weights, frames, kobs, oh * ow, c, mean_out, ldm)
 
     # ------------------------------------------------------------------ autotune
-    def _autotune(self, run):
+    def _autotune(self, run, backward=False):
         """Plan-creation-time choice of the MFMA wave tile (RT x CT) per launch: streaming layers
         want many small waves (memory-level parallelism), deep layers big register tiles (MFMA
         bound); a few 4/8-channel layers are faster on the direct kernel.  Times every candidate
@@ -234,9 +235,10 @@ class RenderPlan:
         self._tuning = True                 # no launch tapes while trial plans run
         results = {}
         trials = [('tile', 16 * r + c) for r in (1, 2, 4) for c in (1, 2, 4)]
-        if not self.fuse_ends:
+        if not self.fuse_ends and not backward:
             trials.append(('direct', 0))    # only the 4/8-channel full-resolution layers ever preferred it
-        trials += [('lds', 32), ('lds', 64), ('lds', 256 + 32), ('lds', 256 + 64)]
+        if not backward:
+            trials += [('lds', 32), ('lds', 64), ('lds', 256 + 32), ('lds', 256 + 64)]
         # split-K: launches with few GEMM rows and a long K (the deep levels; at depth 1024 a 1 x 1-texel level streams 33 MB of
         # weights through 4 rows) need thousands of waves each walking a short K slice to keep HBM busy: up to 128 slices
         trials += [('splitk', (16 * r + c, ks)) for (r, c) in ((1, 1), (1, 2), (2, 2), (1, 4)) for ks in (4, 8, 16, 32, 64, 128)]
@@ -277,7 +279,7 @@ class RenderPlan:
                     self.tile_hints[label], self.splitk_hints[label] = hint
             else:
                 self.tile_hints.setdefault(label, hint)
-        self.tuned = results
+        self.tuned = {**getattr(self, 'tuned', {}), **results}
         self._tuning = False
         self._drop_tapes()
 
@@ -735,9 +737,29 @@ class RenderPlan:
         adj = layer.ADJOINT[layer.mode]
         out_px = n * oh * ow * (4 if adj == C.DECONV_K2S2 else 1) // (4 if adj == C.CONV_K2S2 else 1)
         nbytes = 4 * (n * oh * ow * layer.n_ch_out + out_px * (hi - lo))
+        # wave tile / split-K of this launch: chosen by timing at plan time like the forward's (`_autotune` on the backward)
+        ncols = (hi - lo) * (4 if adj == C.DECONV_K2S2 else 1)
+        rows = n * oh * ow // (4 if adj == C.CONV_K2S2 else 1)
+        tile_hint = self.tile_hints.get(label, self.tile_hints.get('*', 0) if self._tuning else 0)
+        if tile_hint and ((ncols + 15) // 16) % (tile_hint & 15):
+            tile_hint = 0
+        nks = self.splitk_hints.get(label, 1)
+        if self._trial_splitk:
+            rt, ct = (tile_hint >> 4, tile_hint & 15) if tile_hint else (1, 1)
+            waves = -(-rows // (16 * rt)) * (-(-ncols // 16) // ct)
+            npad = -(-ncols // 16) * 16
+            nks = self._trial_splitk if (waves < 4096 and rows * npad * self._trial_splitk <= (1 << 24)) else 1
+        taps = 1 if adj == C.DECONV_K2S2 else 4
+        flops = 2 * rows * taps * layer.n_ch_out * ncols
+        if nks > 1:
+            self._ran_splitk.add(label)
+            self._launch(label, nbytes, C.conv_forward_splitk, adj, nks, dpre, layer.n_ch_out, ldp, None, 0, 0, n, oh, ow, packed,
+                         zero_bias, hi - lo, out, ldo, act=False, alpha=mask_alpha, tile_hint=tile_hint, mask_src=mask_src, ldm=ldm,
+                         accumulate=accumulate, flops=flops)
+            return
         self._launch(label, nbytes, C.conv_forward, adj, dpre, layer.n_ch_out, ldp, None, 0, 0, n, oh, ow, ks, packed,
-                     zero_bias, hi - lo, out, ldo, act=False, alpha=mask_alpha, algo=C.ALGO_MFMA,
-                     mask_src=mask_src, ldm=ldm, accumulate=accumulate)
+                     zero_bias, hi - lo, out, ldo, act=False, alpha=mask_alpha, algo=C.ALGO_MFMA, tile_hint=tile_hint,
+                     mask_src=mask_src, ldm=ldm, accumulate=accumulate, flops=flops)
 
     def backward(self, dpred, base, cvis, lvis, nn_rgb, nn_base, obs_weights=None, generation=None):
         """Gradient of everything `forward` computed, given dpred = dL/d(pred) [N,H,W,3]; uses the
@@ -757,6 +779,15 @@ class RenderPlan:
         q, o, D, U, cl = self.q, self.o, self.n_down, self.n_up, b['C']
         zb = g['zero_bias']
         reg = getattr(self.q.layers[0], '_registry', None)
+        if self.autotune and self.tune_backward and dpred.is_cuda and not b.get('tuned_bwd') and not self._tuning:
+            # plan-time choice of the backward-data launches' wave tiles / split-K (the same trial machinery as the forward).
+            # The trial passes accumulate into the weight-gradient bucket: it is cleared again before the real pass.
+            b['tuned_bwd'] = True
+            self._autotune(lambda: self._backward_streams(dpred, base, cvis, lvis, nn_rgb, nn_base, obs_weights, b, g, n, h, w, k),
+                           backward=True)
+            bucket = getattr(q.layers[0].dkernel, '_base', None)
+            if bucket is not None:
+                bucket.zero_()
         tkey = None
         if (self.use_tape and dpred.is_cuda and self.timer is None and reg is not None and obs_weights is None
                 and all(t.is_contiguous() for t in (dpred, base, cvis, lvis, nn_rgb, nn_base))):

@@ -12,5 +12,5 @@ while IFS= read -r cmd; do
   [ -z "$cmd" ] && continue
   i=$((i+1))
   echo "=== $cmd"
-  (timeout 600 bash -c "$cmd" 2>&1 | tail -60) | tee gpurun_out/cmd_$i.log
+  (timeout 600 bash -c "$cmd" 2>&1 | tail -${TAIL:-60}) | tee gpurun_out/cmd_$i.log
 done <<< "${CMDS:-}"

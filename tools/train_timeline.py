@@ -1,0 +1,68 @@
+#!/usr/bin/env python
+"""Timeline of the train step from a rocprofv3 kernel trace (CSV):  where the step's wall time goes.
+
+    train_timeline.py trace_dir out.txt [n_last_steps]
+
+Steps are delimited by the optimizer kernel (adam_amsgrad_kernel).  For the last n steps: wall span, GPU-busy time (union
+of the kernel intervals over all streams), sum of kernel durations, number of kernels, and the kernels ranked by total
+time; plus the idle gaps (no kernel running on any stream) ranked by the kernel that ENDS the gap."""
+import csv
+import glob
+import os
+import sys
+from collections import defaultdict
+
+
+def main():
+    d, out = sys.argv[1], sys.argv[2]
+    nlast = int(sys.argv[3]) if len(sys.argv) > 3 else 4
+    rows = []
+    for path in glob.glob(os.path.join(d, '**', '*kernel_trace.csv'), recursive=True):
+        with open(path, newline='') as f:
+            for r in csv.DictReader(f):
+                rows.append((int(r['Start_Timestamp']), int(r['End_Timestamp']), r['Kernel_Name'], r.get('Stream_Id') or r.get('Queue_Id')))
+    rows.sort()
+    ends = [i for i, r in enumerate(rows) if 'adam_amsgrad_kernel' in r[2]]
+    if len(ends) < nlast + 1:
+        raise SystemExit('only %d optimizer launches in the trace' % len(ends))
+    lines = []
+    per_kernel = defaultdict(lambda: [0, 0.0])
+    gap_after = defaultdict(lambda: [0, 0.0])
+    spans, busys, sums, counts = [], [], [], []
+    for s in range(len(ends) - nlast, len(ends)):
+        a, b = ends[s - 1] + 1, ends[s] + 1
+        ks = rows[a:b]
+        t0, t1 = rows[ends[s - 1]][1], ks[-1][1]
+        busy, cur_end, tot = 0, t0, 0
+        for st, en, name, _ in ks:
+            tot += en - st
+            short = name.replace('void ', '').replace('(anonymous namespace)::', '').split('(')[0]
+            per_kernel[short][0] += 1
+            per_kernel[short][1] += (en - st) / 1e3
+            if st > cur_end:
+                gap_after[short][0] += 1
+                gap_after[short][1] += (st - cur_end) / 1e3
+            lo = max(st, cur_end)
+            if en > lo:
+                busy += en - lo
+                cur_end = en
+        spans.append((t1 - t0) / 1e3); busys.append(busy / 1e3); sums.append(tot / 1e3); counts.append(len(ks))
+    n = float(nlast)
+    lines.append('train steps analysed: %d   (per step averages, microseconds)' % nlast)
+    lines.append('wall span %.1f   gpu busy (union over streams) %.1f   idle %.1f   sum of kernel durations %.1f   kernels %.1f'
+                 % (sum(spans) / n, sum(busys) / n, (sum(spans) - sum(busys)) / n, sum(sums) / n, sum(counts) / n))
+    lines.append('')
+    lines.append('%-70s %8s %10s %9s' % ('kernel', 'calls', 'us/step', 'avg us'))
+    for name, (c, t) in sorted(per_kernel.items(), key=lambda kv: -kv[1][1]):
+        lines.append('%-70s %8.1f %10.1f %9.1f' % (name[:70], c / n, t / n, t / c))
+    lines.append('')
+    lines.append('idle gaps (no kernel on any stream), by the kernel that ends the gap')
+    for name, (c, t) in sorted(gap_after.items(), key=lambda kv: -kv[1][1])[:25]:
+        lines.append('%-70s %8.1f %10.1f %9.1f' % (name[:70], c / n, t / n, t / c))
+    with open(out, 'w') as f:
+        f.write('\n'.join(lines) + '\n')
+    print('\n'.join(lines[:90]))
+
+
+if __name__ == '__main__':
+    main()
