@@ -186,6 +186,14 @@ int nlt_obs_mean_backward(const float* dmean, int ldm, const float* obs_y, const
                           const float* dobs_partial, int n, int k, int hw, int c, float alpha,
                           float* dpre_obs, void* stream);
 
+/* nlt_lrelu_backward on the query half and nlt_obs_mean_backward on the observation half of one level's
+ * dfm [n,hw,ld >= 2c] = [query c | observation mean c] in ONE launch (nlt/models/nlt.py:155-167 backward):
+ *   dfm[.., 0:c] *= lrelu'(fm_y[.., 0:c]) in place;  dpre_obs[f,i] = (dobs_partial[f,i] + dfm[f][.., c:2c] w_i / k) * lrelu'(obs_y[f,i]).
+ * fm_y = the saved fm[l] (same ld); obs_weights / dobs_partial may be NULL. */
+int nlt_level_split_backward(float* dfm, const float* fm_y, int ld, const float* obs_y, const float* obs_weights,
+                             const float* dobs_partial, int n, int k, int hw, int c, float alpha_q, float alpha_o,
+                             float* dpre_obs, void* stream);
+
 /* Backward of nlt_stem_forward: accumulates dwq (5,c), dbq (c), dwo (3,c), dbo (c) from
  * dfm0 [n,h,w,2c] and the per-observation partial dobs0 [n,k,h,w,c] (may be NULL). */
 int nlt_stem_backward(const float* base, const float* cvis, const float* lvis, const float* nn_rgb,

@@ -47,6 +47,7 @@ SIGNATURES = {
                                                  _vp, _c_int, _c_int, _vp, _vp, _vp, _c_long, _vp]),
     'nlt_lrelu_backward': (_c_int, [_vp, _c_int, _vp, _c_int, _c_int, _c_long, _c_float, _vp, _c_int, _vp]),
     'nlt_obs_mean_backward': (_c_int, [_vp, _c_int, _vp, _vp, _vp, _c_int, _c_int, _c_int, _c_int, _c_float, _vp, _vp]),
+    'nlt_level_split_backward': (_c_int, [_vp, _vp, _c_int, _vp, _vp, _vp, _c_int, _c_int, _c_int, _c_int, _c_float, _c_float, _vp, _vp]),
     'nlt_stem_backward': (_c_int, [_vp] * 6 + [_c_int] * 5 + [_vp] * 6 + [_vp]),
     'nlt_head_backward': (_c_int, [_vp, _c_int, _c_int, _vp, _c_int, _c_int, _vp, _vp, _c_int, _c_int, _c_int,
                                    _vp, _c_int, _vp, _c_int, _vp, _vp, _vp]),
@@ -391,6 +392,13 @@ def lrelu_backward(g, ldg, y, ldy, c, texels, alpha, out, ldo):
 def obs_mean_backward(dmean, ldm, obs_y, obs_weights, dobs_partial, n, k, hw, c, alpha, dpre_obs):
     _check(lib().nlt_obs_mean_backward(_ptr(dmean), ldm, _ptr(obs_y), _ptr(obs_weights), _ptr(dobs_partial),
                                        n, k, hw, c, float(alpha), _ptr(dpre_obs), _stream()), 'nlt_obs_mean_backward')
+
+
+def level_split_backward(dfm, fm_y, ld, obs_y, obs_weights, dobs_partial, n, k, hw, c, alpha_q, alpha_o, dpre_obs):
+    """lrelu_backward on the query half (in place) + obs_mean_backward on the observation half of dfm [n,hw,ld], one launch."""
+    _check(lib().nlt_level_split_backward(_ptr(dfm), _ptr(fm_y), ld, _ptr(obs_y), _ptr(obs_weights), _ptr(dobs_partial),
+                                          n, k, hw, c, float(alpha_q), float(alpha_o), _ptr(dpre_obs), _stream()),
+           'nlt_level_split_backward')
 
 
 def stem_backward(base, cvis, lvis, nn_rgb, nn_base, obs_weights, n, k, h, w, c, dfm0, dobs0, dwq, dbq, dwo, dbo):

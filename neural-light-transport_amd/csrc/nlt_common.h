@@ -1,6 +1,7 @@
 // Shared host/device helpers for libnlt_hip.so (gfx950 only).
 #pragma once
 #include <hip/hip_runtime.h>
+#include <cstdlib>
 #include <stdint.h>
 #include "../../include/nlt_hip.h"
 
@@ -79,6 +80,23 @@ static inline int nlt_fill_conv_params(ConvP& p, int mode, const float* src0, in
   if (M >= (1ll << 31) || in_elems >= (1ll << 31) || out_elems >= (1ll << 31)) return NLT_ERR_UNSUPPORTED;
   p.M = (int)M;
   return NLT_OK;
+}
+
+// 256 zero bytes of device memory, allocated once per process (one process drives one GPU): operand source of the
+// row-walking weight-gradient kernels past the end of a run.
+static inline const float* nlt_zero_page() {
+  static const float* z = [] {
+    void* p = nullptr;
+    if (hipMalloc(&p, 256) != hipSuccess || hipMemset(p, 0, 256) != hipSuccess) return static_cast<const float*>(nullptr);
+    return static_cast<const float*>(p);
+  }();
+  return z;
+}
+
+// NLT_WGRAD_GENERIC=1: keep the index-deriving weight-gradient kernels for every shape (A/B runs, parity tests of both forms)
+static inline bool nlt_wgrad_generic_only() {
+  static const bool v = [] { const char* e = getenv("NLT_WGRAD_GENERIC"); return e && e[0] == '1'; }();
+  return v;
 }
 
 // Entry points implemented per algorithm file.

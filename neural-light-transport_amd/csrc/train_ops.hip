@@ -48,6 +48,38 @@ __global__ __launch_bounds__(256) void obs_mean_bwd_kernel(const float* __restri
   }
 }
 
+// One launch per level for both halves of dfm[l] = [query | observation mean] (the two launches above, fused):
+//   query half, in place:  dfm[tex][0:c]  *= lrelu'(fm_y[tex][0:c])                      -> gradient w.r.t. q.s1's pre-activation
+//   observation half:      dpre_obs[f,i]   = (partial[f,i] + dfm[tex][c:2c] w_i / k) * lrelu'(obs_y[f,i])
+__global__ __launch_bounds__(256) void level_split_bwd_kernel(float* dfm, const float* __restrict__ fm_y, int ld,
+                                                              const float* __restrict__ obs_y, const float* __restrict__ obs_w,
+                                                              const float* partial, int k, int hw, int c, float alpha_q,
+                                                              float alpha_o, long total, float* out) {
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= total) return;
+  const int quads = c >> 2;
+  const int q = idx % quads;
+  const long tex = idx / quads;          // over n*hw
+  const int f = tex / hw;
+  const long pix = tex - (long)f * hw;
+  float* gq = dfm + tex * ld + 4 * q;
+  f32x4 gv = *reinterpret_cast<const f32x4*>(gq);
+  const f32x4 dm = *reinterpret_cast<const f32x4*>(gq + c) * (1.f / (float)k);
+  const f32x4 yq = *reinterpret_cast<const f32x4*>(fm_y + tex * ld + 4 * q);
+#pragma unroll
+  for (int j = 0; j < 4; ++j) gv[j] *= (yq[j] > 0.f) ? 1.f : alpha_q;
+  *reinterpret_cast<f32x4*>(gq) = gv;
+  for (int i = 0; i < k; ++i) {
+    const long o = (((long)f * k + i) * hw + pix) * c + 4 * q;
+    f32x4 g = obs_w ? obs_w[f * k + i] * dm : dm;
+    if (partial) g += *reinterpret_cast<const f32x4*>(partial + o);
+    const f32x4 yv = *reinterpret_cast<const f32x4*>(obs_y + o);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) g[j] *= (yv[j] > 0.f) ? 1.f : alpha_o;
+    *reinterpret_cast<f32x4*>(out + o) = g;
+  }
+}
+
 // Stem backward: weight/bias gradients of the two L0 1x1 convs.  thread = (texel lane, quad);
 // register accumulation over a grid-stride of texels, LDS atomics per block, global atomics.
 __global__ __launch_bounds__(256) void stem_bwd_kernel(
@@ -322,6 +354,20 @@ extern "C" int nlt_obs_mean_backward(const float* dmean, int ldm, const float* o
   const long total = (long)n * hw * (c >> 2);
   hipLaunchKernelGGL(obs_mean_bwd_kernel, dim3(blocks_for(total)), dim3(256), 0, static_cast<hipStream_t>(stream),
                      dmean, ldm, obs_y, obs_weights, dobs_partial, k, hw, c, alpha, total, dpre_obs);
+  NLT_CHECK_LAUNCH();
+  return NLT_OK;
+}
+
+extern "C" int nlt_level_split_backward(float* dfm, const float* fm_y, int ld, const float* obs_y, const float* obs_weights,
+                                        const float* dobs_partial, int n, int k, int hw, int c, float alpha_q, float alpha_o,
+                                        float* dpre_obs, void* stream) {
+  if (!dfm || !fm_y || !obs_y || !dpre_obs || n <= 0 || k <= 0 || hw <= 0 || c <= 0 || ld < 2 * c) return NLT_ERR_BAD_ARG;
+  if ((c & 3) || (ld & 3)) return NLT_ERR_UNSUPPORTED;
+  if (!nlt_aligned16(dfm) || !nlt_aligned16(fm_y) || !nlt_aligned16(dpre_obs) || !nlt_aligned16(obs_y) ||
+      (dobs_partial && !nlt_aligned16(dobs_partial))) return NLT_ERR_BAD_ARG;
+  const long total = (long)n * hw * (c >> 2);
+  hipLaunchKernelGGL(level_split_bwd_kernel, dim3(blocks_for(total)), dim3(256), 0, static_cast<hipStream_t>(stream),
+                     dfm, fm_y, ld, obs_y, obs_weights, dobs_partial, k, hw, c, alpha_q, alpha_o, total, dpre_obs);
   NLT_CHECK_LAUNCH();
   return NLT_OK;
 }

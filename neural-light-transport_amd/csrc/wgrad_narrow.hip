@@ -23,6 +23,7 @@ struct WN {
   ConvP c;
   const float* dp; int ldp;
   float* dw; float* db; float* ws;
+  const float* zeros;           // zero page (walk form) or nullptr (index-deriving form)
   int K, N;                     // taps * (c0 + c1), GEMM columns
   int msplits, rows_per_split;
 };
@@ -187,7 +188,17 @@ __global__ __launch_bounds__(256) void wgrad_narrow_kernel(WN w) {
 // brings the four K values of a channel quad, so a 64-entry slice of K (= all four taps of a 16-channel layer) costs one
 // load + one address computation instead of four; tile e of the four MFMA row tiles it feeds holds K indices
 // 4 * quad + e, i.e. the same [K][N] workspace layout as the scalar form above.  B stays one 4-byte load per 16 columns.
-template <int MODE, int MQ, int NT>
+//
+// WALK (row grid a multiple of 4 texels wide -- every released shape): the rows are walked instead of re-derived.  A wave
+// takes a contiguous run of its slice, 4 rows per step; 4 | gw means the 4 rows of a step share one image row, so the
+// step's position (x0, y) lives in scalar registers, every lane keeps its operand POINTERS and advances them by
+// lane-constant increments (a second constant on steps that wrap to the next image row, where the stride-2 families
+// jump), padding validity is two compares against lane constants, loads are unconditional, and the loads run PF - 1
+// steps ahead.  The generic form's ~70 VALU instructions of index arithmetic per step (for 4 to 16 MFMAs) were this
+// kernel's time; past the end of a run dP is read from a zero page.
+template <int MQ, int NT> struct NarrowPF { static constexpr int value = MQ * NT >= 4 ? 6 : 8; };
+
+template <int MODE, int MQ, int NT, bool WALK>
 __global__ __launch_bounds__(256) void wgrad_narrowq_kernel(WN w) {
   extern __shared__ float xch[];
   const ConvP& p = w.c;
@@ -241,66 +252,159 @@ __global__ __launch_bounds__(256) void wgrad_narrowq_kernel(WN w) {
       for (int e = 0; e < 4; ++e) acc[mq][e][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
   }
 
-  const int m_begin = ms * w.rows_per_split;
-  int m_end = m_begin + w.rows_per_split;
-  if (m_end > p.M) m_end = p.M;
-  int m = m_begin + 4 * wv + kk;
-  int rx, ry, rf;
-  {
-    const int mc = m < p.M ? m : p.M - 1;
-    rx = mc % p.gw; ry = (mc / p.gw) % p.gh; rf = mc / (p.gw * p.gh);
-  }
-  auto issue = [&](f32x4 (&av)[MQ], float (&bv)[NT]) {
-    const bool rv = m < m_end;
-    const int ys = S * ry, xs = S * rx;
-    const int rowtex = (rf * p.h + ys) * p.w + xs;
+  if constexpr (WALK) {
+    const int wvu = __builtin_amdgcn_readfirstlane(wv);
+    const int chunk = w.rows_per_split >> 2;                           // multiple of 4 * PF rows
+    const int m0 = __builtin_amdgcn_readfirstlane(ms * w.rows_per_split + wvu * chunk);
+    int m1 = m0 + chunk;
+    if (m1 > p.M) m1 = p.M;
+    const int nsteps = m1 > m0 ? (m1 - m0) >> 2 : 0;
+    int x0 = m0 % p.gw;                                                // wave-uniform position of the step's first row
+    const int R0 = m0 / p.gw;
+    int y = R0 % p.gh;
+    const float* pa[MQ]; int ainc[MQ], aincw[MQ], xlim[MQ], ylim[MQ], xlo[MQ], ylo[MQ];
 #pragma unroll
     for (int mq = 0; mq < MQ; ++mq) {
-      const bool ok = rv && aok[mq] && (unsigned)(ys + oy[mq]) < (unsigned)p.h && (unsigned)(xs + ox[mq]) < (unsigned)p.w;
-      const int tex = ok ? rowtex + tdelta[mq] : 0;
-      const f32x4 v = *reinterpret_cast<const f32x4*>(ap[mq] + (size_t)tex * ald[mq]);   // unconditional, clamped address
-      av[mq] = ok ? v : (f32x4){0.f, 0.f, 0.f, 0.f};
+      const int a = oy[mq] < 0 ? -oy[mq] : oy[mq], b = ox[mq] < 0 ? -ox[mq] : ox[mq];
+      long tex;
+      if (MODE == NLT_CONV_K2S2) tex = (long)(2 * R0 + a) * p.w + 2 * (x0 + kk) + b;
+      else tex = (long)m0 + kk + tdelta[mq];
+      pa[mq] = nsteps > 0 ? ap[mq] + tex * ald[mq] : ap[mq];           // an empty run (slice past M) must not form an address past the buffer
+      ainc[mq] = (MODE == NLT_CONV_K2S2 ? 8 : 4) * ald[mq];
+      aincw[mq] = MODE == NLT_CONV_K2S2 ? (8 + p.w) * ald[mq] : ainc[mq];
+      xlim[mq] = p.gw - kk - b; ylim[mq] = p.gh - a;                   // k2s1: valid iff x0 < xlim && y < ylim
+      xlo[mq] = b - kk; ylo[mq] = a;                                   // transposed k2s1: valid iff x0 >= xlo && y >= ylo
     }
-    const int rowo = MODE == NLT_DECONV_K2S2 ? (rf * p.oh + 2 * ry) * p.ow + 2 * rx : m;
+    const float* pb[NT]; int binc[NT], bincw[NT];
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
-      const bool ok = rv && bok[nt];
-      const int otex = ok ? rowo + bdelta[nt] : 0;
-      const float v = w.dp[(size_t)otex * w.ldp + boff[nt]];
-      bv[nt] = ok ? v : 0.f;
+      long otex;
+      if (MODE == NLT_DECONV_K2S2) otex = (long)(2 * R0) * p.ow + 2 * (x0 + kk) + bdelta[nt];
+      else otex = (long)m0 + kk;
+      pb[nt] = nsteps > 0 ? w.dp + otex * w.ldp + boff[nt] : w.zeros;
+      binc[nt] = (MODE == NLT_DECONV_K2S2 ? 8 : 4) * w.ldp;
+      bincw[nt] = MODE == NLT_DECONV_K2S2 ? (8 + p.ow) * w.ldp : binc[nt];
     }
-    m += 16; rx += 16;
+    const f32x4 zero4 = (f32x4){0.f, 0.f, 0.f, 0.f};
+    int issued = 0;
+    auto issue = [&](f32x4 (&av)[MQ], float (&bv)[NT]) {
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const bool wx = rx >= p.gw;
-      rx -= wx ? p.gw : 0;
-      ry += wx ? 1 : 0;
-      const bool wy = ry >= p.gh;
-      ry = wy ? 0 : ry;
-      rf += wy ? 1 : 0;
+      for (int mq = 0; mq < MQ; ++mq) {
+        if (MODE == NLT_CONV_K2S1 || MODE == NLT_DECONV_K2S1) {
+          const bool ok = MODE == NLT_CONV_K2S1 ? (x0 < xlim[mq] && y < ylim[mq]) : (x0 >= xlo[mq] && y >= ylo[mq]);
+          const f32x4 v = *reinterpret_cast<const f32x4*>(ok ? pa[mq] : ap[mq]);   // a padded tap must not be dereferenced
+          av[mq] = ok ? v : zero4;
+        } else {
+          av[mq] = *reinterpret_cast<const f32x4*>(pa[mq]);
+        }
+      }
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) bv[nt] = *pb[nt];
+      ++issued;
+      const bool adv = issued < nsteps;                                // everything below is wave-uniform
+      const int xn = x0 + 4;
+      const bool wrap = xn >= p.gw;
+#pragma unroll
+      for (int mq = 0; mq < MQ; ++mq) {
+        const float* nx = pa[mq] + (wrap ? aincw[mq] : ainc[mq]);
+        pa[mq] = adv ? nx : pa[mq];
+      }
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) {
+        const float* nx = pb[nt] + (wrap ? bincw[nt] : binc[nt]);
+        pb[nt] = adv ? nx : w.zeros;
+      }
+      const int yn = y + 1 >= p.gh ? 0 : y + 1;
+      y = (adv && wrap) ? yn : y;
+      x0 = adv ? (wrap ? 0 : xn) : x0;
+    };
+    auto compute = [&](const f32x4 (&av)[MQ], const float (&bv)[NT]) {
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) {
+        bsum[nt] += bv[nt];
+#pragma unroll
+        for (int mq = 0; mq < MQ; ++mq)
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            acc[mq][e][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[mq][e], bv[nt], acc[mq][e][nt], 0, 0, 0);
+      }
+    };
+    constexpr int PF = NarrowPF<MQ, NT>::value;
+    f32x4 av[PF][MQ];
+    float bv[PF][NT];
+#pragma unroll
+    for (int j = 0; j < PF - 1; ++j) issue(av[j], bv[j]);
+    for (int s0 = 0; s0 < nsteps; s0 += PF) {
+#pragma unroll
+      for (int j = 0; j < PF; ++j) {
+        issue(av[(j + PF - 1) % PF], bv[(j + PF - 1) % PF]);
+        __builtin_amdgcn_sched_barrier(0);
+        compute(av[j], bv[j]);
+        __builtin_amdgcn_sched_barrier(0);
+      }
     }
-  };
-  auto compute = [&](const f32x4 (&av)[MQ], const float (&bv)[NT]) {
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt) {
-      bsum[nt] += bv[nt];
-#pragma unroll
-      for (int mq = 0; mq < MQ; ++mq)
-#pragma unroll
-        for (int e = 0; e < 4; ++e)
-          acc[mq][e][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[mq][e], bv[nt], acc[mq][e][nt], 0, 0, 0);
+  } else {
+    const int m_begin = ms * w.rows_per_split;
+    int m_end = m_begin + w.rows_per_split;
+    if (m_end > p.M) m_end = p.M;
+    int m = m_begin + 4 * wv + kk;
+    int rx, ry, rf;
+    {
+      const int mc = m < p.M ? m : p.M - 1;
+      rx = mc % p.gw; ry = (mc / p.gw) % p.gh; rf = mc / (p.gw * p.gh);
     }
-  };
-  const int first = m_begin + 4 * wv;
-  const int nsteps = first < m_end ? (m_end - first + 15) / 16 : 0;
-  f32x4 a0[MQ], a1[MQ], a2[MQ];
-  float b0[NT], b1[NT], b2[NT];
-  issue(a0, b0);
-  issue(a1, b1);
-  for (int s3 = 0; s3 < nsteps; s3 += 3) {
-    issue(a2, b2); compute(a0, b0);
-    issue(a0, b0); compute(a1, b1);
-    issue(a1, b1); compute(a2, b2);
+    auto issue = [&](f32x4 (&av)[MQ], float (&bv)[NT]) {
+      const bool rv = m < m_end;
+      const int ys = S * ry, xs = S * rx;
+      const int rowtex = (rf * p.h + ys) * p.w + xs;
+  #pragma unroll
+      for (int mq = 0; mq < MQ; ++mq) {
+        const bool ok = rv && aok[mq] && (unsigned)(ys + oy[mq]) < (unsigned)p.h && (unsigned)(xs + ox[mq]) < (unsigned)p.w;
+        const int tex = ok ? rowtex + tdelta[mq] : 0;
+        const f32x4 v = *reinterpret_cast<const f32x4*>(ap[mq] + (size_t)tex * ald[mq]);   // unconditional, clamped address
+        av[mq] = ok ? v : (f32x4){0.f, 0.f, 0.f, 0.f};
+      }
+      const int rowo = MODE == NLT_DECONV_K2S2 ? (rf * p.oh + 2 * ry) * p.ow + 2 * rx : m;
+  #pragma unroll
+      for (int nt = 0; nt < NT; ++nt) {
+        const bool ok = rv && bok[nt];
+        const int otex = ok ? rowo + bdelta[nt] : 0;
+        const float v = w.dp[(size_t)otex * w.ldp + boff[nt]];
+        bv[nt] = ok ? v : 0.f;
+      }
+      m += 16; rx += 16;
+  #pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const bool wx = rx >= p.gw;
+        rx -= wx ? p.gw : 0;
+        ry += wx ? 1 : 0;
+        const bool wy = ry >= p.gh;
+        ry = wy ? 0 : ry;
+        rf += wy ? 1 : 0;
+      }
+    };
+    auto compute = [&](const f32x4 (&av)[MQ], const float (&bv)[NT]) {
+  #pragma unroll
+      for (int nt = 0; nt < NT; ++nt) {
+        bsum[nt] += bv[nt];
+  #pragma unroll
+        for (int mq = 0; mq < MQ; ++mq)
+  #pragma unroll
+          for (int e = 0; e < 4; ++e)
+            acc[mq][e][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[mq][e], bv[nt], acc[mq][e][nt], 0, 0, 0);
+      }
+    };
+    const int first = m_begin + 4 * wv;
+    const int nsteps = first < m_end ? (m_end - first + 15) / 16 : 0;
+    f32x4 a0[MQ], a1[MQ], a2[MQ];
+    float b0[NT], b1[NT], b2[NT];
+    issue(a0, b0);
+    issue(a1, b1);
+    for (int s3 = 0; s3 < nsteps; s3 += 3) {
+      issue(a2, b2); compute(a0, b0);
+      issue(a0, b0); compute(a1, b1);
+      issue(a1, b1); compute(a2, b2);
+    }
   }
 
   constexpr int NC = NT * 16, KN = MT * 16 * NC;
@@ -415,7 +519,11 @@ int run_narrow(WN& w, hipStream_t s) {
 template <int MODE, int MQ, int NT>
 int run_narrowq(WN& w, hipStream_t s) {
   constexpr int MT = 4 * MQ, PER = MT * 16 * NT * 16 + NT * 16;
-  hipLaunchKernelGGL((wgrad_narrowq_kernel<MODE, MQ, NT>), dim3((unsigned)w.msplits), dim3(256), PER * sizeof(float), s, w);
+  w.zeros = (w.c.gw % 4 == 0 && !nlt_wgrad_generic_only()) ? nlt_zero_page() : nullptr;
+  if (w.zeros)
+    hipLaunchKernelGGL((wgrad_narrowq_kernel<MODE, MQ, NT, true>), dim3((unsigned)w.msplits), dim3(256), PER * sizeof(float), s, w);
+  else
+    hipLaunchKernelGGL((wgrad_narrowq_kernel<MODE, MQ, NT, false>), dim3((unsigned)w.msplits), dim3(256), PER * sizeof(float), s, w);
   hipLaunchKernelGGL((wgrad_narrow_reduce_kernel<MODE, MT, NT>), dim3(PER / 16), dim3(256), 0, s, w);
   if (MODE == NLT_DECONV_K2S2 && w.db) hipLaunchKernelGGL((wgrad_narrow_bias_k2s2_kernel<MT, NT>), dim3(1), dim3(64), 0, s, w);
   NLT_CHECK_LAUNCH();
@@ -453,9 +561,11 @@ int prepare_narrow(WN& w, int mode, const float* src0, int ld0, int c0, const fl
   if (w.K > 128 || w.N > 32) return NLT_ERR_UNSUPPORTED;
   if (w.c.gw < 4) return NLT_ERR_UNSUPPORTED;                          // the incremental row walk assumes >= 4 texels per grid row
   w.dp = dpre; w.ldp = ldp; w.dw = dw; w.db = db;
-  long rows = (w.c.M + 511) / 512;                                     // ~512 workgroups (2 per CU, 8 waves)
-  if (rows < 256) rows = 256;                                          // >= 16 MFMA steps per wave
-  rows = (rows + 15) & ~15L;
+  const bool walk = w.c.gw % 4 == 0 && !nlt_wgrad_generic_only();
+  long rows = walk ? (w.c.M + 2047) / 2048 : (w.c.M + 511) / 512;      // walk: ~2048 workgroups (the loads run 5-7 steps ahead;
+  if (rows < 256) rows = 256;                                          //  HBM-bound layers want many of them in flight)
+  const long unit = walk ? 384 : 16;                                   // walk: every wave's run a whole number of pipeline rounds (6 or 8 steps)
+  rows = (rows + unit - 1) / unit * unit;
   w.msplits = (int)((w.c.M + rows - 1) / rows);
   w.rows_per_split = (int)rows;
   const int mt = w.K <= 64 ? 4 : 8, nt = w.N <= 16 ? 1 : 2;               // (the quad-A form pads K to 64 / 128)

@@ -11,6 +11,7 @@
 // order and accumulates into the Keras-layout gradient -- deterministic, and no atomics (the first-generation
 // kernel's thousands of waves adding into the 64 addresses of a 4 -> 4 layer were its bottleneck).
 #include "nlt_common.h"
+#include <cstdlib>
 
 namespace {
 
@@ -26,6 +27,7 @@ struct WT {
   const float* dp; int ldp;
   float* dw; float* db;
   float* ws; float* wsb;
+  const float* zeros;  // 16 zero bytes in device memory (the walk kernel's operand source past the end of a run)
   int kq, nq;         // k-quads (taps * (c0 + c1) / 4), n-quads (N / 4)
   int kblocks, nblocks, msplits, rows_per_split;
 };
@@ -150,14 +152,185 @@ __global__ __launch_bounds__(256) void wgrad_tile_kernel(WT w) {
   }
 }
 
+// The same block, with the rows WALKED instead of re-derived (the form used whenever the row grid is a multiple of 4
+// texels wide -- every released shape).  The generic kernel above spends ~70 VALU instructions per 16-MFMA step on
+// (frame, y, x) bookkeeping, 64-bit multiplies for two addresses and exec-masked loads; with two waves per SIMD that
+// address arithmetic, not the matrix pipe, set its speed.  Here a wave takes a contiguous run of its slice, 4 rows per
+// step, and because 4 | gw those 4 rows never straddle an image row: the position (x0, y) of a step is WAVE-UNIFORM
+// (scalar registers), each lane keeps two pointers advanced by lane-constant increments (a second constant on the
+// steps that wrap to the next image row, where the stride-2 families jump), the loads are unconditional, and padding
+// validity (k2s1 families only) is two compares against lane constants.
+constexpr int WALK_PF = 6;
+
+template <int MODE>
+__global__ __launch_bounds__(256) void wgrad_walk_kernel(WT w) {
+  __shared__ __attribute__((aligned(16))) f32x4 part[3][17][64];
+  const ConvP& p = w.c;
+  const int lane = threadIdx.x & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  int blk = blockIdx.x;
+  const int ms = blk % w.msplits; blk /= w.msplits;
+  const int nb = blk % w.nblocks;
+  const int kb = blk / w.nblocks;
+  const int i = lane & 15, kk = lane >> 4;
+  const int q0 = p.c0 >> 2, qpt = (p.c0 + p.c1) >> 2;
+
+  const int kq = kb * 16 + i;
+  const bool a_ok = kq < w.kq;
+  const int tap = a_ok ? kq / qpt : 0;
+  const int cq = a_ok ? kq - tap * qpt : 0;
+  const bool from1 = cq >= q0;
+  const float* asrc = from1 ? p.src1 + 4 * (cq - q0) : p.src0 + 4 * cq;
+  const int ald = from1 ? p.ld1 : p.ld0;
+  const int ta = tap >> 1, tb = tap & 1;
+  const int nq = nb * 16 + i;
+  const bool b_ok = nq < w.nq;
+  const int ncol = b_ok ? 4 * nq : 0;
+  const int ab = MODE == NLT_DECONV_K2S2 ? ncol / p.cout : 0;
+  const int oc = MODE == NLT_DECONV_K2S2 ? ncol - ab * p.cout : ncol;
+
+  // the wave's run of rows [m0, m1): a quarter of the slice, a multiple of 4 rows (rows_per_split % 16 == 0, M % 4 == 0)
+  const int chunk = w.rows_per_split >> 2;
+  const int m0 = __builtin_amdgcn_readfirstlane(ms * w.rows_per_split + wv * chunk);
+  int m1 = m0 + chunk;
+  if (m1 > p.M) m1 = p.M;
+  const int nsteps = m1 > m0 ? (m1 - m0) >> 2 : 0;
+  // wave-uniform position of the step's first row: x0 (multiple of 4), y; R = image row index over all frames
+  int x0 = m0 % p.gw;
+  const int R0 = m0 / p.gw;
+  int y = R0 % p.gh;
+
+  // lane pointers at the step-0 row m0 + kk (unclamped tap position; validity is tracked separately)
+  long atex, btex;
+  if (MODE == NLT_CONV_K2S2) atex = ((long)(2 * R0 + ta)) * p.w + 2 * (x0 + kk) + tb;
+  else if (MODE == NLT_CONV_K2S1) atex = (long)m0 + kk + ta * p.w + tb;
+  else if (MODE == NLT_DECONV_K2S1) atex = (long)m0 + kk - ta * p.w - tb;
+  else atex = (long)m0 + kk;
+  if (MODE == NLT_DECONV_K2S2) btex = ((long)(2 * R0 + (ab >> 1))) * p.ow + 2 * (x0 + kk) + (ab & 1);
+  else btex = (long)m0 + kk;
+  const float* pa = nsteps > 0 ? asrc + atex * ald : asrc;          // an empty run (slice past M) must not form an address past the buffer
+  const float* pb = w.dp + btex * w.ldp + oc;
+  // per-step pointer increments (floats): plain step / step that wraps to the next image row
+  const int a_inc = (MODE == NLT_CONV_K2S2 ? 8 : 4) * ald;
+  const int a_inc_wrap = MODE == NLT_CONV_K2S2 ? (8 + p.w) * ald : a_inc;          // p.w = 2 gw
+  const int b_inc = (MODE == NLT_DECONV_K2S2 ? 8 : 4) * w.ldp;
+  const int b_inc_wrap = MODE == NLT_DECONV_K2S2 ? (8 + p.ow) * w.ldp : b_inc;
+  // padding validity of this lane's tap, as bounds on the uniform (x0, y)
+  //   k2s1:           x0 + kk + tb < gw  and  y + ta < gh        ->  x0 < xlim, y < ylim
+  //   transposed k2s1: x0 + kk - tb >= 0 and  y - ta >= 0        ->  x0 >= xlo (only x0 = 0, kk = 0, tb = 1 fails), y >= ta
+  const int xlim = p.gw - kk - tb, ylim = p.gh - ta;
+  const int xlo = tb - kk;
+
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int e = 0; e < 4; ++e)
+#pragma unroll
+    for (int f = 0; f < 4; ++f) acc[e][f] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  f32x4 bsum = (f32x4){0.f, 0.f, 0.f, 0.f};
+  const f32x4 zero4 = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  // Steps past the end of the run (the pipeline issues two ahead; a run clipped by M may not fill its last triple) read
+  // dP from a zero page, so their products vanish without a select on the data; X is re-read where the walk stopped.
+  const float* const zpage = w.zeros;
+  int issued = 0;
+  auto issue = [&](f32x4& av, f32x4& bv) {
+    bool ok = a_ok;
+    if (MODE == NLT_CONV_K2S1) ok = ok && x0 < xlim && y < ylim;
+    if (MODE == NLT_DECONV_K2S1) ok = ok && x0 >= xlo && y >= ta;
+    const float* la = pa;
+    if (MODE == NLT_CONV_K2S1 || MODE == NLT_DECONV_K2S1) la = ok ? pa : asrc;       // a padded tap must not be dereferenced
+    av = *reinterpret_cast<const f32x4*>(la);
+    bv = *reinterpret_cast<const f32x4*>(pb);
+    if (MODE == NLT_CONV_K2S1 || MODE == NLT_DECONV_K2S1) av = ok ? av : zero4;
+    ++issued;
+    const bool adv = issued < nsteps;                                  // everything below is wave-uniform
+    const int xn = x0 + 4;
+    const bool wrap = xn >= p.gw;
+    const float* pan = pa + (wrap ? a_inc_wrap : a_inc);
+    const float* pbn = pb + (wrap ? b_inc_wrap : b_inc);
+    pa = adv ? pan : pa;
+    pb = adv ? pbn : zpage;
+    const int yn = y + 1 >= p.gh ? 0 : y + 1;
+    y = (adv && wrap) ? yn : y;
+    x0 = adv ? (wrap ? 0 : xn) : x0;
+  };
+  auto compute = [&](const f32x4& av, const f32x4& bv) {
+    bsum += bv;
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+#pragma unroll
+      for (int f4 = 0; f4 < 4; ++f4)
+        acc[e][f4] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[e], bv[f4], acc[e][f4], 0, 0, 0);
+  };
+  if (nsteps == 0) pb = zpage;
+  {
+    // operand loads run PF - 1 steps ahead of the MFMAs (PF register sets; the host sizes the runs to multiples of PF steps)
+    constexpr int PF = WALK_PF;
+    f32x4 av[PF], bv[PF];
+#pragma unroll
+    for (int j = 0; j < PF - 1; ++j) issue(av[j], bv[j]);
+    for (int s0 = 0; s0 < nsteps; s0 += PF) {
+#pragma unroll
+      for (int j = 0; j < PF; ++j) {
+        // (the scheduler would otherwise hoist every load of the iteration to its top and drain them together)
+        issue(av[(j + PF - 1) % PF], bv[(j + PF - 1) % PF]);
+        __builtin_amdgcn_sched_barrier(0);
+        compute(av[j], bv[j]);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+  }
+  // lanes whose k-quad / n-quad is padding carry garbage operands (their loads are unconditional): the rows / columns
+  // they produce are dropped by the reduce pass (kq >= w.kq || nq >= w.nq), but the bias sums need real zeros
+  if (!b_ok) bsum = zero4;
+
+  if (wv > 0) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+#pragma unroll
+      for (int f = 0; f < 4; ++f) part[wv - 1][e * 4 + f][lane] = acc[e][f];
+    part[wv - 1][16][lane] = bsum;
+  }
+  __syncthreads();
+  if (wv > 0) return;
+#pragma unroll
+  for (int o = 0; o < 3; ++o) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+#pragma unroll
+      for (int f = 0; f < 4; ++f) acc[e][f] += part[o][e * 4 + f][lane];
+    bsum += part[o][16][lane];
+  }
+  f32x4* dst = reinterpret_cast<f32x4*>(w.ws) + ((((size_t)ms * w.kblocks + kb) * w.nblocks + nb) * 16) * 64 + lane;
+#pragma unroll
+  for (int e = 0; e < 4; ++e)
+#pragma unroll
+    for (int f = 0; f < 4; ++f) dst[(e * 4 + f) * 64] = acc[e][f];
+  if (w.wsb && kb == 0) {
+#pragma unroll
+    for (int f = 0; f < 4; ++f) {
+      bsum[f] += __shfl_xor(bsum[f], 16);
+      bsum[f] += __shfl_xor(bsum[f], 32);
+    }
+    if (kk == 0) reinterpret_cast<f32x4*>(w.wsb)[((size_t)ms * w.nblocks + nb) * 16 + i] = bsum;
+  }
+}
+
 // Pass 2: 64 dW elements of the block layout per workgroup; the slices are dealt to 4 waves x 4 running sums (16
 // independent load streams per element) and combined in a fixed order.
+template <int MODE> __device__ void wgrad_bias_block(const WT& w, int ocq);
+
 template <int MODE>
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(WT w) {
   __shared__ float part[4][64];
   const ConvP& p = w.c;
   const int lane = threadIdx.x & 63, g = threadIdx.x >> 6;
   const long per_slice = (long)w.kblocks * w.nblocks * 4096;
+  const long dw_blocks = per_slice / 64;
+  if ((long)blockIdx.x >= dw_blocks) {                                // the trailing cout / 4 workgroups: the bias (no extra launch)
+    wgrad_bias_block<MODE>(w, (int)(blockIdx.x - dw_blocks));
+    return;
+  }
   const long idx = (long)blockIdx.x * 64 + lane;
   float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
   int ms = g;
@@ -185,12 +358,13 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(WT w) {
   w.dw[keras_widx<MODE>(tap, c, ncol, p.c0 + p.c1, p.cout)] += s;
 }
 
-// Bias: one workgroup per quad of output channels; 256 threads share the (slice, ab) terms, fixed-order LDS tree.
+// Bias: one workgroup (of the reduce launch) per quad of output channels; 256 threads share the (slice, ab) terms,
+// fixed-order LDS tree.
 template <int MODE>
-__global__ __launch_bounds__(256) void wgrad_bias_reduce_kernel(WT w) {
+__device__ void wgrad_bias_block(const WT& w, int ocq) {
   __shared__ f32x4 part[256];
   const ConvP& p = w.c;
-  const int ocq = blockIdx.x, t = threadIdx.x;
+  const int t = threadIdx.x;
   const int nab = MODE == NLT_DECONV_K2S2 ? 4 : 1;
   const f32x4* wsb4 = reinterpret_cast<const f32x4*>(w.wsb);
   f32x4 s = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -222,7 +396,9 @@ bool fill(WT& w, int mode, long* ws_floats) {
   if (want < 1) want = 1;
   long rows = (p.M + want - 1) / want;
   if (rows < 256) rows = 256;                                 // >= 16 MFMA steps per wave
-  rows = (rows + 15) & ~15L;
+  const bool walk = p.gw % 4 == 0 && !nlt_wgrad_generic_only();
+  const long unit = walk ? 16 * WALK_PF : 16;                 // the walk kernel's runs: whole pipeline rounds
+  rows = (rows + unit - 1) / unit * unit;
   w.msplits = (int)((p.M + rows - 1) / rows);
   w.rows_per_split = (int)rows;
   *ws_floats = (long)w.msplits * w.kblocks * w.nblocks * 4096 + (long)w.msplits * w.nblocks * 64;
@@ -232,10 +408,13 @@ bool fill(WT& w, int mode, long* ws_floats) {
 template <int MODE>
 int run(WT& w, hipStream_t s) {
   const long groups = (long)w.kblocks * w.nblocks * w.msplits;
-  hipLaunchKernelGGL(wgrad_tile_kernel<MODE>, dim3((unsigned)groups), dim3(256), 0, s, w);
+  w.zeros = (w.c.gw % 4 == 0 && !nlt_wgrad_generic_only()) ? nlt_zero_page() : nullptr;
+  if (w.zeros)
+    hipLaunchKernelGGL(wgrad_walk_kernel<MODE>, dim3((unsigned)groups), dim3(256), 0, s, w);
+  else
+    hipLaunchKernelGGL(wgrad_tile_kernel<MODE>, dim3((unsigned)groups), dim3(256), 0, s, w);
   const long items = (long)w.kblocks * w.nblocks * 4096;
-  hipLaunchKernelGGL(wgrad_reduce_kernel<MODE>, dim3((unsigned)(items / 64)), dim3(256), 0, s, w);
-  if (w.db) hipLaunchKernelGGL(wgrad_bias_reduce_kernel<MODE>, dim3((unsigned)(w.c.cout / 4)), dim3(256), 0, s, w);
+  hipLaunchKernelGGL(wgrad_reduce_kernel<MODE>, dim3((unsigned)(items / 64 + (w.db ? w.c.cout / 4 : 0))), dim3(256), 0, s, w);
   NLT_CHECK_LAUNCH();
   return NLT_OK;
 }

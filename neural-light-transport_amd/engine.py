@@ -901,14 +901,21 @@ class RenderPlan:
             (oa, oact_a), (ob, oact_b) = o.layers[l].convs()
             c, cp = cl[l], cl[l - 1]
             lab = 'bwd.L%d' % l
-            # query half of dfm[l] -> gradient w.r.t. the pre-activation of q.s1
-            self._launch(lab + '.q.s1.act', 12 * n * hh * ww * c, C.lrelu_backward, g['fm'][l], mult * c, b['fm'][l], mult * c,
-                         c, n * hh * ww, qact_b.alpha, g['fm'][l], mult * c)
-            if self.use_obs:
-                # observation half: distribute the mean's gradient, add the obs path's own, activation backward
-                self._launch(lab + '.o.mean', 4 * n * hh * ww * c * (1 + 3 * k), C.obs_mean_backward,
-                             g['fm'][l].view(-1)[c:], 2 * c, b['obs'][l], obs_weights, g['obs'][l] if l < D else None,
-                             n, k, hh * ww, c, oact_b.alpha, g['obs'][l])
+            if self.use_obs and obs_weights is None:
+                # both halves of dfm[l] in one launch: query half -> gradient w.r.t. q.s1's pre-activation (in place);
+                # observation half: the mean's gradient distributed, the obs path's own added, its activation backward
+                self._launch(lab + '.split', 4 * n * hh * ww * c * (3 + 1 + 3 * k), C.level_split_backward, g['fm'][l], b['fm'][l],
+                             2 * c, b['obs'][l], None, g['obs'][l] if l < D else None, n, k, hh * ww, c, qact_b.alpha,
+                             oact_b.alpha, g['obs'][l])
+            else:
+                # query half of dfm[l] -> gradient w.r.t. the pre-activation of q.s1
+                self._launch(lab + '.q.s1.act', 12 * n * hh * ww * c, C.lrelu_backward, g['fm'][l], mult * c, b['fm'][l], mult * c,
+                             c, n * hh * ww, qact_b.alpha, g['fm'][l], mult * c)
+                if self.use_obs:
+                    # observation half: distribute the mean's gradient, add the obs path's own, activation backward
+                    self._launch(lab + '.o.mean', 4 * n * hh * ww * c * (1 + 3 * k), C.obs_mean_backward,
+                                 g['fm'][l].view(-1)[c:], 2 * c, b['obs'][l], obs_weights, g['obs'][l] if l < D else None,
+                                 n, k, hh * ww, c, oact_b.alpha, g['obs'][l])
             # q.s1 / q.s2
             self._wgrad(lab + '.q.s1.wgrad', qb, b['qtmp'][l], c, c, None, 0, 0, n, hh, ww, g['fm'][l], mult * c)
             self._dgrad(lab + '.q.s1.dgrad', qb, 0, c, g['fm'][l], mult * c, n, hh, ww, g['qtmp'][l], c,

@@ -137,6 +137,11 @@ def obs_mean_backward(dmean, ldm, obs_y, obs_weights, dobs_partial, n, k, hw, c,
     dpre_obs.copy_(g.reshape(dpre_obs.shape))
 
 
+def level_split_backward(dfm, fm_y, ld, obs_y, obs_weights, dobs_partial, n, k, hw, c, alpha_q, alpha_o, dpre_obs):
+    obs_mean_backward(dfm.view(-1)[c:], ld, obs_y, obs_weights, dobs_partial, n, k, hw, c, alpha_o, dpre_obs)
+    lrelu_backward(dfm, ld, fm_y, ld, c, n * hw, alpha_q, dfm, ld)
+
+
 def stem_backward(base, cvis, lvis, nn_rgb, nn_base, obs_weights, n, k, h, w, c, dfm0, dobs0, dwq, dbq, dwo, dbo):
     x = torch.cat((base, cvis, lvis), -1).reshape(-1, 5)
     gq = dfm0[..., :c].reshape(-1, c)
@@ -216,7 +221,7 @@ def adam_amsgrad_step(param, grad, m, v, vhat, lr_t, beta1, beta2, eps):
         param.sub_(lr_t * m / (vhat.sqrt() + eps))
 
 
-_TRAIN = ('conv_backward_weights', 'lrelu_backward', 'obs_mean_backward', 'stem_backward', 'head_backward',
+_TRAIN = ('conv_backward_weights', 'lrelu_backward', 'obs_mean_backward', 'level_split_backward', 'stem_backward', 'head_backward',
           'warp_backward', 'resize_bilinear_backward', 'l2_loss_forward', 'l2_loss_backward', 'barron_loss',
           'scale_rows', 'adam_amsgrad_step', 'clip_by_norm_slots')
 
