@@ -108,6 +108,9 @@ def parse():
     ap.add_argument('--cpu-threads', type=int, default=0, help='host threads for the CPU oracle leg (0 = all)')
     ap.add_argument('--batches', type=int, default=3, help='distinct batches rotated through the timed steps (>= 3)')
     ap.add_argument('--store-frames', type=int, default=16, help='frames of the synthetic uint8 capture store')
+    ap.add_argument('--warp', type=str, default='charts', choices=['charts', 'random'],
+                    help="synthetic uv2cam map: 'charts' = piecewise-smooth like a rendered UV pass (default); 'random' = independent "
+                         "uniform coordinates per pixel (adversarial: every resampler tap on its own cache line)")
     ap.add_argument('--per-op', action='store_true', help='print a per-launch timing table to stderr')
     ap.add_argument('--dominant', type=str, default=None, help='label of the kernel to time in the timed region')
     ap.add_argument('--train-steps', type=int, default=-1, help='train steps to time per loss for the train_step field (-1: max(50, steps//2), 0: skip)')
@@ -142,7 +145,7 @@ def make_loader(args, device, k, mode, seed, loss='l2'):
     frames = max(args.store_frames, nb * args.frames)
     cfg = nlt_amd.make_config(depth=args.depth, uvh=args.uv, uvw=args.uv, imh=args.cam, imw=args.cam, bs=args.frames,
                               loss=loss, lr=1e-3)
-    store = synthetic_store(frames, args.uv, args.cam, device=device, seed=seed, k=k)
+    store = synthetic_store(frames, args.uv, args.cam, device=device, seed=seed, k=k, warp=args.warp)
     ds = get_dataset_class('nlt')(cfg, mode, store, k=k, device=device, ring=nb)
     id_lists = [store['ids'][i * args.frames:(i + 1) * args.frames] for i in range(nb)]
     return cfg, ds, id_lists
@@ -471,7 +474,8 @@ def main():
             "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32" if args.precision == 'fp32' else "bf16 (fp32 accumulate) for the middle of the network, f32 ends",
-            "data": "synthetic (seeded random texel buffers, random-init weights of the released architecture)",
+            "data": "synthetic (seeded random uint8 texel buffers, %s uv2cam map, random-init weights of the released architecture)"
+                    % ("chart-structured piecewise-smooth" if args.warp == 'charts' else "per-pixel uniform-random (adversarial)"),
             "config": {"workload": "BASELINE config 3: dragon_specular relight+view-synth, depth0 16/depth %d, "
                                    "%d frames/GPU, %d^2 UV, k=%d obs maps, %d^2 camera warp"
                                    % (args.depth, args.frames, args.uv, args.k, args.cam),

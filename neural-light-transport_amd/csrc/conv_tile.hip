@@ -21,11 +21,12 @@
 namespace {
 
 constexpr int TH = 8, TW = 16;
+constexpr int QS2 = 272, ODD2 = 132;        // k2s2 slab, in 16-byte slots: channel-quad stride (2 x 128 + pad, = 0 mod 16), odd-x plane offset (= 4 mod 8)
 constexpr int PL = 160;                      // k2s1 haloed tile: 9 x 17 = 153 texels, plane padded to 160 slots
 
 template <int MODE> struct TileTraits;
 template <> struct TileTraits<NLT_CONV_K2S1> { static constexpr int STAGE_TAPS = 4, B_UNITS = 153 * 4, B_FLOATS = 4 * PL * 4; };
-template <> struct TileTraits<NLT_CONV_K2S2> { static constexpr int STAGE_TAPS = 2, B_UNITS = 256 * 4, B_FLOATS = 4 * 2 * 128 * 4; };
+template <> struct TileTraits<NLT_CONV_K2S2> { static constexpr int STAGE_TAPS = 2, B_UNITS = 256 * 4, B_FLOATS = 4 * QS2 * 4; };
 
 struct TileP {
   const float* src; const float* packed; const float* bias;
@@ -69,24 +70,33 @@ __global__ __launch_bounds__(256) void conv_tile_kernel(TileP p) {
   const int total_stages = stages_per_frame * p.kobs;
   const long in_frame = (long)p.h * p.w;
 
-  // B-slab addressing of this thread's copy units (fixed across stages except for the channel slab / tap row)
-  int b_lds[NB]; long b_tex[NB]; bool b_ok[NB];
+  // B-slab addressing of this thread's copy units (fixed across stages except for the channel slab / tap row).
+  // Unit -> thread: 8 consecutive lanes copy the SAME channel quad of 8 consecutive texels (a 32-lane group covers
+  // 8 texels x 4 quads = the same 512 contiguous-per-texel bytes whichever way its lanes are dealt), because a
+  // ds_write_b128 is serviced 8 contiguous lanes at a time over 32 banks: 8 consecutive 16-byte slots of one plane are
+  // conflict-free, whereas the 4 quads of a texel sit a whole plane apart = on the same banks (measured 4-way / 8-way
+  // store conflicts, SQ_LDS_BANK_CONFLICT 2.9 / 12.4 cycles per DS instruction for k2s1 / k2s2).  k2s2: the odd-x plane
+  // sits 132 slots after the even one (4 mod 8) so that the two parities of those 8 texels fall on different banks too.
+  int b_lds[NB], b_q[NB]; long b_tex[NB]; bool b_ok[NB], b_st[NB];
 #pragma unroll
   for (int i = 0; i < NB; ++i) {
     const int u = tid + 256 * i;
-    const int q = u & 3, tx = u >> 2;
+    const int q = (u >> 3) & 3, tx = (u >> 5) * 8 + (u & 7);
+    b_q[i] = q;
     if (MODE == NLT_CONV_K2S1) {
       const int hy = tx / 17, hx = tx % 17;
       const int gy = ty0 + hy, gx = tx0 + hx;
-      b_ok[i] = u < TT::B_UNITS && gy < p.h && gx < p.w;             // beyond the image: TF's bottom/right zero padding
+      b_st[i] = tx < 153;
+      b_ok[i] = b_st[i] && gy < p.h && gx < p.w;                     // beyond the image: TF's bottom/right zero padding
       b_tex[i] = (long)gy * p.w + gx;
       b_lds[i] = (q * PL + tx) * 4;
     } else {
       const int y = tx >> 5, xx = tx & 31;
       const int gy = 2 * (ty0 + y), gx = 2 * tx0 + xx;               // + a (tap row) per stage
+      b_st[i] = true;
       b_ok[i] = (ty0 + y) < p.oh && gx < p.w;                      // h, w even: both tap rows / parities exist
       b_tex[i] = (long)gy * p.w + gx;
-      b_lds[i] = ((q * 2 + (xx & 1)) * 128 + y * 16 + (xx >> 1)) * 4;
+      b_lds[i] = (q * QS2 + (xx & 1) * ODD2 + y * 16 + (xx >> 1)) * 4;
     }
   }
 
@@ -101,8 +111,7 @@ __global__ __launch_bounds__(256) void conv_tile_kernel(TileP p) {
     const float* sp = p.src + ((long)(f * p.kobs + i) * in_frame + (long)a * p.w) * p.ld + cc * 16;
 #pragma unroll
     for (int n = 0; n < NB; ++n) {
-      const int u = tid + 256 * n;
-      const f32x4 v = *reinterpret_cast<const f32x4*>(sp + (b_ok[n] ? b_tex[n] : 0) * p.ld + 4 * (u & 3));
+      const f32x4 v = *reinterpret_cast<const f32x4*>(sp + (b_ok[n] ? b_tex[n] : 0) * p.ld + 4 * b_q[n]);
       rb[n] = b_ok[n] ? v : (f32x4){0.f, 0.f, 0.f, 0.f};
     }
   };
@@ -112,7 +121,7 @@ __global__ __launch_bounds__(256) void conv_tile_kernel(TileP p) {
     for (int n = 0; n < NA; ++n) *reinterpret_cast<f32x4*>(base + (tid + 256 * n) * 4) = ra[n];
 #pragma unroll
     for (int n = 0; n < NB; ++n)
-      if (tid + 256 * n < TT::B_UNITS) *reinterpret_cast<f32x4*>(base + A_FLOATS + b_lds[n]) = rb[n];
+      if (b_st[n]) *reinterpret_cast<f32x4*>(base + A_FLOATS + b_lds[n]) = rb[n];
   };
 
   f32x4 acc[RT][CT], mean[RT][CT];
@@ -136,7 +145,7 @@ __global__ __launch_bounds__(256) void conv_tile_kernel(TileP p) {
       for (int rt = 0; rt < RT; ++rt) {
         const int y = wm * RT + rt;
         const int off = MODE == NLT_CONV_K2S1 ? (kk * PL + (y + (tl >> 1)) * 17 + j + (tl & 1)) * 4
-                                              : ((kk * 2 + tl) * 128 + y * 16 + j) * 4;
+                                              : (kk * QS2 + tl * ODD2 + y * 16 + j) * 4;
         bf[rt] = *reinterpret_cast<const f32x4*>(B + off);
       }
 #pragma unroll

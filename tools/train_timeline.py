@@ -1,9 +1,9 @@
 #!/usr/bin/env python
 """Timeline of the train step from a rocprofv3 kernel trace (CSV):  where the step's wall time goes.
 
-    train_timeline.py trace_dir out.txt [n_last_steps]
+    train_timeline.py trace_dir out.txt [n_last_steps] [delimiter kernel substring]
 
-Steps are delimited by the optimizer kernel (adam_amsgrad_kernel).  For the last n steps: wall span, GPU-busy time (union
+Steps are delimited by the optimizer kernel (adam_amsgrad_kernel; pass e.g. warp_kernel for forward-only traces).  For the last n steps: wall span, GPU-busy time (union
 of the kernel intervals over all streams), sum of kernel durations, number of kernels, and the kernels ranked by total
 time; plus the idle gaps (no kernel running on any stream) ranked by the kernel that ENDS the gap."""
 import csv
@@ -16,15 +16,16 @@ from collections import defaultdict
 def main():
     d, out = sys.argv[1], sys.argv[2]
     nlast = int(sys.argv[3]) if len(sys.argv) > 3 else 4
+    delim = sys.argv[4] if len(sys.argv) > 4 else 'adam_amsgrad_kernel'
     rows = []
     for path in glob.glob(os.path.join(d, '**', '*kernel_trace.csv'), recursive=True):
         with open(path, newline='') as f:
             for r in csv.DictReader(f):
                 rows.append((int(r['Start_Timestamp']), int(r['End_Timestamp']), r['Kernel_Name'], r.get('Stream_Id') or r.get('Queue_Id')))
     rows.sort()
-    ends = [i for i, r in enumerate(rows) if 'adam_amsgrad_kernel' in r[2]]
+    ends = [i for i, r in enumerate(rows) if delim in r[2]]
     if len(ends) < nlast + 1:
-        raise SystemExit('only %d optimizer launches in the trace' % len(ends))
+        raise SystemExit('only %d %s launches in the trace' % (len(ends), delim))
     lines = []
     per_kernel = defaultdict(lambda: [0, 0.0])
     gap_after = defaultdict(lambda: [0, 0.0])
@@ -48,7 +49,7 @@ def main():
                 cur_end = en
         spans.append((t1 - t0) / 1e3); busys.append(busy / 1e3); sums.append(tot / 1e3); counts.append(len(ks))
     n = float(nlast)
-    lines.append('train steps analysed: %d   (per step averages, microseconds)' % nlast)
+    lines.append('steps analysed: %d   (per step averages, microseconds)' % nlast)
     lines.append('wall span %.1f   gpu busy (union over streams) %.1f   idle %.1f   sum of kernel durations %.1f   kernels %.1f'
                  % (sum(spans) / n, sum(busys) / n, (sum(spans) - sum(busys)) / n, sum(sums) / n, sum(counts) / n))
     lines.append('')
