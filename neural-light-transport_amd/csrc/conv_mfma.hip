@@ -31,10 +31,16 @@ __global__ void pack_weights_kernel(const float* __restrict__ wk, int c0, int c1
   wp[idx] = nlt_mfma_fragment<MODE>(wk, idx, c0, c1, cout, N, ntiles, cout, 0);
 }
 
+// k2s1 families on a 1 x 1 texel grid: taps 1-3 only ever see zero padding, so their weights (3/4 of the layer) are
+// neither streamed nor multiplied; tap 0's chunks come first in the packed order.
+template <int MODE>
+__host__ __device__ inline int live_taps(const ConvP& p) {
+  return ((MODE == NLT_CONV_K2S1 || MODE == NLT_DECONV_K2S1) && p.gh == 1 && p.gw == 1) ? 1 : ConvTraits<MODE>::TAPS;
+}
+
 template <int MODE, int RT, int CT>
 __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvP p, int mtiles, int ngroups, int ntiles, int ksplit,
-                                                        float* __restrict__ ws) {
-  constexpr int TAPS = ConvTraits<MODE>::TAPS;
+                                                        float* ws) {
   const int lane = threadIdx.x & 63;
   int wave = blockIdx.x * 4 + (threadIdx.x >> 6);
   const int ng = wave % ngroups; wave /= ngroups;
@@ -66,7 +72,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvP p, int mtiles, int
   const size_t wstride = (size_t)ntiles * 64;   // f32x4 per K-chunk
   const int ch0 = chunks16(p.c0), ch1 = chunks16(p.c1);
   const int cps = ch0 + ch1;                    // K-chunks per tap: source 0 then source 1
-  const int total = TAPS * cps;
+  const int total = live_taps<MODE>(p) * cps;
   const int per = (total + ksplit - 1) / ksplit;
   const int kbeg = ks * per;
   const int kend = kbeg + per < total ? kbeg + per : total;
@@ -125,15 +131,17 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvP p, int mtiles, int
     for (int rt = 0; rt < RT; ++rt) b_cur[rt] = b_nxt[rt];
   }
 
-  if (ksplit > 1) {                             // raw partial sums -> workspace [ks][M][ntiles*16]; nlt epilogue pass finishes
+  if (ksplit > 1) {                             // raw partial sums -> workspace [ks][M][ntiles*16]; the epilogue pass finishes
+    float* part = ws;
+    const int npad = ntiles * 16;
 #pragma unroll
     for (int ct = 0; ct < CT; ++ct) {
       const int ncol = (ng * CT + ct) * 16 + kk * 4;
 #pragma unroll
       for (int rt = 0; rt < RT; ++rt)
-        if (rv[rt]) *reinterpret_cast<f32x4*>(ws + ((size_t)ks * p.M + rm[rt]) * (ntiles * 16) + ncol) = acc[rt][ct];
+        if (rv[rt]) *reinterpret_cast<f32x4*>(part + ((size_t)ks * p.M + rm[rt]) * npad + ncol) = acc[rt][ct];
     }
-    return;
+    return;                                     // the epilogue launch adds the slices in order
   }
 
   // Epilogue: lane holds outputs [ncol, ncol+4) of texel px for every (rt, ct).
@@ -169,14 +177,33 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvP p, int mtiles, int
 // mask / LeakyReLU and the mode's output addressing, exactly as the single-pass epilogue.
 template <int MODE>
 __global__ __launch_bounds__(256) void splitk_epilogue_kernel(ConvP p, int ntiles, int ksplit, const float* __restrict__ ws) {
+  // 32 output quads per workgroup x 8 slice lanes: lane group j adds slices j, j + 8, ... (four independent running
+  // sums: a serial walk over 64-128 slices is pure load latency), the 8 partial sums meet in LDS in a fixed order.
+  __shared__ f32x4 part[8][32];
   const int quads = p.N >> 2;
-  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx >= (long)p.M * quads) return;
-  const int m = idx / quads;
-  const int ncol = (idx - (long)m * quads) * 4;
+  const int il = threadIdx.x & 31, ksl = threadIdx.x >> 5;
+  const long idx = (long)blockIdx.x * 32 + il;
+  const bool live = idx < (long)p.M * quads;
+  const int m = live ? idx / quads : 0;
+  const int ncol = live ? (idx - (long)m * quads) * 4 : 0;
   const int npad = ntiles * 16;
-  f32x4 v = *reinterpret_cast<const f32x4*>(ws + (size_t)m * npad + ncol);
-  for (int ks = 1; ks < ksplit; ++ks) v += *reinterpret_cast<const f32x4*>(ws + ((size_t)ks * p.M + m) * npad + ncol);
+  const size_t slice = (size_t)p.M * npad;
+  const float* src = ws + (size_t)m * npad + ncol;
+  f32x4 s0 = (f32x4){0.f, 0.f, 0.f, 0.f}, s1 = s0, s2 = s0, s3 = s0;
+  int ks = ksl;
+  for (; ks + 24 < ksplit; ks += 32) {
+    s0 += *reinterpret_cast<const f32x4*>(src + (size_t)ks * slice);
+    s1 += *reinterpret_cast<const f32x4*>(src + (size_t)(ks + 8) * slice);
+    s2 += *reinterpret_cast<const f32x4*>(src + (size_t)(ks + 16) * slice);
+    s3 += *reinterpret_cast<const f32x4*>(src + (size_t)(ks + 24) * slice);
+  }
+  for (; ks < ksplit; ks += 8) s0 += *reinterpret_cast<const f32x4*>(src + (size_t)ks * slice);
+  part[ksl][il] = (s0 + s1) + (s2 + s3);
+  __syncthreads();
+  if (ksl || !live) return;
+  f32x4 v = part[0][il];
+#pragma unroll
+  for (int j = 1; j < 8; ++j) v += part[j][il];
   int oc = ncol, ab = 0;
   if (MODE == NLT_DECONV_K2S2) { ab = ncol / p.cout; oc = ncol - ab * p.cout; }
   int otex = m;
@@ -205,7 +232,7 @@ int launch_tile(const ConvP& p, int ksplit, float* ws, hipStream_t s) {
   const int ntiles = (p.N + 15) >> 4;
   const int ngroups = ntiles / CT;
   const int mtiles = (p.M + 16 * RT - 1) / (16 * RT);
-  const int total = taps_of(MODE) * (chunks16(p.c0) + chunks16(p.c1));
+  const int total = live_taps<MODE>(p) * (chunks16(p.c0) + chunks16(p.c1));
   if (ksplit > total) ksplit = total;
   if (ksplit < 1 || !ws) ksplit = 1;
   const long waves = (long)mtiles * ngroups * ksplit;
@@ -213,7 +240,7 @@ int launch_tile(const ConvP& p, int ksplit, float* ws, hipStream_t s) {
   hipLaunchKernelGGL((conv_mfma_kernel<MODE, RT, CT>), dim3(blocks), dim3(256), 0, s, p, mtiles, ngroups, ntiles, ksplit, ws);
   if (ksplit > 1) {
     const long items = (long)p.M * (p.N >> 2);
-    hipLaunchKernelGGL(splitk_epilogue_kernel<MODE>, dim3((unsigned)((items + 255) / 256)), dim3(256), 0, s, p, ntiles, ksplit, ws);
+    hipLaunchKernelGGL(splitk_epilogue_kernel<MODE>, dim3((unsigned)((items + 31) / 32)), dim3(256), 0, s, p, ntiles, ksplit, ws);
   }
   NLT_CHECK_LAUNCH();
   return NLT_OK;
