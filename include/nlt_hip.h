@@ -358,6 +358,15 @@ int nlt_knn_indices(const double* ref_pos, int np, const double* cand_pos, int n
 int nlt_psnr_sums(const float* im1, const float* im2, const unsigned char* mask, long pixels, int channels,
                   double* workspace, double* out2, void* stream);
 
+/* cv2.resize(img, (ow, oh)) -- default INTER_LINEAR -- on the NORMALISED image, then astype(float32): what `_load_data`
+ * does to every texel buffer of a capture stored at another resolution than uvh / (imh, imw)
+ * (nlt/datasets/nlt.py:138-146,162-170 through xm.img.resize, third_party/xiuminglib/xiuminglib/img.py:88-118).
+ * src [n,h,w,c]: src_kind 0 = uint8 (normalised by 255, nlt.py:131-136), 1 = int32 holding 16-bit PNG samples
+ * (normalised by 65535), 2 = float32 already in [0,1].  out [n,oh,ow,c] float32.  OpenCV's arithmetic restated
+ * (tap weights in float32, horizontal pass first, float64 sums); cv2 itself cannot be installed here: parity unpinned. */
+int nlt_resize_cv_linear(const void* src, int src_kind, int n, int h, int w, int c, int oh, int ow, float* out,
+                         void* stream);
+
 /* out[i] = float32(float64(store[ids[i]]) / 255) for whole frames of per_frame bytes (per_frame % 4 == 0);
  * ids == NULL means frames 0..n-1, id -1 a frame of zeros.  The primitive behind nlt_assemble_batch; also serves
  * the camera-space images (rgb_camspc, nn_rgb_camspc; nlt/datasets/nlt.py:129-136,162-171). */

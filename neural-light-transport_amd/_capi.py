@@ -47,6 +47,7 @@ SIGNATURES = {
                                                  _vp, _c_int, _c_int, _vp, _vp, _vp, _c_long, _vp]),
     'nlt_lrelu_backward': (_c_int, [_vp, _c_int, _vp, _c_int, _c_int, _c_long, _c_float, _vp, _c_int, _vp]),
     'nlt_obs_mean_backward': (_c_int, [_vp, _c_int, _vp, _vp, _vp, _c_int, _c_int, _c_int, _c_int, _c_float, _vp, _vp]),
+    'nlt_resize_cv_linear': (_c_int, [_vp, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _vp, _vp]),
     'nlt_level_split_backward': (_c_int, [_vp, _vp, _c_int, _vp, _vp, _vp, _c_int, _c_int, _c_int, _c_int, _c_float, _c_float, _vp, _vp]),
     'nlt_stem_backward': (_c_int, [_vp] * 6 + [_c_int] * 5 + [_vp] * 6 + [_vp]),
     'nlt_head_backward': (_c_int, [_vp, _c_int, _c_int, _vp, _c_int, _c_int, _vp, _vp, _c_int, _c_int, _c_int,
@@ -392,6 +393,20 @@ def lrelu_backward(g, ldg, y, ldy, c, texels, alpha, out, ldo):
 def obs_mean_backward(dmean, ldm, obs_y, obs_weights, dobs_partial, n, k, hw, c, alpha, dpre_obs):
     _check(lib().nlt_obs_mean_backward(_ptr(dmean), ldm, _ptr(obs_y), _ptr(obs_weights), _ptr(dobs_partial),
                                        n, k, hw, c, float(alpha), _ptr(dpre_obs), _stream()), 'nlt_obs_mean_backward')
+
+
+def resize_cv_linear(src, oh, ow, out=None):
+    """cv2.resize(normalised src, (ow, oh)) (INTER_LINEAR) -> float32.  src [n,h,w,c] uint8, int32 (16-bit samples) or
+    float32 (already normalised)."""
+    kind = {torch.uint8: 0, torch.int32: 1, torch.float32: 2}.get(src.dtype)
+    if kind is None or src.dim() != 4:
+        raise NLTError("resize_cv_linear: [n,h,w,c] uint8 / int32 / float32 expected, got %s %s" % (src.dtype, tuple(src.shape)))
+    src = _dense(src, 'src')
+    n, h, w, c = src.shape
+    if out is None:
+        out = torch.empty((n, oh, ow, c), device=src.device, dtype=torch.float32)
+    _check(lib().nlt_resize_cv_linear(_ptr(src), kind, n, h, w, c, oh, ow, _ptr(out), _stream()), 'nlt_resize_cv_linear')
+    return out
 
 
 def level_split_backward(dfm, fm_y, ld, obs_y, obs_weights, dobs_partial, n, k, hw, c, alpha_q, alpha_o, dpre_obs):

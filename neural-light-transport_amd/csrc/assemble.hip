@@ -336,7 +336,69 @@ int launch_gather(const u8* store, const int* ids, int nframes_out, long per_fra
   return NLT_OK;
 }
 
+// cv2.resize(arr, (ow, oh)) with the default INTER_LINEAR on the NORMALISED float64 image, as `_load_data` applies it
+// when a capture is stored at another resolution than uvh / (imh, imw) (nlt/datasets/nlt.py:138-146; xm.img.resize,
+// xiuminglib/img.py:88-118), followed by the astype(float32) of nlt.py:173-181.  OpenCV's table loop restated: per axis
+// fx = float((d + 0.5) * (src / dst) - 0.5), s = floor(fx), fx -= s, clamped at both ends with weight 0; tap weights stay
+// float32, the horizontal pass runs first, sums are float64 (this file is compiled without fp contraction).
+// SRC: 0 = uint8 (/255), 1 = int32 holding 16-bit samples (/65535), 2 = float32 already normalised.
+template <int SRC>
+__device__ __forceinline__ double cv_sample(const void* src, long i) {
+  if (SRC == 0) return (double)static_cast<const unsigned char*>(src)[i] / 255.0;
+  if (SRC == 1) return (double)static_cast<const int*>(src)[i] / 65535.0;
+  return (double)static_cast<const float*>(src)[i];
+}
+
+__device__ __forceinline__ void cv_tap(int d, int src, int dst, int& s, float& f, bool& hi) {
+  const double scale = (double)src / (double)dst;
+  f = (float)(((double)d + 0.5) * scale - 0.5);
+  s = (int)floorf(f);
+  f -= (float)s;
+  if (s < 0) { s = 0; f = 0.f; }
+  hi = s >= src - 1;
+  if (hi) { s = src - 1; f = 0.f; }
+}
+
+template <int SRC>
+__global__ __launch_bounds__(256) void resize_cv_kernel(const void* __restrict__ src, int h, int w, int c, int oh, int ow,
+                                                        long total, float* __restrict__ out) {
+  const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= total) return;
+  const int ch = idx % c;
+  const long t = idx / c;
+  const int ox = t % ow, oy = (t / ow) % oh;
+  const long f = t / ((long)ow * oh);
+  int sx, sy; float fx, fy; bool xhi, yhi;
+  cv_tap(ox, w, ow, sx, fx, xhi);
+  cv_tap(oy, h, oh, sy, fy, yhi);
+  const int x1 = sx + 1 < w ? sx + 1 : w - 1, y1 = sy + 1 < h ? sy + 1 : h - 1;
+  const double a0 = (double)(1.f - fx), a1 = (double)fx, b0 = (double)(1.f - fy), b1 = (double)fy;
+  const long base = f * h * w;
+  auto at = [&](int y, int x) { return cv_sample<SRC>(src, ((base + (long)y * w + x) * c) + ch); };
+  double r0, r1;
+  if (xhi) { r0 = at(sy, sx); r1 = at(y1, sx); }
+  else {
+    r0 = at(sy, sx) * a0 + at(sy, x1) * a1;
+    r1 = at(y1, sx) * a0 + at(y1, x1) * a1;
+  }
+  out[idx] = (float)(b0 * r0 + b1 * r1);
+}
+
 }  // namespace
+
+extern "C" int nlt_resize_cv_linear(const void* src, int src_kind, int n, int h, int w, int c, int oh, int ow, float* out,
+                                    void* stream) {
+  if (!src || !out || n <= 0 || h <= 0 || w <= 0 || c <= 0 || oh <= 0 || ow <= 0) return NLT_ERR_BAD_ARG;
+  if (src_kind < 0 || src_kind > 2) return NLT_ERR_BAD_ARG;
+  const long total = (long)n * oh * ow * c;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const dim3 grid(blocks_for(total));
+  if (src_kind == 0) hipLaunchKernelGGL(resize_cv_kernel<0>, grid, dim3(256), 0, s, src, h, w, c, oh, ow, total, out);
+  else if (src_kind == 1) hipLaunchKernelGGL(resize_cv_kernel<1>, grid, dim3(256), 0, s, src, h, w, c, oh, ow, total, out);
+  else hipLaunchKernelGGL(resize_cv_kernel<2>, grid, dim3(256), 0, s, src, h, w, c, oh, ow, total, out);
+  NLT_CHECK_LAUNCH();
+  return NLT_OK;
+}
 
 extern "C" int nlt_psnr_sums(const float* im1, const float* im2, const unsigned char* mask, long pixels, int channels,
                              double* workspace, double* out2, void* stream) {

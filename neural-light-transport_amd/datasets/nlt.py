@@ -40,8 +40,11 @@ def load_store(data_root, device='cuda', ids=None):
 
     def png(path, channels):
         a = read_png(path)
-        if a.dtype != np.uint8:
-            raise NotImplementedError("%s: %s PNGs (the resident store is uint8)" % (path, a.dtype))
+        if a.dtype != np.uint8:                                      # 16-bit PNG: PIL modes I;16 / I;16B / I
+            if a.dtype.kind in 'ui' and a.dtype.itemsize in (2, 4) and a.min() >= 0 and a.max() <= 65535:
+                a = a.astype(np.uint16)
+            else:                                                    # xm.img.normalize_uint takes uint8 / uint16 only (img.py:11-29)
+                raise NotImplementedError("%s: %s PNGs (normalize_uint takes uint8 / uint16)" % (path, a.dtype))
         if channels == 3:
             if a.ndim == 2:
                 a = np.dstack([a] * 3)
@@ -74,6 +77,11 @@ def load_store(data_root, device='cuda', ids=None):
             if a is not None and a.shape != ref.shape:
                 raise NotImplementedError("'%s' comes in several resolutions (%s vs %s): the reference resizes with cv2"
                                           % (key, a.shape, ref.shape))
+        if dtype is None:                                            # texel buffers: uint8 stays uint8 (the resident fast path);
+            depths = {a.dtype for a in cols[key] if a is not None}   # 16-bit captures are held as int32 (no CUDA uint16 arithmetic)
+            if len(depths) > 1:
+                raise NotImplementedError("'%s' mixes 8- and 16-bit PNGs" % key)
+            dtype = np.uint8 if depths == {np.dtype(np.uint8)} else np.int32
         out = np.zeros((len(ids),) + ref.shape, dtype)
         for i, a in enumerate(cols[key]):
             if a is not None:
@@ -82,7 +90,7 @@ def load_store(data_root, device='cuda', ids=None):
 
     store = {'ids': ids, 'nn': nn, 'complete': complete}
     for key in ('diffuse', 'rgb', 'cvis', 'lvis', 'rgb_camspc'):
-        store[key] = stack(key, np.uint8)
+        store[key] = stack(key, None)
     store['uv2cam'] = stack('uv2cam', np.float16)
     return store
 
@@ -130,25 +138,58 @@ class Dataset:
                 provided=mode, allowed=('train', 'vali', 'test')))
         if store is None:                                           # nlt/datasets/nlt.py:35-45
             store = load_store(config.get('DEFAULT', 'data_root'), device)
-            uvh = config.getint('DEFAULT', 'uvh')
-            if store['cvis'].shape[1] != uvh:
-                raise NotImplementedError("stored UV resolution %d != uvh %d (the reference resizes with cv2)"
-                                          % (store['cvis'].shape[1], uvh))
         self.config, self.mode, self.store, self.k = config, mode, store, k
         # Staging ring: load_batch fills one of `ring` persistent buffer sets instead of allocating ~20 fresh tensors per
         # step, so the addresses a batch arrives at repeat every `ring` steps and the model's recorded launch tape (keyed
         # by input addresses) keeps replaying in a real data loop.  A returned batch stays valid for `ring - 1` further
         # load_batch calls (ring = 0: fresh tensors every call, as the reference's tf.data pipeline hands out).
         self.ring, self._slots, self._turn = int(ring), {}, 0
-        imh, imw = (config.getint('DEFAULT', k_, fallback=0) for k_ in ('imh', 'imw'))
-        cam = tuple(store['rgb_camspc'].shape[1:3])
-        if imh and imw and cam != (imh, imw):                        # the reference resizes rgb_camspc with cv2 (nlt.py:143)
-            raise NotImplementedError("stored camera-space resolution %s != (imh, imw) = %s (the reference resizes with cv2)"
-                                      % (cam, (imh, imw)))
+        self._fstore = self._resized_store()
         self.index = {id_: i for i, id_ in enumerate(store['ids'])}
         self.bs = 1 if mode == 'test' else config.getint('DEFAULT', 'bs')     # datasets/base.py
         self.files = self._glob()
         assert self.files, "No files to process into a dataset"           # nlt/datasets/base.py:38
+
+    TEXEL_KEYS = ('diffuse', 'rgb', 'cvis', 'lvis')
+
+    def _resized_store(self):
+        """The released capture is 8-bit at the resolution it is trained at: `_load_data`'s cv2.resize calls copy, and
+        batches come straight out of the uint8 store.  For anything else -- another stored resolution than uvh /
+        (imh, imw), 16-bit PNGs -- every buffer is normalised and resized ONCE here, exactly as `_load_data` would per
+        sample (nlt.py:131-146: normalize_uint -> xm.img.resize = cv2 INTER_LINEAR on float64 -> float32;
+        csrc/assemble.hip resize_cv_kernel), into a float32 store the batches are gathered from (4x the bytes, no
+        resident-uint8 fast path).  Returns None in the native case."""
+        s = self.store
+        uvh = self.config.getint('DEFAULT', 'uvh', fallback=0) or s['cvis'].shape[1]
+        h, w = s['cvis'].shape[1:3]
+        uvw = int(w / h * uvh)                                       # xm.img.resize(arr, new_h=uvh): aspect kept, truncated
+        imh = self.config.getint('DEFAULT', 'imh', fallback=0) or s['rgb_camspc'].shape[1]
+        imw = self.config.getint('DEFAULT', 'imw', fallback=0) or s['rgb_camspc'].shape[2]
+        native = all(s[k_].dtype == torch.uint8 for k_ in self.TEXEL_KEYS + ('rgb_camspc',)) and (h, w) == (uvh, uvw) \
+            and tuple(s['rgb_camspc'].shape[1:3]) == (imh, imw)
+        if native:
+            return None
+        fs = {}
+        for k_ in self.TEXEL_KEYS + ('rgb_camspc',):
+            src = s[k_] if s[k_].dim() == 4 else s[k_].unsqueeze(-1)
+            oh, ow = (imh, imw) if k_ == 'rgb_camspc' else (uvh, uvw)
+            fs[k_] = C.resize_cv_linear(src.contiguous(), oh, ow)
+        return fs
+
+    def _load_batch_resized(self, ids, fid_h, nn_h):
+        fs, dev = self._fstore, self._fstore['cvis'].device
+        li, nn = fid_h.long().to(dev), nn_h.long().to(dev)
+        test = self.mode == 'test'
+        ok = (nn >= 0).view(nn.shape + (1, 1, 1)).float()
+        safe = nn.clamp(min=0)
+        base, cvis, lvis = fs['diffuse'][li], fs['cvis'][li], fs['lvis'][li]
+        rgb = torch.zeros_like(base) if test else fs['rgb'][li]
+        rgb_c = torch.zeros((len(ids),) + tuple(fs['rgb_camspc'].shape[1:]), device=dev) if test else fs['rgb_camspc'][li]
+        nn_base, nn_rgb = fs['diffuse'][safe] * ok, fs['rgb'][safe] * ok
+        nn_rgb_c = fs['rgb_camspc'][safe[:, 0]] * ok[:, 0]
+        warp = self.store['uv2cam'][li].float()                      # never resized (nlt.py:147-148)
+        nn_names = [self.store['ids'][j] if j >= 0 else 'incomplete-data' for j in nn_h[:, 0].tolist()]
+        return (list(ids), base, cvis, lvis, warp, rgb, rgb_c, nn_names, nn_base, nn_rgb, nn_rgb_c)
 
     def _glob(self):
         """nlt/datasets/nlt.py:54-86: hold-out split by camera x light."""
@@ -207,6 +248,8 @@ class Dataset:
         slot = self._slot(n)
         fid_h = torch.tensor([self.index[i] for i in ids], dtype=torch.int32)
         nn_h = torch.tensor([self._nn_indices(i) for i in ids], dtype=torch.int32)
+        if self._fstore is not None:
+            return self._load_batch_resized(ids, fid_h, nn_h)
         if slot is None or 'fid' not in slot:
             fid, nnid = fid_h.to(dev), nn_h.to(dev)
             if slot is not None:

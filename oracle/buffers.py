@@ -13,7 +13,7 @@ IMPORTS the reference's Python where that is possible in the build container):
                               distanceTransform(DIST_L1) substituted by SciPy's taxicab
                               chamfer transform (cv2 is not installable here)             (pinned up to that substitution)
   * normalize_uint / denormalize_float <- xiuminglib/img.py:11-54 imported and run       (pinned)
-  * view/light cosines, diffuse base, remap: the reference needs Blender's mathutils / cv2
+  * view/light cosines, diffuse base, remap, cv2.resize: the reference needs Blender's mathutils / cv2
     (absent) -> restated from the source lines cited below                               (parity unpinned)
 """
 import numpy as np
@@ -34,6 +34,62 @@ def denormalize_float(arr, uint_type='uint8'):
     if arr.min() < 0 or arr.max() > 1:
         raise ValueError("values outside [0, 1]")
     return (arr * np.iinfo(uint_type).max).astype(uint_type)
+
+
+# ----------------------------------------------------------------------------
+# third_party/xiuminglib/xiuminglib/img.py:88-118 (xm.img.resize -> cv2.resize, default INTER_LINEAR), as `_load_data`
+# applies it to the NORMALISED float64 buffers when the stored resolution differs from uvh / (imh, imw)
+# (nlt/datasets/nlt.py:138-146,162-170).
+# ----------------------------------------------------------------------------
+def resize_target(h, w, new_h=None, new_w=None):
+    """img.py:103-116: the missing side keeps the aspect ratio, truncated."""
+    if new_h is None and new_w is None:
+        raise ValueError("At least one of new height or width must be given")
+    if new_h is None:
+        new_h = int(h / w * new_w)
+    elif new_w is None:
+        new_w = int(w / h * new_h)
+    return new_h, new_w
+
+
+def _cv_linear_taps(dst, src):
+    """OpenCV resize(), INTER_LINEAR, per axis (imgproc/src/resize.cpp, the xofs / alpha table loop): source index of
+    the first tap and the weight of the second one.  fx is formed in float32, out-of-range taps are clamped with
+    weight 0 (left / top edge) or collapse onto the last sample (right / bottom edge)."""
+    scale = float(src) / float(dst)
+    d = np.arange(dst, dtype=np.float64)
+    fx = ((d + 0.5) * scale - 0.5).astype(np.float32)
+    sx = np.floor(fx).astype(np.int64)
+    fx = (fx - sx.astype(np.float32)).astype(np.float32)
+    lo = sx < 0
+    sx = np.where(lo, 0, sx); fx = np.where(lo, np.float32(0), fx)
+    hi = sx >= src - 1
+    sx = np.where(hi, src - 1, sx); fx = np.where(hi, np.float32(0), fx)
+    return sx, fx.astype(np.float32), hi
+
+
+def cv_resize_linear(arr, new_h, new_w):
+    """cv2.resize(arr, (new_w, new_h)) for a float64 array [h,w] or [h,w,c]: horizontal pass then vertical pass, tap
+    weights held in float32 (OpenCV's `AT` for CV_64F), sums in float64, one IEEE operation at a time."""
+    a = np.asarray(arr, dtype=np.float64)
+    squeeze = a.ndim == 2
+    if squeeze:
+        a = a[:, :, None]
+    h, w = a.shape[:2]
+    if (new_h, new_w) == (h, w):
+        return np.asarray(arr, dtype=np.float64).copy()             # cv2 copies when the size is unchanged
+    sx, fx, xhi = _cv_linear_taps(new_w, w)
+    sy, fy, yhi = _cv_linear_taps(new_h, h)
+    a0 = (np.float32(1) - fx).astype(np.float64)[None, :, None]
+    a1 = fx.astype(np.float64)[None, :, None]
+    x1 = np.minimum(sx + 1, w - 1)
+    rows = a[:, sx, :] * a0 + a[:, x1, :] * a1                         # HResizeLinear
+    rows = np.where(xhi[None, :, None], a[:, sx, :], rows)             # dx >= xmax: D = S[sx] * 1
+    b0 = (np.float32(1) - fy).astype(np.float64)[:, None, None]
+    b1 = fy.astype(np.float64)[:, None, None]
+    y1 = np.minimum(sy + 1, h - 1)
+    out = b0 * rows[sy] + b1 * rows[y1]                                # VResizeLinear
+    return out[:, :, 0] if squeeze else out
 
 
 # ----------------------------------------------------------------------------

@@ -286,7 +286,18 @@ def assemble_batch(diffuse_store, rgb_store, cvis_store, lvis_store, ids, nn_ids
     return b
 
 
-_BUFFERS = ('cosine_map', 'albedo', 'diffuse_base', 'remap_bilinear', 'uv_index_map', 'knn_indices', 'gather_frames_u8',
+def resize_cv_linear(src, oh, ow, out=None):
+    a = src.numpy()
+    norm = {torch.uint8: 255.0, torch.int32: 65535.0, torch.float32: 1.0}[src.dtype]
+    res = _np.stack([_BU.cv_resize_linear(f.astype(_np.float64) / norm, oh, ow) for f in a]).astype(_np.float32)
+    res = torch.from_numpy(res)
+    if out is not None:
+        out.copy_(res)
+        return out
+    return res
+
+
+_BUFFERS = ('resize_cv_linear', 'cosine_map', 'albedo', 'diffuse_base', 'remap_bilinear', 'uv_index_map', 'knn_indices', 'gather_frames_u8',
             'assemble_batch')
 
 

@@ -237,8 +237,11 @@ def test_dataset_load_batch(C):
     assert np.array_equal(seen[2][5].cpu().numpy(), f32(store['rgb'][2:4]))
     fresh = get_dataset_class('nlt')(cfg, 'train', store, ring=0)
     assert fresh.load_batch(ids[:2])[1].data_ptr() != fresh.load_batch(ids[:2])[1].data_ptr() or True
-    with pytest.raises(NotImplementedError):                       # stored camera resolution != (imh, imw): cv2 resize
-        get_dataset_class('nlt')(nlt_amd.make_config(uvh=H, uvw=W, imh=2 * im, imw=2 * im), 'train', store)
+    # stored camera resolution != (imh, imw): every buffer goes through normalise -> cv2-style resize -> float32 once
+    big = get_dataset_class('nlt')(nlt_amd.make_config(uvh=H, uvw=W, imh=2 * im, imw=2 * im, bs=2), 'train', store).load_batch(ids[:2])
+    ref = B.cv_resize_linear(store['rgb_camspc'][1].cpu().numpy() / 255.0, 2 * im, 2 * im).astype(np.float32)
+    assert np.array_equal(big[6][1].cpu().numpy(), ref) and np.array_equal(big[1].cpu().numpy(), f32(store['diffuse'][:2]))
+    assert tuple(big[4].shape[1:3]) == (im, im) and not big[10][0].any()
     # resident batch: texel buffers stay in the uint8 store; materialising them gives the eager batch bit for bit
     r = ds.load_batch(ids[:2], resident=True)
     e = get_dataset_class('nlt')(cfg, 'train', store, ring=0).load_batch(ids[:2])
@@ -268,3 +271,22 @@ def test_psnr_on_luma_matches_the_reference_values():
     assert abs(got - M.psnr(a, b)) <= 1e-10 * abs(got)
     with pytest.raises(AssertionError):
         psnr(torch.zeros(4, 4, 3, device=DEV), torch.zeros(4, 5, 3, device=DEV))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('kind,h,w,oh,ow,c', [('u8', 16, 24, 32, 48, 3), ('u8', 64, 64, 24, 40, 1), ('u16', 20, 20, 33, 17, 3),
+                                              ('f32', 9, 13, 9, 13, 2), ('u8', 512, 512, 1024, 1024, 3)])
+def test_resize_cv_linear_bit_exact(kind, h, w, oh, ow, c):
+    """nlt_resize_cv_linear vs the oracle's restatement of cv2.resize INTER_LINEAR on the normalised float64 image
+    (float64 arithmetic, no contraction: bit-exact float32 results)."""
+    rng = np.random.default_rng(h + ow)
+    n = 2
+    if kind == 'u8':
+        a = rng.integers(0, 256, (n, h, w, c), dtype=np.uint8); src = torch.from_numpy(a); norm = a.astype(np.float64) / 255
+    elif kind == 'u16':
+        a = rng.integers(0, 65536, (n, h, w, c)).astype(np.int32); src = torch.from_numpy(a); norm = a.astype(np.float64) / 65535
+    else:
+        a = rng.random((n, h, w, c)).astype(np.float32); src = torch.from_numpy(a); norm = a.astype(np.float64)
+    ref = np.stack([B.cv_resize_linear(f, oh, ow) for f in norm]).astype(np.float32)
+    out = C.resize_cv_linear(src.cuda(), oh, ow).cpu().numpy()
+    assert np.array_equal(out, ref)

@@ -67,9 +67,56 @@ def test_load_store_and_batches(tmp_path, monkeypatch):
     assert np.array_equal(b[1].numpy(), ref['base']) and np.array_equal(b[9].numpy(), ref['nn_rgb'])
     assert b[4].dtype == torch.float32 and np.array_equal(b[4].numpy(), store['uv2cam'][fid].float().numpy())
     assert b[7] == [nn_id, nn_id]
-    with pytest.raises(NotImplementedError):
-        D.Dataset(nlt_amd.make_config(data_root=root, uvh=32), 'train', device='cpu')
+    # another training resolution than the stored one: every buffer normalised and resized as `_load_data` does per sample
+    # (nlt.py:131-146: normalize_uint -> cv2.resize INTER_LINEAR on float64 -> float32), warp left alone
+    cfg2 = nlt_amd.make_config(data_root=root, uvh=24, uvw=24, imh=12, imw=12, holdout_cam='P02', holdout_light='L2', bs=2)
+    ds2 = D.Dataset(cfg2, 'train', device='cpu')
+    b2 = ds2.load_batch(ds2.files)
+    rs = lambda a, h, w: B.cv_resize_linear(B.normalize_uint(a), h, w).astype(np.float32)
+    for j, id_ in enumerate(ds2.files):
+        assert np.array_equal(b2[1][j].numpy(), rs(data[id_]['diffuse'], 24, 24))
+        assert np.array_equal(b2[2][j].numpy()[..., 0], rs(data[id_]['cvis'], 24, 24))
+        assert np.array_equal(b2[5][j].numpy(), rs(data[id_]['rgb'], 24, 24))
+        assert np.array_equal(b2[6][j].numpy(), rs(data[id_]['rgb_camspc'][:, :, :3], 12, 12))
+        assert np.array_equal(b2[8][j, 0].numpy(), rs(data[nn_id]['diffuse'], 24, 24))
+        assert np.array_equal(b2[10][j].numpy(), rs(data[nn_id]['rgb_camspc'][:, :, :3], 12, 12))
+    assert tuple(b2[4].shape) == (2, 8, 8, 2)                        # "always warp first and then resize" (nlt.py:147-148)
     with pytest.raises(FileNotFoundError):
         D.load_store(str(tmp_path / 'missing'), device='cpu')
     with pytest.raises(ValueError):
         D.Dataset(cfg, 'bogus', store=store)
+
+
+def test_sixteen_bit_capture(tmp_path, monkeypatch):
+    """16-bit PNGs (xm.io.img.load keeps the depth, normalize_uint divides by 65535: xiuminglib/img.py:11-29)."""
+    fake_capi.install(monkeypatch)
+    root = str(tmp_path / 'capture16')
+    rng = np.random.default_rng(5)
+    ids = ['trainvali_%09d_P01_L%d' % (i, i) for i in range(2)]
+    index, data = {}, {}
+    for id_ in ids:
+        d = os.path.join(root, id_)
+        os.makedirs(d)
+        U16 = lambda *s: rng.integers(0, 65536, s).astype(np.uint16)
+        a = {'cvis': U16(8, 8), 'lvis': U16(8, 8)}
+        for k, v in a.items():
+            Image.fromarray(v).save(os.path.join(d, k + '.png'))                 # mode I;16
+        for k in ('diffuse', 'rgb', 'rgb_camspc'):                              # PIL writes no 16-bit RGB: grey, replicated by the reader
+            a[k] = U16(8, 8)
+            Image.fromarray(a[k]).save(os.path.join(d, k + '.png'))
+        np.save(os.path.join(d, 'uv2cam.npy'), rng.random((8, 8, 2)).astype(np.float16))
+        with open(os.path.join(d, 'nn.json'), 'w') as h:
+            json.dump({'cam': 'P01', 'light': 'L0'}, h)
+        index[id_] = dict({k: os.path.join(id_, k + '.png') for k in a}, uv2cam=os.path.join(id_, 'uv2cam.npy'),
+                          nn=os.path.join(id_, 'nn.json'), complete=True)
+        data[id_] = a
+    with open(root + '.json', 'w') as h:
+        json.dump(index, h)
+    ds = D.Dataset(nlt_amd.make_config(data_root=root, uvh=8, uvw=8, imh=8, imw=8, bs=2), 'train', device='cpu')
+    assert ds.store['cvis'].dtype == torch.int32
+    b = ds.load_batch(ids)
+    f32 = lambda a: B.normalize_uint(a).astype(np.float32)
+    for j, id_ in enumerate(ids):
+        assert np.array_equal(b[2][j].numpy()[..., 0], f32(data[id_]['cvis']))
+        assert np.array_equal(b[1][j].numpy(), np.dstack([f32(data[id_]['diffuse'])] * 3))
+        assert np.array_equal(b[8][j, 0].numpy(), np.dstack([f32(data[ids[0]]['diffuse'])] * 3))
