@@ -405,7 +405,7 @@ def resize_cv_linear(src, oh, ow, out=None):
     n, h, w, c = src.shape
     if out is None:
         out = torch.empty((n, oh, ow, c), device=src.device, dtype=torch.float32)
-    _check(lib().nlt_resize_cv_linear(_ptr(src), kind, n, h, w, c, oh, ow, _ptr(out), _stream()), 'nlt_resize_cv_linear')
+    _check(lib().nlt_resize_cv_linear(_tptr(src, src.dtype, 'src'), kind, n, h, w, c, oh, ow, _ptr(out), _stream()), 'nlt_resize_cv_linear')
     return out
 
 

@@ -173,10 +173,48 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvP p, int mtiles, int
   }
 }
 
-// Second pass of a split-K launch: sums the K slices in slice order (deterministic), then bias / accumulate /
-// mask / LeakyReLU and the mode's output addressing, exactly as the single-pass epilogue.
+// bias / accumulate / mask / LeakyReLU and the mode's output addressing of one output quad, exactly as the single-pass epilogue
+template <int MODE>
+__device__ __forceinline__ void splitk_finish(const ConvP& p, int m, int ncol, f32x4 v) {
+  int oc = ncol, ab = 0;
+  if (MODE == NLT_DECONV_K2S2) { ab = ncol / p.cout; oc = ncol - ab * p.cout; }
+  int otex = m;
+  if (MODE == NLT_DECONV_K2S2) {
+    const int x = m % p.gw, y = (m / p.gw) % p.gh, f = m / (p.gw * p.gh);
+    otex = (f * p.oh + 2 * y + (ab >> 1)) * p.ow + 2 * x + (ab & 1);
+  }
+  v += *reinterpret_cast<const f32x4*>(p.bias + oc);
+  f32x4* o = reinterpret_cast<f32x4*>(p.out + (size_t)otex * p.ldo + oc);
+  if (p.accumulate) v += *o;
+  if (p.mask_src) {
+    const f32x4 mk = *reinterpret_cast<const f32x4*>(p.mask_src + (size_t)otex * p.ldm + oc);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) v[j] *= (mk[j] > 0.f) ? 1.f : p.alpha;
+  } else if (p.act) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) v[j] = v[j] > 0.f ? v[j] : p.alpha * v[j];
+  }
+  *o = v;
+}
+
+// Second pass of a split-K launch: sums the K slices in slice order (deterministic), then the usual epilogue.  Few slices
+// (the mid-network shapes: thousands of rows, 4-8 slices): one thread per output quad walks them.
 template <int MODE>
 __global__ __launch_bounds__(256) void splitk_epilogue_kernel(ConvP p, int ntiles, int ksplit, const float* __restrict__ ws) {
+  const int quads = p.N >> 2;
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (long)p.M * quads) return;
+  const int m = idx / quads;
+  const int ncol = (idx - (long)m * quads) * 4;
+  const int npad = ntiles * 16;
+  f32x4 v = *reinterpret_cast<const f32x4*>(ws + (size_t)m * npad + ncol);
+  for (int ks = 1; ks < ksplit; ++ks) v += *reinterpret_cast<const f32x4*>(ws + ((size_t)ks * p.M + m) * npad + ncol);
+  splitk_finish<MODE>(p, m, ncol, v);
+}
+
+// Many slices (the deep levels: a handful of rows, 16-128 slices):
+template <int MODE>
+__global__ __launch_bounds__(256) void splitk_epilogue_wide_kernel(ConvP p, int ntiles, int ksplit, const float* __restrict__ ws) {
   // 32 output quads per workgroup x 8 slice lanes: lane group j adds slices j, j + 8, ... (four independent running
   // sums: a serial walk over 64-128 slices is pure load latency), the 8 partial sums meet in LDS in a fixed order.
   __shared__ f32x4 part[8][32];
@@ -204,25 +242,7 @@ __global__ __launch_bounds__(256) void splitk_epilogue_kernel(ConvP p, int ntile
   f32x4 v = part[0][il];
 #pragma unroll
   for (int j = 1; j < 8; ++j) v += part[j][il];
-  int oc = ncol, ab = 0;
-  if (MODE == NLT_DECONV_K2S2) { ab = ncol / p.cout; oc = ncol - ab * p.cout; }
-  int otex = m;
-  if (MODE == NLT_DECONV_K2S2) {
-    const int x = m % p.gw, y = (m / p.gw) % p.gh, f = m / (p.gw * p.gh);
-    otex = (f * p.oh + 2 * y + (ab >> 1)) * p.ow + 2 * x + (ab & 1);
-  }
-  v += *reinterpret_cast<const f32x4*>(p.bias + oc);
-  f32x4* o = reinterpret_cast<f32x4*>(p.out + (size_t)otex * p.ldo + oc);
-  if (p.accumulate) v += *o;
-  if (p.mask_src) {
-    const f32x4 mk = *reinterpret_cast<const f32x4*>(p.mask_src + (size_t)otex * p.ldm + oc);
-#pragma unroll
-    for (int j = 0; j < 4; ++j) v[j] *= (mk[j] > 0.f) ? 1.f : p.alpha;
-  } else if (p.act) {
-#pragma unroll
-    for (int j = 0; j < 4; ++j) v[j] = v[j] > 0.f ? v[j] : p.alpha * v[j];
-  }
-  *o = v;
+  splitk_finish<MODE>(p, m, ncol, v);
 }
 
 int taps_of(int mode) { return (mode == NLT_CONV1X1 || mode == NLT_DECONV_K2S2) ? 1 : 4; }
@@ -240,7 +260,10 @@ int launch_tile(const ConvP& p, int ksplit, float* ws, hipStream_t s) {
   hipLaunchKernelGGL((conv_mfma_kernel<MODE, RT, CT>), dim3(blocks), dim3(256), 0, s, p, mtiles, ngroups, ntiles, ksplit, ws);
   if (ksplit > 1) {
     const long items = (long)p.M * (p.N >> 2);
-    hipLaunchKernelGGL(splitk_epilogue_kernel<MODE>, dim3((unsigned)((items + 31) / 32)), dim3(256), 0, s, p, ntiles, ksplit, ws);
+    if (ksplit > 8)
+      hipLaunchKernelGGL(splitk_epilogue_wide_kernel<MODE>, dim3((unsigned)((items + 31) / 32)), dim3(256), 0, s, p, ntiles, ksplit, ws);
+    else
+      hipLaunchKernelGGL(splitk_epilogue_kernel<MODE>, dim3((unsigned)((items + 255) / 256)), dim3(256), 0, s, p, ntiles, ksplit, ws);
   }
   NLT_CHECK_LAUNCH();
   return NLT_OK;

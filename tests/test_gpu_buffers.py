@@ -276,7 +276,7 @@ def test_psnr_on_luma_matches_the_reference_values():
 @pytest.mark.gpu
 @pytest.mark.parametrize('kind,h,w,oh,ow,c', [('u8', 16, 24, 32, 48, 3), ('u8', 64, 64, 24, 40, 1), ('u16', 20, 20, 33, 17, 3),
                                               ('f32', 9, 13, 9, 13, 2), ('u8', 512, 512, 1024, 1024, 3)])
-def test_resize_cv_linear_bit_exact(kind, h, w, oh, ow, c):
+def test_resize_cv_linear_bit_exact(C, kind, h, w, oh, ow, c):
     """nlt_resize_cv_linear vs the oracle's restatement of cv2.resize INTER_LINEAR on the normalised float64 image
     (float64 arithmetic, no contraction: bit-exact float32 results)."""
     rng = np.random.default_rng(h + ow)

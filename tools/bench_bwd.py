@@ -66,7 +66,7 @@ for label, mode, cin, cout, h in ops:
         narrow = ncols <= 32 and cin * (1 if mode == C.DECONV_K2S2 else 4) <= 128
         fn = C.conv_backward_weights_narrow if narrow else C.conv_backward_weights_tiled
         t = timeit(lambda: fn(mode, x, cin, cin, None, 0, 0, n, h, h, dp, cout, cout, dw, db))
-        print('%-10s %5d %5d %5d  %9.2f %8.1f   %6.1f   wgrad %s' % (label, cin, cout, h, gf, t, gf / t * 1e-3, 'narrow' if narrow else 'tiled'))
+        print('%-10s %5d %5d %5d  %9.2f %8.1f   %6.1f   wgrad %s' % (label, cin, cout, h, gf, t, gf / t * 1e3, 'narrow' if narrow else 'tiled'))
     if args.only in (None, 'dgrad'):
         wk = torch.randn_like(dw) * 0.01
         adj = ADJ[mode]
@@ -87,4 +87,4 @@ for label, mode, cin, cout, h in ops:
             res.append((t, tile))
         best = min(res)
         print('%-10s %5d %5d %5d  %9.2f %8.1f   %6.1f   dgrad best tile %d (default %.1f us)' %
-              (label, cin, cout, h, gf, best[0], gf / best[0] * 1e-3, best[1], res[0][0]))
+              (label, cin, cout, h, gf, best[0], gf / best[0] * 1e3, best[1], res[0][0]))

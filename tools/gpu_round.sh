@@ -29,4 +29,12 @@ if [ "${PMC:-1}" = "1" ]; then
   python tools/pmc_summary.py gpurun_out/pmc_traffic.json gpurun_out/pmc_fetch gpurun_out/pmc_write
   find gpurun_out/pmc_fetch gpurun_out/pmc_write -name "*.csv" -size +8M -delete
 fi
+if [ "${EXTRAS:-1}" = "1" ]; then
+  # timelines of the forward and of the train step (overlap / idle analysis), the adversarial warp map, the other configs
+  bash tools/prof_fwd.sh > gpurun_out/fwd_timeline.log 2>&1; head -4 gpurun_out/fwd_timeline.txt
+  LOSS=l2 bash tools/prof_train.sh > gpurun_out/train_timeline.log 2>&1; head -4 gpurun_out/train_timeline_l2.txt
+  timeout 300 python bench.py --steps 50 --warmup 5 --headline-only --warp random --tune-cache gpurun_out/tune_fused.json > gpurun_out/bench_warp_random.json 2>/dev/null; cut -c1-260 gpurun_out/bench_warp_random.json
+  (timeout 300 python tools/bench_cfg.py 1024 256 4 1 256; timeout 300 python tools/bench_cfg.py 256 512 4 1 512) > gpurun_out/other_configs.txt 2>&1; grep "ms / step" gpurun_out/other_configs.txt
+  timeout 300 python tools/bench_bwd.py > gpurun_out/bench_bwd.txt 2>&1; tail -3 gpurun_out/bench_bwd.txt
+fi
 du -sh gpurun_out
