@@ -143,6 +143,117 @@ __global__ __launch_bounds__(256) void grad_finish_kernel(const float* __restric
     dpred[p * 3 + ic] = -(g0 * kSYUV[ic * 3 + 0] + g1 * kSYUV[ic * 3 + 1] + g2 * kSYUV[ic * 3 + 2]);
 }
 
+// ---- fewer, fatter launches (the loss is ~20 tiny passes: launch count, not bytes, is its cost) -------------------------
+// Second (column) analysis pass of a level for BOTH row sets in one launch, with the Charbonnier term of every band that
+// is final fused in: blockIdx.z = 0: rows of `lo` -> (LL, LH), 1: rows of `hi` -> (HL, HH); blockIdx.y = frame.
+// LH / HL / HH are final at every level, LL only at the last one (`ll_final`).  Same sums, same order as dwt_axis_kernel +
+// charbonnier_kernel (the per-frame loss is accumulated with float atomics there as well).
+__global__ __launch_bounds__(256) void dwt_cols_charb_kernel(const float* __restrict__ lo_rows, const float* __restrict__ hi_rows,
+                                                             int hl, int hh, int w, float* LL, float* LH, float* HL, float* HH,
+                                                             int ll_final, float inv_total, int want_grad, float* loss) {
+  __shared__ float red[4];
+  const int z = blockIdx.z, f = blockIdx.y;
+  const int A = z == 0 ? hl : hh;
+  const float* src = z == 0 ? lo_rows : hi_rows;
+  float* out_lo = z == 0 ? LL : HL;
+  float* out_hi = z == 0 ? LH : HH;
+  const int wl = n_lo(w), wh = n_hi(w);
+  const long per_frame = 3l * A * wl;
+  float s = 0.f;
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx < per_frame) {
+    const int b = idx % wl;
+    const int a = (idx / wl) % A;
+    const long pl = (long)f * 3 + idx / ((long)A * wl);
+    const float* x = src + pl * (long)A * w + (long)a * w;
+    float sl = 0.f;
+#pragma unroll
+    for (int t = 0; t < 9; ++t) sl += kLO[t] * x[reflect(2 * b + t - 4, w)];
+    if (z == 1 || ll_final) {
+      const float u = sl / kScale;
+      const float r = sqrtf(u * u + 1.f);
+      s += r - 1.f;
+      if (want_grad) sl = (u / kScale) / r * inv_total;
+    }
+    out_lo[pl * (long)A * wl + (long)a * wl + b] = sl;
+    if (b < wh) {
+      float sh = 0.f;
+#pragma unroll
+      for (int t = 0; t < 7; ++t) sh += kHI[t] * x[reflect(2 * b + 1 + t - 3, w)];
+      const float u = sh / kScale;
+      const float r = sqrtf(u * u + 1.f);
+      s += r - 1.f;
+      if (want_grad) sh = (u / kScale) / r * inv_total;
+      out_hi[pl * (long)A * wh + (long)a * wh + b] = sh;
+    }
+  }
+  s = wave_sum(s);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) atomicAdd(loss + f, (red[0] + red[1] + red[2] + red[3]) * inv_total);
+}
+
+// Adjoint of one analysis pass in GATHER form: one thread per element of the pass's INPUT adds the (tap, coefficient) pairs
+// that touched it -- no zero-fill, no atomics, deterministic.  With n >= 6 every tap position lies in [-4, n + 3] and is
+// reflected at most once, so element i collects the virtual positions {i, -i, 2(n-1) - i}.
+__device__ __forceinline__ float dwt_T_gather(const float* __restrict__ glo, const float* __restrict__ ghi, long lo_stride,
+                                              long hi_stride, int i, int n) {
+  const int nl = n_lo(n), nh = n_hi(n);
+  float s = 0.f;
+#pragma unroll
+  for (int v = 0; v < 3; ++v) {
+    if ((v == 1 && i == 0) || (v == 2 && i == n - 1)) continue;
+    const int p = v == 0 ? i : (v == 1 ? -i : 2 * (n - 1) - i);
+    if (p < -4 || p > n + 3) continue;
+    // lo: position 2 j + t - 4 = p, t in [0, 8]
+    int j0 = (p - 4 + 1) >> 1, j1 = (p + 4) >> 1;                 // ceil((p - 4) / 2), floor((p + 4) / 2)  (arithmetic shifts)
+    if (j0 < 0) j0 = 0;
+    if (j1 > nl - 1) j1 = nl - 1;
+    for (int j = j0; j <= j1; ++j) s += kLO[p - 2 * j + 4] * glo[(long)j * lo_stride];
+    // hi: position 2 j + 1 + t - 3 = p, t in [0, 6]
+    j0 = (p - 4 + 1) >> 1; j1 = (p + 2) >> 1;
+    if (j0 < 0) j0 = 0;
+    if (j1 > nh - 1) j1 = nh - 1;
+    for (int j = j0; j <= j1; ++j) s += kHI[p - 2 * j + 2] * ghi[(long)j * hi_stride];
+  }
+  return s;
+}
+
+// columns: (LL, LH) -> lo rows and (HL, HH) -> hi rows in one launch (blockIdx.z as above)
+__global__ __launch_bounds__(256) void dwt_cols_T_kernel(const float* __restrict__ LL, const float* __restrict__ LH,
+                                                         const float* __restrict__ HL, const float* __restrict__ HH,
+                                                         int hl, int hh, int w, long planes, float* lo_rows, float* hi_rows) {
+  const int z = blockIdx.z;
+  const int A = z == 0 ? hl : hh;
+  const long total = planes * A * w;
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= total) return;
+  const int wl = n_lo(w), wh = n_hi(w);
+  const int b = idx % w;
+  const long row = idx / w;                                          // plane * A + a
+  const float* glo = (z == 0 ? LL : HL) + row * wl;
+  const float* ghi = (z == 0 ? LH : HH) + row * wh;
+  (z == 0 ? lo_rows : hi_rows)[idx] = dwt_T_gather(glo, ghi, 1, 1, b, w);
+}
+
+// rows: (lo, hi) -> the level's input image
+__global__ __launch_bounds__(256) void dwt_rows_T_kernel(const float* __restrict__ lo_rows, const float* __restrict__ hi_rows,
+                                                         int h, int w, long planes, float* din) {
+  const long total = planes * h * w;
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= total) return;
+  const int hl = n_lo(h), hh = n_hi(h);
+  const int b = idx % w;
+  const int a = (idx / w) % h;
+  const long pl = idx / ((long)h * w);
+  din[idx] = dwt_T_gather(lo_rows + pl * (long)hl * w + b, hi_rows + pl * (long)hh * w + b, w, w, a, h);
+}
+
+__global__ void init_loss_kernel(float* loss, int n, float c) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) loss[i] = c;
+}
+
 struct Level { int h, w, hl, hh, wl, wh; long lo, hi, HH, LH, HL, LL; };
 
 constexpr int kLevels = 5;                      // nlt/losses.py:103
@@ -186,7 +297,8 @@ extern "C" int nlt_barron_loss(const float* pred, const float* gt, int n, int h,
   const long P = (long)n * 3;
   const int want_grad = dpred_unit != nullptr;
   const float inv_total = 1.f / ((float)h * (float)w * 3.f);
-  if (hipMemsetAsync(loss, 0, (size_t)n * sizeof(float), s) != hipSuccess) return NLT_ERR_LAUNCH;
+  // the NLL's constant first (every later pass adds its Charbonnier sums to it): no zero-fill + add-constant pair
+  hipLaunchKernelGGL(init_loss_kernel, dim3((n + 63) / 64), dim3(64), 0, s, loss, n, (float)(log((double)kScale) + kLogZ1));
   {
     const long total = (long)n * h * w;
     hipLaunchKernelGGL(residual_syuv_kernel, dim3(blocks_for(total)), dim3(256), 0, s, pred, gt, h * w, total, ws + x0);
@@ -200,21 +312,22 @@ extern "C" int nlt_barron_loss(const float* pred, const float* gt, int n, int h,
   long xin = x0;
   for (int l = 0; l < kLevels; ++l) {
     const Level& L = lv[l];
+    const bool last = l == kLevels - 1;
     hipLaunchKernelGGL(dwt_axis_kernel, dim3(blocks_for(P * L.hl * L.w)), dim3(256), 0, s, ws + xin, L.h, L.w, 0,
                        P * L.hl * L.w, ws + L.lo, ws + L.hi);
-    // rows of `hi` -> (HL = lo-filter, HH = hi-filter); rows of `lo` -> (LL, LH)
-    if (L.hh > 0)
-      hipLaunchKernelGGL(dwt_axis_kernel, dim3(blocks_for(P * L.hh * L.wl)), dim3(256), 0, s, ws + L.hi, L.hh, L.w, 1,
-                         P * L.hh * L.wl, ws + L.HL, ws + L.HH);
-    hipLaunchKernelGGL(dwt_axis_kernel, dim3(blocks_for(P * L.hl * L.wl)), dim3(256), 0, s, ws + L.lo, L.hl, L.w, 1,
-                       P * L.hl * L.wl, ws + L.LL, ws + L.LH);
-    if ((long)L.hh * L.wh > 0) charb(L.HH, (long)L.hh * L.wh);
-    if ((long)L.hl * L.wh > 0) charb(L.LH, (long)L.hl * L.wh);
-    if ((long)L.hh * L.wl > 0) charb(L.HL, (long)L.hh * L.wl);
+    if (L.hh > 0) {
+      // rows of `lo` -> (LL, LH), rows of `hi` -> (HL, HH), Charbonnier of the final bands: one launch
+      const long per_frame = 3l * L.hl * L.wl;                         // hl >= hh: the z = 1 half exits early
+      hipLaunchKernelGGL(dwt_cols_charb_kernel, dim3(blocks_for(per_frame), (unsigned)n, 2), dim3(256), 0, s, ws + L.lo, ws + L.hi,
+                         L.hl, L.hh, L.w, ws + L.LL, ws + L.LH, ws + L.HL, ws + L.HH, last ? 1 : 0, inv_total, want_grad, loss);
+    } else {
+      hipLaunchKernelGGL(dwt_axis_kernel, dim3(blocks_for(P * L.hl * L.wl)), dim3(256), 0, s, ws + L.lo, L.hl, L.w, 1,
+                         P * L.hl * L.wl, ws + L.LL, ws + L.LH);
+      if ((long)L.hl * L.wh > 0) charb(L.LH, (long)L.hl * L.wh);
+      if (last) charb(L.LL, (long)L.hl * L.wl);
+    }
     xin = L.LL;
   }
-  charb(lv[kLevels - 1].LL, (long)lv[kLevels - 1].hl * lv[kLevels - 1].wl);
-  hipLaunchKernelGGL(add_const_kernel, dim3((n + 63) / 64), dim3(64), 0, s, loss, n, (float)(log((double)kScale) + kLogZ1));
   NLT_CHECK_LAUNCH();
   if (!want_grad) return NLT_OK;
 
@@ -222,16 +335,26 @@ extern "C" int nlt_barron_loss(const float* pred, const float* gt, int n, int h,
   for (int l = kLevels - 1; l >= 0; --l) {
     const Level& L = lv[l];
     const long dst = l == 0 ? x0 : lv[l - 1].LL;          // gradient w.r.t. this level's input image
-    if (hipMemsetAsync(ws + L.lo, 0, (size_t)P * L.hl * L.w * sizeof(float), s) != hipSuccess) return NLT_ERR_LAUNCH;
-    if (hipMemsetAsync(ws + L.hi, 0, (size_t)P * L.hh * L.w * sizeof(float), s) != hipSuccess) return NLT_ERR_LAUNCH;
-    hipLaunchKernelGGL(dwt_axis_T_kernel, dim3(blocks_for(P * L.hl * L.wl)), dim3(256), 0, s, ws + L.LL, ws + L.LH,
-                       L.hl, L.w, 1, P * L.hl * L.wl, ws + L.lo);
-    if (L.hh > 0)
-      hipLaunchKernelGGL(dwt_axis_T_kernel, dim3(blocks_for(P * L.hh * L.wl)), dim3(256), 0, s, ws + L.HL, ws + L.HH,
-                         L.hh, L.w, 1, P * L.hh * L.wl, ws + L.hi);
-    if (hipMemsetAsync(ws + dst, 0, (size_t)P * L.h * L.w * sizeof(float), s) != hipSuccess) return NLT_ERR_LAUNCH;
-    hipLaunchKernelGGL(dwt_axis_T_kernel, dim3(blocks_for(P * L.hl * L.w)), dim3(256), 0, s, ws + L.lo, ws + L.hi,
-                       L.h, L.w, 0, P * L.hl * L.w, ws + dst);
+    if (L.w >= 6 && L.hh > 0) {
+      hipLaunchKernelGGL(dwt_cols_T_kernel, dim3(blocks_for(P * L.hl * L.w), 1, 2), dim3(256), 0, s, ws + L.LL, ws + L.LH,
+                         ws + L.HL, ws + L.HH, L.hl, L.hh, L.w, P, ws + L.lo, ws + L.hi);
+    } else {
+      if (hipMemsetAsync(ws + L.lo, 0, (size_t)P * L.hl * L.w * sizeof(float), s) != hipSuccess) return NLT_ERR_LAUNCH;
+      if (hipMemsetAsync(ws + L.hi, 0, (size_t)P * L.hh * L.w * sizeof(float), s) != hipSuccess) return NLT_ERR_LAUNCH;
+      hipLaunchKernelGGL(dwt_axis_T_kernel, dim3(blocks_for(P * L.hl * L.wl)), dim3(256), 0, s, ws + L.LL, ws + L.LH,
+                         L.hl, L.w, 1, P * L.hl * L.wl, ws + L.lo);
+      if (L.hh > 0)
+        hipLaunchKernelGGL(dwt_axis_T_kernel, dim3(blocks_for(P * L.hh * L.wl)), dim3(256), 0, s, ws + L.HL, ws + L.HH,
+                           L.hh, L.w, 1, P * L.hh * L.wl, ws + L.hi);
+    }
+    if (L.h >= 6) {
+      hipLaunchKernelGGL(dwt_rows_T_kernel, dim3(blocks_for(P * L.h * L.w)), dim3(256), 0, s, ws + L.lo, ws + L.hi, L.h, L.w, P,
+                         ws + dst);
+    } else {
+      if (hipMemsetAsync(ws + dst, 0, (size_t)P * L.h * L.w * sizeof(float), s) != hipSuccess) return NLT_ERR_LAUNCH;
+      hipLaunchKernelGGL(dwt_axis_T_kernel, dim3(blocks_for(P * L.hl * L.w)), dim3(256), 0, s, ws + L.lo, ws + L.hi,
+                         L.h, L.w, 0, P * L.hl * L.w, ws + dst);
+    }
   }
   {
     const long total = (long)n * h * w;
