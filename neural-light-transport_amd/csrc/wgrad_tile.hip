@@ -30,17 +30,37 @@ struct WT {
   const float* zeros;  // 16 zero bytes in device memory (the walk kernel's operand source past the end of a run)
   int kq, nq;         // k-quads (taps * (c0 + c1) / 4), n-quads (N / 4)
   int kblocks, nblocks, msplits, rows_per_split;
+  int xcd_order;      // slice ms pinned to XCD ms % 8, its tiles consecutive there (wgrad_block)
 };
+
+// Workgroup -> (row slice, k-block, n-block).  Every tile of dW re-reads the slice's X rows (once per n-block and tap) and dP
+// rows (once per k-block): 134 MB of L2 misses for 17 MB of operands at level 4 when those workgroups are dealt round-robin
+// over the 8 XCDs (measured: FETCH_SIZE, TCC_MISS; that traffic, not the matrix pipe, was the kernel's time).  Workgroup ids go
+// to XCDs modulo 8, so slice ms is pinned to XCD ms % 8 and its tiles are consecutive there: the slice is fetched into ONE L2 once.
+__device__ __forceinline__ bool wgrad_block(const WT& w, int& ms, int& kb, int& nb) {
+  const int tiles = w.kblocks * w.nblocks;
+  if (!w.xcd_order) {                                                // few slices (deep levels): slices fastest, every XCD busy
+    int blk = blockIdx.x;
+    ms = blk % w.msplits; blk /= w.msplits;
+    nb = blk % w.nblocks;
+    kb = blk / w.nblocks;
+    return true;
+  }
+  const int xcd = blockIdx.x & 7, r = blockIdx.x >> 3;
+  const int tile = r % tiles;
+  ms = (r / tiles) * 8 + xcd;
+  nb = tile % w.nblocks;
+  kb = tile / w.nblocks;
+  return ms < w.msplits;
+}
 
 template <int MODE>
 __global__ __launch_bounds__(256) void wgrad_tile_kernel(WT w) {
   __shared__ __attribute__((aligned(16))) f32x4 part[3][17][64];      // waves 1..3 -> wave 0 (16 blocks + bias sums)
   const ConvP& p = w.c;
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  int blk = blockIdx.x;                                              // one workgroup = one (row slice, kb, nb)
-  const int ms = blk % w.msplits; blk /= w.msplits;
-  const int nb = blk % w.nblocks;
-  const int kb = blk / w.nblocks;
+  int ms, kb, nb;                                                    // one workgroup = one (row slice, kb, nb)
+  if (!wgrad_block(w, ms, kb, nb)) return;
   const int i = lane & 15, kk = lane >> 4;
   const int q0 = p.c0 >> 2, qpt = (p.c0 + p.c1) >> 2;
 
@@ -168,10 +188,8 @@ __global__ __launch_bounds__(256) void wgrad_walk_kernel(WT w) {
   const ConvP& p = w.c;
   const int lane = threadIdx.x & 63;
   const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  int blk = blockIdx.x;
-  const int ms = blk % w.msplits; blk /= w.msplits;
-  const int nb = blk % w.nblocks;
-  const int kb = blk / w.nblocks;
+  int ms, kb, nb;                                                    // one workgroup = one (row slice, kb, nb)
+  if (!wgrad_block(w, ms, kb, nb)) return;
   const int i = lane & 15, kk = lane >> 4;
   const int q0 = p.c0 >> 2, qpt = (p.c0 + p.c1) >> 2;
 
@@ -400,14 +418,20 @@ bool fill(WT& w, int mode, long* ws_floats) {
   const long unit = walk ? 16 * WALK_PF : 16;                 // the walk kernel's runs: whole pipeline rounds
   rows = (rows + unit - 1) / unit * unit;
   w.msplits = (int)((p.M + rows - 1) / rows);
+  if (w.msplits >= 8 && w.msplits % 8) {                      // whole XCD rounds if a slightly shorter slice gives them
+    const long target = (w.msplits + 7) / 8 * 8;
+    const long r2 = ((p.M + target - 1) / target + unit - 1) / unit * unit;
+    if (r2 >= 16 * unit / 16 && (p.M + r2 - 1) / r2 == target) { rows = r2; w.msplits = (int)target; }
+  }
   w.rows_per_split = (int)rows;
+  w.xcd_order = w.msplits >= 8 && (w.msplits % 8 == 0 || w.msplits >= 24);
   *ws_floats = (long)w.msplits * w.kblocks * w.nblocks * 4096 + (long)w.msplits * w.nblocks * 64;
   return true;
 }
 
 template <int MODE>
 int run(WT& w, hipStream_t s) {
-  const long groups = (long)w.kblocks * w.nblocks * w.msplits;
+  const long groups = (long)w.kblocks * w.nblocks * (w.xcd_order ? (w.msplits + 7) / 8 * 8 : w.msplits);   // (whole XCD rounds)
   w.zeros = (w.c.gw % 4 == 0 && !nlt_wgrad_generic_only()) ? nlt_zero_page() : nullptr;
   if (w.zeros)
     hipLaunchKernelGGL(wgrad_walk_kernel<MODE>, dim3((unsigned)groups), dim3(256), 0, s, w);

@@ -13,6 +13,7 @@ from nlt_amd import capi as C                                    # noqa: E402
 
 ap = argparse.ArgumentParser()
 ap.add_argument('--only', default=None)
+ap.add_argument('--label', default=None, help='only the ops whose label contains this (PMC passes)')
 ap.add_argument('--uv', type=int, default=1024)
 ap.add_argument('--frames', type=int, default=4)
 ap.add_argument('--reps', type=int, default=50)
@@ -52,6 +53,8 @@ ADJ = {C.CONV_K2S2: C.DECONV_K2S2, C.CONV_K2S1: C.DECONV_K2S1, C.DECONV_K2S2: C.
 
 print('%-10s %5s %5s %5s  %9s %8s   %s' % ('op', 'cin', 'cout', 'h_in', 'GFLOP', 'us', 'TF/s'))
 for label, mode, cin, cout, h in ops:
+    if args.label and args.label not in label:
+        continue
     tr = mode in (C.DECONV_K2S2, C.DECONV_K2S1)
     oh = h // 2 if mode == C.CONV_K2S2 else (2 * h if mode == C.DECONV_K2S2 else h)
     taps = 1 if mode == C.DECONV_K2S2 else 4
