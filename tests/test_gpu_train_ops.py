@@ -175,6 +175,25 @@ def test_lrelu_and_obs_mean_backward():
         np.testing.assert_allclose(pd.cpu().numpy(), ref, atol=1e-6)
 
 
+@pytest.mark.parametrize('k,use_w,use_p', [(1, False, True), (3, True, True), (4, False, False)])
+def test_level_split_backward_equals_the_two_launches(k, use_w, use_p):
+    """nlt_level_split_backward = nlt_lrelu_backward on the query half + nlt_obs_mean_backward on the observation half,
+    bit for bit (same operations per element), in one launch."""
+    rng = np.random.default_rng(k)
+    n, hw, c = 2, 77, 32
+    dfm = rng.standard_normal((n, hw, 2 * c)).astype(np.float32)
+    fm_y = rng.standard_normal((n, hw, 2 * c)).astype(np.float32)
+    obs_y = rng.standard_normal((n, k, hw, c)).astype(np.float32)
+    part = rng.standard_normal((n, k, hw, c)).astype(np.float32)
+    ow = rng.random((n, k), dtype=np.float32)
+    g2, out2 = d(dfm), d(part)
+    C.obs_mean_backward(g2.view(-1)[c:], 2 * c, d(obs_y), d(ow) if use_w else None, out2 if use_p else None, n, k, hw, c, 0.2, out2)
+    C.lrelu_backward(g2, 2 * c, d(fm_y), 2 * c, c, n * hw, 0.3, g2, 2 * c)
+    g1, out1 = d(dfm), d(part)
+    C.level_split_backward(g1, d(fm_y), 2 * c, d(obs_y), d(ow) if use_w else None, out1 if use_p else None, n, k, hw, c, 0.3, 0.2, out1)
+    assert torch.equal(g1, g2) and torch.equal(out1, out2)
+
+
 @pytest.mark.parametrize('k,weights,partial', [(1, False, True), (3, True, True), (2, False, False)])
 def test_stem_backward(k, weights, partial):
     rng = np.random.default_rng(k)
