@@ -56,13 +56,36 @@ def main():
     lines.append('%-70s %8s %10s %9s' % ('kernel', 'calls', 'us/step', 'avg us'))
     for name, (c, t) in sorted(per_kernel.items(), key=lambda kv: -kv[1][1]):
         lines.append('%-70s %8.1f %10.1f %9.1f' % (name[:70], c / n, t / n, t / c))
+    # per hardware queue (= stream) of the LAST analysed step: busy time, first start / last end relative to the step start
+    s = len(ends) - 1
+    ks = rows[ends[s - 1] + 1:ends[s] + 1]
+    t0 = rows[ends[s - 1]][1]
+    per_q = defaultdict(lambda: [0.0, None, 0.0, 0])
+    for st, en, name, q in ks:
+        r = per_q[q]
+        r[0] += (en - st) / 1e3
+        r[1] = (st - t0) / 1e3 if r[1] is None else r[1]
+        r[2] = (en - t0) / 1e3
+        r[3] += 1
+    lines.append('')
+    lines.append('streams of the last step: queue, kernels, sum of durations us, first start us, last end us')
+    for q, r in sorted(per_q.items(), key=lambda kv: -kv[1][0]):
+        lines.append('  queue %-6s %5d %10.1f %10.1f %10.1f' % (q, r[3], r[0], r[1], r[2]))
+    lines.append('')
+    lines.append('kernels of the last step longer than 40 us: start us, duration us, queue, name')
+    for st, en, name, q in ks:
+        if en - st > 40000:
+            lines.append('  %8.1f %7.1f  q%-4s %s' % ((st - t0) / 1e3, (en - st) / 1e3, q,
+                                                   name.replace('void ', '').replace('(anonymous namespace)::', '').split('(')[0][:60]))
     lines.append('')
     lines.append('idle gaps (no kernel on any stream), by the kernel that ends the gap')
     for name, (c, t) in sorted(gap_after.items(), key=lambda kv: -kv[1][1])[:25]:
         lines.append('%-70s %8.1f %10.1f %9.1f' % (name[:70], c / n, t / n, t / c))
     with open(out, 'w') as f:
         f.write('\n'.join(lines) + '\n')
-    print('\n'.join(lines[:90]))
+    print('\n'.join(lines[:8]))
+    i = lines.index('streams of the last step: queue, kernels, sum of durations us, first start us, last end us')
+    print('\n'.join(lines[i:i + 70]))
 
 
 if __name__ == '__main__':
