@@ -34,6 +34,7 @@ __global__ __launch_bounds__(256) void back_bwd_kernel(
     float* __restrict__ dx, float* __restrict__ dfm1, float* __restrict__ ws) {
   __shared__ __attribute__((aligned(16))) float dvp[(BFH + 1) * (BFW + 1) * 4];
   __shared__ __attribute__((aligned(16))) float dup[BFH * BFW * 4];
+  __shared__ __attribute__((aligned(16))) float utile[(BFH + 1) * (BFW + 1) * 4];   // u with its top / left halo: u(Y0 - 1 + ly, X0 - 1 + lx)
   __shared__ float red[4][BB_TOT];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int kk = lane >> 4, j = lane & 15;
@@ -51,9 +52,8 @@ __global__ __launch_bounds__(256) void back_bwd_kernel(
 #pragma unroll
   for (int e = 0; e < 12; ++e) wh[e] = w_head[e];
 
-  float acc1[64], acch[12], accbh[3], accb1[4], accb2[4];
-#pragma unroll
-  for (int e = 0; e < 64; ++e) acc1[e] = 0.f;
+  float acch[12], accbh[3], accb1[4], accb2[4];
+  f32x4 acc1m = (f32x4){0.f, 0.f, 0.f, 0.f};                            // dW_s1 on the matrix pipe: rows (tap, c), columns o
 #pragma unroll
   for (int e = 0; e < 12; ++e) acch[e] = 0.f;
 #pragma unroll
@@ -67,18 +67,65 @@ __global__ __launch_bounds__(256) void back_bwd_kernel(
     const int ty0 = (int)(tr % tiles_y) * BTH, f = (int)(tr / tiles_y);
     const int Y0 = 2 * ty0, X0 = 2 * tx0;
 
+    // ---- every global load of the tile is issued HERE, before the first barrier: the three phases used to fetch their own
+    // operands one after the other, and with two workgroups per CU the kernel spent 74 % of its wave-cycles waiting for
+    // memory (PMC: SQ_WAIT_ANY) at 2 TB/s.  (v, dpred) -> phase 1; the u tile with its top / left halo -> LDS -> phase 2 and
+    // the dW_s1 MFMAs; x | fm1 -> phase 3.
+    f32x4 pv[3], pu[3];
+    float pg[3][3];
+    bool in_v[3], in_u[3];
+#pragma unroll
+    for (int it = 0; it < 3; ++it) {
+      const int e = threadIdx.x + 256 * it;
+      const int ec = e < (BFH + 1) * (BFW + 1) ? e : 0;
+      const int ly = ec / (BFW + 1), lx = ec - ly * (BFW + 1);
+      const int y = Y0 + ly, xg = X0 + lx;
+      in_v[it] = e < (BFH + 1) * (BFW + 1) && y < h && xg < w;
+      const long tex = in_v[it] ? ((long)f * h + y) * w + xg : 0;
+      pv[it] = *reinterpret_cast<const f32x4*>(v + tex * 4);
+      pg[it][0] = dpred[tex * 3]; pg[it][1] = dpred[tex * 3 + 1]; pg[it][2] = dpred[tex * 3 + 2];
+      const int yu = y - 1, xu = xg - 1;
+      in_u[it] = e < (BFH + 1) * (BFW + 1) && yu >= 0 && xu >= 0 && yu < h && xu < w;
+      const long texu = in_u[it] ? ((long)f * h + yu) * w + xu : 0;
+      pu[it] = *reinterpret_cast<const f32x4*>(u + texu * 4);
+    }
+    float pb[8][3];                                                    // phase 3a's B operands (x | fm1 channels 16 mt + j of texel (gi, kk))
+    const int na = j >> 3, nb = (j >> 2) & 1, no = j & 3;
+#pragma unroll
+    for (int g8 = 0; g8 < 8; ++g8) {
+      const int gi = wave + 4 * g8;
+      const int ii = gi >> 2, jj = (gi & 3) * 4 + kk;
+      const int gy = ty0 + ii, gx = tx0 + jj;
+      const bool inside = gy < h2 && gx < w2;
+      const long tex2 = inside ? ((long)f * h2 + gy) * w2 + gx : 0;
+#pragma unroll
+      for (int mt = 0; mt < 3; ++mt) {
+        const int c = 16 * mt + j;
+        const float vx = x[tex2 * 8 + (c < 8 ? c : 0)];
+        const float vf = fm1[tex2 * 32 + ((c >= 8 && c < 40) ? c - 8 : 0)];
+        pb[g8][mt] = !inside ? 0.f : (c < 8 ? vx : (c < 40 ? vf : 0.f));
+      }
+    }
+    f32x4 pxv[2];                                                      // phase 3b: x at channels 4 kk (kk < 2) of texel (ty0 + wave + 4 r, tx0 + j)
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+      const int gy = ty0 + wave + 4 * r, gx = tx0 + j;
+      const bool inside = gy < h2 && gx < w2 && kk < 2;
+      const long tex2 = inside ? ((long)f * h2 + gy) * w2 + gx : 0;
+      pxv[r] = *reinterpret_cast<const f32x4*>(x + tex2 * 8 + (kk < 2 ? 4 * kk : 0));
+    }
+
     // ---- phase 1
 #pragma unroll
-    for (int it = 0; it < 3; ++it) {                                   // 17 * 33 = 561 texels, all loads of the 3 trips in flight together
+    for (int it = 0; it < 3; ++it) {
       const int e = threadIdx.x + 256 * it;
       if (e >= (BFH + 1) * (BFW + 1)) break;
       const int ly = e / (BFW + 1), lx = e - ly * (BFW + 1);
       const int y = Y0 + ly, xg = X0 + lx;
       f32x4 d = (f32x4){0.f, 0.f, 0.f, 0.f};
-      if (y < h && xg < w) {
-        const long tex = ((long)f * h + y) * w + xg;
-        const f32x4 vv = *reinterpret_cast<const f32x4*>(v + tex * 4);
-        float g[3] = {dpred[tex * 3], dpred[tex * 3 + 1], dpred[tex * 3 + 2]};
+      if (in_v[it]) {
+        const f32x4 vv = pv[it];
+        float g[3] = {pg[it][0], pg[it][1], pg[it][2]};
         if ((y | xg) == 0) { g[0] = 0.f; g[1] = 0.f; g[2] = 0.f; }   // set_left_top_corner
 #pragma unroll
         for (int o = 0; o < 4; ++o) {
@@ -96,6 +143,7 @@ __global__ __launch_bounds__(256) void back_bwd_kernel(
         }
       }
       *reinterpret_cast<f32x4*>(dvp + e * 4) = d;
+      *reinterpret_cast<f32x4*>(utile + e * 4) = in_u[it] ? pu[it] : (f32x4){0.f, 0.f, 0.f, 0.f};
     }
     __syncthreads();
 
@@ -107,13 +155,8 @@ __global__ __launch_bounds__(256) void back_bwd_kernel(
       const int y = Y0 + ly, xg = X0 + lx;
       f32x4 dp = (f32x4){0.f, 0.f, 0.f, 0.f};
       if (y < h && xg < w) {
-        const long tex = ((long)f * h + y) * w + xg;
         const f32x4 zero = (f32x4){0.f, 0.f, 0.f, 0.f};
-        f32x4 ut[4];                                                   // u at (y - a, x - b), zero above / left of the image
-        ut[0] = *reinterpret_cast<const f32x4*>(u + tex * 4);
-        ut[1] = xg > 0 ? *reinterpret_cast<const f32x4*>(u + (tex - 1) * 4) : zero;
-        ut[2] = y > 0 ? *reinterpret_cast<const f32x4*>(u + (tex - w) * 4) : zero;
-        ut[3] = (y > 0 && xg > 0) ? *reinterpret_cast<const f32x4*>(u + (tex - w - 1) * 4) : zero;
+        const f32x4 u0 = *reinterpret_cast<const f32x4*>(utile + ((ly + 1) * (BFW + 1) + lx + 1) * 4);
         f32x4 du = zero;
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
@@ -123,45 +166,37 @@ __global__ __launch_bounds__(256) void back_bwd_kernel(
 #pragma unroll
             for (int c = 0; c < 4; ++c) du[c] = fmaf(w_s1[(t * 4 + o) * 4 + c], dv[o], du[c]);
         }
-        const f32x4 dv0 = *reinterpret_cast<const f32x4*>(dvp + (ly * (BFW + 1) + lx) * 4);
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
-          dp[c] = ut[0][c] > 0.f ? du[c] : alpha * du[c];
+          dp[c] = u0[c] > 0.f ? du[c] : alpha * du[c];
           accb2[c] += dp[c];
         }
-#pragma unroll
-        for (int t = 0; t < 4; ++t)
-#pragma unroll
-          for (int o = 0; o < 4; ++o)
-#pragma unroll
-            for (int c = 0; c < 4; ++c) acc1[(t * 4 + o) * 4 + c] = fmaf(ut[t][c], dv0[o], acc1[(t * 4 + o) * 4 + c]);
       }
       *reinterpret_cast<f32x4*>(dup + e * 4) = dp;
+    }
+    // dW_s1[t][o][c] += sum_texels u(y - a, x - b)[c] dv(y, x)[o]: rows (t, c) = lane & 15, columns o = lane & 15 (< 4), K = 4
+    // texels per MFMA; the wave takes a quarter of the tile (dv is zero outside the image, so clipped tiles need no mask)
+    {
+      const int ta = (j >> 3) & 1, tb = (j >> 2) & 1, cc = j & 3;
+#pragma unroll 4
+      for (int m = 0; m < 32; ++m) {
+        const int k = wave * 128 + 4 * m + kk;
+        const int ly = k >> 5, lx = k & 31;
+        const float av = utile[((ly + 1 - ta) * (BFW + 1) + lx + 1 - tb) * 4 + cc];
+        const float bv = j < 4 ? dvp[(ly * (BFW + 1) + lx) * 4 + j] : 0.f;
+        acc1m = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, acc1m, 0, 0, 0);
+      }
     }
     __syncthreads();
 
     // ---- phase 3a: dW_s2^T, rows n = (a, b, o), columns c, K = half-resolution texels
-    {
-      const int na = j >> 3, nb = (j >> 2) & 1, no = j & 3;
 #pragma unroll
-      for (int g8 = 0; g8 < 8; ++g8) {                                 // unrolled: the 24 operand loads of a tile are issued together
-        const int gi = wave + 4 * g8;
-        const int ii = gi >> 2, jj = (gi & 3) * 4 + kk;
-        const int gy = ty0 + ii, gx = tx0 + jj;
-        const bool inside = gy < h2 && gx < w2;
-        const float av = dup[((2 * ii + na) * BFW + 2 * jj + nb) * 4 + no];
-        const long tex2 = ((long)f * h2 + gy) * w2 + gx;
+    for (int g8 = 0; g8 < 8; ++g8) {
+      const int gi = wave + 4 * g8;
+      const int ii = gi >> 2, jj = (gi & 3) * 4 + kk;
+      const float av = dup[((2 * ii + na) * BFW + 2 * jj + nb) * 4 + no];
 #pragma unroll
-        for (int mt = 0; mt < 3; ++mt) {
-          const int c = 16 * mt + j;
-          float bv = 0.f;
-          if (inside) {
-            if (c < 8) bv = x[tex2 * 8 + c];
-            else if (c < 40) bv = fm1[tex2 * 32 + c - 8];
-          }
-          accw2[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, accw2[mt], 0, 0, 0);
-        }
-      }
+      for (int mt = 0; mt < 3; ++mt) accw2[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, pb[g8][mt], accw2[mt], 0, 0, 0);
     }
     // ---- phase 3b: d_in = W_s2^T du, 16 texels (one tile row) per MFMA column block
     for (int ii = wave; ii < BTH; ii += 4) {
@@ -177,7 +212,7 @@ __global__ __launch_bounds__(256) void back_bwd_kernel(
         const int c0 = 16 * mt + 4 * kk;
         if (inside) {
           if (c0 < 8) {                                                // x is the previous block's LeakyReLU output: hand back the
-            const f32x4 xv = *reinterpret_cast<const f32x4*>(x + tex2 * 8 + c0);   // gradient w.r.t. its PRE-activation
+            const f32x4 xv = pxv[(ii - wave) >> 2];                       // gradient w.r.t. its PRE-activation
 #pragma unroll
             for (int e = 0; e < 4; ++e) acc[e] = xv[e] > 0.f ? acc[e] : alpha * acc[e];
             *reinterpret_cast<f32x4*>(dx + tex2 * 8 + c0) = acc;
@@ -197,8 +232,13 @@ __global__ __launch_bounds__(256) void back_bwd_kernel(
 #pragma unroll
     for (int rr = 0; rr < 4; ++rr)
       if (16 * mt + j < 40) r[BB_DW2 + (4 * kk + rr) * 40 + 16 * mt + j] = accw2[mt][rr];
+  if (j < 4) {                                                         // D rows 4 kk + rr = (t, c), column j = o  ->  [(t * 4 + o) * 4 + c]
 #pragma unroll
-  for (int e = 0; e < 64; ++e) { const float s = wave_sum(acc1[e]); if (lane == 0) r[BB_DW1 + e] = s; }
+    for (int rr = 0; rr < 4; ++rr) {
+      const int i = 4 * kk + rr;
+      r[BB_DW1 + ((i >> 2) * 4 + j) * 4 + (i & 3)] = acc1m[rr];
+    }
+  }
 #pragma unroll
   for (int e = 0; e < 12; ++e) { const float s = wave_sum(acch[e]); if (lane == 0) r[BB_DWH + e] = s; }
 #pragma unroll
