@@ -28,6 +28,7 @@ constexpr int T_GO = 1024;     // [row tap*3+c 16 (12 used)][o 16]
 constexpr int T_SQ = 1280, T_SO = 1296, T_P = 1312;   // [16] each (P: col tap'*3+o)
 constexpr int T_TOT = 1328;
 
+template <bool PIPE>
 __global__ __launch_bounds__(256) void front_bwd_kernel(
     const float* __restrict__ base, const float* __restrict__ cvis, const float* __restrict__ lvis,
     const float* __restrict__ nn_rgb, const float* __restrict__ nn_base, const float* __restrict__ dy1q,
@@ -45,23 +46,24 @@ __global__ __launch_bounds__(256) void front_bwd_kernel(
   f32x4 rr[2] = {gq[0], gq[0]};
   f32x4 go = gq[0];
   float sq = 0.f, so = 0.f, sp = 0.f;
-  for (long g = (long)blockIdx.x * 4 + wave; g < groups; g += (long)gridDim.x * 4) {
+  // One group = 4 half-resolution texels (the K index of the MFMAs).  The operands of the NEXT group are requested before the
+  // current group's MFMAs: with every load of an iteration consumed in that iteration the waves spent 74 % of their cycles
+  // waiting for memory (PMC: SQ_WAIT_ANY; 9 four-byte gathers per lane per group at k = 1).
+  struct Ops { float bq, br, aq[2], ao0, bo0; };
+  auto fetch = [&](long g, Ops& q) {
     const int x0 = (int)(g % gpr) * 4;
     const long row = g / gpr;
     const int y = (int)(row % h2), f = (int)(row / h2);
     const int xh = x0 + kk;                                            // this lane's half-resolution texel (K index kk)
     const long tq = (long)f * hw2 + (long)y * w2 + xh;
-    // B operands
-    const float bq = dy1q[tq * 16 + i];
-    float br = 0.f;
+    q.bq = dy1q[tq * 16 + i];
+    q.br = 0.f;
     if (i < 12) {
       const int fy = 2 * y + (otap >> 1), fx = 2 * xh + (otap & 1);
-      br = (fy | fx) ? dpred[((long)f * hw + (long)fy * w + fx) * 3 + oc] : 0.f;   // texel (0,0): set_left_top_corner
+      q.br = (fy | fx) ? dpred[((long)f * hw + (long)fy * w + fx) * 3 + oc] : 0.f;   // texel (0,0): set_left_top_corner
     }
-    // query A operands: raw channel c at tap (a, b)
-    float aq[2];
 #pragma unroll
-    for (int a = 0; a < 2; ++a) {
+    for (int a = 0; a < 2; ++a) {                                      // query A operands: raw channel c at tap (a, b)
       const long pix = (long)(2 * y + a) * w + 2 * xh + b;
       const long tex = (long)f * hw + pix;
       float v;
@@ -76,26 +78,60 @@ __global__ __launch_bounds__(256) void front_bwd_kernel(
         }
         v *= inv_k;
       }
-      aq[a] = v;
+      q.aq[a] = v;
     }
+    const long opix = (long)(2 * y + (otap >> 1)) * w + 2 * xh + (otap & 1);
+    const long fo = (long)f * k;
+    q.ao0 = 0.f;
+    if (i < 12) {
+      const long ot = (fo * hw + opix) * 3 + oc;
+      q.ao0 = nn_rgb[ot] - nn_base[ot];
+    }
+    q.bo0 = dy1o[(fo * hw2 + (long)y * w2 + xh) * 16 + i];
+  };
+  auto consume = [&](long g, const Ops& q) {
 #pragma unroll
     for (int a = 0; a < 2; ++a) {
-      gq[a] = __builtin_amdgcn_mfma_f32_16x16x4f32(aq[a], bq, gq[a], 0, 0, 0);
-      rr[a] = __builtin_amdgcn_mfma_f32_16x16x4f32(aq[a], br, rr[a], 0, 0, 0);
+      gq[a] = __builtin_amdgcn_mfma_f32_16x16x4f32(q.aq[a], q.bq, gq[a], 0, 0, 0);
+      rr[a] = __builtin_amdgcn_mfma_f32_16x16x4f32(q.aq[a], q.br, rr[a], 0, 0, 0);
     }
-    sq += bq; sp += br;
-    // observation path
-    const long opix = (long)(2 * y + (otap >> 1)) * w + 2 * xh + (otap & 1);
-    for (int io = 0; io < k; ++io) {
-      const long fo = (long)f * k + io;
-      float ao = 0.f;
-      if (i < 12) {
-        const long ot = (fo * hw + opix) * 3 + oc;
-        ao = nn_rgb[ot] - nn_base[ot];
+    sq += q.bq; sp += q.br;
+    go = __builtin_amdgcn_mfma_f32_16x16x4f32(q.ao0, q.bo0, go, 0, 0, 0);
+    so += q.bo0;
+    if (k > 1) {                                                       // further observations of this group
+      const int x0 = (int)(g % gpr) * 4;
+      const long row = g / gpr;
+      const int y = (int)(row % h2), f = (int)(row / h2);
+      const int xh = x0 + kk;
+      const long opix = (long)(2 * y + (otap >> 1)) * w + 2 * xh + (otap & 1);
+      for (int io = 1; io < k; ++io) {
+        const long fo = (long)f * k + io;
+        float ao = 0.f;
+        if (i < 12) {
+          const long ot = (fo * hw + opix) * 3 + oc;
+          ao = nn_rgb[ot] - nn_base[ot];
+        }
+        const float bo = dy1o[(fo * hw2 + (long)y * w2 + xh) * 16 + i];
+        go = __builtin_amdgcn_mfma_f32_16x16x4f32(ao, bo, go, 0, 0, 0);
+        so += bo;
       }
-      const float bo = dy1o[(fo * hw2 + (long)y * w2 + xh) * 16 + i];
-      go = __builtin_amdgcn_mfma_f32_16x16x4f32(ao, bo, go, 0, 0, 0);
-      so += bo;
+    }
+  };
+  {
+    const long stride = (long)gridDim.x * 4;
+    long g = (long)blockIdx.x * 4 + wave;
+    Ops cur, nxt;
+    if (PIPE) {
+      if (g < groups) fetch(g, cur);
+      while (g < groups) {
+        const long gn = g + stride;
+        if (gn < groups) fetch(gn, nxt);
+        consume(g, cur);
+        cur = nxt;
+        g = gn;
+      }
+    } else {
+      for (; g < groups; g += stride) { fetch(g, cur); consume(g, cur); }
     }
   }
   // lane (kk, i) holds rows 4kk..4kk+3, column i of every accumulator
@@ -255,8 +291,13 @@ extern "C" int nlt_front_backward(const float* base, const float* cvis, const fl
   const long groups = (long)n * (h / 2) * (w / 8);
   const int blocks = front_bwd_blocks(groups);
   float* totals = workspace + (long)blocks * T_TOT;
-  hipLaunchKernelGGL(front_bwd_kernel, dim3(blocks), dim3(256), 0, s, base, cvis, lvis, nn_rgb, nn_base, dy1q, dy1o, dpred,
-                     k, h, w, groups, workspace);
+  static const bool pipe = [] { const char* e = getenv("NLT_FRONT_BWD_PIPE"); return !(e && e[0] == '0'); }();
+  if (pipe)
+    hipLaunchKernelGGL(front_bwd_kernel<true>, dim3(blocks), dim3(256), 0, s, base, cvis, lvis, nn_rgb, nn_base, dy1q, dy1o, dpred,
+                       k, h, w, groups, workspace);
+  else
+    hipLaunchKernelGGL(front_bwd_kernel<false>, dim3(blocks), dim3(256), 0, s, base, cvis, lvis, nn_rgb, nn_base, dy1q, dy1o, dpred,
+                       k, h, w, groups, workspace);
   NLT_CHECK_LAUNCH();
   static_assert(T_TOT % 16 == 0, "reduce kernel: 16 entries per workgroup");
   hipLaunchKernelGGL(front_bwd_reduce_kernel, dim3(T_TOT / 16), dim3(256), 0, s, workspace, blocks, totals);
