@@ -154,6 +154,179 @@ __global__ __launch_bounds__(256) void front_bwd_kernel(
     ws[(long)blockIdx.x * T_TOT + idx] = (part[0][idx] + part[1][idx]) + (part[2][idx] + part[3][idx]);
 }
 
+// ---- second generation: operands staged through wave-private LDS ------------------------------------------------------
+// The kernel above is bound by load ISSUE: 15 four-byte gather instructions per group (each of the five raw arrays behind its
+// own lane branch) for 5 MFMAs -- 3.9 M vector-memory instructions per launch, the texture addresser busy half the time
+// (PMC, r02_c_pmc_train.json).  Here a wave takes a run of 16 half-resolution texels (4 groups) per iteration and fetches
+// everything they need -- two full-resolution rows of 32 texels of base / cvis / lvis / dpred / nn_rgb[k] / nn_base[k], the 16
+// texels of dy1q and dy1o[k] -- with 3 + 3 k SIXTEEN-byte loads per lane (every lane of an instruction active, each array
+// a row-contiguous run), parks them in its own LDS rows, and forms the MFMA operands with 4-byte LDS reads.  The loads of the
+// next run are in flight while the current one is multiplied.  No workgroup barrier in the loop.  Needs w % 32 == 0,
+// 16-byte aligned arrays and k <= 4 (LDS and registers grow with k); the kernel above stays for everything else.
+__device__ __forceinline__ void fb_wave_sync() {       // orders this wave's LDS traffic for the compiler; no instruction
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+constexpr int FB_QB = 0, FB_QC = 192, FB_QL = 256, FB_QD = 320, FB_DYQ = 512, FB_OBS = 768;   // wave-private LDS map (floats)
+constexpr int FB_O_RGB = 0, FB_O_BASE = 192, FB_O_DY = 384, FB_O_SIZE = 640;                  // per observation
+
+template <int K>
+__global__ __launch_bounds__(256) void front_bwd2_kernel(
+    const float* __restrict__ base, const float* __restrict__ cvis, const float* __restrict__ lvis,
+    const float* __restrict__ nn_rgb, const float* __restrict__ nn_base, const float* __restrict__ dy1q,
+    const float* __restrict__ dy1o, const float* __restrict__ dpred, int h, int w, long runs, float* __restrict__ ws) {
+  __shared__ float part[4][T_TOT];
+  extern __shared__ __attribute__((aligned(16))) float stage[];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  float* L = stage + wave * (FB_OBS + K * FB_O_SIZE);
+  const int i = lane & 15, kk = lane >> 4;
+  const int h2 = h >> 1, w2 = w >> 1, rpr = w2 >> 4;                   // runs per half-resolution row
+  const long hw = (long)h * w, hw2 = (long)h2 * w2;
+  const int c = i & 7, b = i >> 3;                                     // query A rows: (b, c) of M tile a
+  const int otap = i / 3, oc = i - 3 * otap;                           // obs A rows / R columns: (tap, channel) for i < 12
+  const float inv_k = 1.f / (float)K;
+
+  // staging descriptors (lane constants).  slot 0: base r0 (24 lanes) | base r1 (24) | cvis r0 (8) | cvis r1 (8)
+  //                                        slot 1: lvis r0 (8) | lvis r1 (8) | dpred r0 (24) | dpred r1 (24)
+  const float* p0; int ch0, r0, j0, l0;
+  if (lane < 48) { p0 = base; ch0 = 3; r0 = lane >= 24; j0 = lane - 24 * r0; l0 = FB_QB + r0 * 96 + 4 * j0; }
+  else { p0 = cvis; ch0 = 1; r0 = lane >= 56; j0 = lane - 48 - 8 * r0; l0 = FB_QC + r0 * 32 + 4 * j0; }
+  const float* p1; int ch1, r1, j1, l1;
+  if (lane < 16) { p1 = lvis; ch1 = 1; r1 = lane >= 8; j1 = lane - 8 * r1; l1 = FB_QL + r1 * 32 + 4 * j1; }
+  else { p1 = dpred; ch1 = 3; r1 = lane >= 40; j1 = lane - 16 - 24 * r1; l1 = FB_QD + r1 * 96 + 4 * j1; }
+  // per observation: slot A: nn_rgb r0 (24) | nn_rgb r1 (24) | nn_base r0 units 0-15;  slot B: nn_base r0 units 16-23 (8) |
+  //                  nn_base r1 (24) | 32 idle lanes;  slot C: dy1o, 16 texels x 4 quads
+  const bool a_rgb = lane < 48;
+  const int ra = a_rgb ? (lane >= 24) : 0, ja = a_rgb ? lane - 24 * ra : lane - 48;
+  const int la = (a_rgb ? FB_O_RGB : FB_O_BASE) + ra * 96 + 4 * ja;
+  const bool b_on = lane < 32;
+  const int rb = lane >= 8, jb = lane < 8 ? 16 + lane : (b_on ? lane - 8 : 0);
+  const int lb = FB_O_BASE + rb * 96 + 4 * jb;
+
+  f32x4 gq[2] = {(f32x4){0.f, 0.f, 0.f, 0.f}, (f32x4){0.f, 0.f, 0.f, 0.f}};
+  f32x4 rr[2] = {gq[0], gq[0]};
+  f32x4 go = gq[0];
+  float sq = 0.f, so = 0.f, sp = 0.f;
+
+  struct Regs { f32x4 q0, q1, dq, oa[K], ob[K], od[K]; };
+  auto issue = [&](long run, Regs& v) {
+    const int xq = (int)(run % rpr);
+    const long row = run / rpr;
+    const int y = (int)(row % h2), f = (int)(row / h2);
+    const long t0 = (long)f * hw + (long)(2 * y) * w + 32 * xq;        // first full-resolution texel of row 2y
+    v.q0 = *reinterpret_cast<const f32x4*>(p0 + (t0 + (long)r0 * w) * ch0 + 4 * j0);
+    v.q1 = *reinterpret_cast<const f32x4*>(p1 + (t0 + (long)r1 * w) * ch1 + 4 * j1);
+    const long tq = (long)f * hw2 + (long)y * w2 + 16 * xq;
+    v.dq = *reinterpret_cast<const f32x4*>(dy1q + tq * 16 + 4 * lane);
+#pragma unroll
+    for (int io = 0; io < K; ++io) {
+      const long fo = (long)f * K + io;
+      const long o0 = fo * hw + (long)(2 * y) * w + 32 * xq;
+      v.oa[io] = *reinterpret_cast<const f32x4*>((a_rgb ? nn_rgb : nn_base) + (o0 + (long)ra * w) * 3 + 4 * ja);
+      v.ob[io] = *reinterpret_cast<const f32x4*>(nn_base + (o0 + (long)rb * w) * 3 + 4 * jb);   // (idle lanes re-read unit 0: in bounds)
+      v.od[io] = *reinterpret_cast<const f32x4*>(dy1o + (fo * hw2 + (long)y * w2 + 16 * xq) * 16 + 4 * lane);
+    }
+  };
+  auto park = [&](const Regs& v) {
+    *reinterpret_cast<f32x4*>(L + l0) = v.q0;
+    *reinterpret_cast<f32x4*>(L + l1) = v.q1;
+    *reinterpret_cast<f32x4*>(L + FB_DYQ + 4 * lane) = v.dq;
+#pragma unroll
+    for (int io = 0; io < K; ++io) {
+      float* O = L + FB_OBS + io * FB_O_SIZE;
+      *reinterpret_cast<f32x4*>(O + la) = v.oa[io];
+      if (b_on) *reinterpret_cast<f32x4*>(O + lb) = v.ob[io];
+      *reinterpret_cast<f32x4*>(O + FB_O_DY + 4 * lane) = v.od[io];
+    }
+  };
+  auto multiply = [&](long run) {
+    const int xq = (int)(run % rpr);
+    const int y = (int)((run / rpr) % h2);
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const int xl = 4 * g + kk;                                       // this lane's half-resolution texel of the run (K index kk)
+      const float bq = L[FB_DYQ + xl * 16 + i];
+      float br = 0.f;
+      if (i < 12) {
+        const int fy = 2 * y + (otap >> 1), fx = 2 * (16 * xq + xl) + (otap & 1);
+        br = (fy | fx) ? L[FB_QD + (otap >> 1) * 96 + (2 * xl + (otap & 1)) * 3 + oc] : 0.f;   // texel (0,0): set_left_top_corner
+      }
+      float aq[2];
+#pragma unroll
+      for (int a = 0; a < 2; ++a) {
+        const int tx = 2 * xl + b;
+        float v;
+        if (c < 3) v = L[FB_QB + a * 96 + tx * 3 + c];
+        else if (c == 3) v = L[FB_QC + a * 32 + tx];
+        else if (c == 4) v = L[FB_QL + a * 32 + tx];
+        else {
+          v = 0.f;
+#pragma unroll
+          for (int io = 0; io < K; ++io) {
+            const float* O = L + FB_OBS + io * FB_O_SIZE;
+            v += O[FB_O_RGB + a * 96 + tx * 3 + c - 5] - O[FB_O_BASE + a * 96 + tx * 3 + c - 5];
+          }
+          v *= inv_k;
+        }
+        aq[a] = v;
+      }
+#pragma unroll
+      for (int a = 0; a < 2; ++a) {
+        gq[a] = __builtin_amdgcn_mfma_f32_16x16x4f32(aq[a], bq, gq[a], 0, 0, 0);
+        rr[a] = __builtin_amdgcn_mfma_f32_16x16x4f32(aq[a], br, rr[a], 0, 0, 0);
+      }
+      sq += bq; sp += br;
+#pragma unroll
+      for (int io = 0; io < K; ++io) {
+        const float* O = L + FB_OBS + io * FB_O_SIZE;
+        float ao = 0.f;
+        if (i < 12) {
+          const int oo = (otap >> 1) * 96 + (2 * xl + (otap & 1)) * 3 + oc;
+          ao = O[FB_O_RGB + oo] - O[FB_O_BASE + oo];
+        }
+        const float bo = O[FB_O_DY + xl * 16 + i];
+        go = __builtin_amdgcn_mfma_f32_16x16x4f32(ao, bo, go, 0, 0, 0);
+        so += bo;
+      }
+    }
+  };
+  {
+    const long stride = (long)gridDim.x * 4;
+    long run = (long)blockIdx.x * 4 + wave;
+    Regs v;
+    if (run < runs) issue(run, v);
+    while (run < runs) {
+      park(v);
+      fb_wave_sync();
+      const long nxt = run + stride;
+      if (nxt < runs) issue(nxt, v);
+      multiply(run);
+      fb_wave_sync();                                                  // the reads are done before the next run is parked
+      run = nxt;
+    }
+  }
+  // lane (kk, i) holds rows 4kk..4kk+3, column i of every accumulator
+  float* p = part[wave];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+#pragma unroll
+    for (int a = 0; a < 2; ++a) {
+      p[T_GQ + (a * 16 + 4 * kk + r) * 16 + i] = gq[a][r];
+      p[T_R + (a * 16 + 4 * kk + r) * 16 + i] = rr[a][r];
+    }
+    p[T_GO + (4 * kk + r) * 16 + i] = go[r];
+  }
+  sq += __shfl_xor(sq, 16); sq += __shfl_xor(sq, 32);
+  so += __shfl_xor(so, 16); so += __shfl_xor(so, 32);
+  sp += __shfl_xor(sp, 16); sp += __shfl_xor(sp, 32);
+  if (kk == 0) { p[T_SQ + i] = sq; p[T_SO + i] = so; p[T_P + i] = sp; }
+  __syncthreads();
+  for (int idx = threadIdx.x; idx < T_TOT; idx += 256)
+    ws[(long)blockIdx.x * T_TOT + idx] = (part[0][idx] + part[1][idx]) + (part[2][idx] + part[3][idx]);
+}
+
 // totals[idx] = sum over the nblocks partial rows: 16 entries per workgroup, rows dealt to 16 thread groups x 4 running sums
 // (a serial walk over ~1000 rows is pure load latency), combined in a fixed order
 __global__ __launch_bounds__(256) void front_bwd_reduce_kernel(const float* __restrict__ ws, int nblocks, float* __restrict__ totals) {
@@ -292,7 +465,17 @@ extern "C" int nlt_front_backward(const float* base, const float* cvis, const fl
   const int blocks = front_bwd_blocks(groups);
   float* totals = workspace + (long)blocks * T_TOT;
   static const bool pipe = [] { const char* e = getenv("NLT_FRONT_BWD_PIPE"); return !(e && e[0] == '0'); }();
-  if (pipe)
+  static const bool staged = [] { const char* e = getenv("NLT_FRONT_BWD_STAGED"); return !(e && e[0] == '0'); }();
+  const bool aligned = nlt_aligned16(base) && nlt_aligned16(cvis) && nlt_aligned16(lvis) && nlt_aligned16(nn_rgb) &&
+                       nlt_aligned16(nn_base) && nlt_aligned16(dy1q) && nlt_aligned16(dy1o) && nlt_aligned16(dpred);
+  if (staged && aligned && (w & 31) == 0 && k <= 4) {
+    const long runs = (long)n * (h / 2) * (w / 32);
+    const size_t lds = (size_t)4 * (FB_OBS + k * FB_O_SIZE) * sizeof(float);
+#define NLT_FB2(K_) hipLaunchKernelGGL(front_bwd2_kernel<K_>, dim3(blocks), dim3(256), lds, s, base, cvis, lvis, nn_rgb, nn_base, \
+                                       dy1q, dy1o, dpred, h, w, runs, workspace)
+    if (k == 1) NLT_FB2(1); else if (k == 2) NLT_FB2(2); else if (k == 3) NLT_FB2(3); else NLT_FB2(4);
+#undef NLT_FB2
+  } else if (pipe)
     hipLaunchKernelGGL(front_bwd_kernel<true>, dim3(blocks), dim3(256), 0, s, base, cvis, lvis, nn_rgb, nn_base, dy1q, dy1o, dpred,
                        k, h, w, groups, workspace);
   else

@@ -69,7 +69,8 @@ def test_back_forward_train_keeps_the_last_blocks_maps(n, h2, w2):
         assert rel_l2(got.cpu(), ref) <= 1e-5
 
 
-@pytest.mark.parametrize('n,h,w,k', [(1, 8, 8, 1), (2, 24, 40, 3), (1, 64, 128, 4), (3, 32, 16, 2), (1, 256, 512, 1)])
+@pytest.mark.parametrize('n,h,w,k', [(1, 8, 8, 1), (2, 24, 40, 3), (1, 64, 128, 4), (3, 32, 16, 2), (1, 256, 512, 1), (2, 32, 64, 2),
+                                     (1, 16, 32, 3), (3, 2, 32, 1)])
 def test_front_backward_matches_autograd_through_the_unfolded_layers(n, h, w, k):
     rng = np.random.default_rng(h * 5 + w + k)
     U = lambda *s: torch.from_numpy(rng.random(s, dtype=np.float32))
