@@ -160,8 +160,9 @@ __global__ __launch_bounds__(256) void dwt_cols_charb_kernel(const float* __rest
   const int wl = n_lo(w), wh = n_hi(w);
   const long per_frame = 3l * A * wl;
   float s = 0.f;
-  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx < per_frame) {
+  // grid-stride: the launcher caps the workgroups per frame, because each ends in ONE float atomic on the frame's loss and
+  // device-scope atomics on one address serialise (~50 ns each: 1500 of them per frame at level 0 were most of this launch)
+  for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < per_frame; idx += (long)gridDim.x * blockDim.x) {
     const int b = idx % wl;
     const int a = (idx / wl) % A;
     const long pl = (long)f * 3 + idx / ((long)A * wl);
@@ -305,7 +306,7 @@ extern "C" int nlt_barron_loss(const float* pred, const float* gt, int n, int h,
   }
   auto charb = [&](long off, long per_plane) {
     const long per_frame = per_plane * 3;
-    long bx = (per_frame + 255) / 256; if (bx > 256) bx = 256;
+    long bx = (per_frame + 255) / 256; if (bx > 48) bx = 48;
     hipLaunchKernelGGL(charbonnier_kernel, dim3((unsigned)bx, (unsigned)n), dim3(256), 0, s, ws + off, per_frame,
                        inv_total, want_grad, loss);
   };
@@ -318,7 +319,9 @@ extern "C" int nlt_barron_loss(const float* pred, const float* gt, int n, int h,
     if (L.hh > 0) {
       // rows of `lo` -> (LL, LH), rows of `hi` -> (HL, HH), Charbonnier of the final bands: one launch
       const long per_frame = 3l * L.hl * L.wl;                         // hl >= hh: the z = 1 half exits early
-      hipLaunchKernelGGL(dwt_cols_charb_kernel, dim3(blocks_for(per_frame), (unsigned)n, 2), dim3(256), 0, s, ws + L.lo, ws + L.hi,
+      unsigned bx = blocks_for(per_frame);
+      if (bx > 48) bx = 48;
+      hipLaunchKernelGGL(dwt_cols_charb_kernel, dim3(bx, (unsigned)n, 2), dim3(256), 0, s, ws + L.lo, ws + L.hi,
                          L.hl, L.hh, L.w, ws + L.LL, ws + L.LH, ws + L.HL, ws + L.HH, last ? 1 : 0, inv_total, want_grad, loss);
     } else {
       hipLaunchKernelGGL(dwt_axis_kernel, dim3(blocks_for(P * L.hl * L.wl)), dim3(256), 0, s, ws + L.lo, L.hl, L.w, 1,
