@@ -221,6 +221,13 @@ int nlt_l2_loss_forward(const float* pred, const float* gt, int n, long per_exam
 int nlt_l2_loss_backward(const float* pred, const float* gt, const float* gloss, int n, long per_example,
                          float* dpred, void* stream);
 
+/* The l2 train step's loss in one launch (nlt/models/nlt.py:238-245 `gt = rgb_camspc * fg`; losses.L2 keep_batch;
+ * trainvali.py:277-278 `sum / global batch`; and the gradient w.r.t. pred): gt = rgb * fg, loss[0] = sum_f mean((pred_f - gt_f)^2)
+ * / global_bs, dpred = 2 (pred - gt) / per_example / global_bs.  Same arithmetic as nlt_mul_forward + nlt_l2_loss_forward +
+ * nlt_l2_loss_backward with gloss = 1 / global_bs. */
+int nlt_l2_train_loss(const float* pred, const float* rgb, const float* fg, int n, long per_example, float inv_global_bs,
+                      float* gt, float* dpred, float* loss, void* stream);
+
 /* losses.Barron with keep_batch=True (nlt/losses.py:90-118; robust_loss adaptive.py:453-538 with
  * alpha = 1, scale = 0.01, CDF9/7, 5 levels, sYUV): loss[f]; if dpred_unit != NULL also
  * d loss[f] / d pred (multiply by the upstream per-example gradient with nlt_scale_rows).

@@ -48,6 +48,7 @@ SIGNATURES = {
     'nlt_lrelu_backward': (_c_int, [_vp, _c_int, _vp, _c_int, _c_int, _c_long, _c_float, _vp, _c_int, _vp]),
     'nlt_obs_mean_backward': (_c_int, [_vp, _c_int, _vp, _vp, _vp, _c_int, _c_int, _c_int, _c_int, _c_float, _vp, _vp]),
     'nlt_resize_cv_linear': (_c_int, [_vp, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _vp, _vp]),
+    'nlt_l2_train_loss': (_c_int, [_vp, _vp, _vp, _c_int, _c_long, _c_float, _vp, _vp, _vp, _vp]),
     'nlt_level_split_backward': (_c_int, [_vp, _vp, _c_int, _vp, _vp, _vp, _c_int, _c_int, _c_int, _c_int, _c_float, _c_float, _vp, _vp]),
     'nlt_stem_backward': (_c_int, [_vp] * 6 + [_c_int] * 5 + [_vp] * 6 + [_vp]),
     'nlt_head_backward': (_c_int, [_vp, _c_int, _c_int, _vp, _c_int, _c_int, _vp, _vp, _c_int, _c_int, _c_int,
@@ -448,6 +449,17 @@ def l2_loss_forward(pred, gt):
     _check(lib().nlt_l2_loss_forward(_ptr(_dense(pred, 'pred')), _ptr(_dense(gt, 'gt')), n, pred[0].numel(),
                                      _ptr(loss), _stream()), 'nlt_l2_loss_forward')
     return loss
+
+
+def l2_train_loss(pred, rgb, fg, global_bs):
+    """gt = rgb * fg, loss = sum_f mean((pred_f - gt_f)^2) / global_bs (0-dim tensor), dpred: one launch."""
+    _same_shape(pred, rgb, 'l2_train_loss'); _same_shape(pred, fg, 'l2_train_loss')
+    gt, dpred = torch.empty_like(pred), torch.empty_like(pred)
+    loss = torch.empty((), device=pred.device, dtype=torch.float32)
+    _check(lib().nlt_l2_train_loss(_ptr(_dense(pred, 'pred')), _ptr(_dense(rgb, 'rgb')), _ptr(_dense(fg, 'fg')), pred.shape[0],
+                                   pred[0].numel(), 1.0 / float(global_bs), _ptr(gt), _ptr(dpred), _ptr(loss), _stream()),
+           'nlt_l2_train_loss')
+    return loss, gt, dpred
 
 
 def l2_loss_backward(pred, gt, gloss):

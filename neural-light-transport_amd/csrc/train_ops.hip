@@ -279,6 +279,29 @@ __global__ __launch_bounds__(256) void l2_bwd_kernel(const float* __restrict__ p
   dpred[i] = gloss[i / per] * 2.f * (pred[i] - gt[i]) / (float)per;
 }
 
+// The l2 train step's loss glue in one pass (gt = rgb * fg; per-example mean square; sum over examples / global batch; its
+// gradient): replaces mul + l2 forward + sum + divide + their autograd mirror + l2 backward = 12 launches between the
+// resampler and the first backward kernel.  blockIdx.y = frame; loss (one float, zeroed by the launcher) += sum_f mean_f / gbs.
+__global__ __launch_bounds__(256) void l2_step_kernel(const float* __restrict__ pred, const float* __restrict__ rgb,
+                                                      const float* __restrict__ fg, long per, float inv_gbs,
+                                                      float* __restrict__ gt, float* __restrict__ dpred, float* loss) {
+  __shared__ float ws[4];
+  const int f = blockIdx.y;
+  float s = 0.f;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < per; i += (long)gridDim.x * blockDim.x) {
+    const long e = f * per + i;
+    const float g = rgb[e] * fg[e];
+    const float d = pred[e] - g;
+    gt[e] = g;
+    dpred[e] = inv_gbs * 2.f * d / (float)per;                       // = gloss[f] * 2 (pred - gt) / per with gloss = 1 / gbs (l2_bwd_kernel's form)
+    s += d * d;
+  }
+  s = wave_sum(s);
+  if ((threadIdx.x & 63) == 0) ws[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) atomicAdd(loss, (ws[0] + ws[1] + ws[2] + ws[3]) / (float)per * inv_gbs);
+}
+
 // x[f, :] *= s[f]
 __global__ __launch_bounds__(256) void scale_rows_kernel(const float* __restrict__ x, const float* __restrict__ s,
                                                          long per, long total, float* __restrict__ out) {
@@ -451,6 +474,19 @@ extern "C" int nlt_l2_loss_backward(const float* pred, const float* gt, const fl
   const long total = (long)n * per_example;
   hipLaunchKernelGGL(l2_bwd_kernel, dim3(blocks_for(total)), dim3(256), 0, static_cast<hipStream_t>(stream), pred, gt,
                      gloss, per_example, total, dpred);
+  NLT_CHECK_LAUNCH();
+  return NLT_OK;
+}
+
+extern "C" int nlt_l2_train_loss(const float* pred, const float* rgb, const float* fg, int n, long per_example, float inv_global_bs,
+                                 float* gt, float* dpred, float* loss, void* stream) {
+  if (!pred || !rgb || !fg || !gt || !dpred || !loss || n <= 0 || per_example <= 0) return NLT_ERR_BAD_ARG;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  if (hipMemsetAsync(loss, 0, sizeof(float), s) != hipSuccess) return NLT_ERR_LAUNCH;
+  long bx = (per_example + 255) / 256;
+  if (bx > 48) bx = 48;
+  hipLaunchKernelGGL(l2_step_kernel, dim3((unsigned)bx, (unsigned)n), dim3(256), 0, s, pred, rgb, fg, per_example, inv_global_bs,
+                     gt, dpred, loss);
   NLT_CHECK_LAUNCH();
   return NLT_OK;
 }

@@ -323,11 +323,17 @@ class Model(BaseModel):
             pred, pred_camspc, base_camspc, fg_camspc, _ = self._render(base, cvis, lvis, warp, nn_rgb, nn_base, None, None,
                                                                         False, inference=False)
             gen = self.plan.generation
-            gt_camspc = C.mul_forward(rgb_camspc, fg_camspc)
-        leaf = pred_camspc.detach().requires_grad_(True)
-        with torch.enable_grad():
-            loss = self.compute_loss(leaf, gt_camspc, keep_batch=True).sum() / global_bs
-            (d_pred_c,) = torch.autograd.grad(loss, leaf)
+            plain_l2 = len(self.wloss) == 1 and self.wloss[0][0] == 1 and type(self.wloss[0][1]).__name__ == 'L2'
+            if plain_l2:
+                # gt = rgb * fg, the per-example means, their sum / global batch and the gradient in one launch (12 otherwise)
+                loss, gt_camspc, d_pred_c = C.l2_train_loss(pred_camspc, rgb_camspc, fg_camspc, global_bs)
+            else:
+                gt_camspc = C.mul_forward(rgb_camspc, fg_camspc)
+        if not plain_l2:
+            leaf = pred_camspc.detach().requires_grad_(True)
+            with torch.enable_grad():
+                loss = self.compute_loss(leaf, gt_camspc, keep_batch=True).sum() / global_bs
+                (d_pred_c,) = torch.autograd.grad(loss, leaf)
         with torch.no_grad():
             self._render_backward(d_pred_c, (base, cvis, lvis, warp, nn_rgb, nn_base, None), gen)
             to_vis = {'id': id_, 'nn_id': nn_id, 'base_camspc': base_camspc, 'pred': pred.clone(), 'pred_camspc': pred_camspc,

@@ -2,6 +2,8 @@
 per GPU: per-example loss -> sum / GLOBAL batch size -> backward -> ONE all-reduce(sum) of the flat
 fp32 gradient bucket over RCCL/xGMI -> fused Adam-AMSGrad (bit-identical on every rank) -> scalar
 loss all-reduce(sum).  MirroredStrategy's in-process replicas become torch.distributed ranks."""
+import os
+
 import torch
 import torch.distributed as dist
 
@@ -39,6 +41,9 @@ def restore_checkpoint(path, model, optimizer=None):
     return ck['step']
 
 
+AUTOGRAD_STEP = os.environ.get('NLT_AUTOGRAD_STEP', '0') == '1'   # single-rank step through torch.autograd (the reference-shaped path)
+
+
 def _world(group):
     return dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
 
@@ -54,6 +59,13 @@ def distributed_train_step(model, batch, optimizer, global_bs, group=None, overl
     backward.  overlap=False issues both after the backward (same result)."""
     assert model.trainable_registered, "Register the trainable layers before using `trainable_variables`"
     world = _world(group)
+    if world == 1 and not AUTOGRAD_STEP:
+        # same arithmetic without a torch.autograd graph around the network (only the loss is differentiated): no AccumulateGrad
+        # copy of the 13.5 MB bucket, no expand / fill launches for the sum and the division
+        loss, to_vis = model.train_forward_backward(batch, global_bs)
+        model.flat_params.grad = model.flat_grads
+        optimizer.step(model.flat_grads)
+        return loss.clone(), to_vis
     if world == 1:
         pred, gt, loss_kwargs, to_vis = model(batch, mode='train')
         loss_kwargs['keep_batch'] = True

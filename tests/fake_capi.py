@@ -137,6 +137,14 @@ def obs_mean_backward(dmean, ldm, obs_y, obs_weights, dobs_partial, n, k, hw, c,
     dpre_obs.copy_(g.reshape(dpre_obs.shape))
 
 
+def l2_train_loss(pred, rgb, fg, global_bs):
+    gt = rgb * fg
+    per = pred[0].numel()
+    d = pred - gt
+    loss = ((d * d).reshape(pred.shape[0], -1).sum(1) / per).sum() / global_bs
+    return loss, gt, 2.0 * d / per / global_bs
+
+
 def level_split_backward(dfm, fm_y, ld, obs_y, obs_weights, dobs_partial, n, k, hw, c, alpha_q, alpha_o, dpre_obs):
     obs_mean_backward(dfm.view(-1)[c:], ld, obs_y, obs_weights, dobs_partial, n, k, hw, c, alpha_o, dpre_obs)
     lrelu_backward(dfm, ld, fm_y, ld, c, n * hw, alpha_q, dfm, ld)
@@ -221,7 +229,7 @@ def adam_amsgrad_step(param, grad, m, v, vhat, lr_t, beta1, beta2, eps):
         param.sub_(lr_t * m / (vhat.sqrt() + eps))
 
 
-_TRAIN = ('conv_backward_weights', 'lrelu_backward', 'obs_mean_backward', 'level_split_backward', 'stem_backward', 'head_backward',
+_TRAIN = ('conv_backward_weights', 'lrelu_backward', 'obs_mean_backward', 'level_split_backward', 'l2_train_loss', 'stem_backward', 'head_backward',
           'warp_backward', 'resize_bilinear_backward', 'l2_loss_forward', 'l2_loss_backward', 'barron_loss',
           'scale_rows', 'adam_amsgrad_step', 'clip_by_norm_slots')
 

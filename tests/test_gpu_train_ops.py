@@ -175,6 +175,21 @@ def test_lrelu_and_obs_mean_backward():
         np.testing.assert_allclose(pd.cpu().numpy(), ref, atol=1e-6)
 
 
+def test_l2_train_loss_equals_its_parts():
+    """nlt_l2_train_loss = nlt_mul_forward + nlt_l2_loss_forward (+ sum / global batch) + nlt_l2_loss_backward in one launch."""
+    rng = np.random.default_rng(3)
+    n, h, w, gbs = 3, 37, 29, 8
+    pred, rgb = rng.random((n, h, w, 3), dtype=np.float32), rng.random((n, h, w, 3), dtype=np.float32)
+    fg = (rng.random((n, h, w, 1)) > 0.3).astype(np.float32).repeat(3, -1)
+    loss, gt, dpred = C.l2_train_loss(d(pred), d(rgb), d(fg), gbs)
+    gt_ref = C.mul_forward(d(rgb), d(fg))
+    per = C.l2_loss_forward(d(pred), gt_ref)
+    gl = torch.full((n,), 1.0 / gbs, device='cuda')
+    assert torch.equal(gt, gt_ref)
+    np.testing.assert_allclose(float(loss), float(per.sum()) / gbs, rtol=1e-6)
+    np.testing.assert_allclose(dpred.cpu().numpy(), C.l2_loss_backward(d(pred), gt_ref, gl).cpu().numpy(), rtol=1e-6, atol=1e-12)
+
+
 @pytest.mark.parametrize('k,use_w,use_p', [(1, False, True), (3, True, True), (4, False, False)])
 def test_level_split_backward_equals_the_two_launches(k, use_w, use_p):
     """nlt_level_split_backward = nlt_lrelu_backward on the query half + nlt_obs_mean_backward on the observation half,

@@ -78,6 +78,17 @@ def main():
             lines.append('  %8.1f %7.1f  q%-4s %s' % ((st - t0) / 1e3, (en - st) / 1e3, q,
                                                    name.replace('void ', '').replace('(anonymous namespace)::', '').split('(')[0][:60]))
     lines.append('')
+    lines.append('loss window of the last step (every kernel from the resampler to the first backward launch): start us, duration us, queue, name')
+    on = False
+    for st, en, name, q in ks:
+        short = name.replace('void ', '').replace('(anonymous namespace)::', '').split('(')[0][:70]
+        if short.startswith('warp_kernel'):
+            on = True
+        if on:
+            lines.append('  %8.1f %7.1f  q%-4s %s' % ((st - t0) / 1e3, (en - st) / 1e3, q, short))
+        if on and 'back_bwd_kernel' in short:
+            break
+    lines.append('')
     lines.append('idle gaps (no kernel on any stream), by the kernel that ends the gap')
     for name, (c, t) in sorted(gap_after.items(), key=lambda kv: -kv[1][1])[:25]:
         lines.append('%-70s %8.1f %10.1f %9.1f' % (name[:70], c / n, t / n, t / c))
@@ -85,7 +96,9 @@ def main():
         f.write('\n'.join(lines) + '\n')
     print('\n'.join(lines[:8]))
     i = lines.index('streams of the last step: queue, kernels, sum of durations us, first start us, last end us')
-    print('\n'.join(lines[i:i + 70]))
+    print('\n'.join(lines[i:i + 6]))
+    i = [n for n, l in enumerate(lines) if l.startswith('loss window')][0]
+    print('\n'.join(lines[i:i + 30]))
 
 
 if __name__ == '__main__':
