@@ -59,7 +59,7 @@ def distributed_train_step(model, batch, optimizer, global_bs, group=None, overl
     backward.  overlap=False issues both after the backward (same result)."""
     assert model.trainable_registered, "Register the trainable layers before using `trainable_variables`"
     world = _world(group)
-    if world == 1 and not AUTOGRAD_STEP:
+    if world == 1 and not AUTOGRAD_STEP and not getattr(model, 'generic', False):     # (branch configs run layer by layer through autograd)
         # same arithmetic without a torch.autograd graph around the network (only the loss is differentiated): no AccumulateGrad
         # copy of the 13.5 MB bucket, no expand / fill launches for the sum and the division
         loss, to_vis = model.train_forward_backward(batch, global_bs)
@@ -76,6 +76,8 @@ def distributed_train_step(model, batch, optimizer, global_bs, group=None, overl
         grad = model.flat_params.grad
         optimizer.step(grad)
         return weighted_loss.detach().clone(), to_vis
+    if getattr(model, 'generic', False):
+        raise NotImplementedError("data-parallel training of the layer-by-layer branch configs (elu / pixel norm / pooling)")
     grad, split = model.flat_grads, model.bucket_split
     works = []
     if overlap:
