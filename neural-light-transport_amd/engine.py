@@ -320,29 +320,34 @@ class RenderPlan:
                 and prev[1][0].n_ch_out == 8 and q.layers[-1].n_ch_out == 3
                 and all(a is not None for a in acts) and len({a.alpha for a in acts}) == 1)
 
-    def _front_weights(self, dev):
-        """Folded + fragment-packed weights of the front kernel, re-derived when any source kernel changed."""
+    def _front_weights(self, dev, l2=True):
+        """Folded + fragment-packed weights of the front kernel, re-derived when any source kernel changed.  l2 = False
+        (training: the level-2 fold is an inference-only part of the kernel) leaves the level-2 blob alone."""
         q, o, D, U = self.q, self.o, self.n_down, self.n_up
         q0, o0, head = q.layers[0], o.layers[0], q.layers[-1]
         (qa, _), (qb, _) = q.layers[1].convs()
         (oa, _), (ob, _) = o.layers[1].convs()
         q0.build(5, dev); o0.build(3, dev); qa.build(32, dev); qb.build(16, dev); oa.build(16, dev); ob.build(16, dev)
         head.build(36, dev)
-        convs = (q0, o0, qa, qb, oa, ob, head)
-        ver = tuple((c.kernel.data_ptr(), c.kernel._version, c.bias._version, c._epoch[0]) for c in convs)
-        (qa2, _), _ = q.layers[2].convs()
-        (oa2, _), _ = o.layers[2].convs()
-        qa2.build(32, dev); oa2.build(16, dev)
-        ver += tuple((c.kernel.data_ptr(), c.kernel._version, c.bias._version, c._epoch[0]) for c in (qa2, oa2))
-        if self._front_blob is None or self._front_blob[0] != ver:
-            w = lambda c: (c.kernel.detach(), c.bias.detach())
-            old = self._front_blob                          # refilled in place: launch tapes / graphs keep the addresses
-            blob = C.front_pack_weights(*w(q0), *w(o0), *w(qa), *w(qb), *w(oa), *w(ob), *w(head), out=old[1] if old else None)
-            blob_l2 = None
-            if qa2.n_ch_out == 32 and oa2.n_ch_out == 32 and qa2.cin == 32 and oa2.cin == 16:
-                blob_l2 = C.front_pack_l2_weights(*w(qa2), *w(oa2), out=old[2] if old else None)
-            self._front_blob = [ver, blob, blob_l2]
-        return self._front_blob[1], self._front_blob[2]
+        stamp = lambda cs: tuple((c.kernel.data_ptr(), c.kernel._version, c.bias._version, c._epoch[0]) for c in cs)
+        w = lambda c: (c.kernel.detach(), c.bias.detach())
+        if self._front_blob is None:
+            self._front_blob = [None, None, None, None]              # [stamp, blob, level-2 blob, its stamp]
+        fb = self._front_blob                                        # refilled in place: launch tapes / graphs keep the addresses
+        ver = stamp((q0, o0, qa, qb, oa, ob, head))
+        if fb[0] != ver:
+            fb[1] = C.front_pack_weights(*w(q0), *w(o0), *w(qa), *w(qb), *w(oa), *w(ob), *w(head), out=fb[1])
+            fb[0] = ver
+        if l2:
+            (qa2, _), _ = q.layers[2].convs()
+            (oa2, _), _ = o.layers[2].convs()
+            qa2.build(32, dev); oa2.build(16, dev)
+            ver2 = stamp((qa2, oa2))
+            if fb[3] != ver2:
+                ok = qa2.n_ch_out == 32 and oa2.n_ch_out == 32 and qa2.cin == 32 and oa2.cin == 16
+                fb[2] = C.front_pack_l2_weights(*w(qa2), *w(oa2), out=fb[2]) if ok else None
+                fb[3] = ver2
+        return fb[1], fb[2]
 
     def resident_ok(self, n, k, h, w, alpha=0.3):
         """Can `forward(resident=...)` read the uint8 capture store directly (csrc/front4.hip, uint8 variant)?"""
@@ -379,7 +384,7 @@ class RenderPlan:
                                                 skip_connect_base, algo, inference))
         # launch tape (second sight of the same inputs records, later sights replay)
         if fused:
-            self._front_weights(dev)        # folded front-kernel weights, refreshed in place OUTSIDE any tape
+            self._front_weights(dev, l2=inference)   # folded front-kernel weights, refreshed in place OUTSIDE any tape
         tkey = None
         if (self.use_tape and base.is_cuda and self.timer is None and not self._tuning and reg is not None
                 and obs_weights is None and obs_override is None
@@ -537,7 +542,7 @@ class RenderPlan:
         alpha = q.layers[1].convs()[0][1].alpha
         if b['skip3'] is None:
             b['skip3'] = torch.empty((n, h, w, 3), device=dev, dtype=torch.float32)
-        blob, blob_l2 = self._front_weights(dev)
+        blob, blob_l2 = self._front_weights(dev, l2=not train)
         # With k <= 4 the front kernel also runs level 2's stride-2 convs (its 8 x 16 level-1 tile is a 4 x 8 tile of
         # level 2): the per-observation level-1 maps never reach HBM and L2.{q,o}.s2 are not launched.
         v4 = self.front_v4 and 0.0 <= alpha <= 1.0 and (resident is not None or C.front4_supported(base, cvis, lvis, nn_rgb, nn_base))
