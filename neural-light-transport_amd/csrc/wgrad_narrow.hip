@@ -516,10 +516,17 @@ int run_narrow(WN& w, hipStream_t s) {
   return NLT_OK;
 }
 
+// The row-walking loop pays for every shape except the k2s1 families at K = 128, N = 32 (two A quads x two column tiles: 260 VALU
+// instructions of padding checks per 6 steps at 2 waves per SIMD -- measured 55-57 us against 44-45 for the index-deriving loop).
+inline bool narrow_walks(int mode, int K, int N, int gw) {
+  if (gw % 4 || nlt_wgrad_generic_only()) return false;
+  return !((mode == NLT_CONV_K2S1 || mode == NLT_DECONV_K2S1) && K > 64 && N > 16);
+}
+
 template <int MODE, int MQ, int NT>
 int run_narrowq(WN& w, hipStream_t s) {
   constexpr int MT = 4 * MQ, PER = MT * 16 * NT * 16 + NT * 16;
-  w.zeros = (w.c.gw % 4 == 0 && !nlt_wgrad_generic_only()) ? nlt_zero_page() : nullptr;
+  w.zeros = narrow_walks(MODE, w.K, w.N, w.c.gw) ? nlt_zero_page() : nullptr;
   if (w.zeros)
     hipLaunchKernelGGL((wgrad_narrowq_kernel<MODE, MQ, NT, true>), dim3((unsigned)w.msplits), dim3(256), PER * sizeof(float), s, w);
   else
@@ -561,7 +568,7 @@ int prepare_narrow(WN& w, int mode, const float* src0, int ld0, int c0, const fl
   if (w.K > 128 || w.N > 32) return NLT_ERR_UNSUPPORTED;
   if (w.c.gw < 4) return NLT_ERR_UNSUPPORTED;                          // the incremental row walk assumes >= 4 texels per grid row
   w.dp = dpre; w.ldp = ldp; w.dw = dw; w.db = db;
-  const bool walk = w.c.gw % 4 == 0 && !nlt_wgrad_generic_only();
+  const bool walk = narrow_walks(mode, w.K, w.N, w.c.gw);
   long rows = walk ? (w.c.M + 2047) / 2048 : (w.c.M + 511) / 512;      // walk: ~2048 workgroups (the loads run 5-7 steps ahead;
   if (rows < 256) rows = 256;                                          //  HBM-bound layers want many of them in flight)
   const long unit = walk ? 384 : 16;                                   // walk: every wave's run a whole number of pipeline rounds (6 or 8 steps)
