@@ -569,7 +569,8 @@ int prepare_narrow(WN& w, int mode, const float* src0, int ld0, int c0, const fl
   if (w.c.gw < 4) return NLT_ERR_UNSUPPORTED;                          // the incremental row walk assumes >= 4 texels per grid row
   w.dp = dpre; w.ldp = ldp; w.dw = dw; w.db = db;
   const bool walk = narrow_walks(mode, w.K, w.N, w.c.gw);
-  long rows = walk ? (w.c.M + 2047) / 2048 : (w.c.M + 511) / 512;      // walk: ~2048 workgroups (the loads run 5-7 steps ahead;
+  static const long nwant = [] { const char* e = getenv("NLT_WGRAD_NARROW_WANT"); return e ? atol(e) : 2048l; }();
+  long rows = walk ? (w.c.M + nwant - 1) / nwant : (w.c.M + 511) / 512;   // walk: ~2048 workgroups (the loads run 5-7 steps ahead;
   if (rows < 256) rows = 256;                                          //  HBM-bound layers want many of them in flight)
   const long unit = walk ? 384 : 16;                                   // walk: every wave's run a whole number of pipeline rounds (6 or 8 steps)
   rows = (rows + unit - 1) / unit * unit;

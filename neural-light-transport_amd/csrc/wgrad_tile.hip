@@ -410,7 +410,9 @@ bool fill(WT& w, int mode, long* ws_floats) {
   w.nq = p.N >> 2;
   w.kblocks = (w.kq + 15) / 16;
   w.nblocks = (w.nq + 15) / 16;
-  long want = 1024 / ((long)w.kblocks * w.nblocks);          // ~4 workgroups (16 waves) per CU
+  static const long target = [] { const char* e = getenv("NLT_WGRAD_WANT"); return e ? atol(e) : 512l; }();
+  long want = target / ((long)w.kblocks * w.nblocks);        // ~512 workgroups = the 2 per CU that are resident at once (measured:
+                                                             // 1024 -> 512 takes 4 us off a 35 us mid-network launch: half the slices to reduce)
   if (want < 1) want = 1;
   long rows = (p.M + want - 1) / want;
   if (rows < 256) rows = 256;                                 // >= 16 MFMA steps per wave
