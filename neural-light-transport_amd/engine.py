@@ -241,7 +241,9 @@ class RenderPlan:
             trials += [('lds', 32), ('lds', 64), ('lds', 256 + 32), ('lds', 256 + 64)]
         # split-K: launches with few GEMM rows and a long K (the deep levels; at depth 1024 a 1 x 1-texel level streams 33 MB of
         # weights through 4 rows) need thousands of waves each walking a short K slice to keep HBM busy: up to 128 slices
-        trials += [('splitk', (16 * r + c, ks)) for (r, c) in ((1, 1), (1, 2), (2, 2), (1, 4)) for ks in (4, 8, 16, 32, 64, 128)]
+        mode = os.environ.get('NLT_SPLITK', 'all')                   # 'all' | 'fwd' (forward plans only) | 'off': A/B switch
+        if mode == 'all' or (mode == 'fwd' and not backward):
+            trials += [('splitk', (16 * r + c, ks)) for (r, c) in ((1, 1), (1, 2), (2, 2), (1, 4)) for ks in (4, 8, 16, 32, 64, 128)]
         saved_lds, saved_sk = dict(self.lds_hints), dict(self.splitk_hints)
         for kind, hint in trials:
             self.tile_hints = {'*': hint} if kind == 'tile' else ({'*': hint[0]} if kind == 'splitk' else {})
