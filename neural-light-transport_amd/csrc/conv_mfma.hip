@@ -38,7 +38,7 @@ __host__ __device__ inline int live_taps(const ConvP& p) {
   return ((MODE == NLT_CONV_K2S1 || MODE == NLT_DECONV_K2S1) && p.gh == 1 && p.gw == 1) ? 1 : ConvTraits<MODE>::TAPS;
 }
 
-template <int MODE, int RT, int CT>
+template <int MODE, int RT, int CT, int PF>
 __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvP p, int mtiles, int ngroups, int ntiles, int ksplit,
                                                         float* ws) {
   const int lane = threadIdx.x & 63;
@@ -107,30 +107,74 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvP p, int mtiles, int
 #pragma unroll
     for (int ct = 0; ct < CT; ++ct) a[ct] = wp[(size_t)kci * wstride + ct * 64];
   };
-  f32x4 a_cur[CT], b_cur[RT], a_nxt[CT], b_nxt[RT];
-  int t_n = kbeg / cps, r_n = kbeg - t_n * cps;   // (tap, chunk-in-tap) of the NEXT load
-  if (kbeg < kend) {
-    set_tap(t_n);
-    load_frags(r_n, kbeg, a_cur, b_cur);
-  }
-  for (int kc = kbeg; kc < kend; ++kc) {
-    if (kc + 1 < kend) {
-      if (++r_n == cps) { r_n = 0; set_tap(++t_n); }
-      load_frags(r_n, kc + 1, a_nxt, b_nxt);
+  if constexpr (PF == 2) {
+    f32x4 a_cur[CT], b_cur[RT], a_nxt[CT], b_nxt[RT];
+    int t_n = kbeg / cps, r_n = kbeg - t_n * cps;   // (tap, chunk-in-tap) of the NEXT load
+    if (kbeg < kend) {
+      set_tap(t_n);
+      load_frags(r_n, kbeg, a_cur, b_cur);
     }
+    for (int kc = kbeg; kc < kend; ++kc) {
+      if (kc + 1 < kend) {
+        if (++r_n == cps) { r_n = 0; set_tap(++t_n); }
+        load_frags(r_n, kc + 1, a_nxt, b_nxt);
+      }
 #pragma unroll
-    for (int s4 = 0; s4 < 4; ++s4)
+      for (int s4 = 0; s4 < 4; ++s4)
 #pragma unroll
-      for (int rt = 0; rt < RT; ++rt)
+        for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
-        for (int ct = 0; ct < CT; ++ct)
-          acc[rt][ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_cur[ct][s4], b_cur[rt][s4], acc[rt][ct], 0, 0, 0);
+          for (int ct = 0; ct < CT; ++ct)
+            acc[rt][ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_cur[ct][s4], b_cur[rt][s4], acc[rt][ct], 0, 0, 0);
 #pragma unroll
-    for (int ct = 0; ct < CT; ++ct) a_cur[ct] = a_nxt[ct];
+      for (int ct = 0; ct < CT; ++ct) a_cur[ct] = a_nxt[ct];
 #pragma unroll
-    for (int rt = 0; rt < RT; ++rt) b_cur[rt] = b_nxt[rt];
-  }
+      for (int rt = 0; rt < RT; ++rt) b_cur[rt] = b_nxt[rt];
+    }
 
+  } else {
+    // Fragment loads run PF - 1 chunks ahead of the MFMAs (PF register sets).  With one chunk of lookahead a wave of the
+    // mid-network launches spent 36 % of its cycles waiting for memory and the matrix pipe sat at 0.33 (PMC, level-4
+    // backward-data, 2 waves per SIMD).  Loads stay UNCONDITIONAL (past the slice they re-read its last chunk and the texel
+    // operand is zeroed): a branch around them makes the wait-count insertion drain every outstanding load.
+    f32x4 af[PF][CT], bf[PF][RT];
+    int t_n = kbeg / cps, r_n = kbeg - t_n * cps;   // (tap, chunk-in-tap) of the NEXT load
+    int kload = kbeg;
+    if (kbeg < kend) set_tap(t_n);
+    auto issue = [&](f32x4 (&a)[CT], f32x4 (&b)[RT]) {
+      const bool live = kload < kend;               // wave-uniform
+      if (live && kload > kbeg) {
+        if (++r_n == cps) { r_n = 0; set_tap(++t_n); }
+      }
+      load_frags(r_n, live ? kload : kend - 1, a, b);
+      if (!live) {
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) b[rt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      }
+      ++kload;
+    };
+    auto compute = [&](const f32x4 (&a)[CT], const f32x4 (&b)[RT]) {
+#pragma unroll
+      for (int s4 = 0; s4 < 4; ++s4)
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+          for (int ct = 0; ct < CT; ++ct)
+            acc[rt][ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[ct][s4], b[rt][s4], acc[rt][ct], 0, 0, 0);
+    };
+    if (kbeg < kend) {
+#pragma unroll
+      for (int j = 0; j < PF - 1; ++j) issue(af[j], bf[j]);
+      for (int kc = kbeg; kc < kend; kc += PF) {
+#pragma unroll
+        for (int j = 0; j < PF; ++j) {
+          issue(af[(j + PF - 1) % PF], bf[(j + PF - 1) % PF]);
+          compute(af[j], bf[j]);
+        }
+      }
+    }
+
+  }
   if (ksplit > 1) {                             // raw partial sums -> workspace [ks][M][ntiles*16]; the epilogue pass finishes
     float* part = ws;
     const int npad = ntiles * 16;
@@ -257,7 +301,13 @@ int launch_tile(const ConvP& p, int ksplit, float* ws, hipStream_t s) {
   if (ksplit < 1 || !ws) ksplit = 1;
   const long waves = (long)mtiles * ngroups * ksplit;
   const unsigned blocks = (unsigned)((waves + 3) / 4);
-  hipLaunchKernelGGL((conv_mfma_kernel<MODE, RT, CT>), dim3(blocks), dim3(256), 0, s, p, mtiles, ngroups, ntiles, ksplit, ws);
+  // long K loops (>= 24 sixteen-channel chunks per wave): three register sets, loads two chunks ahead; short ones keep the
+  // two-set loop (a deeper pipeline costs them its prologue and up to two zero-operand rounds: measured slower below ~16 chunks)
+  const int per_wave = (total + ksplit - 1) / ksplit;
+  if (per_wave >= 24)
+    hipLaunchKernelGGL((conv_mfma_kernel<MODE, RT, CT, 3>), dim3(blocks), dim3(256), 0, s, p, mtiles, ngroups, ntiles, ksplit, ws);
+  else
+    hipLaunchKernelGGL((conv_mfma_kernel<MODE, RT, CT, 2>), dim3(blocks), dim3(256), 0, s, p, mtiles, ngroups, ntiles, ksplit, ws);
   if (ksplit > 1) {
     const long items = (long)p.M * (p.N >> 2);
     if (ksplit > 8)
