@@ -112,11 +112,15 @@ class ResidentTexels:
         return tuple(t.data_ptr() for t in (self.diffuse, self.rgb, self.cvis, self.lvis, self.ids, self.nn_ids)) + (self.n, self.k)
 
     def base_float(self, out=None):
-        """base [n,h,w,3] float32 alone (the UV -> camera warp of Model.call needs it)."""
+        """base [n,h,w,3] float32 alone (the UV -> camera warp of Model.call needs it).  With a caller-owned `out`
+        (a buffer the caller shares between batches) the gather is redone every call and nothing is cached here: a
+        cached alias would silently show whatever batch filled that buffer last."""
         if self._float is not None:
             return self._float['base']
+        if out is not None:
+            return C.gather_frames_u8(self.diffuse, self.ids, out=out)
         if self._base is None:
-            self._base = C.gather_frames_u8(self.diffuse, self.ids, out=out)
+            self._base = C.gather_frames_u8(self.diffuse, self.ids)
         return self._base
 
     def materialize(self):
@@ -132,7 +136,7 @@ class Dataset:
     'cvis','lvis' [F,H,W] uint8, 'uv2cam' [F,imh,imw,2] fp16, 'rgb_camspc' [F,imh,imw,3] uint8,
     'complete': [bool]}.  ids follow the reference's '{trainvali|test}_{i:09d}_{cam}_{light}'."""
 
-    def __init__(self, config, mode, store=None, k=1, device='cuda', ring=3):
+    def __init__(self, config, mode, store=None, k=1, device='cuda', ring=0):
         if mode not in ('train', 'vali', 'test'):
             raise ValueError("Invalid mode: {provided}. Allowed modes: {allowed}".format(
                 provided=mode, allowed=('train', 'vali', 'test')))
@@ -142,7 +146,9 @@ class Dataset:
         # Staging ring: load_batch fills one of `ring` persistent buffer sets instead of allocating ~20 fresh tensors per
         # step, so the addresses a batch arrives at repeat every `ring` steps and the model's recorded launch tape (keyed
         # by input addresses) keeps replaying in a real data loop.  A returned batch stays valid for `ring - 1` further
-        # load_batch calls (ring = 0: fresh tensors every call, as the reference's tf.data pipeline hands out).
+        # load_batch calls.  OPT-IN (bench.py, a training loop that consumes each batch before asking for the next): the
+        # default ring = 0 hands out fresh tensors every call, as the reference's tf.data pipeline does, so a vali / vis loop
+        # may keep any number of batches (and the `to_vis` tensors Model.call builds from them).
         self.ring, self._slots, self._turn = int(ring), {}, 0
         self._fstore = self._resized_store()
         self.index = {id_: i for i, id_ in enumerate(store['ids'])}

@@ -709,13 +709,17 @@ class RenderPlan:
             return
         self._wgrad_now(label, layer, src0, c0, ld0, src1, c1, ld1, n, h, w, dpre, ldp)
 
-    def _decoder_grads_queued(self):
+    def _fire_grad_hook(self, side):
+        """Runs `grad_hook` on the stream the expanding blocks' weight gradients were queued on.  `side` is an ARGUMENT
+        of the recorded call (not looked up in `_bside`, whose cursor only exists while a plan is being issued): a
+        launch-tape replay re-invokes this with the same stream the recorded wgrad launches keep, so the collective the
+        hook starts is ordered after them -- on the main stream it would race the side stream's accumulation.
+        Plan-time trial passes (`_tuning`) never fire it: their gradients are garbage and their count differs per rank."""
         hook = self.grad_hook
-        if hook is None:
+        if hook is None or self._tuning:
             return
-        bs = self._bside
-        if bs is not None and bs[2] is not None:                     # the weight gradients are on the side stream: so is the hook
-            with torch.cuda.stream(bs[0]):
+        if side is not None:
+            with torch.cuda.stream(side):
                 hook()
         else:
             hook()
@@ -900,7 +904,8 @@ class RenderPlan:
 
         # every weight gradient of the expanding blocks is queued now: the leading range of the flat gradient
         # bucket (models/nlt.py:_flatten) can start its all-reduce while the encoder's backward runs
-        C.tape_call(self._decoder_grads_queued)
+        bs = self._bside
+        C.tape_call(self._fire_grad_hook, bs[0] if (bs is not None and bs[2] is not None) else None)
 
         # ---- encoder (contracting blocks), deepest first; hh, ww = dims of level D
         for l in range(D, 0, -1):

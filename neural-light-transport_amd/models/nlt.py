@@ -173,6 +173,7 @@ class Model(BaseModel):
                 late.update(id(c) for c in _convs_of(layer))
         order = [c for c in convs if id(c) in late] + [c for c in convs if id(c) not in late]
         where, off = {}, 0
+        self.bucket_split = 0               # (a query net without expanding Sequential blocks: one range)
         for c in order:
             for name in ('kernel', 'bias'):
                 t = getattr(c, name)
@@ -316,6 +317,9 @@ class Model(BaseModel):
         hipGraph): returns (loss summed over this rank's examples / global_bs, to_vis) and leaves the gradients in
         `flat_grads`.  Same arithmetic as `call(batch, 'train')` + `compute_loss` + `.backward()`."""
         id_, base, cvis, lvis, warp, rgb, rgb_camspc, nn_id, nn_base, nn_rgb, nn_rgb_camspc = batch
+        if isinstance(base, ResidentTexels):                     # load_batch(resident=True): training reads the float buffers
+            m = base.materialize()
+            base, cvis, lvis, rgb, nn_base, nn_rgb = (m[x] for x in ('base', 'cvis', 'lvis', 'rgb', 'nn_base', 'nn_rgb'))
         if nn_rgb.dim() == 4:
             nn_rgb, nn_base = nn_rgb.unsqueeze(1), nn_base.unsqueeze(1)
         nn_rgb, nn_base = nn_rgb.contiguous(), nn_base.contiguous()

@@ -38,6 +38,10 @@ class AdamAMSGrad:
         return {'t': self.t, 'm': self.m, 'v': self.v, 'vhat': self.vhat}
 
     def load_state_dict(self, sd):
-        self.t = sd['t']
         for k in ('m', 'v', 'vhat'):
-            getattr(self, k).copy_(sd[k])
+            if not torch.is_tensor(sd.get(k)) or sd[k].numel() != getattr(self, k).numel():
+                raise ValueError("optimizer state '%s' has %s elements, this model's flat bucket has %d"
+                                 % (k, sd[k].numel() if torch.is_tensor(sd.get(k)) else None, getattr(self, k).numel()))
+        self.t = int(sd['t'])
+        for k in ('m', 'v', 'vhat'):
+            getattr(self, k).copy_(sd[k].reshape(getattr(self, k).shape))

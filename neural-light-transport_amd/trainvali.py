@@ -11,10 +11,24 @@ from . import optim
 
 
 def make_optimizer(model, config):
-    """nlt/trainvali.py:122-127."""
+    """nlt/trainvali.py:122-127: `Adam(lr, amsgrad=True, clipnorm=mgm)` when mgm > 0.
+
+    What `clipnorm` DOES in the reference's loop is a property of the pinned TensorFlow 2.2.0 (environment.yml:14), not of
+    the reference's code: the loop calls `tape.gradient` + `optimizer.apply_gradients` (trainvali.py:279-280), and
+    OptimizerV2 2.2 clips only inside `get_gradients` / `_compute_gradients` (the `minimize` path); `apply_gradients` takes
+    the gradients as given.  So, as far as can be established without a TF 2.2 install, mgm > 0 changes NOTHING in the
+    reference's training.  Default here = that run-time behaviour (no clipping, one warning).  The per-variable
+    `tf.clip_by_norm` a reader of the config would expect is built (nlt_clip_by_norm_slots) and OPT-IN: config key
+    `mgm_apply = true` (not a reference key) or NLT_APPLY_CLIPNORM=1.  The released configs set mgm = -1 either way."""
     lr = config.getfloat('DEFAULT', 'lr')
     mgm = config.getfloat('DEFAULT', 'mgm')
-    return optim.AdamAMSGrad(model, lr, clipnorm=mgm if mgm > 0 else None)
+    apply_clip = (config.getboolean('DEFAULT', 'mgm_apply', fallback=False)
+                  or os.environ.get('NLT_APPLY_CLIPNORM', '0') == '1')
+    if mgm > 0 and not apply_clip:
+        import warnings
+        warnings.warn("mgm = %g: TF 2.2's apply_gradients (the reference's train loop) does not apply clipnorm; not clipping. "
+                      "Set mgm_apply = true (or NLT_APPLY_CLIPNORM=1) for per-variable tf.clip_by_norm." % mgm)
+    return optim.AdamAMSGrad(model, lr, clipnorm=mgm if (mgm > 0 and apply_clip) else None)
 
 
 def save_checkpoint(path, model, optimizer, step):
@@ -30,7 +44,7 @@ def save_checkpoint(path, model, optimizer, step):
 def restore_checkpoint(path, model, optimizer=None):
     """Loads what `save_checkpoint` wrote into a built model (and optimizer); returns the global step.  The optimizer may be
     omitted (inference: nlt/nlt_test.py:92-97 restores the net alone)."""
-    ck = torch.load(path, map_location='cpu', weights_only=False)
+    ck = torch.load(path, map_location='cpu', weights_only=True)     # tensors, ints, strings, tuples only: no pickle code runs
     if ck.get('format') != 'nlt_amd-ckpt-1':
         raise ValueError("%s is not an nlt_amd checkpoint" % path)
     model.load_state_dict(ck['net'])

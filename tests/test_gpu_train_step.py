@@ -159,6 +159,60 @@ def test_rccl_two_bucket_overlapped_step_equals_the_single_rank_step(monkeypatch
         dist.destroy_process_group()
 
 
+def test_overlapped_bucket_collective_runs_on_the_weight_gradient_stream_in_replayed_steps_too(monkeypatch):
+    """The first-range gradient collective is started by a hook recorded INSIDE the backward plan.  It has to be queued on
+    the stream the expanding blocks' weight-gradient launches run on (the side stream) -- also when the step is a launch-tape
+    replay, where no plan is being issued and the side-stream cursor does not exist.  A stand-in collective that is NOT an
+    identity (in-place x2 on the stream it is called on, completion = an event on that stream) makes a misplaced hook
+    visible: on the main stream it would double half-accumulated sums.  overlap=True must match overlap=False, and every
+    first-range call of an overlapped step must sit on the side stream."""
+    import torch.distributed as dist
+
+    class Work:
+        def __init__(self):
+            self.ev = torch.cuda.Event()
+            self.ev.record(torch.cuda.current_stream())
+
+        def wait(self):
+            torch.cuda.current_stream().wait_event(self.ev)
+
+    calls = []
+
+    def fake_all_reduce(t, op=None, group=None, async_op=False):
+        calls.append((t.numel(), torch.cuda.current_stream().cuda_stream))
+        if t.numel() > 1:
+            t.mul_(2.0)
+        return Work()
+
+    monkeypatch.setattr(dist, 'all_reduce', fake_all_reduce)
+    monkeypatch.setattr(trainvali, '_world', lambda g: 2)
+    batches = [to_device_batch(*O.synth_batch(2, 128, 128, 64, 64, 64, 64, k=1, seed=90 + i)) for i in range(2)]
+    res = []
+    for overlap in (False, True):
+        _, pm = make_pair(depth=256, uv=128, im=64, loss='l2', seed=13)
+        pm.build('cuda')
+        opt = nlt_amd.optim.AdamAMSGrad(pm, 1e-3)
+        del calls[:]
+        grads = []
+        for i in range(8):
+            trainvali.distributed_train_step(pm, batches[i % 2], opt, 2, overlap=overlap)
+            grads.append(pm.flat_grads.clone())
+        torch.cuda.synchronize()
+        res.append((grads, pm.flat_params.detach().clone(), list(calls), pm.plan.tape_replays, pm.plan._bside, pm.bucket_split))
+    (g0, p0, c0, _, _, _), (g1, p1, c1, replays, bside, split) = res
+    assert replays > 0 and bside is not None
+    main = torch.cuda.current_stream().cuda_stream
+    side = bside[0].cuda_stream
+    assert side != main
+    first = [st for n, st in c1 if n == split]
+    assert len(first) == 8 and all(st == side for st in first), (first, side, main)      # replayed steps included
+    assert all(st == main for n, st in c0)                                              # overlap=False: after the backward
+    assert len(c0) == len(c1) == 8 * 3
+    for a, b in zip(g0, g1):
+        assert float((a - b).norm() / a.norm()) < 1e-5
+    assert float((p0 - p1).abs().max()) < 2e-5
+
+
 @pytest.mark.parametrize('loss', ['l2', 'barron'])
 def test_full_size_gradient_agrees_with_directional_finite_differences(loss):
     """BASELINE config 4's per-GPU shape (1024^2 UV, 512^2 camera; 2 frames here), a size-independent property check

@@ -132,6 +132,21 @@ def test_checkpoint_save_restore_resumes_training_bit_for_bit(monkeypatch, tmp_p
     deep.build('cpu')
     with pytest.raises(ValueError, match='different architecture'):
         trainvali.restore_checkpoint(path, deep)
+    # optimizer slots of another size are refused before anything is overwritten; a resident batch trains like its float twin
+    sd = opt.state_dict()
+    sd['v'] = sd['v'][:100]
+    with pytest.raises(ValueError, match="optimizer state 'v'"):
+        opt2.load_state_dict(sd)
+    # the file is loaded with weights_only=True: a pickle that would run code is refused
+    import pickle
+
+    class Evil:
+        def __reduce__(self):
+            return (print, ('code ran',))
+    bad = str(tmp_path / 'evil.pt')
+    torch.save({'format': 'nlt_amd-ckpt-1', 'step': 1, 'net': Evil(), 'optimizer': None}, bad)
+    with pytest.raises(pickle.UnpicklingError):
+        trainvali.restore_checkpoint(bad, pm3)
 
 
 def test_backward_after_a_later_forward_raises(monkeypatch):
@@ -169,6 +184,10 @@ def test_clipnorm_train_step_matches_oracle(monkeypatch):
     pm.config.set('DEFAULT', 'mgm', '1e-3')
     batch, nn = O.synth_batch(2, 64, 64, 32, 32, 32, 32, k=1, seed=41)
     opt_o = O.KerasAdamAMSGrad(om.parameters(), 1e-3)
+    # default = what TF 2.2's tape.gradient + apply_gradients loop does with clipnorm: nothing (a warning says so)
+    with pytest.warns(UserWarning, match='does not apply clipnorm'):
+        assert trainvali.make_optimizer(pm, pm.config).clipnorm is None
+    pm.config.set('DEFAULT', 'mgm_apply', 'true')               # opt-in: per-variable tf.clip_by_norm
     opt_p = trainvali.make_optimizer(pm, pm.config)
     assert opt_p.clipnorm == 1e-3
     clipped = 0
