@@ -277,6 +277,22 @@ int nlt_pixelnorm_backward(const float* g, const float* x, long texels, int c, f
 int nlt_pool2x2_forward(const float* x, int n, int h, int w, int c, int kind, float* y, void* stream);
 int nlt_pool2x2_backward(const float* g, const float* x, int n, int h, int w, int c, int kind, float* dx, void* stream);
 
+/* norm = layer / batch (nlt/networks/elements.py:51-56; between every conv and its activation, convnet.py:50-59,67-76),
+ * per texel over its c channels (NHWC fp32, c <= 1024):  y[ch] = (x[ch] - m) * r * gamma[ch] + beta[ch]
+ *   kind 0  tf.keras.layers.LayerNormalization(epsilon, center, scale): m = mean_ch(x), r = rsqrt(biased var_ch(x) + eps);
+ *   kind 1  tf.keras.layers.BatchNormalization(momentum=0.99, epsilon) in INFERENCE mode -- the mode the reference's loop
+ *           runs it in (no `training=True` anywhere under nlt/: networks/seq.py:36-41, models/nlt.py:154-195), so
+ *           m = mean[ch] (moving_mean), r = rsqrt(var[ch] + eps) (moving_variance), both never updated.
+ * backward: dx, and dgamma / dbeta ACCUMULATED (+=) in a fixed order (per-workgroup partial rows in `workspace`,
+ * nlt_norm_workspace_floats(texels, c) floats; -1: unsupported c).  mean / var may be NULL for kind 0.
+ *   replaces: elements.norm('layer' | 'batch') layers and their gradients under nlt/trainvali.py:272-280. */
+long nlt_norm_workspace_floats(long texels, int c);
+int nlt_norm_forward(int kind, const float* x, long texels, int c, const float* gamma, const float* beta,
+                     const float* mean, const float* var, float eps, float* y, void* stream);
+int nlt_norm_backward(int kind, const float* g, const float* x, long texels, int c, const float* gamma,
+                      const float* mean, const float* var, float eps, float* dx, float* dgamma, float* dbeta,
+                      float* workspace, void* stream);
+
 /* Keras `clipnorm` (config key mgm > 0): every variable's gradient g -> g * clip / max(||g||_2, clip)
  * (tf.clip_by_norm, multiply then divide), in place, over the slots of the flat gradient bucket.
  * slots: device int64 [n_slots][2] = (first element, element count) of each kernel / bias.

@@ -68,6 +68,9 @@ SIGNATURES = {
     'nlt_pixelnorm_backward': (_c_int, [_vp, _vp, _c_long, _c_int, _c_float, _vp, _vp]),
     'nlt_pool2x2_forward': (_c_int, [_vp, _c_int, _c_int, _c_int, _c_int, _c_int, _vp, _vp]),
     'nlt_pool2x2_backward': (_c_int, [_vp, _vp, _c_int, _c_int, _c_int, _c_int, _c_int, _vp, _vp]),
+    'nlt_norm_workspace_floats': (_c_long, [_c_long, _c_int]),
+    'nlt_norm_forward': (_c_int, [_c_int, _vp, _c_long, _c_int, _vp, _vp, _vp, _vp, _c_float, _vp, _vp]),
+    'nlt_norm_backward': (_c_int, [_c_int, _vp, _vp, _c_long, _c_int, _vp, _vp, _vp, _c_float, _vp, _vp, _vp, _vp, _vp]),
     'nlt_clip_by_norm_slots': (_c_int, [_vp, _vp, _c_int, _c_float, _vp]),
     'nlt_adam_amsgrad_step': (_c_int, [_vp] * 5 + [_c_long] + [_c_float] * 4 + [_vp]),
     'nlt_front_packed_floats': (_c_long, []),
@@ -542,6 +545,33 @@ def pixelnorm_backward(g, x, eps=1e-8):
     c = x.shape[-1]
     _check(lib().nlt_pixelnorm_backward(_ptr(_dense(g, 'g')), _ptr(_dense(x, 'x')), x.numel() // c, c, float(eps), _ptr(dx), _stream()),
            'nlt_pixelnorm_backward')
+    return dx
+
+
+NORM_LAYER, NORM_BATCH = 0, 1
+
+
+def norm_forward(kind, x, gamma, beta, mean, var, eps):
+    """LayerNormalization (kind 0) / inference-mode BatchNormalization (kind 1) over the channel axis of x [..., c]."""
+    c = x.shape[-1]
+    y = torch.empty_like(x)
+    _check(lib().nlt_norm_forward(kind, _ptr(_dense(x, 'x')), x.numel() // c, c, _ptr(gamma), _ptr(beta), _ptr(mean), _ptr(var),
+                                  float(eps), _ptr(y), _stream()), 'nlt_norm_forward')
+    return y
+
+
+def norm_backward(kind, g, x, gamma, mean, var, eps, dgamma, dbeta):
+    """dx; dgamma / dbeta are ACCUMULATED into the given views (of the flat gradient bucket)."""
+    _same_shape(g, x, 'norm_backward')
+    c = x.shape[-1]
+    texels = x.numel() // c
+    need = lib().nlt_norm_workspace_floats(texels, c)
+    if need < 0:
+        raise NLTError("norm over %d channels (the kernel takes c <= 1024)" % c)
+    ws = _workspace('norm', x.device, need)
+    dx = torch.empty_like(x)
+    _check(lib().nlt_norm_backward(kind, _ptr(_dense(g, 'g')), _ptr(_dense(x, 'x')), texels, c, _ptr(gamma), _ptr(mean), _ptr(var),
+                                   float(eps), _ptr(dx), _ptr(dgamma), _ptr(dbeta), _ptr(ws), _stream()), 'nlt_norm_backward')
     return dx
 
 

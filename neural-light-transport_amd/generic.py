@@ -1,6 +1,6 @@
 """Layer-by-layer execution of the two-path U-Net with a hand-rolled backward tape: the path for the config branches the
-fused RenderPlan does not cover (act = elu, norm = pixel, pool = max / avg and the `upconv` that comes with pooling --
-nlt/networks/elements.py:42-48,69-94,103-121; nlt/networks/convnet.py:50-76).
+fused RenderPlan does not cover (act = elu, norm = pixel / layer / batch, pool = max / avg and the `upconv` that comes with
+pooling -- nlt/networks/elements.py:42-56,69-94,103-121; nlt/networks/convnet.py:50-76).
 
 It follows Model._call statement for statement (nlt/models/nlt.py:141-199: per-layer observation maps, their mean,
 concat with the query map, the skip stack, the bottleneck self-concat) on the generic layer objects of
@@ -12,7 +12,7 @@ These branches are about coverage, not speed; the released configs never come he
 import torch
 
 from . import _capi as C
-from .networks.elements import Act, Conv2D, Identity, PixelNorm, Pool2D, Sequential, UpSample2D
+from .networks.elements import Act, ChannelNorm, Conv2D, Identity, PixelNorm, Pool2D, Sequential, UpSample2D
 
 
 class Node:
@@ -136,7 +136,7 @@ def run_layer(tape, layer, x):
             x = run_layer(tape, l, x)
         elif isinstance(l, Act):
             x = unary(tape, l, x, saved='output')
-        elif isinstance(l, (PixelNorm, Pool2D, UpSample2D)):
+        elif isinstance(l, (PixelNorm, ChannelNorm, Pool2D, UpSample2D)):   # (ChannelNorm.backward also adds dgamma / dbeta)
             x = unary(tape, l, x)
         elif not isinstance(l, Identity):
             raise NotImplementedError(type(l).__name__)

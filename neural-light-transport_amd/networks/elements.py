@@ -4,8 +4,9 @@ executed by libnlt_hip.so.  Weights live in Keras layouts (conv: (kh,kw,Cin,Cout
 
 The released-config branch (conv, deconv, leakyrelu / relu, iden, norm / pool 'none') runs on the fused RenderPlan
 (engine.py).  act = elu, norm = pixel, pool = max / avg and `upconv` are stand-alone layers executed layer by layer
-(generic.py; csrc/branches.hip).  norm = batch / layer / instance raise NotImplementedError: they add trainable
-variables the flat bucket / checkpoint layout does not carry (and `instance` is tf.contrib, absent from TF 2.2).
+(generic.py; csrc/branches.hip), and so are norm = layer / batch (csrc/norms.hip), whose gamma / beta are two more
+slots per layer of the model's flat parameter bucket.  norm = instance raises NotImplementedError: it is tf.contrib,
+which TF 2.2 does not have -- the reference itself cannot run it.
 """
 import math
 
@@ -249,6 +250,70 @@ class PixelNorm(Layer):
         return C.pixelnorm_backward(g.contiguous(), x, self.eps)
 
 
+class ChannelNorm(Layer):
+    """norm = 'layer' | 'batch' (elements.py:51-56), per texel over the channel axis: y = (x - m) r gamma + beta.
+
+    layer: tf.keras.layers.LayerNormalization(epsilon=0.001, center=True, scale=True) -- m, r from the texel's own channels.
+    batch: tf.keras.layers.BatchNormalization(momentum=0.99, epsilon=0.001) the way the reference's loop executes it.
+      Nothing under nlt/ passes `training=True` (networks/seq.py:36-41, models/nlt.py:154-195 call `layer(x)`), so Keras
+      runs the layer in inference mode in train, vali and test alike: m = moving_mean, r = rsqrt(moving_variance + eps),
+      and the moving statistics keep their initial values (0, 1) for ever, because only training-mode calls update them.
+      gamma / beta are trainable and do get gradients.  (A driver that did pass training=True would need batch statistics
+      and, data-parallel, a cross-replica mean: not what the reference does.)
+    Variables in Keras order: gamma (ones), beta (zeros) [, moving_mean (zeros), moving_variance (ones): not trainable].
+    `kernel` / `bias` alias gamma / beta so that the flat-bucket slot code treats a norm like any other two-variable layer."""
+    eps = 1.0e-3
+
+    def __init__(self, kind):
+        self.kind = C.NORM_LAYER if kind == 'layer' else C.NORM_BATCH
+        self.name = kind
+        self.built = False
+        self.kernel = self.bias = self.dkernel = self.dbias = None
+        self.moving_mean = self.moving_variance = None
+        self.c = None
+        self._epoch = [0]
+        self._packed = {}
+        self._registry = None
+
+    gamma = property(lambda self: self.kernel)
+    beta = property(lambda self: self.bias)
+
+    def build(self, cin, device='cuda'):
+        if not self.built:
+            self.kernel = torch.ones(cin, device=device)
+            self.bias = torch.zeros(cin, device=device)
+            self.c, self.built = cin, True
+        if self.kind == C.NORM_BATCH and self.moving_mean is None:
+            self.moving_mean = torch.zeros(cin, device=device)
+            self.moving_variance = torch.ones(cin, device=device)
+        return cin
+
+    def set_weights(self, gamma, beta):
+        gamma = torch.as_tensor(gamma, dtype=torch.float32)
+        beta = torch.as_tensor(beta, dtype=torch.float32)
+        if self.built and tuple(gamma.shape) == tuple(self.kernel.shape):
+            with torch.no_grad():
+                self.kernel.copy_(gamma)
+                self.bias.copy_(beta)
+        else:
+            dev = self.kernel.device if self.built else 'cuda'
+            self.kernel, self.bias = gamma.to(dev).contiguous(), beta.to(dev).contiguous()
+            self.c, self.built = gamma.numel(), True
+            self.build(self.c, dev)
+
+    def variables(self):
+        return [self.kernel, self.bias]
+
+    def __call__(self, x):
+        self.build(x.shape[-1], x.device)
+        return C.norm_forward(self.kind, x.contiguous(), self.kernel.detach(), self.bias.detach(), self.moving_mean,
+                              self.moving_variance, self.eps)
+
+    def backward(self, g, x):
+        return C.norm_backward(self.kind, g.contiguous(), x, self.kernel.detach(), self.moving_mean, self.moving_variance, self.eps,
+                               self.dkernel, self.dbias)
+
+
 class Pool2D(Layer):
     """MaxPooling2D / AveragePooling2D(pool_size=2, strides=2, padding='same') (elements.py:81-94)."""
 
@@ -296,14 +361,15 @@ class Sequential(Layer):
     def variables(self):
         return [v for l in self.layers for v in l.variables()]
 
-    def all_convs(self):
-        """Every Conv2D inside, nested Sequentials (upconv) included, in execution order."""
+    def all_convs(self, norms=True):
+        """Every layer with variables inside -- Conv2D (kernel, bias) and, with norms=True, ChannelNorm (gamma, beta) --
+        nested Sequentials (upconv) included, in execution order = the order Keras lists the block's variables in."""
         out = []
         for l in self.layers:
-            if isinstance(l, Conv2D):
+            if isinstance(l, Conv2D) or (norms and isinstance(l, ChannelNorm)):
                 out.append(l)
             elif isinstance(l, Sequential):
-                out += l.all_convs()
+                out += l.all_convs(norms)
         return out
 
     def is_plain(self):
@@ -352,9 +418,11 @@ def norm(type_):
         return iden()
     if type_ == 'pixel':
         return PixelNorm()
-    if type_ in ('batch', 'layer', 'instance'):
-        raise NotImplementedError("norm = %s: trainable gamma / beta (and, for batch, moving statistics) are not carried by "
-                                  "the flat parameter bucket; `instance` is tf.contrib, which TF 2.2 does not have" % type_)
+    if type_ in ('batch', 'layer'):
+        return ChannelNorm(type_)
+    if type_ == 'instance':
+        raise NotImplementedError("norm = instance is tf.contrib.layers.instance_norm (elements.py:97-100): TF 2.2, the "
+                                  "reference's pinned version, has no tf.contrib -- the reference cannot run it either")
     raise NotImplementedError(type_)
 
 

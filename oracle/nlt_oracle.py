@@ -139,11 +139,18 @@ def apply_layer_bf16(L, w, x, alpha, keep_fp32_out=False):
     return z if keep_fp32_out else rb(z)
 
 
-def apply_layer(L, w, x, alpha=T.LRELU_ALPHA, norm=None, pool=None, act='leakyrelu'):
+def apply_layer(L, w, x, alpha=T.LRELU_ALPHA, norm=None, pool=None, act='leakyrelu', masks=None):
     """One entry of Network.layers (convnet.py:44,50-59,67-76,85); alpha = negative slope (lrelu / relu) or ELU's alpha;
-    norm in (None, 'pixel'); pool in (None, 'max', 'avg') -- with pooling the expanding blocks start with `upconv`."""
+    norm in (None, 'pixel'); pool in (None, 'max', 'avg') -- with pooling the expanding blocks start with `upconv`.
+    masks (test instrument, LeakyReLU / ReLU only): one boolean tensor per activation of the block, True where the
+    activation takes its positive branch -- `where(mask, v, alpha * v)` instead of deciding on v's own sign (see
+    OracleModel.act_masks)."""
     nrm = (lambda v: pixel_norm(v)) if norm == 'pixel' else (lambda v: v)
     a = (lambda v: torch.nn.functional.elu(v, alpha)) if act == 'elu' else (lambda v: T.leaky_relu(v, alpha))
+    if masks is not None:
+        assert act != 'elu'
+        it = iter(masks)
+        a = lambda v: torch.where(next(it), v, alpha * v)
     if L['kind'] == 'conv1x1':
         return T.conv2d_same(x, w[0][0], w[0][1], 1)
     if L['kind'] == 'down':
@@ -169,6 +176,12 @@ class OracleModel:
         # precision = 'bf16' (BASELINE config 5): layers [3, n_layers - 4] -- encoder levels >= 3 and the expanding blocks
         # with >= 64 input channels -- on bf16 operands / bf16 storage, fp32 accumulation (csrc/conv_bf16.hip)
         self.bf16_layers = None
+        # Test instrument for gradient parity (not reference behaviour): {('q', layer) | ('o', layer, obs index): (mask of the
+        # block's first activation, mask of its second)} -- the branch every LeakyReLU takes is DICTATED (the sign pattern of
+        # the implementation under test) instead of decided by this model's own pre-activations.  LeakyReLU's derivative is
+        # discontinuous: two correct evaluations that round a pre-activation to opposite sides of zero get gradients that
+        # differ by a whole texel's contribution.  With the masks shared, what remains is accumulation error only.
+        self.act_masks = None
         self.uvh, self.uvw, self.imh, self.imw = uvh, uvw, imh, imw
         self.use_obs, self.skip_connect_base = use_obs, skip_connect_base
         self.loss_spec = loss
@@ -199,11 +212,14 @@ class OracleModel:
         self.bf16_layers = (3, n - 4) if precision == 'bf16' else None     # depth 256: layers 3 .. 10 of 14
         return self
 
-    def _layer(self, i, L, w, x):
+    def _layer(self, i, L, w, x, path=('q',)):
         r = self.bf16_layers
         if r is not None and r[0] <= i <= r[1]:
             return apply_layer_bf16(L, w, x, self.alpha, keep_fp32_out=(i == r[1]))
-        return apply_layer(L, w, x, self.alpha, self.norm, self.pool, self.act)
+        masks = None
+        if self.act_masks is not None and L['kind'] != 'conv1x1':
+            masks = self.act_masks[(path[0], i) + tuple(path[1:])]
+        return apply_layer(L, w, x, self.alpha, self.norm, self.pool, self.act, masks=masks)
 
     def _call(self, query_x, obs_xs, obs_weights=None, obs_override=None, return_feats=False, layer_outputs=None):
         """layer_outputs: a list that receives the query path's output of every layer (tests of intermediate maps)."""
@@ -214,7 +230,7 @@ class OracleModel:
         query_y = None
         for i, (L, c) in enumerate(zip(self.layers, self.is_contracting)):
             if c:
-                obs_ys = [self._layer(i, L, self.wo[i], x) for x in obs_xs]              # :154-155
+                obs_ys = [self._layer(i, L, self.wo[i], x, ('o', j)) for j, x in enumerate(obs_xs)]   # :154-155
                 obs_agg = torch.stack(obs_ys, -1)                               # :161
                 if obs_weights is not None:
                     obs_agg = obs_weights * obs_agg                             # :162-163

@@ -33,3 +33,21 @@ def to_device_batch(batch, nn_list, device='cuda'):
     out = [dev(t) if torch.is_tensor(t) else t for t in b]
     out[8], out[9] = dev(nn_base), dev(nn_rgb)
     return tuple(out)
+
+
+def hip_activation_masks(pm, dtype=torch.bool):
+    """The branch every LeakyReLU of the LAST TRAIN FORWARD took on the HIP side, in OracleModel.act_masks' keys: read off
+    the post-activation maps the plan keeps for its backward pass (y > 0 <=> pre-activation > 0 for alpha >= 0; the
+    backward kernels test exactly `y > 0`).  Level l: qtmp[l] / fm[l][..., :C] (query), otmp[l][:, j] / obs[l][:, j]
+    (observation j); expanding block j: dtmp[j] / dec[j]."""
+    (b,) = pm.plan._bufs.values()
+    D, U, cl = pm.plan.n_down, pm.plan.n_up, b['C']
+    cpu = lambda t: (t > 0).cpu()
+    masks = {}
+    for l in range(1, D + 1):
+        masks[('q', l)] = (cpu(b['qtmp'][l]), cpu(b['fm'][l][..., :cl[l]]))
+        for j in range(b['obs'][l].shape[1]):
+            masks[('o', l, j)] = (cpu(b['otmp'][l][:, j]), cpu(b['obs'][l][:, j]))
+    for j in range(U):
+        masks[('q', D + 1 + j)] = (cpu(b['dtmp'][j]), cpu(b['dec'][j]))
+    return masks

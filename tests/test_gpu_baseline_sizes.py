@@ -24,15 +24,15 @@ pytestmark = pytest.mark.gpu
 TOL = 1e-4
 # Bounds on train-step gradients vs the FLOAT64 oracle:
 #   flat gradient bucket (what the all-reduce and Adam see)          <= 1e-5 rel-L2 (measured 1e-7)
-#   every single kernel / bias, kink-free network (alpha = 1)        <= GRAD_TOL_SMOOTH (measured 1e-6; the fp32 torch-CPU
-#       oracle itself sits at 1.4e-5 .. 1.9e-5 from float64 on its worst tensor)
-#   every single kernel / bias, released LeakyReLU(0.3)              <= max(GRAD_TOL_KINK, 3 x what the fp32 torch-CPU
-#       oracle itself is away from float64 on its worst tensor): derivative-mask flips of the few texels whose
-#       pre-activation is within fp32 rounding of zero.  Whether a flip lands on a tensor is chance; at a 32^2-texel deep
-#       layer under the Barron loss ONE flipped texel moved a 256-channel kernel gradient by 2.4e-3 (measured, r02).
+#   every single kernel / bias                                       <= GRAD_TOL_TENSOR
+# For the released LeakyReLU(0.3) the per-tensor comparison is MASK-CONDITIONED: the float64 oracle takes, at every
+# activation, the branch the HIP forward took (`OracleModel.act_masks` <- `gpu_util.hip_activation_masks`).  LeakyReLU's
+# derivative is discontinuous, so two correct forwards that round a pre-activation to opposite sides of zero differ by one
+# whole texel's contribution to a gradient (r02: 2.4e-3 on a 256-channel kernel of a 32^2-texel level) -- that is a
+# property of the function, not an error of either side, and with the branches shared what is left is accumulation error.
+# (alpha = 1 needs no conditioning: the activation is the identity.)
 GRAD_TOL_FLAT = 1e-5
-GRAD_TOL_SMOOTH = 1e-5
-GRAD_TOL_KINK = 5e-3
+GRAD_TOL_TENSOR = 1e-5
 DUMP = os.environ.get('NLT_PARITY_DUMP')
 
 
@@ -91,6 +91,49 @@ def test_config1_depth1024_256_4_frames():
     _forward_vs_oracle('config1_d1024_256_k1_n4', 1024, 256, 256, 4, 1, True, seed=1)
 
 
+@pytest.mark.parametrize('n', [1, 2])
+def test_config5_2048_fp32_and_bf16(n):
+    """BASELINE config 5's size: depth 256, 2048^2 UV, k = 1, 512^2 random fg/bg warp, 1 and 2 frames (the bench's
+    `config5_2048_bf16` sub-line runs 2).  The plan-time choices (wave tile, split-K, LDS-tiled vs register-tiled kernel)
+    depend on size, so the launch configurations the sub-line is measured with are exactly the ones compared here.
+      fp32 plan   vs the fp32 oracle: rendered texels <= 1e-4 rel-L2, UV gather indices bit-exact;
+      bf16 middle vs OracleModel.set_precision('bf16') (same operands rounded to bf16 at the same places, fp32
+      accumulation): <= 5e-3 on the map leaving the bf16 region, <= 1e-4 on the rendered texels (DESIGN.md section 3;
+      tests/test_gpu_bf16.py states the same bars at 128^2 / 256^2); the distance to the fp32 oracle is recorded."""
+    import nlt_amd
+    from nlt_amd.models import get_model_class
+    uv, cam = 2048, 512
+    pm, db, o_vis = _forward_vs_oracle('config5_2048_k1_n%d_fp32' % n, 256, uv, cam, n, 1, False, seed=50 + n)
+    # same weights, same batch, bf16 middle
+    om = O.OracleModel(depth=256, uvh=uv, uvw=uv, imh=cam, imw=cam, seed=50 + n)
+    batch, nn = O.synth_batch(n, uv, uv, cam, cam, cam, cam, k=1, seed=150 + n)
+    pb = get_model_class('nlt')(nlt_amd.make_config(depth=256, uvh=uv, uvw=uv, imh=cam, imw=cam, precision='bf16'))
+    pb.load_weights(om.numpy_weights())
+    pb.register_trainable()
+    om.set_precision('bf16')
+    outs = []
+    with torch.no_grad():
+        om._call(torch.cat((batch[1], batch[2], batch[3]), 3), [r - b for b, r in nn], layer_outputs=outs)
+        o16_c, _, _, o16 = om.call(batch, 'test', nn_list=nn)
+    for _ in range(3):
+        p_c, _, _, p_vis = pb.call(db, 'test', want_indices=True)
+    torch.cuda.synchronize()
+    bufs = next(iter(pb.plan._bufs.values()))
+    D = pb.plan.n_down
+    assert bufs['fm'][3].dtype == torch.bfloat16 and bufs['dec'][D - 3].dtype == torch.float32
+    e_region = rel_l2(bufs['dec'][D - 3].cpu(), outs[D + 1 + D - 3])
+    e16_uv, e16_cam = rel_l2(p_vis['pred'].cpu(), o16['pred']), rel_l2(p_c.cpu(), o16_c)
+    e32_uv = rel_l2(p_vis['pred'].cpu(), o_vis['pred'])
+    _dump('config5_2048_k1_n%d_bf16' % n, {'rel_l2_region_out_vs_bf16_oracle': e_region, 'rel_l2_pred_uv_vs_bf16_oracle': e16_uv,
+                                           'rel_l2_pred_camspc_vs_bf16_oracle': e16_cam, 'rel_l2_pred_uv_vs_fp32_oracle': e32_uv})
+    assert e_region <= 5e-3 and e16_uv <= TOL and e16_cam <= TOL, (e_region, e16_uv, e16_cam)
+    fx, fy, inside = T.resampler_indices(o16['warp_px'].numpy(), uv, uv)
+    idx = p_vis['uv_indices'].cpu().numpy()
+    np.testing.assert_array_equal(idx[..., 0], fx)
+    np.testing.assert_array_equal(idx[..., 1], fy)
+    np.testing.assert_array_equal(idx[..., 2], inside.astype(np.int32))
+
+
 def _set_alpha(om, pm, alpha):
     """Same negative slope on both sides (alpha = 1: LeakyReLU becomes the identity -- a kink-free network)."""
     from nlt_amd.networks.elements import Act, Sequential
@@ -103,10 +146,11 @@ def _set_alpha(om, pm, alpha):
                         l.alpha = alpha
 
 
-def _oracle_grads(loss, uv, cam, n, dtype, batch, nn, alpha=None):
+def _oracle_grads(loss, uv, cam, n, dtype, batch, nn, alpha=None, masks=None):
     om = O.OracleModel(depth=256, uvh=uv, uvw=uv, imh=cam, imw=cam, loss=loss, seed=41, dtype=dtype)
     if alpha is not None:
         om.alpha = alpha
+    om.act_masks = masks
     b = tuple(t.to(dtype) if torch.is_tensor(t) else t for t in batch)
     nnl = [(a.to(dtype), c.to(dtype)) for a, c in nn]
     po, go, _, _ = om.call(b, 'train', nn_list=nnl)
@@ -115,25 +159,39 @@ def _oracle_grads(loss, uv, cam, n, dtype, batch, nn, alpha=None):
     return float(lo.detach()), grads
 
 
-@pytest.mark.parametrize('alpha', [0.3, 1.0])
-@pytest.mark.parametrize('loss', ['l2', 'barron'])
-def test_config4_train_step_1024_per_tensor_gradients(loss, alpha):
-    """BASELINE config 4's per-GPU shape (1024^2 UV, 512^2 camera, k = 1; one frame): loss and EVERY weight / bias
-    gradient of one train step against the oracle's float64 autograd (nlt/trainvali.py:272-281).
+def _per_tensor(pm, grads):
+    it = iter(grads)
+    names, errs = [], []
+    num = den = 0.0
+    for li, c in enumerate(pm._conv_layers()):
+        for nm in ('dkernel', 'dbias'):
+            g = next(it)
+            got = getattr(c, nm).detach().cpu().double()
+            d = float((got - g).norm())
+            r = float(g.norm())
+            num += d * d; den += r * r
+            names.append('conv%d.%s%s' % (li, nm, tuple(g.shape)))
+            errs.append(d / max(r, 1e-300))
+    return (num / den) ** 0.5, sorted(zip(errs, names), reverse=True)[:8]
 
-    alpha = 0.3 is the released LeakyReLU.  Its derivative is discontinuous, so ANY fp32 forward flips the mask of
-    the few texels whose pre-activation is within fp32 rounding of zero; the fp32 torch-CPU oracle itself is
-    0.4-1.0e-3 away from the float64 oracle on single tensors (asserted below, beside the HIP numbers).  alpha = 1.0
-    turns the activation into the identity: no kinks, and every tensor has to agree to GRAD_TOL_SMOOTH."""
+
+@pytest.mark.parametrize('loss,alpha,n', [('l2', 0.3, 1), ('barron', 0.3, 1), ('l2', 1.0, 1), ('barron', 1.0, 1), ('l2', 0.3, 4)])
+def test_config4_train_step_1024_per_tensor_gradients(loss, alpha, n):
+    """BASELINE config 4's per-GPU shape (1024^2 UV, 512^2 camera, k = 1; n = 4 frames is exactly what bench.py trains):
+    loss and EVERY weight / bias gradient of one train step against the oracle's float64 autograd
+    (nlt/trainvali.py:272-281), every tensor <= 1e-5.
+
+    alpha = 0.3 is the released LeakyReLU: compared against the float64 oracle evaluated on the HIP forward's own
+    activation branches (see GRAD_TOL_TENSOR above); the unconditioned float64 oracle still has to give the same loss and
+    the same flat bucket to 1e-5.  alpha = 1.0 is the kink-free twin and needs no conditioning."""
+    from gpu_util import hip_activation_masks
     torch.set_num_threads(min(os.cpu_count() or 1, 64))
-    uv, cam, n = 1024, 512, 1
+    uv, cam = 1024, 512
     om32, pm = make_pair(depth=256, uv=uv, im=cam, loss=loss, seed=41)
     _set_alpha(om32, pm, alpha)
     pm.build('cuda')
     batch, nn = O.synth_batch(n, uv, uv, cam, cam, cam, cam, k=1, seed=141)
     lo, grads = _oracle_grads(loss, uv, cam, n, torch.float64, batch, nn, alpha)
-    _, grads32 = _oracle_grads(loss, uv, cam, n, torch.float32, batch, nn, alpha)
-    o32_worst = max(float((a - b).norm() / b.norm()) for a, b in zip(grads32, grads))
 
     db = to_device_batch(batch, nn)
     recs = []
@@ -144,25 +202,21 @@ def test_config4_train_step_1024_per_tensor_gradients(loss, alpha):
         lp.backward()
         torch.cuda.synchronize()
         assert abs(float(lp.detach()) - lo) <= 1e-5 * abs(lo), (loss, float(lp.detach()), lo)
-        it = iter(grads)
-        names, errs = [], []
-        num = den = 0.0
-        for li, c in enumerate(pm._conv_layers()):
-            for nm in ('dkernel', 'dbias'):
-                g = next(it)
-                got = getattr(c, nm).detach().cpu().double()
-                d = float((got - g).norm())
-                r = float(g.norm())
-                num += d * d; den += r * r
-                names.append('conv%d.%s%s' % (li, nm, tuple(g.shape)))
-                errs.append(d / max(r, 1e-300))
-        recs.append({'loss_hip': float(lp.detach()), 'loss_oracle_f64': lo, 'flat_rel': (num / den) ** 0.5,
-                     'fp32_oracle_worst_tensor_vs_f64': o32_worst,
-                     'worst': sorted(zip(errs, names), reverse=True)[:8]})
-    _dump('config4_train_1024_%s_alpha%g' % (loss, alpha), recs[-1])
+        flat, worst = _per_tensor(pm, grads)
+        rec = {'loss_hip': float(lp.detach()), 'loss_oracle_f64': lo, 'flat_rel': flat, 'worst_unconditioned': worst}
+        if alpha != 1.0:
+            masks = hip_activation_masks(pm)
+            lo_m, grads_m = _oracle_grads(loss, uv, cam, n, torch.float64, batch, nn, alpha, masks=masks)
+            flat_m, worst_m = _per_tensor(pm, grads_m)
+            rec.update({'loss_oracle_f64_hip_masks': lo_m, 'flat_rel_hip_masks': flat_m, 'worst_hip_masks': worst_m})
+            assert abs(float(lp.detach()) - lo_m) <= 1e-5 * abs(lo_m)
+        recs.append(rec)
+        if n > 1:
+            break                                           # (the 4-frame float64 oracle pass is the expensive part)
+    _dump('config4_train_1024_%s_alpha%g_n%d' % (loss, alpha, n), recs[-1])
     for r in recs:
         assert r['flat_rel'] <= GRAD_TOL_FLAT, (loss, r['flat_rel'])
-        if alpha == 1.0:
-            assert r['worst'][0][0] <= GRAD_TOL_SMOOTH, (loss, r['worst'][:4])
-        else:
-            assert r['worst'][0][0] <= max(GRAD_TOL_KINK, 3 * o32_worst), (loss, o32_worst, r['worst'][:4])
+        worst = r['worst_unconditioned'] if alpha == 1.0 else r['worst_hip_masks']
+        assert worst[0][0] <= GRAD_TOL_TENSOR, (loss, alpha, worst[:4])
+        if alpha != 1.0:
+            assert r['flat_rel_hip_masks'] <= GRAD_TOL_FLAT

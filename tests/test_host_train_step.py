@@ -227,3 +227,43 @@ def test_train_step_without_observation_path(monkeypatch):
                 assert g is not None and float((got - g).norm()) <= 2e-4 * float(g.norm()), (i, name)
             else:
                 assert g is None and not got.any(), (i, name)
+
+
+def test_mask_conditioned_oracle_is_the_plain_oracle_on_its_own_branches(monkeypatch):
+    """The instrument behind the per-tensor gradient bars of tests/test_gpu_baseline_sizes.py: `OracleModel.act_masks`
+    dictates the branch of every LeakyReLU (keys / shapes as `gpu_util.hip_activation_masks` reads them off the plan's
+    buffers).  With the branches the forward took anyway the float64 oracle must not change at all; with ONE texel of one
+    deep activation flipped, the gradient of the conv feeding it moves -- that is the discontinuity the conditioning removes."""
+    from gpu_util import hip_activation_masks
+    fake_capi.install(monkeypatch)
+    om, pm = make(256, 64, 32, loss='l2')
+    pm.build('cpu'); pm.register_trainable()
+    batch, nn = O.synth_batch(2, 64, 64, 32, 32, 32, 32, k=2, seed=7)
+    lp, _ = pm.train_forward_backward(cpu_batch(batch, nn), 2)
+    masks = hip_activation_masks(pm)
+    assert set(masks) == ({('q', l) for l in range(1, 13)} | {('o', l, j) for l in range(1, 7) for j in range(2)})
+    om64 = O.OracleModel(depth=256, uvh=64, uvw=64, imh=32, imw=32, loss='l2', dtype=torch.float64)
+    for a, b in zip(om64.parameters(), om.parameters()):
+        a.data.copy_(b.data.double())
+
+    def grads(m):
+        om64.act_masks = m
+        b = tuple(t.double() if torch.is_tensor(t) else t for t in batch)
+        po, go, _, _ = om64.call(b, 'train', nn_list=[(a.double(), c.double()) for a, c in nn])
+        lo = om64.compute_loss(po, go, keep_batch=True).sum() / 2
+        return lo.detach(), torch.autograd.grad(lo, om64.parameters())
+    l0, g0 = grads(None)
+    l1, g1 = grads(masks)
+    assert float(l0) == float(l1) and all(torch.equal(a, b) for a, b in zip(g0, g1))
+    assert abs(float(lp) - float(l0)) <= 1e-6 * abs(float(l0))
+    it = iter(g1)
+    for c in pm._conv_layers():
+        for nm in ('dkernel', 'dbias'):
+            g = next(it)
+            assert float((getattr(c, nm).double() - g).norm()) <= 1e-5 * float(g.norm())
+    flipped = dict(masks)
+    m0, m1 = masks[('q', 5)]
+    m1 = m1.clone(); m1[0, 0, 0, 0] = ~m1[0, 0, 0, 0]
+    flipped[('q', 5)] = (m0, m1)
+    _, g2 = grads(flipped)
+    assert not all(torch.equal(a, b) for a, b in zip(g1, g2))
