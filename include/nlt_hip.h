@@ -134,6 +134,22 @@ int nlt_warp_forward(const float* pred, const float* base, const float* warp,
                      int n, int uvh, int uvw, int hc, int wc,
                      float* pred_cam, float* base_cam, float* fg_cam, int* idx_out, void* stream);
 
+/* nlt_warp_forward on a STORE-RESIDENT batch (Dataset.load_batch(ids, resident=True)): base comes from the uint8 diffuse
+ * store [F,uvh,uvw,3] and the map from the fp16 uv2cam store [F,hc,wc,2] (data_gen/util.py:67-70), frame ids[f] of each,
+ * converted in registers exactly as `_load_data` does (uint8 -> float64 / 255 -> float32, nlt/datasets/nlt.py:131-136;
+ * fp16 -> fp32, :125,176).  Bit-identical outputs to nlt_warp_forward on the assembled float batch.
+ *   replaces: the same reference lines as nlt_warp_forward + the `base` / `warp` entries of `_load_data`'s 11-tuple. */
+int nlt_warp_forward_store(const float* pred, const unsigned char* diffuse_store, const unsigned short* uv2cam_store,
+                           const int* ids, int n, int uvh, int uvw, int hc, int wc,
+                           float* pred_cam, float* base_cam, float* fg_cam, int* idx_out, void* stream);
+
+/* The raw resampler op on a map of c channels (c % 4 == 0): data [n,h,w,c], warp_px [n,hc,wc,2] in PIXEL units (x first)
+ * -> out [n,hc,wc,c]; tfa.image.resampler's tap rule and order (no corner mask, no scaling).  The channel-width stress
+ * point of the per-texel kernels ("1024^2 x 64-ch"); the model itself only warps 3-channel maps.
+ *   replaces: tfa.image.resampler(data, warp) (nlt/models/nlt.py:112-114) for a wider `data`. */
+int nlt_resample_forward(const float* data, const float* warp_px, int n, int h, int w, int c, int hc, int wc,
+                         float* out, void* stream);
+
 /*
  * Bilinear resize, half-pixel centres, no antialias.
  *   replaces: tf.image.resize via nlt/util/img.py:92-120 (nlt/models/nlt.py:116-120).

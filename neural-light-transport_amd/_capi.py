@@ -34,6 +34,8 @@ SIGNATURES = {
     'nlt_head_forward': (_c_int, [_vp, _c_int, _c_int, _vp, _c_int, _c_int, _vp, _vp, _vp,
                                   _c_int, _c_int, _c_int, _vp, _vp]),
     'nlt_warp_forward': (_c_int, [_vp, _vp, _vp] + [_c_int] * 5 + [_vp] * 5),
+    'nlt_warp_forward_store': (_c_int, [_vp] * 4 + [_c_int] * 5 + [_vp] * 5),
+    'nlt_resample_forward': (_c_int, [_vp, _vp] + [_c_int] * 6 + [_vp, _vp]),
     'nlt_resize_bilinear_forward': (_c_int, [_vp] + [_c_int] * 6 + [_vp, _vp]),
     'nlt_mul_forward': (_c_int, [_vp, _vp, _c_long, _vp, _vp]),
     'nlt_conv_backward_weights': (_c_int, [_c_int, _c_int, _vp, _c_int, _c_int, _vp, _c_int, _c_int,
@@ -313,6 +315,27 @@ def warp_forward(pred, base, warp, n, uvh, uvw, hc, wc, pred_cam, base_cam, fg_c
     _check(lib().nlt_warp_forward(_ptr(pred), _ptr(base), _ptr(_dense(warp, 'warp')), n, uvh, uvw, hc, wc,
                                   _ptr(pred_cam), _ptr(base_cam), _ptr(fg_cam), _ptr(idx_out), _stream()),
            'nlt_warp_forward')
+
+
+def warp_forward_store(pred, diffuse_store, uv2cam_store, ids, n, uvh, uvw, hc, wc, pred_cam, base_cam, fg_cam, idx_out=None):
+    """warp_forward for a store-resident batch: base / map read from the uint8 diffuse and fp16 uv2cam stores (frame ids)."""
+    if tuple(diffuse_store.shape[1:]) != (uvh, uvw, 3) or tuple(uv2cam_store.shape[1:]) != (hc, wc, 2):
+        raise NLTError("stores %s / %s do not match uv %dx%d, camera %dx%d"
+                       % (tuple(diffuse_store.shape), tuple(uv2cam_store.shape), uvh, uvw, hc, wc))
+    _check(lib().nlt_warp_forward_store(_ptr(pred), _tptr(diffuse_store, torch.uint8, 'diffuse store'),
+                                        _tptr(uv2cam_store, torch.float16, 'uv2cam store'), _tptr(ids, torch.int32, 'ids'),
+                                        n, uvh, uvw, hc, wc, _ptr(pred_cam), _ptr(base_cam), _ptr(fg_cam), _ptr(idx_out),
+                                        _stream()), 'nlt_warp_forward_store')
+
+
+def resample_forward(data, warp_px):
+    """tfa.image.resampler(data [n,h,w,c], warp_px [n,hc,wc,2] in pixel units) for c % 4 == 0 (the 64-channel stress point)."""
+    n, h, w, c = data.shape
+    hc, wc = warp_px.shape[1:3]
+    out = torch.empty((n, hc, wc, c), device=data.device, dtype=torch.float32)
+    _check(lib().nlt_resample_forward(_ptr(_dense(data, 'data')), _ptr(_dense(warp_px, 'warp_px')), n, h, w, c, hc, wc, _ptr(out),
+                                      _stream()), 'nlt_resample_forward')
+    return out
 
 
 def resize_bilinear_forward(x, oh, ow):

@@ -41,14 +41,7 @@ struct Front4In {
   const int *ids, *nn_ids;                              // U8 only: frame of each sample [n], of each observation [n,k] (-1: zeros)
 };
 
-// float32(float64(u) / 255.0) -- `_load_data`'s normalize_uint + astype(float32) -- without a table or a division:
-// q = u * r, q += fma(-255, q, u) * r with r = fl(1 / 255); equal for all 256 bytes (tests/test_front3_index_math.py)
-__device__ __forceinline__ float u8_unit(unsigned u) {
-  const float r = 1.0f / 255.0f;
-  const float uf = (float)u;
-  const float q = __fmul_rn(uf, r);
-  return __fmaf_rn(__fmaf_rn(-255.0f, q, uf), r, q);
-}
+// u8_unit (nlt_common.h): float32(float64(u) / 255.0), `_load_data`'s normalize_uint + astype(float32)
 __device__ __forceinline__ f32x4 u8x4_unit(unsigned v) {
   return (f32x4){u8_unit(v & 255u), u8_unit((v >> 8) & 255u), u8_unit((v >> 16) & 255u), u8_unit(v >> 24)};
 }

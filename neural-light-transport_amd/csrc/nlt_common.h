@@ -14,6 +14,16 @@ static inline bool nlt_aligned16(const void* p) { return (reinterpret_cast<uintp
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
+// float32(float64(u) / 255.0) -- `_load_data`'s normalize_uint + astype(float32) (nlt/datasets/nlt.py:131-136) -- without a
+// table or a division: q = u * r, q += fma(-255, q, u) * r with r = fl(1 / 255); equal for all 256 bytes
+// (tests/test_front4_index_math.py).  Explicitly rounded operations: immune to -ffp-contract and `#pragma clang fp`.
+__device__ __forceinline__ float u8_unit(unsigned u) {
+  const float r = 1.0f / 255.0f;
+  const float uf = (float)u;
+  const float q = __fmul_rn(uf, r);
+  return __fmaf_rn(__fmaf_rn(-255.0f, q, uf), r, q);
+}
+
 // Implicit-GEMM view of every conv family (SURVEY.md 8a a-C1..a-D3):
 //   rows    = texels of the "GEMM grid" (gh x gw per frame): output texels for the conv
 //             modes, INPUT texels for DECONV_K2S2 (each owns a 2x2 output block);

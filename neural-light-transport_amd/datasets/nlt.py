@@ -103,10 +103,18 @@ class ResidentTexels:
 
     def __init__(self, store, ids, nn_ids, test_mode=False):
         self.diffuse, self.rgb, self.cvis, self.lvis = store['diffuse'], store['rgb'], store['cvis'], store['lvis']
+        self.uv2cam = store['uv2cam']                                # fp16 [F,hc,wc,2]: the warp reads it in place too
         self.ids, self.nn_ids, self.test_mode = ids, nn_ids, test_mode
         self.n, self.k = ids.numel(), nn_ids.shape[1]
         self.h, self.w = self.cvis.shape[1:3]
-        self._float, self._base = None, None
+        self.hc, self.wc = self.uv2cam.shape[1:3]
+        self._float, self._base, self._warp = None, None, None
+
+    def warp_float(self):
+        """warp [n,hc,wc,2] float32 (fp16 `.npy` -> float32, never resized: nlt/datasets/nlt.py:125,147-148,176)."""
+        if self._warp is None:
+            self._warp = self.uv2cam[self.ids.long()].float()
+        return self._warp
 
     def key(self):
         return tuple(t.data_ptr() for t in (self.diffuse, self.rgb, self.cvis, self.lvis, self.ids, self.nn_ids)) + (self.n, self.k)
@@ -128,6 +136,7 @@ class ResidentTexels:
         if self._float is None:
             self._float = C.assemble_batch(self.diffuse, self.rgb, self.cvis, self.lvis, self.ids, self.nn_ids,
                                            test_mode=self.test_mode)
+            self._float['warp'] = self.warp_float()
         return self._float
 
 
@@ -245,39 +254,56 @@ class Dataset:
 
     def load_batch(self, ids, resident=False):
         """`_load_data` (nlt.py:115-184) for a list of sample ids, as the model's 11-tuple.
-        resident=True leaves the six UV-space texel buffers in the uint8 store: entry 1 (base) is a ResidentTexels and
-        entries 2, 3, 5, 8, 9 are None -- `Model.call` feeds the store to the fused front kernel (29 B per texel read
-        instead of 116 written + 116 read at k = 4) and materialises floats only where something asks for them."""
+        resident=True leaves the six UV-space texel buffers in the uint8 store and the uv2cam map in its fp16 store:
+        entry 1 (base) is a ResidentTexels and entries 2, 3, 4, 5, 8, 9 are None -- `Model.call` feeds the stores to the
+        fused front kernel (29 B per texel read instead of 116 written + 116 read at k = 4) and to the warp, and
+        materialises floats only where something asks for them (`ResidentTexels.materialize`: training, obs_override)."""
         s = self.store
         dev = s['cvis'].device
         n = len(ids)
         slot = self._slot(n)
-        fid_h = torch.tensor([self.index[i] for i in ids], dtype=torch.int32)
-        nn_h = torch.tensor([self._nn_indices(i) for i in ids], dtype=torch.int32)
+        fid_l = [self.index[i] for i in ids]
+        nn_l = [self._nn_indices(i) for i in ids]
+        nn_h = torch.tensor(nn_l, dtype=torch.int32)
         if self._fstore is not None:
-            return self._load_batch_resized(ids, fid_h, nn_h)
-        if slot is None or 'fid' not in slot:
-            fid, nnid = fid_h.to(dev), nn_h.to(dev)
-            if slot is not None:
-                slot['fid'], slot['nnid'] = fid, nnid
-        else:
-            fid, nnid = slot['fid'], slot['nnid']
-            fid.copy_(fid_h); nnid.copy_(nn_h)
-        test = self.mode == 'test'
-        li = fid.long()
-        cam_shape = (n,) + tuple(s['rgb_camspc'].shape[1:])
+            return self._load_batch_resized(ids, torch.tensor(fid_l, dtype=torch.int32), nn_h)
         if slot is None:
-            warp = s['uv2cam'][li].float()                                       # never resized (nlt.py:147-148)
+            both = torch.tensor(fid_l + [x for row in nn_l for x in row], dtype=torch.int32).to(dev)
+        else:
+            # ONE host-to-device copy of (frame ids | neighbour ids) per batch, out of a pinned staging buffer of the slot
+            if 'ids_dev' not in slot:
+                slot['ids_dev'] = torch.empty(n + n * self.k, device=dev, dtype=torch.int32)
+                slot['ids_pin'] = torch.empty(n + n * self.k, dtype=torch.int32, pin_memory=dev.type == 'cuda')
+                slot['ids_ev'] = torch.cuda.Event() if dev.type == 'cuda' else None
+            elif slot['ids_ev'] is not None:
+                slot['ids_ev'].synchronize()                         # the slot's previous upload has left the pinned buffer
+            pin = slot['ids_pin']
+            pin[:n] = torch.tensor(fid_l, dtype=torch.int32)
+            pin[n:] = nn_h.reshape(-1)
+            both = slot['ids_dev']
+            both.copy_(pin, non_blocking=True)
+            if slot['ids_ev'] is not None:
+                slot['ids_ev'].record()
+        fid, nnid = both[:n], both[n:].view(n, self.k)
+        test = self.mode == 'test'
+        cam_shape = (n,) + tuple(s['rgb_camspc'].shape[1:])
+        warp = None                                                  # (store-resident batches: the warp reads the fp16 store)
+        if slot is None:
+            if not resident:
+                warp = s['uv2cam'][fid.long()].float()                           # never resized (nlt.py:147-148)
             rgb_c = torch.zeros(cam_shape, device=dev) if test else C.gather_frames_u8(s['rgb_camspc'], fid)   # nlt.py:126-128
             nn_rgb_c = C.gather_frames_u8(s['rgb_camspc'], nnid[:, 0].contiguous())
         else:
-            if 'warp' not in slot:
-                slot['warp'] = torch.empty((n,) + tuple(s['uv2cam'].shape[1:]), device=dev, dtype=torch.float32)
+            if 'rgb_c' not in slot:
                 slot['rgb_c'] = torch.zeros(cam_shape, device=dev)
                 slot['nn_rgb_c'] = torch.empty(cam_shape, device=dev)
                 slot['nn0'] = torch.empty(n, device=dev, dtype=torch.int32)
-            warp, rgb_c, nn_rgb_c = slot['warp'], slot['rgb_c'], slot['nn_rgb_c']
-            warp.copy_(s['uv2cam'][li])                                          # fp16 -> fp32 on the way in
+            rgb_c, nn_rgb_c = slot['rgb_c'], slot['nn_rgb_c']
+            if not resident:
+                if 'warp' not in slot:
+                    slot['warp'] = torch.empty((n,) + tuple(s['uv2cam'].shape[1:]), device=dev, dtype=torch.float32)
+                warp = slot['warp']
+                warp.copy_(s['uv2cam'][fid.long()])                              # fp16 -> fp32 on the way in
             if not test:
                 C.gather_frames_u8(s['rgb_camspc'], fid, out=rgb_c)
             slot['nn0'].copy_(nnid[:, 0])
@@ -285,7 +311,7 @@ class Dataset:
         nn_names = [s['ids'][j] if j >= 0 else 'incomplete-data' for j in nn_h[:, 0].tolist()]
         if resident:
             res = ResidentTexels(s, fid, nnid, test_mode=test)
-            return (list(ids), res, None, None, warp, None, rgb_c, nn_names, None, None, nn_rgb_c)
+            return (list(ids), res, None, None, None, None, rgb_c, nn_names, None, None, nn_rgb_c)
         b = C.assemble_batch(s['diffuse'], s['rgb'], s['cvis'], s['lvis'], fid, nnid, test_mode=test,
                              out=slot.get('texels') if slot is not None else None)
         if slot is not None:

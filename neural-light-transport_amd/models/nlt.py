@@ -256,19 +256,23 @@ class Model(BaseModel):
     # ---------------------------------------------------------------- forward
     def _render(self, base, cvis, lvis, warp, nn_rgb, nn_base, obs_weights, obs_override, want_indices, inference=True,
                 resident=None):
-        n, hc, wc, _ = warp.shape
+        if resident is not None:
+            n, hc, wc, dev = resident.n, resident.hc, resident.wc, resident.cvis.device
+        else:
+            (n, hc, wc, _), dev = warp.shape, base.device
         pred, _ = self.plan.forward(base, cvis, lvis, nn_rgb, nn_base, obs_weights=obs_weights,
                                     obs_override=obs_override, skip_connect_base=self.skip_connect_base,
                                     algo=self.conv_algo, inference=inference, resident=resident)
-        if resident is not None:                                 # the warp gathers base as float32: base alone is materialised
-            keep = getattr(self, '_res_base', None)              # (persistent destination: launch tapes / allocator churn)
-            if keep is None or tuple(keep.shape) != (resident.n, resident.h, resident.w, 3) or keep.device != warp.device:
-                keep = self._res_base = torch.empty((resident.n, resident.h, resident.w, 3), device=warp.device)
-            base = resident.base_float(out=keep)
-        E = lambda: torch.empty((n, hc, wc, 3), device=base.device, dtype=torch.float32)
+        E = lambda: torch.empty((n, hc, wc, 3), device=dev, dtype=torch.float32)
         pred_camspc, base_camspc, fg_camspc = E(), E(), E()
-        idx = torch.empty((n, hc, wc, 4), device=base.device, dtype=torch.int32) if want_indices else None
-        C.warp_forward(pred, base, warp, n, self.uvh, self.uvw, hc, wc, pred_camspc, base_camspc, fg_camspc, idx)
+        idx = torch.empty((n, hc, wc, 4), device=dev, dtype=torch.int32) if want_indices else None
+        if resident is not None:
+            # base and the uv2cam map are gathered where they live (uint8 diffuse store, fp16 map store): neither the float32
+            # base nor a float32 copy of the map is ever written
+            C.warp_forward_store(pred, resident.diffuse, resident.uv2cam, resident.ids, n, self.uvh, self.uvw, hc, wc,
+                                 pred_camspc, base_camspc, fg_camspc, idx)
+        else:
+            C.warp_forward(pred, base, warp, n, self.uvh, self.uvw, hc, wc, pred_camspc, base_camspc, fg_camspc, idx)
         if (hc, wc) != (self.imh, self.imw):
             fg_camspc = C.resize_bilinear_forward(fg_camspc, self.imh, self.imw)
             base_camspc = C.resize_bilinear_forward(base_camspc, self.imh, self.imw)
@@ -320,6 +324,7 @@ class Model(BaseModel):
         if isinstance(base, ResidentTexels):                     # load_batch(resident=True): training reads the float buffers
             m = base.materialize()
             base, cvis, lvis, rgb, nn_base, nn_rgb = (m[x] for x in ('base', 'cvis', 'lvis', 'rgb', 'nn_base', 'nn_rgb'))
+            warp = m['warp'] if warp is None else warp
         if nn_rgb.dim() == 4:
             nn_rgb, nn_base = nn_rgb.unsqueeze(1), nn_base.unsqueeze(1)
         nn_rgb, nn_base = nn_rgb.contiguous(), nn_base.contiguous()
@@ -392,6 +397,7 @@ class Model(BaseModel):
             else:
                 m = base.materialize()
                 base, cvis, lvis, rgb, nn_base, nn_rgb = (m[x] for x in ('base', 'cvis', 'lvis', 'rgb', 'nn_base', 'nn_rgb'))
+                warp = m['warp'] if warp is None else warp
         if resident is None:
             if nn_rgb.dim() == 4:           # the reference's single neighbour
                 nn_rgb, nn_base = nn_rgb.unsqueeze(1), nn_base.unsqueeze(1)

@@ -91,7 +91,23 @@ def distributed_train_step(model, batch, optimizer, global_bs, group=None, overl
         optimizer.step(grad)
         return weighted_loss.detach().clone(), to_vis
     if getattr(model, 'generic', False):
-        raise NotImplementedError("data-parallel training of the layer-by-layer branch configs (elu / pixel norm / pooling)")
+        # the layer-by-layer branch configs (elu / pixel, layer, batch norm / pooling): the same step, the network differentiated
+        # through its hand-rolled tape (generic.py) into the same flat bucket, then ONE all-reduce of the whole bucket (no
+        # backward plan to overlap with).  Batch norm needs no cross-replica statistics: the reference runs it in inference
+        # mode (networks/elements.py ChannelNorm).
+        pred, gt, loss_kwargs, to_vis = model(batch, mode='train')
+        loss_kwargs['keep_batch'] = True
+        loss = model.compute_loss(pred, gt, **loss_kwargs).sum() / global_bs
+        model.flat_params.grad = None
+        loss.backward()
+        grad = model.flat_params.grad
+        loss = loss.detach().clone()
+        works = [dist.all_reduce(grad, op=dist.ReduceOp.SUM, group=group, async_op=True),
+                 dist.all_reduce(loss, op=dist.ReduceOp.SUM, group=group, async_op=True)]
+        for w in works:
+            w.wait()
+        optimizer.step(grad)
+        return loss, to_vis
     grad, split = model.flat_grads, model.bucket_split
     works = []
     if overlap:

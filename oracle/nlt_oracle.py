@@ -77,10 +77,12 @@ def _layer_in_channels(layers, is_c, cin_query, cin_obs, use_obs=True):
     return q_in, o_in
 
 
-def init_weights(layers, in_channels, rng, bias_range=0.1, contracting_only=None, pool=False):
+def init_weights(layers, in_channels, rng, bias_range=0.1, contracting_only=None, pool=False, norm=None):
     """Keras-layout weights.  conv: (kh,kw,Cin,Cout); deconv: (kh,kw,Cout,Cin).
     Kernels glorot-uniform (Keras default); biases U(-bias_range,bias_range) instead of
-    Keras' zeros so the bias path is exercised."""
+    Keras' zeros so the bias path is exercised.  norm = 'layer' / 'batch': a (gamma, beta) pair follows each
+    conv of a down / up block (Keras variable order of the Sequential, convnet.py:50-59,67-76); gamma U(0.5, 1.5) and beta
+    U(-bias_range, bias_range) instead of Keras' ones / zeros, for the same reason."""
     ws = []
     for i, (L, cin) in enumerate(zip(layers, in_channels)):
         if contracting_only is not None and not contracting_only[i]:
@@ -89,21 +91,31 @@ def init_weights(layers, in_channels, rng, bias_range=0.1, contracting_only=None
 
         def bias():
             return rng.uniform(-bias_range, bias_range, size=(n,)).astype(np.float32)
+
+        def with_norms(lw, first=0):
+            if norm not in ('layer', 'batch'):
+                return lw
+            out = []
+            for j, cw in enumerate(lw):
+                out.append(cw)
+                if j >= first:
+                    out.append((rng.uniform(0.5, 1.5, size=(n,)).astype(np.float32), bias()))
+            return out
         if L['kind'] == 'conv1x1':
             ws.append([(T.glorot_uniform(rng, (1, 1, cin, n)), bias())])
         elif L['kind'] == 'down':
             k = L['k']
-            ws.append([(T.glorot_uniform(rng, (k, k, cin, n)), bias()),
-                       (T.glorot_uniform(rng, (k, k, n, n)), bias())])
+            ws.append(with_norms([(T.glorot_uniform(rng, (k, k, cin, n)), bias()),
+                                  (T.glorot_uniform(rng, (k, k, n, n)), bias())]))
         elif pool:                                               # upconv's Conv2D(n, 2) first (elements.py:42-48), then the deconvs
             k = L['k']
-            ws.append([(T.glorot_uniform(rng, (2, 2, cin, n)), bias()),
-                       (T.glorot_uniform(rng, (k, k, n, n)), bias()),
-                       (T.glorot_uniform(rng, (k, k, n, n)), bias())])
+            ws.append(with_norms([(T.glorot_uniform(rng, (2, 2, cin, n)), bias()),
+                                  (T.glorot_uniform(rng, (k, k, n, n)), bias()),
+                                  (T.glorot_uniform(rng, (k, k, n, n)), bias())], first=1))   # (upconv's conv has no norm)
         else:
             k = L['k']
-            ws.append([(T.glorot_uniform(rng, (k, k, n, cin)), bias()),
-                       (T.glorot_uniform(rng, (k, k, n, n)), bias())])
+            ws.append(with_norms([(T.glorot_uniform(rng, (k, k, n, cin)), bias()),
+                                  (T.glorot_uniform(rng, (k, k, n, n)), bias())]))
     return ws
 
 
@@ -113,6 +125,26 @@ ACT_ALPHA = {'leakyrelu': T.LRELU_ALPHA, 'relu': 0.0, 'elu': 1.0}     # elements
 def pixel_norm(x, eps=1.0e-8):
     """elements.py:103-121."""
     return x * torch.rsqrt((x * x).mean(-1, keepdim=True) + eps)
+
+
+NORM_EPS = 1.0e-3                                                # elements.py:53,56: epsilon=0.001 for both
+
+
+def layer_norm(x, gamma, beta, eps=NORM_EPS):
+    """tf.keras.layers.LayerNormalization(epsilon=0.001, center=True, scale=True), default axis = -1 (elements.py:55-56):
+    per texel over its channels, biased variance; TF 2.2 normalises first ((x - mean) * rsqrt(var + eps), its fused path
+    with scale 1 / offset 0) and applies gamma / beta afterwards."""
+    m = x.mean(-1, keepdim=True)
+    v = ((x - m) ** 2).mean(-1, keepdim=True)
+    return (x - m) * torch.rsqrt(v + eps) * gamma + beta
+
+
+def batch_norm_inference(x, gamma, beta, moving_mean=0.0, moving_var=1.0, eps=NORM_EPS):
+    """tf.keras.layers.BatchNormalization(momentum=0.99, epsilon=0.001) (elements.py:52-53) AS CALLED by the reference:
+    `layer(x)` without `training=` (networks/seq.py:36-41; models/nlt.py:154-195) => Keras inference mode in every mode
+    of the loop: (x - moving_mean) * rsqrt(moving_variance + eps) * gamma + beta, and since only training-mode calls
+    update them, the moving statistics stay at their initial 0 / 1."""
+    return (x - moving_mean) * torch.rsqrt(torch.as_tensor(moving_var + eps, dtype=x.dtype)) * gamma + beta
 
 
 def pool2x2(x, kind):
@@ -141,11 +173,28 @@ def apply_layer_bf16(L, w, x, alpha, keep_fp32_out=False):
 
 def apply_layer(L, w, x, alpha=T.LRELU_ALPHA, norm=None, pool=None, act='leakyrelu', masks=None):
     """One entry of Network.layers (convnet.py:44,50-59,67-76,85); alpha = negative slope (lrelu / relu) or ELU's alpha;
-    norm in (None, 'pixel'); pool in (None, 'max', 'avg') -- with pooling the expanding blocks start with `upconv`.
+    norm in (None, 'pixel', 'layer', 'batch'); pool in (None, 'max', 'avg') -- with pooling the expanding blocks start with `upconv`.
     masks (test instrument, LeakyReLU / ReLU only): one boolean tensor per activation of the block, True where the
     activation takes its positive branch -- `where(mask, v, alpha * v)` instead of deciding on v's own sign (see
     OracleModel.act_masks)."""
-    nrm = (lambda v: pixel_norm(v)) if norm == 'pixel' else (lambda v: v)
+    if norm in ('layer', 'batch') and L['kind'] != 'conv1x1':
+        # w = [conv, (gamma, beta), conv, (gamma, beta)] (upconv: one more conv in front): split into convs and norm pairs
+        convs, norms = [], []
+        rest = list(w)
+        if pool and L['kind'] == 'up':
+            convs.append(rest.pop(0))
+        while rest:
+            convs.append(rest.pop(0))
+            norms.append(rest.pop(0))
+        w = convs
+        nit = iter(norms)
+        fn = layer_norm if norm == 'layer' else batch_norm_inference
+
+        def nrm(v):
+            g_, b_ = next(nit)
+            return fn(v, g_, b_)
+    else:
+        nrm = (lambda v: pixel_norm(v)) if norm == 'pixel' else (lambda v: v)
     a = (lambda v: torch.nn.functional.elu(v, alpha)) if act == 'elu' else (lambda v: T.leaky_relu(v, alpha))
     if masks is not None:
         assert act != 'elu'
@@ -187,8 +236,8 @@ class OracleModel:
         self.loss_spec = loss
         q_in, o_in = _layer_in_channels(self.layers, self.is_contracting, 5, 3, use_obs)
         rng = np.random.default_rng(seed)
-        wq = init_weights(self.layers, q_in, rng, pool=bool(pool))
-        wo = init_weights(self.layers, o_in, rng, contracting_only=self.is_contracting, pool=bool(pool))
+        wq = init_weights(self.layers, q_in, rng, pool=bool(pool), norm=norm)
+        wo = init_weights(self.layers, o_in, rng, contracting_only=self.is_contracting, pool=bool(pool), norm=norm)
         tt = lambda a: torch.tensor(a, dtype=dtype, requires_grad=True)
         self.wq = [[(tt(k), tt(b)) for k, b in lw] for lw in wq]
         self.wo = [[(tt(k), tt(b)) for k, b in lw] for lw in wo]   # obs net keeps contracting layers only (nlt.py:57-59)

@@ -272,6 +272,11 @@ def knn_indices(ref_pos, cand_pos, k=1):
     return _t(_BU.knn_indices(ref_pos.numpy(), cand_pos.numpy(), k))
 
 
+def warp_forward_store(pred, diffuse_store, uv2cam_store, ids, n, uvh, uvw, hc, wc, pred_cam, base_cam, fg_cam, idx_out=None):
+    base = gather_frames_u8(diffuse_store, ids)
+    warp_forward(pred, base, uv2cam_store[ids.long()].float(), n, uvh, uvw, hc, wc, pred_cam, base_cam, fg_cam, idx_out)
+
+
 def gather_frames_u8(store, ids, out=None):
     i = ids.numpy()
     res = (store.numpy()[_np.maximum(i, 0)] / 255.0).astype(_np.float32)
@@ -305,7 +310,7 @@ def resize_cv_linear(src, oh, ow, out=None):
     return res
 
 
-_BUFFERS = ('resize_cv_linear', 'cosine_map', 'albedo', 'diffuse_base', 'remap_bilinear', 'uv_index_map', 'knn_indices', 'gather_frames_u8',
+_BUFFERS = ('resize_cv_linear', 'cosine_map', 'albedo', 'diffuse_base', 'remap_bilinear', 'uv_index_map', 'knn_indices', 'gather_frames_u8', 'warp_forward_store',
             'assemble_batch')
 
 
@@ -468,6 +473,27 @@ def pixelnorm_backward(g, x, eps=1e-8):
         return torch.autograd.grad(O.pixel_norm(xx, eps), xx, g)[0]
 
 
+def _norm_fn(kind, x, gamma, beta, mean, var, eps):
+    if kind == 0:
+        return O.layer_norm(x, gamma, beta, eps)
+    return (x - mean) * torch.rsqrt(var + eps) * gamma + beta
+
+
+def norm_forward(kind, x, gamma, beta, mean, var, eps):
+    return _norm_fn(kind, x, gamma, beta, mean, var, eps)
+
+
+def norm_backward(kind, g, x, gamma, mean, var, eps, dgamma, dbeta):
+    with torch.enable_grad():
+        xx = x.detach().clone().requires_grad_(True)
+        gg = gamma.detach().clone().requires_grad_(True)
+        bb = torch.zeros_like(gg).requires_grad_(True)
+        dx, dg, db = torch.autograd.grad(_norm_fn(kind, xx, gg, bb, mean, var, eps), (xx, gg, bb), g)
+    dgamma += dg
+    dbeta += db
+    return dx
+
+
 def pool2x2_forward(x, kind):
     return O.pool2x2(x, 'max' if kind == 0 else 'avg').contiguous()
 
@@ -514,7 +540,7 @@ def front4_forward_u8(diffuse_store, rgb_store, cvis_store, lvis_store, ids, nn_
 
 
 _FUSED = _FUSED + ('front_pack_l2_weights', 'front2_forward', 'front4_supported', 'front4_forward', 'front4_forward_u8', 'dec_block_forward', 'act_forward', 'act_backward',
-                  'pixelnorm_forward', 'pixelnorm_backward', 'pool2x2_forward', 'pool2x2_backward', 'sub_forward', 'finish_pred')
+                  'pixelnorm_forward', 'pixelnorm_backward', 'norm_forward', 'norm_backward', 'pool2x2_forward', 'pool2x2_backward', 'sub_forward', 'finish_pred')
 
 
 _FORWARD = ('conv_forward', 'pack_conv_weights', 'repack_table', 'repack_weights', 'stem_forward', 'obs_mean_forward', 'head_forward', 'warp_forward',

@@ -1,4 +1,4 @@
-"""CPU, world_size 2 and 4 over gloo: the data-parallel train step (frames sharded across ranks, the gradient sum as TWO
+"""CPU, world_size 2, 4 and 8 over gloo: the data-parallel train step (frames sharded across ranks, the gradient sum as TWO
 all-reduces of fixed ranges of the flat bucket -- the first issued from inside the backward plan --, identical Adam step
 on every rank, scalar loss all-reduce) reproduces the single-process oracle on the full batch
 (nlt/trainvali.py:267-325).  Device kernels are replaced by the TEST-ONLY C-ABI emulation; the collective path is the
@@ -14,7 +14,7 @@ import torch.distributed as dist
 import torch.multiprocessing as mp
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-GLOBAL = {2: 4, 4: 7}                          # global batch per world size (7 over 4 ranks: shards 2, 2, 2, 1)
+GLOBAL = {2: 4, 4: 7, 8: 32}                   # global batch per world size (7 over 4 ranks: shards 2, 2, 2, 1; 32 over 8 = BASELINE config 4)
 
 
 def _shard(world, rank):
@@ -37,10 +37,15 @@ def _worker(rank, world, port, outdir, mode):
         def setattr(self, obj, name, val):
             setattr(obj, name, val)
     fake_capi.install(MP())
-    om, pm = make(256, 64, 32, loss='l2')
+    if mode == 'branch':                                                    # a layer-by-layer config: norm = layer (generic.py)
+        from test_host_generic import make as make_branch
+        om, pm = make_branch(32, 64, 32, loss='l2', norm='layer')
+        assert pm.generic
+    else:
+        om, pm = make(256, 64, 32, loss='l2')
     pm.build('cpu'); pm.register_trainable()
     gbs = GLOBAL[world]
-    batch, nn = O.synth_batch(gbs, 64, 64, 32, 32, 32, 32, k=2, seed=5)   # the GLOBAL batch
+    batch, nn = O.synth_batch(gbs, 64, 64, 32, 32, 32, 32, k=1 if world == 8 else 2, seed=5)   # the GLOBAL batch
     sl = _shard(world, rank)                                                # contiguous shard per rank
     shard = tuple(t[sl] if torch.is_tensor(t) else t for t in batch)
     nn_s = [(b[sl], r[sl]) for b, r in nn]
@@ -74,8 +79,9 @@ def _worker(rank, world, port, outdir, mode):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize('world,mode', [(2, 'overlap'), (2, 'after'), (4, 'overlap'), (2, 'graphed')])
+@pytest.mark.parametrize('world,mode', [(2, 'overlap'), (2, 'after'), (4, 'overlap'), (2, 'graphed'), (2, 'branch'), (8, 'overlap')])
 def test_data_parallel_train_step(world, mode):
+    """(8, overlap) is north_star's config 4 partition: global batch 32, 4 frames per rank, k = 1."""
     sys.path.insert(0, os.path.join(ROOT, 'tests'))
     from oracle import nlt_oracle as O
     with tempfile.TemporaryDirectory() as td:
@@ -86,14 +92,17 @@ def test_data_parallel_train_step(world, mode):
     for x in r[1:]:
         assert torch.equal(r[0]['params'], x['params']) and torch.equal(r[0]['grad'], x['grad'])
         assert r[0]['losses'] == x['losses'] and r[0]['vali'] == x['vali']
-    if mode != 'graphed':
+    if mode == 'branch':
+        assert r[0]['fired'] == [r[0]['params'].numel(), 1] * 2      # layer-by-layer configs: the whole bucket at once
+    elif mode != 'graphed':
         # per step: the bucket's leading range (expanding blocks), the rest, the scalar loss -- in this order
         n, split = r[0]['params'].numel(), r[0]['split']
         assert 0 < split < n and r[0]['fired'] == [split, n - split, 1] * 2
     # ... and they equal the single-process oracle on the full batch
     gbs = GLOBAL[world]
-    om = O.OracleModel(depth=256, uvh=64, uvw=64, imh=32, imw=32, seed=1, loss='l2')
-    batch, nn = O.synth_batch(gbs, 64, 64, 32, 32, 32, 32, k=2, seed=5)
+    om = (O.OracleModel(depth=32, uvh=64, uvw=64, imh=32, imw=32, seed=1, loss='l2', norm='layer') if mode == 'branch' else
+          O.OracleModel(depth=256, uvh=64, uvw=64, imh=32, imw=32, seed=1, loss='l2'))
+    batch, nn = O.synth_batch(gbs, 64, 64, 32, 32, 32, 32, k=1 if world == 8 else 2, seed=5)
     opt = O.KerasAdamAMSGrad(om.parameters(), 1e-3)
     ref_losses = [float(O.train_step(om, opt, batch, global_bs=gbs, nn_list=nn)[0]) for _ in range(2)]
     np.testing.assert_allclose(r[0]['losses'], ref_losses, rtol=1e-5)

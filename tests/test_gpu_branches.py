@@ -1,5 +1,5 @@
-"""-m gpu: the config branches the released .ini files leave off -- act = elu, norm = pixel, pool = max / avg, upconv
-(nlt/networks/elements.py:42-48,69-94,103-121) -- on csrc/branches.hip + the layer-by-layer path (nlt_amd/generic.py):
+"""-m gpu: the config branches the released .ini files leave off -- act = elu, norm = pixel / layer / batch, pool = max / avg,
+upconv (nlt/networks/elements.py:42-56,69-94,103-121) -- on csrc/branches.hip, csrc/norms.hip + the layer-by-layer path (nlt_amd/generic.py):
 each layer's forward / backward against torch-CPU autograd on the oracle's restatement, then whole models (forward and
 one train step, every weight gradient) against oracle.OracleModel with the same branch."""
 import numpy as np
@@ -40,6 +40,49 @@ def test_pixelnorm_forward_backward(c):
     assert rel_l2(y.cpu(), O.pixel_norm(x)) <= 1e-6 and rel_l2(dx.cpu(), _grad(O.pixel_norm, x, g)) <= 1e-5
 
 
+@pytest.mark.parametrize('kind,name', [(C.NORM_LAYER, 'layer'), (C.NORM_BATCH, 'batch')])
+@pytest.mark.parametrize('shape', [(2, 6, 5, 3), (1, 33, 17, 16), (3, 4, 4, 40), (1, 9, 7, 256), (1, 2, 3, 1024), (2, 96, 96, 32)])
+def test_layer_and_batch_norm_forward_backward(kind, name, shape):
+    """csrc/norms.hip vs torch autograd on the oracle's restatement (elements.py:51-56): y, dx, and dgamma / dbeta
+    ACCUMULATED on top of what the gradient views already hold; two runs are bit-identical (fixed-order reductions)."""
+    gen = torch.Generator().manual_seed(sum(shape) + kind)
+    c = shape[-1]
+    x = torch.randn(shape, generator=gen) * 2 + 0.5
+    g = torch.randn(shape, generator=gen)
+    gamma = torch.rand(c, generator=gen) + 0.5
+    beta = torch.rand(c, generator=gen) - 0.5
+    mean, var = torch.randn(c, generator=gen) * 0.1, torch.rand(c, generator=gen) + 0.5
+    if kind == C.NORM_LAYER:
+        f = lambda xx, gg, bb: O.layer_norm(xx, gg, bb)
+    else:
+        f = lambda xx, gg, bb: (xx - mean) * torch.rsqrt(var + O.NORM_EPS) * gg + bb
+    xx, gg, bb = (t.clone().requires_grad_(True) for t in (x, gamma, beta))
+    ref = f(xx, gg, bb)
+    rdx, rdg, rdb = torch.autograd.grad(ref, (xx, gg, bb), g)
+    d = lambda t: t.cuda()
+    y = C.norm_forward(kind, d(x), d(gamma), d(beta), d(mean), d(var), O.NORM_EPS)
+    outs = []
+    for _ in range(2):
+        dg, db = torch.full((c,), 2.0, device='cuda'), torch.full((c,), -1.0, device='cuda')
+        dx = C.norm_backward(kind, d(g), d(x), d(gamma), d(mean), d(var), O.NORM_EPS, dg, db)
+        torch.cuda.synchronize()
+        outs.append((dx.cpu(), dg.cpu(), db.cpu()))
+    assert all(torch.equal(a, b) for a, b in zip(*outs))
+    dx, dg, db = outs[0]
+    assert rel_l2(y.cpu(), ref.detach()) <= 1e-6
+    assert rel_l2(dx, rdx) <= 2e-5 and rel_l2(dg - 2.0, rdg) <= 2e-5 and rel_l2(db + 1.0, rdb) <= 2e-5
+    if kind == C.NORM_BATCH:
+        # the reference's run-time form: moving statistics at their initial (0, 1)
+        y0 = C.norm_forward(kind, d(x), d(gamma), d(beta), torch.zeros(c, device='cuda'), torch.ones(c, device='cuda'), O.NORM_EPS)
+        assert rel_l2(y0.cpu(), O.batch_norm_inference(x, gamma, beta)) <= 1e-6
+
+
+def test_norm_refuses_more_than_1024_channels():
+    x = torch.zeros(1, 2, 2, 1100, device='cuda')
+    with pytest.raises(C.NLTError):
+        C.norm_forward(C.NORM_LAYER, x, torch.ones(1100, device='cuda'), torch.zeros(1100, device='cuda'), None, None, 1e-3)
+
+
 @pytest.mark.parametrize('kind,name', [(C.POOL_MAX, 'max'), (C.POOL_AVG, 'avg')])
 def test_pool_forward_backward(kind, name):
     x = torch.randn(2, 8, 12, 5)
@@ -60,7 +103,8 @@ def _pair(**kw):
     return om, pm
 
 
-BRANCHES = [dict(act='elu'), dict(norm='pixel'), dict(pool='max'), dict(pool='avg', act='elu', norm='pixel')]
+BRANCHES = [dict(act='elu'), dict(norm='pixel'), dict(pool='max'), dict(pool='avg', act='elu', norm='pixel'),
+            dict(norm='layer'), dict(norm='batch'), dict(norm='layer', pool='avg', act='relu')]
 
 
 @pytest.mark.parametrize('kw', BRANCHES, ids=lambda kw: '+'.join('%s=%s' % x for x in kw.items()))

@@ -245,11 +245,20 @@ def test_dataset_load_batch(C):
     # resident batch: texel buffers stay in the uint8 store; materialising them gives the eager batch bit for bit
     r = ds.load_batch(ids[:2], resident=True)
     e = get_dataset_class('nlt')(cfg, 'train', store, ring=0).load_batch(ids[:2])
-    assert all(r[i] is None for i in (2, 3, 5, 8, 9)) and r[1].n == 2 and r[1].k == 1 and (r[1].h, r[1].w) == (H, W)
+    assert all(r[i] is None for i in (2, 3, 4, 5, 8, 9)) and r[1].n == 2 and r[1].k == 1 and (r[1].h, r[1].w) == (H, W)
+    assert (r[1].hc, r[1].wc) == (im, im)
     m = r[1].materialize()
-    for key, i in (('base', 1), ('cvis', 2), ('lvis', 3), ('rgb', 5), ('nn_base', 8), ('nn_rgb', 9)):
+    for key, i in (('base', 1), ('cvis', 2), ('lvis', 3), ('warp', 4), ('rgb', 5), ('nn_base', 8), ('nn_rgb', 9)):
         assert torch.equal(m[key].cpu(), e[i].cpu()), key
-    assert torch.equal(r[1].base_float().cpu(), e[1].cpu()) and torch.equal(r[4].cpu(), e[4].cpu())
+    assert torch.equal(r[1].base_float().cpu(), e[1].cpu()) and torch.equal(r[1].warp_float().cpu(), e[4].cpu())
+    assert torch.equal(r[6].cpu(), e[6].cpu()) and torch.equal(r[10].cpu(), e[10].cpu())
+    # the ring's single pinned upload of (frame ids | neighbour ids) per batch: contents follow the ids slot after slot
+    rr = [ds3.load_batch(ids[i:i + 2], resident=True) for i in range(4)]
+    if torch.cuda.is_available():
+        torch.cuda.synchronize()
+    for i, b_ in enumerate(rr[1:], 1):                              # (rr[0]'s slot was refilled by rr[3])
+        assert b_[1].ids.cpu().tolist() == [i, i + 1]
+        assert torch.equal(b_[1].materialize()['base'].cpu(), torch.from_numpy(f32(store['diffuse'][i:i + 2])))
 
 
 def test_psnr_on_luma_matches_the_reference_values():

@@ -128,12 +128,14 @@ def test_model_call_on_a_store_resident_batch_equals_the_eager_float_batch():
     ds = get_dataset_class('nlt')(cfg, 'train', store, k=k, ring=0)
     ids = store['ids'][2:4]
     eager, res = ds.load_batch(ids), ds.load_batch(ids, resident=True)
-    assert res[2] is None and eager[8].shape == (2, k, uv, uv, 3)
+    assert res[2] is None and res[4] is None and eager[8].shape == (2, k, uv, uv, 3)
     for mode in ('test', 'vali'):
-        a, b = pm.call(eager, mode), pm.call(res, mode)
+        a, b = pm.call(eager, mode, want_indices=True), pm.call(res, mode, want_indices=True)
         torch.cuda.synchronize()
         assert torch.equal(a[0], b[0]) and torch.equal(a[3]['pred'], b[3]['pred'])
-        assert torch.equal(a[3]['base_camspc'], b[3]['base_camspc'])
+        # base and the uv2cam map gathered straight from the uint8 / fp16 stores (nlt_warp_forward_store): same bits,
+        # same integer UV indices
+        assert torch.equal(a[3]['base_camspc'], b[3]['base_camspc']) and torch.equal(a[3]['uv_indices'], b[3]['uv_indices'])
         if mode == 'vali':
             assert torch.equal(a[1], b[1]) and torch.equal(a[3]['gt'], b[3]['gt'])
     for _ in range(3):                                          # recorded launch tape, then replays

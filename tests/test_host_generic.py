@@ -1,5 +1,5 @@
 """CPU: the layer-by-layer path (nlt_amd/generic.py) for the config branches the fused plan does not execute -- act = elu,
-norm = pixel, pool = max / avg (+ upconv) -- driven through the TEST-ONLY C-ABI emulation against the oracle: forward,
+norm = pixel / layer / batch, pool = max / avg (+ upconv) -- driven through the TEST-ONLY C-ABI emulation against the oracle: forward,
 and one train step's loss and every weight gradient (the hand-rolled backward tape: conv adjoints, concat splits, the
 observation mean, the skip stack's fan-in).  Also: the generic path on the DEFAULT config equals the fused plan."""
 import numpy as np
@@ -23,12 +23,16 @@ def make(depth, uv, im, **kw):
             assert len(convs) == len(lw)
             for c, (k, b) in zip(convs, lw):
                 c.kernel, c.bias = torch.tensor(k), torch.tensor(b)
-                c.cin = k.shape[3] if c.transpose else k.shape[2]
+                if hasattr(c, 'transpose'):
+                    c.cin = k.shape[3] if c.transpose else k.shape[2]
+                else:                                            # ChannelNorm: (gamma, beta)
+                    c.c = k.shape[0]
                 c.built = True
     return om, pm
 
 
-BRANCHES = [dict(act='elu'), dict(norm='pixel'), dict(pool='max'), dict(pool='avg'), dict(act='elu', norm='pixel', pool='max')]
+BRANCHES = [dict(act='elu'), dict(norm='pixel'), dict(pool='max'), dict(pool='avg'), dict(act='elu', norm='pixel', pool='max'),
+            dict(norm='layer'), dict(norm='batch'), dict(norm='layer', pool='avg', act='relu')]
 
 
 @pytest.mark.parametrize('kw', BRANCHES, ids=lambda kw: '+'.join('%s=%s' % x for x in kw.items()))
@@ -59,9 +63,8 @@ def test_branch_forward_and_train_step_match_oracle(monkeypatch, kw):
 
 
 def test_unsupported_norms_say_why():
-    for norm in ('batch', 'layer', 'instance'):
-        with pytest.raises(NotImplementedError, match='flat parameter bucket'):
-            get_model_class('nlt')(nlt_amd.make_config(depth=32, norm=norm))
+    with pytest.raises(NotImplementedError, match='tf.contrib'):
+        get_model_class('nlt')(nlt_amd.make_config(depth=32, norm='instance'))
     with pytest.raises(NotImplementedError):
         get_model_class('nlt')(nlt_amd.make_config(depth=32, act='gelu'))
 

@@ -34,7 +34,7 @@ def test_convnet_structure():
     assert convnet.Network(16, 1024, 2, 2, act_type='relu').layers[1].convs()[0][1].alpha == 0.0
     with pytest.raises(AssertionError):
         convnet.Network(8, 64, 2, 2)                       # depth0 must be 16
-    for bad in (dict(norm_type='batch'), dict(norm_type='layer'), dict(norm_type='instance'), dict(act_type='gelu'), dict(pool_type='l2')):
+    for bad in (dict(norm_type='instance'), dict(act_type='gelu'), dict(pool_type='l2')):
         with pytest.raises(NotImplementedError):
             convnet.Network(16, 256, 2, 2, **bad)
     # the branches that ARE built: stand-alone layers, executed by nlt_amd/generic.py
@@ -43,6 +43,13 @@ def test_convnet_structure():
     down, up = pooled.layers[1], pooled.layers[4]
     assert [type(l).__name__ for l in down.layers] == ['Conv2D', 'PixelNorm', 'Act', 'Conv2D', 'PixelNorm', 'Act', 'Pool2D']
     assert isinstance(up.layers[0], E.Sequential) and [type(l).__name__ for l in up.layers[0].layers] == ['UpSample2D', 'Conv2D']
+    # norm = layer / batch (elements.py:51-56): a two-variable layer (gamma, beta) after every conv of a block
+    for kind in ('layer', 'batch'):
+        normed = convnet.Network(16, 32, 2, 2, norm_type=kind, act_type='leakyrelu')
+        blk = normed.layers[1]
+        assert [type(l).__name__ for l in blk.layers] == ['Conv2D', 'ChannelNorm', 'Act', 'Conv2D', 'ChannelNorm', 'Act', 'Identity']
+        assert [type(l).__name__ for l in blk.all_convs()] == ['Conv2D', 'ChannelNorm', 'Conv2D', 'ChannelNorm'] and not blk.is_plain()
+        assert blk.layers[1].eps == 1e-3 and blk.layers[1].name == kind
     assert down.layers[2].kind == 'elu' and not down.is_plain() and len(up.all_convs()) == 3
     assert pooled.spatsize_changes[1] == 0.25 and pooled.spatsize_changes[4] == 4
     assert convnet.Network.str2none('None') is None and convnet.Network.str2none('x') == 'x'
