@@ -47,10 +47,12 @@ def pmc_traffic(label):
             continue
         for name, rec in d.get('kernels', {}).items():
             if any(fr in name for fr in frags) and rec.get('hbm_bytes') is not None:
-                return int(rec['hbm_bytes'])
-    return None
+                return int(rec['hbm_bytes']), os.path.basename(path)
+    return None, None
 
 BYTES_PER_TEXEL = {1: 961.5, 4: 1755.75}   # SURVEY.md 8d, fp32 layer-wise algorithmic bytes
+# layer-wise conv FLOP (2 x MAC) per rendered texel of the forward; the obs path adds 4448 per extra neighbour
+FLOP_PER_TEXEL = {256: lambda k: 13464 + 4448 * (k - 1), 1024: lambda k: 17944 + 4448 * (k - 1)}
 
 
 def pmc_step_bytes():
@@ -119,6 +121,7 @@ def parse():
                     help='train step: replay forward + loss + backward as one hipGraph (trainvali.GraphedTrainStep); measured '
                          'slower than eager launches on ROCm 7.0 (5.15 vs 4.75 ms), so off by default')
     ap.add_argument('--headline-only', action='store_true', help='only the timed forward (profiling runs): no loader-inclusive legs, train steps or CPU leg')
+    ap.add_argument('--no-released-shapes', action='store_true', help='skip the config 1 / config 2 sub-lines (released .ini shapes)')
     ap.add_argument('--per-op-train', action='store_true', help='per-launch timing table of one train step (stderr)')
     return ap.parse_args()
 
@@ -266,7 +269,7 @@ def bench_train(args, device, world, rank, n_steps, loss):
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for i in range(n_steps):
-            loss_v, _ = run(batches[0 if same_batch else i % len(batches)])
+            loss_v, _ = run(batches[0 if same_batch else i % len(batches)])   # (`run` is looked up at call time)
         enq = time.perf_counter() - t0                               # host enqueue time (the GPU may still be running)
         torch.cuda.synchronize()
         if world > 1:
@@ -280,7 +283,25 @@ def bench_train(args, device, world, rank, n_steps, loss):
     el, enq, last = timed(False)
     replays = model.plan.tape_replays - replays0
     el_same, _, _ = timed(True)
-    return {"loss": loss, "value": round(world * args.frames * args.uv * args.uv * n_steps / el / 1e6, 2), "unit": "Mtexels/s",
+    # what a multi-GPU run has to document about itself: the collective library's own world size, the two all-reduce
+    # ranges, and the step with the first range issued from inside the backward plan (overlap) vs after it (serial)
+    comm = {"rccl_world": dist.get_world_size() if (world > 1 and dist.is_initialized()) else 1,
+            "allreduce_floats": [int(model.bucket_split), int(model.flat_params.numel() - model.bucket_split)],
+            "allreduce_MB": [round(4e-6 * model.bucket_split, 2), round(4e-6 * (model.flat_params.numel() - model.bucket_split), 2)],
+            "backend": "nccl (RCCL over xGMI)" if world > 1 else "none (single rank: no collective is issued)"}
+    if world > 1 and not args.train_graph:
+        run_serial = lambda b: trainvali.distributed_train_step(model, b, opt, gbs, overlap=False)
+        for i in range(len(batches)):
+            run_serial(batches[i])
+        run_saved, run = run, run_serial
+        el_serial, _, _ = timed(False)
+        run = run_saved
+        comm["ms_per_step_overlapped"] = round(1e3 * el / n_steps, 3)
+        comm["ms_per_step_serial"] = round(1e3 * el_serial / n_steps, 3)
+    flops = 3 * FLOP_PER_TEXEL[args.depth](1) * args.frames * args.uv * args.uv      # forward + backward-data + weight gradients
+    return {"loss": loss, "comm": comm,
+            "layerwise_flops_per_step_per_gpu": int(flops),
+            "frac_of_fp32_mfma_peak": round(flops / (el / n_steps) / 1e12 / MFMA_F32_PEAK_TFLOPS, 4), "value": round(world * args.frames * args.uv * args.uv * n_steps / el / 1e6, 2), "unit": "Mtexels/s",
             "ms_per_step": round(1e3 * el / n_steps, 3), "ms_per_step_same_batch_every_step": round(1e3 * el_same / n_steps, 3),
             "host_enqueue_ms_per_step": round(1e3 * enq / n_steps, 3),
             "steps": n_steps, "global_batch": gbs, "distinct_batches_rotated": len(batches),
@@ -303,6 +324,7 @@ def bench_config5(args, device):
     a5 = copy.copy(args)
     a5.uv, a5.frames, a5.k, a5.batches, a5.store_frames = 2048, 2, 1, 3, 6
     out = {"workload": "BASELINE config 5: depth0 16/depth %d, 2 frames, 2048^2 UV, k=1, %d^2 camera warp" % (args.depth, args.cam)}
+    preds = {}
     for prec in ('fp32', 'bf16'):
         cfg, ds, id_lists = make_loader(a5, device, 1, 'train', seed=500)
         cfg.set('DEFAULT', 'precision', prec)
@@ -324,8 +346,147 @@ def bench_config5(args, device):
         out[prec] = {"ms_per_step": round(1e3 * dt, 4), "Mtexels_per_s": round(a5.frames * a5.uv * a5.uv / dt / 1e6, 1),
                      "dtype": "f32" if prec == 'fp32' else "bf16 storage + bf16 MFMA (fp32 accumulate) for levels >= 3 and the "
                               "expanding blocks mirroring them; fp32 ends"}
+        preds[prec] = model.call(batches[0], 'test')[3]['pred'].double()
         del model, batches, ds
         torch.cuda.empty_cache()
+    # same weights (seeded), same batch: how far the bf16 middle moves the rendered texels, measured in THIS run on the GPU;
+    # the comparison against the CPU oracle at this size is tests/test_gpu_baseline_sizes.py::test_config5_2048_fp32_and_bf16
+    out["bf16"]["rel_l2_pred_vs_fp32_plan"] = float((preds['bf16'] - preds['fp32']).norm() / preds['fp32'].norm())
+    out["bf16"]["oracle_parity"] = parity_record(('config5_2048_k1_n2_bf16', 'config5_2048_k1_n2_fp32'))
+    return out
+
+
+def parity_record(keys):
+    """The newest committed HIP-vs-oracle figures for these test ids (profiles/*_parity_sizes.json, written by the -m gpu
+    tests under NLT_PARITY_DUMP); bench.py itself never runs the oracle outside its cpu_baseline leg."""
+    import glob
+    for path in sorted(glob.glob(os.path.join(ROOT, 'profiles', '*_parity_sizes.json')), reverse=True):
+        try:
+            with open(path) as f:
+                d = json.load(f)
+        except (OSError, ValueError):
+            continue
+        got = {k_: d[k_] for k_ in keys if k_ in d}
+        if got:
+            got["source"] = "profiles/" + os.path.basename(path)
+            return got
+    return None
+
+
+def identity_batches(n, uv, cam, k, device, nb=3):
+    """`nb` float32 11-tuples of seeded uniform buffers; relight-only shapes (cam == uv) get the identity warp of
+    nlt/README.md "Relighting Only?"."""
+    import torch
+    batches = [synth_device_batch(n, uv, cam, k, device, seed=900 + i) for i in range(nb)]
+    if cam == uv:
+        jj, ii = torch.meshgrid(torch.arange(cam, device=device), torch.arange(cam, device=device), indexing='xy')
+        wp = torch.stack((jj / cam, ii / cam), -1)[None].repeat(n, 1, 1, 1).float().contiguous()
+        batches = [b[:4] + (wp,) + b[5:] for b in batches]
+    return batches
+
+
+def time_forward(model, batches, steps):
+    import torch
+    for i in range(3 * len(batches)):                             # plan-time autotune, tape record, replays
+        model.call(batches[i % len(batches)], 'test')
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(steps):
+        model.call(batches[i % len(batches)], 'test')
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / steps
+
+
+def bench_released_shapes(args, device, world, rank):
+    """The two shapes the reference releases configs for, beside the headline: BASELINE config 2 (dragon_specular.ini: depth
+    256, 512^2 UV, bs 4, k = 1, relight only: identity warp) forward AND train step with the released loss (barron), and
+    BASELINE config 1 (dragon_sss.ini: depth 1024, 256^2) forward; each with its fraction of the fp32 MFMA roof by SURVEY
+    8d's layer-wise FLOP, and how the forward's throughput grows with frames per call (nlt_test.py --batch_size_override,
+    nlt/nlt_test.py:33-42,78-94): these shapes are latency-bound at 4 frames."""
+    import copy
+    import torch
+    import nlt_amd
+    from nlt_amd.models import get_model_class
+    out = {}
+    for name, depth, uv in (("config2_512_depth256", 256, 512), ("config1_256_depth1024", 1024, 256)):
+        cfg = nlt_amd.make_config(depth=depth, uvh=uv, uvw=uv, imh=uv, imw=uv, bs=4)
+        model = get_model_class('nlt')(cfg).build(device)
+        g = torch.Generator(device=device).manual_seed(1234)
+        for v in model.register_trainable() or model.trainable_variables:
+            if v.dim() == 1:
+                v.data.uniform_(-0.1, 0.1, generator=g)
+        rec = {"workload": "depth0 16/depth %d, %d^2 UV, k=1, identity warp (relight only), fp32" % (depth, uv), "forward": {}}
+        for frames in (4, 16, 64):
+            batches = identity_batches(frames, uv, uv, 1, device)
+            dt = time_forward(model, batches, 60 if frames <= 16 else 20)
+            fl = FLOP_PER_TEXEL[depth](1) * frames * uv * uv
+            rec["forward"]["%d_frames" % frames] = {
+                "ms_per_step": round(1e3 * dt, 4), "Mtexels_per_s": round(frames * uv * uv / dt / 1e6, 1),
+                "frac_of_fp32_mfma_peak": round(fl / dt / 1e12 / MFMA_F32_PEAK_TFLOPS, 4)}
+            del batches
+            torch.cuda.empty_cache()
+        out[name] = rec
+        del model
+        torch.cuda.empty_cache()
+    a2 = copy.copy(args)
+    a2.uv, a2.cam, a2.frames, a2.k, a2.depth, a2.per_op_train, a2.tune_cache = 512, 512, 4, 1, 256, False, None
+    t = bench_train(a2, device, world, rank, 50, 'barron')
+    out["config2_512_depth256"]["train_step_barron_bs4"] = {k_: t[k_] for k_ in (
+        "ms_per_step", "value", "unit", "frac_of_fp32_mfma_peak", "layerwise_flops_per_step_per_gpu", "host_enqueue_ms_per_step",
+        "launch_tape_replays", "final_loss")}
+    return out
+
+
+def bench_stress_64ch(device):
+    """north_star's "1024^2 UV x 64-ch" point: no tensor of the released net is 64 channels wide at full
+    resolution, so this is the channel-width stress of the per-texel kernels, reported beside the exact shapes: 1x1
+    channel mix 64 -> 64 (fp32 MFMA and bf16 MFMA), the same 1x1 on a virtual concat (32 | 32 -> 64), and the resampler
+    on a 64-channel map (1024^2 -> 512^2 camera pixels, chart-structured map).  One frame of 1024^2 texels; GB/s =
+    compulsory bytes (each input element read once, each output element written once) / time, fraction of 8 TB/s."""
+    import torch
+    from nlt_amd import capi as C
+    from nlt_amd.datasets.synth import chart_warp
+    n, uv, c = 1, 1024, 64
+    g = torch.Generator(device=device).manual_seed(7)
+    x = torch.rand((n, uv, uv, c), device=device, generator=g)
+    w = (torch.rand((1, 1, c, c), device=device, generator=g) - 0.5) * 0.3
+    b = torch.rand(c, device=device, generator=g) - 0.5
+    y = torch.empty_like(x)
+    packed = C.pack_conv_weights(C.CONV1X1, w, c, 0, c)
+    packed2 = C.pack_conv_weights(C.CONV1X1, w, c // 2, c // 2, c)
+    xa, xb = x[..., :c // 2].contiguous(), x[..., c // 2:].contiguous()
+    xh = x.to(torch.bfloat16)
+    pb = C.chmix_bf16_pack(w)
+    warp_px = (chart_warp(n, 512, g, device).float() * uv).contiguous()
+
+    def timeit(fn, reps=30):
+        for _ in range(5):
+            fn()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / reps * 1e-3
+    texels = n * uv * uv
+    legs = {
+        "conv1x1_f32_64to64": (lambda: C.conv_forward(C.CONV1X1, x, c, c, None, 0, 0, n, uv, uv, w, packed, b, c, y, c, act=True, alpha=0.3,
+                                                     algo=C.ALGO_MFMA), 4 * 2 * c * texels, 2 * c * c * texels),
+        "conv1x1_f32_virtual_concat_32_32to64": (lambda: C.conv_forward(C.CONV1X1, xa, c // 2, c // 2, xb, c // 2, c // 2, n, uv, uv, w, packed2, b,
+                                                                       c, y, c, act=True, alpha=0.3, algo=C.ALGO_MFMA),
+                                                 4 * 2 * c * texels, 2 * c * c * texels),
+        "conv1x1_bf16_64to64": (lambda: C.chmix_bf16_forward(xh, pb, b, c, act=True, alpha=0.3), 2 * 2 * c * texels, 2 * c * c * texels),
+        "resampler_f32_64ch_to_512cam": (lambda: C.resample_forward(x, warp_px), 512 * 512 * n * (8 + 4 * c * 4 + 4 * c), 0),
+    }
+    out = {"workload": "1 frame, 1024^2 UV, 64 channels (NHWC)"}
+    for name, (fn, nbytes, flops) in legs.items():
+        dt = timeit(fn)
+        out[name] = {"ms": round(1e3 * dt, 4), "Gtexels_per_s": round(texels / dt / 1e9, 2), "GBps": round(nbytes / dt / 1e9, 1),
+                     "frac_of_hbm_peak": round(nbytes / dt / 1e9 / HBM_PEAK_GBS, 4)}
+        if flops:
+            out[name]["TFLOPs"] = round(flops / dt / 1e12, 1)
     return out
 
 
@@ -451,20 +612,29 @@ def main():
         for loss in args.train_loss.split(','):
             train.append(bench_train(args, device, world, rank, n_train, loss))
 
+    released = None
+    if not args.headline_only and not args.no_released_shapes and args.uv == 1024:
+        released = bench_released_shapes(args, device, world, rank)     # (its train leg is collective on every rank)
+
     if rank == 0:
         texels = world * args.frames * args.uv * args.uv * args.steps
         value = texels / elapsed / 1e6
         ach = dom_bytes / (dom_ms * 1e-3) / 1e9
         bpt = algorithmic_bytes_per_texel(args.k)
+        # HBM bytes per launch of the dominant kernel: NOT measured in this run (PMC needs rocprofv3 around the process) --
+        # read from the newest committed counter pass; `traffic_source` names the file so a stale figure is visible
+        traffic, traffic_src = pmc_traffic(dominant)
+        if traffic_src is not None:
+            traffic_src = "profiles/%s (committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, not this run)" % traffic_src
         if dom_flops / max(dom_bytes, 1) > MFMA_F32_PEAK_TFLOPS * 1e12 / (HBM_PEAK_GBS * 1e9):   # above the fp32 ridge
             tf = dom_flops / (dom_ms * 1e-3) / 1e12
             roof = {"bound": "mfma", "kernel": dominant, "achieved": round(tf, 2), "peak": MFMA_F32_PEAK_TFLOPS,
-                    "unit": "TFLOP/s", "frac": round(tf / MFMA_F32_PEAK_TFLOPS, 4), "traffic": pmc_traffic(dominant),
+                    "unit": "TFLOP/s", "frac": round(tf / MFMA_F32_PEAK_TFLOPS, 4), "traffic": traffic, "traffic_source": traffic_src,
                     "launch_ms": round(dom_ms, 4), "flops_per_launch": int(dom_flops),
                     "algorithmic_bytes_per_launch": int(dom_bytes)}
         else:
             roof = {"bound": "hbm", "kernel": dominant, "achieved": round(ach, 1), "peak": HBM_PEAK_GBS,
-                    "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": pmc_traffic(dominant),
+                    "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
                     "launch_ms": round(dom_ms, 4), "algorithmic_bytes_per_launch": int(dom_bytes)}
         if dom_layerwise != dom_bytes:                          # fused launch: also what it replaces, layer by layer
             roof["layerwise_bytes_replaced"] = int(dom_layerwise)
@@ -492,6 +662,9 @@ def main():
             out["forward_including_loader"] = with_loader
         if world == 1 and not args.headline_only and args.uv == 1024:
             out["config5_2048_bf16"] = bench_config5(args, device)
+            out["stress_64ch"] = bench_stress_64ch(device)
+        if released:
+            out["released_shapes"] = released
         if train:
             out["train_step"] = train[0]
             if len(train) > 1:

@@ -105,6 +105,42 @@ def test_warp_matches_oracle_and_indices_bit_exact(identity):
         np.testing.assert_array_equal(pc.cpu().numpy(), pred)      # identity warp == no-op
 
 
+@pytest.mark.parametrize('c', [4, 64])
+def test_resampler_on_a_wide_map_matches_the_oracle(c):
+    """nlt_resample_forward (the 64-channel stress point of SURVEY 8d): tfa.image.resampler's rule on a c-channel map, pixel
+    units, no corner mask; same taps / order as the 3-channel warp, so within 1e-6 absolute of the oracle's float32 restatement (the bar of the 3-channel warp test above)."""
+    n, h, w, hc, wc = 2, 24, 40, 16, 24
+    _, _, warp = _warp_case(n, h, w, hc, wc, 5)
+    rng = np.random.default_rng(c)
+    data = rng.random((n, h, w, c), dtype=np.float32)
+    wpx = (warp * np.float32([w, h])).astype(np.float32)
+    got = C.resample_forward(d(data), d(wpx)).cpu().numpy()
+    np.testing.assert_allclose(got, T.resampler_naive(data, wpx), atol=1e-6, rtol=0)
+    with pytest.raises(C.NLTError):
+        C.resample_forward(d(data[..., :3].copy()), d(wpx))
+
+
+def test_warp_from_the_stores_equals_the_float_warp_bit_for_bit():
+    """nlt_warp_forward_store: base from the uint8 diffuse store, the map from the fp16 uv2cam store (frame ids), against
+    nlt_warp_forward on the float32 tensors `_load_data` would have produced -- identical bits and identical UV indices."""
+    n, uvh, uvw, hc, wc, F = 3, 32, 48, 16, 24, 5
+    rng = np.random.default_rng(11)
+    pred, _, warp = _warp_case(n, uvh, uvw, hc, wc, 7)
+    diffuse = torch.from_numpy(rng.integers(0, 256, (F, uvh, uvw, 3), dtype=np.uint8)).cuda()
+    maps = torch.from_numpy(rng.random((F, hc, wc, 2), dtype=np.float32)).half()
+    ids = torch.tensor([4, 0, 2], dtype=torch.int32)
+    maps[ids.long()] = torch.from_numpy(warp).half()                  # (the test map is fp16-representable)
+    maps = maps.cuda()
+    base = (diffuse[ids.long().cuda()].double() / 255.0).float()
+    E = lambda: torch.empty(n, hc, wc, 3, device='cuda')
+    a, b = [E(), E(), E()], [E(), E(), E()]
+    ia, ib = (torch.empty(n, hc, wc, 4, dtype=torch.int32, device='cuda') for _ in range(2))
+    C.warp_forward(d(pred), base, maps[ids.long().cuda()].float(), n, uvh, uvw, hc, wc, *a, ia)
+    C.warp_forward_store(d(pred), diffuse, maps, ids.cuda(), n, uvh, uvw, hc, wc, *b, ib)
+    torch.cuda.synchronize()
+    assert all(torch.equal(x, y) for x, y in zip(a, b)) and torch.equal(ia, ib)
+
+
 @pytest.mark.parametrize('oh,ow', [(8, 8), (32, 24), (5, 7), (16, 16)])
 def test_resize(oh, ow):
     rng = np.random.default_rng(oh)
