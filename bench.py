@@ -333,6 +333,12 @@ def bench_config5(args, device):
         for v in model.register_trainable() or model.trainable_variables:
             if v.dim() == 1:
                 v.data.uniform_(-0.1, 0.1, generator=g)
+        if preds:                                                # the SAME weights in both precisions (kernels are drawn per instance)
+            with torch.no_grad():
+                model.flat_params.copy_(weights)
+            model.mark_weights_updated()
+        else:
+            weights = model.flat_params.detach().clone()
         batches = [ds.load_batch(ids) for ids in id_lists]
         for i in range(9):
             model.call(batches[i % 3], 'test')
@@ -471,22 +477,36 @@ def bench_stress_64ch(device):
         torch.cuda.synchronize()
         return e0.elapsed_time(e1) / reps * 1e-3
     texels = n * uv * uv
+    # the fp32 1x1s run on the network's own implicit-GEMM kernel with the wave tile chosen by timing, as the plan does
+    def conv1x1(hint, concat):
+        if concat:
+            return lambda: C.conv_forward(C.CONV1X1, xa, c // 2, c // 2, xb, c // 2, c // 2, n, uv, uv, w, packed2, b, c, y, c,
+                                          act=True, alpha=0.3, algo=C.ALGO_MFMA, tile_hint=hint)
+        return lambda: C.conv_forward(C.CONV1X1, x, c, c, None, 0, 0, n, uv, uv, w, packed, b, c, y, c, act=True, alpha=0.3,
+                                      algo=C.ALGO_MFMA, tile_hint=hint)
+    best = {}
+    for concat in (False, True):
+        tried = [(timeit(conv1x1(16 * r + ct, concat), reps=8), 16 * r + ct) for r in (1, 2, 4) for ct in (1, 2, 4)]
+        best[concat] = min(tried)[1]
+    cam_px = 512 * 512 * n
     legs = {
-        "conv1x1_f32_64to64": (lambda: C.conv_forward(C.CONV1X1, x, c, c, None, 0, 0, n, uv, uv, w, packed, b, c, y, c, act=True, alpha=0.3,
-                                                     algo=C.ALGO_MFMA), 4 * 2 * c * texels, 2 * c * c * texels),
-        "conv1x1_f32_virtual_concat_32_32to64": (lambda: C.conv_forward(C.CONV1X1, xa, c // 2, c // 2, xb, c // 2, c // 2, n, uv, uv, w, packed2, b,
-                                                                       c, y, c, act=True, alpha=0.3, algo=C.ALGO_MFMA),
-                                                 4 * 2 * c * texels, 2 * c * c * texels),
+        "conv1x1_f32_64to64": (conv1x1(best[False], False), 4 * 2 * c * texels, 2 * c * c * texels),
+        "conv1x1_f32_virtual_concat_32_32to64": (conv1x1(best[True], True), 4 * 2 * c * texels, 2 * c * c * texels),
         "conv1x1_bf16_64to64": (lambda: C.chmix_bf16_forward(xh, pb, b, c, act=True, alpha=0.3), 2 * 2 * c * texels, 2 * c * c * texels),
-        "resampler_f32_64ch_to_512cam": (lambda: C.resample_forward(x, warp_px), 512 * 512 * n * (8 + 4 * c * 4 + 4 * c), 0),
+        # compulsory bytes of the gather: the map (8 B), ONE new texel per camera pixel (the other taps are shared with the
+        # neighbouring pixels of a chart and cache-served), the output
+        "resampler_f32_64ch_to_512cam": (lambda: C.resample_forward(x, warp_px), cam_px * (8 + 4 * c + 4 * c), 0),
     }
-    out = {"workload": "1 frame, 1024^2 UV, 64 channels (NHWC)"}
+    out = {"workload": "1 frame, 1024^2 UV, 64 channels (NHWC)",
+           "conv1x1_f32_wave_tile": {"plain": "%dx%d" % (best[False] >> 4, best[False] & 15), "virtual_concat": "%dx%d" % (best[True] >> 4, best[True] & 15)}}
     for name, (fn, nbytes, flops) in legs.items():
         dt = timeit(fn)
         out[name] = {"ms": round(1e3 * dt, 4), "Gtexels_per_s": round(texels / dt / 1e9, 2), "GBps": round(nbytes / dt / 1e9, 1),
                      "frac_of_hbm_peak": round(nbytes / dt / 1e9 / HBM_PEAK_GBS, 4)}
         if flops:
             out[name]["TFLOPs"] = round(flops / dt / 1e12, 1)
+    r = out["resampler_f32_64ch_to_512cam"]
+    r["tap_GBps_cache_served"] = round(cam_px * (8 + 4 * 4 * c + 4 * c) / (r["ms"] * 1e-3) / 1e9, 1)   # all four taps counted
     return out
 
 
