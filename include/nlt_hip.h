@@ -630,6 +630,26 @@ int nlt_conv_forward_splitk(int mode, int tile_hint, int ksplit, float* workspac
                             int cout, float* out, int ldo, int act, float alpha,
                             const float* mask_src, int ldm, int accumulate, void* stream);
 
+/*
+ * Backward-data of one conv: the gradient w.r.t. the layer's input channels from the gradient w.r.t. its pre-activation
+ * output dpre [n,h,w,cpre] (stride ldp), as the ADJOINT conv family on the same Keras array (CONV_K2Sx <-> DECONV_K2Sx;
+ * w_packed = nlt_pack_conv_weights(adj_mode, slice of the forward kernel), zero_bias = cout zeros), MFMA path, optional
+ * split-K (ksplit > 1: workspace of nlt_conv_splitk_workspace_floats(adj_mode, n, h, w, cout, ksplit) floats).
+ * Epilogue, per output element:  v (+= out when accumulate);
+ *   mask_src != NULL: v *= LeakyReLU'(mask_src) -- the result is then the gradient w.r.t. the PRODUCER's pre-activation;
+ *   split_c > 0 (the target is dfm[l] = [query c | observation-mean c], ONE observation per frame): channels >= split_c are
+ *     not stored to out; (v + (split_partial ? split_d : 0)) * LeakyReLU'(split_y) goes to split_d [rows, split_c] -- the
+ *     gradient w.r.t. the observation path's pre-activation.  The tf.reduce_mean adjoint of nlt/models/nlt.py:161-164 and
+ *     both activations' derivatives thus cost no pass of their own (nlt_level_split_backward's work).
+ *   replaces: the input-gradient half of tf.GradientTape.gradient through Conv2D / Conv2DTranspose (nlt/trainvali.py:279).
+ */
+int nlt_conv_backward_data(int adj_mode, int tile_hint, int ksplit, float* workspace,
+                           const float* dpre, int ldp, int cpre, int n, int h, int w,
+                           const float* w_packed, const float* zero_bias, int cout, float* out, int ldo,
+                           const float* mask_src, int ldm, float mask_alpha, int accumulate,
+                           int split_c, const float* split_y, float* split_d, float split_alpha, int split_partial,
+                           void* stream);
+
 /* ======================= LDS-tiled encoder convs (csrc/conv_tile.hip) =======================
  * Same arithmetic as nlt_conv_forward for mode NLT_CONV_K2S2 / NLT_CONV_K2S1 with a single source (bias +
  * optional LeakyReLU), laid out for the MFMA-bound levels: 8 x 16 output tile x tn output channels per

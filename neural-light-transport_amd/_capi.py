@@ -95,6 +95,8 @@ SIGNATURES = {
     'nlt_conv_forward_splitk': (_c_int, [_c_int, _c_int, _c_int, _vp, _vp, _c_int, _c_int, _vp, _c_int, _c_int,
                                          _c_int, _c_int, _c_int, _vp, _vp, _c_int, _vp, _c_int, _c_int, _c_float,
                                          _vp, _c_int, _c_int, _vp]),
+    'nlt_conv_backward_data': (_c_int, [_c_int, _c_int, _c_int, _vp, _vp, _c_int, _c_int, _c_int, _c_int, _c_int, _vp, _vp, _c_int,
+                                        _vp, _c_int, _vp, _c_int, _c_float, _c_int, _c_int, _vp, _vp, _c_float, _c_int, _vp]),
     'nlt_conv_tile_packed_floats': (_c_long, [_c_int] * 4),
     'nlt_pack_conv_tile_weights': (_c_int, [_c_int, _vp, _c_int, _c_int, _c_int, _vp, _vp]),
     'nlt_conv_tile_forward': (_c_int, [_c_int, _vp, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _vp, _vp, _c_int, _c_int,
@@ -646,6 +648,30 @@ def conv_forward_splitk(mode, ksplit, src0, c0, ld0, src1, c1, ld1, n, h, w, w_p
     _check(lib().nlt_conv_forward_splitk(mode, tile_hint, ksplit, _ptr(ws), _ptr(src0), ld0, c0, _ptr(src1), ld1, c1, n, h, w,
                                          _ptr(w_packed), _ptr(bias), cout, _ptr(out), ldo, 1 if act else 0, float(alpha),
                                          _ptr(mask_src), ldm, 1 if accumulate else 0, _stream()), 'nlt_conv_forward_splitk')
+
+
+def conv_backward_data(adj_mode, dpre, cpre, ldp, n, h, w, w_packed, zero_bias, cout, out, ldo, mask_src=None, ldm=0,
+                       mask_alpha=0.3, accumulate=False, tile_hint=0, ksplit=1, split=None, w_keras=None):
+    """Gradient w.r.t. a conv's input channels (include/nlt_hip.h: nlt_conv_backward_data).  split = (c, obs_y, dobs,
+    alpha_o, has_partial): the target is dfm[l] with one observation per frame; its observation half goes, finished, to dobs.
+    (w_keras -- the Keras-layout slice the fragments were packed from -- is not read here; the host tests' CPU emulation of
+    this adapter computes from it.)"""
+    ws = None
+    if ksplit > 1:
+        need = lib().nlt_conv_splitk_workspace_floats(adj_mode, n, h, w, cout, ksplit)
+        if need <= 0:
+            raise NLTError("nlt_conv_splitk_workspace_floats failed")
+        key = (str(dpre.device), _stream())
+        ws = _splitk_ws.get(key)
+        if ws is None or ws.numel() < need:
+            ws = torch.empty(need, device=dpre.device, dtype=torch.float32)
+            _splitk_ws[key] = ws
+            _alloc_epoch[0] += 1
+    sc, sy, sd, sa, sp = split if split is not None else (0, None, None, 0.0, False)
+    _check(lib().nlt_conv_backward_data(adj_mode, tile_hint, ksplit, _ptr(ws), _ptr(dpre), ldp, cpre, n, h, w, _ptr(w_packed),
+                                        _ptr(zero_bias), cout, _ptr(out), ldo, _ptr(mask_src), ldm, float(mask_alpha),
+                                        1 if accumulate else 0, sc, _ptr(sy), _ptr(sd), float(sa), 1 if sp else 0, _stream()),
+           'nlt_conv_backward_data')
 
 
 # ---------------------------------------------------------------- one-launch refresh of all packed weights

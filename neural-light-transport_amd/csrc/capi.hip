@@ -62,3 +62,22 @@ extern "C" int nlt_conv_forward_splitk(int mode, int tile_hint, int ksplit, floa
   if (st != NLT_OK) return st;
   return nlt_conv_mfma_launch(mode, p, tile_hint, static_cast<hipStream_t>(stream), ksplit, workspace);
 }
+
+extern "C" int nlt_conv_backward_data(int adj_mode, int tile_hint, int ksplit, float* workspace,
+                                      const float* dpre, int ldp, int cpre, int n, int h, int w,
+                                      const float* w_packed, const float* zero_bias, int cout, float* out, int ldo,
+                                      const float* mask_src, int ldm, float mask_alpha, int accumulate,
+                                      int split_c, const float* split_y, float* split_d, float split_alpha, int split_partial,
+                                      void* stream) {
+  if (ksplit < 1 || (ksplit > 1 && (!workspace || !nlt_aligned16(workspace)))) return NLT_ERR_BAD_ARG;
+  ConvP p;
+  const int st = nlt_fill_conv_params(p, adj_mode, dpre, ldp, cpre, nullptr, 0, 0, n, h, w, w_packed, zero_bias, cout, out, ldo,
+                                      0, mask_alpha, mask_src, ldm, accumulate);
+  if (st != NLT_OK) return st;
+  if (split_c) {
+    if (split_c < 0 || (split_c & 3) || split_c >= cout || !split_y || !split_d) return NLT_ERR_BAD_ARG;
+    if (!nlt_aligned16(split_y) || !nlt_aligned16(split_d)) return NLT_ERR_BAD_ARG;
+    p.split_c = split_c; p.split_y = split_y; p.split_d = split_d; p.split_alpha = split_alpha; p.split_partial = split_partial;
+  }
+  return nlt_conv_mfma_launch(adj_mode, p, tile_hint, static_cast<hipStream_t>(stream), ksplit, workspace);
+}

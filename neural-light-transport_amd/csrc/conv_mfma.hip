@@ -38,6 +38,17 @@ __host__ __device__ inline int live_taps(const ConvP& p) {
   return ((MODE == NLT_CONV_K2S1 || MODE == NLT_DECONV_K2S1) && p.gh == 1 && p.gw == 1) ? 1 : ConvTraits<MODE>::TAPS;
 }
 
+// observation half of dfm[l] (ConvP::split_*): dmean (+ the observation path's own gradient) times LeakyReLU'(obs y)
+__device__ __forceinline__ void split_store(const ConvP& p, int otex, int oc, f32x4 v) {
+  const size_t at = (size_t)otex * p.split_c + (oc - p.split_c);
+  f32x4* d = reinterpret_cast<f32x4*>(p.split_d + at);
+  if (p.split_partial) v += *d;
+  const f32x4 mk = *reinterpret_cast<const f32x4*>(p.split_y + at);
+#pragma unroll
+  for (int j = 0; j < 4; ++j) v[j] *= (mk[j] > 0.f) ? 1.f : p.split_alpha;
+  *d = v;
+}
+
 template <int MODE, int RT, int CT, int PF>
 __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvP p, int mtiles, int ngroups, int ntiles, int ksplit,
                                                         float* ws) {
@@ -204,6 +215,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvP p, int mtiles, int
       f32x4 v = acc[rt][ct] + bv;
       f32x4* o = reinterpret_cast<f32x4*>(p.out + (size_t)otex * p.ldo + oc);
       if (p.accumulate) v += *o;
+      if (p.split_c && oc >= p.split_c) { split_store(p, otex, oc, v); continue; }
       if (p.mask_src) {
         const f32x4 mk = *reinterpret_cast<const f32x4*>(p.mask_src + (size_t)otex * p.ldm + oc);
 #pragma unroll
@@ -230,6 +242,7 @@ __device__ __forceinline__ void splitk_finish(const ConvP& p, int m, int ncol, f
   v += *reinterpret_cast<const f32x4*>(p.bias + oc);
   f32x4* o = reinterpret_cast<f32x4*>(p.out + (size_t)otex * p.ldo + oc);
   if (p.accumulate) v += *o;
+  if (p.split_c && oc >= p.split_c) { split_store(p, otex, oc, v); return; }
   if (p.mask_src) {
     const f32x4 mk = *reinterpret_cast<const f32x4*>(p.mask_src + (size_t)otex * p.ldm + oc);
 #pragma unroll

@@ -44,6 +44,14 @@ struct ConvP {
   int N;                 // GEMM columns
   int act, accumulate;
   float alpha;
+  // backward-data only (nlt_conv_backward_data): output channels >= split_c are the OBSERVATION half of dfm[l] (one
+  // observation per frame).  They are not stored to `out`: v (+ *split_d when split_partial) times the LeakyReLU
+  // derivative taken from split_y goes to split_d -- the gradient w.r.t. the observation path's pre-activation
+  // (what level_split_bwd_kernel computes in its own pass).  split_y / split_d [rows, split_c].
+  int split_c, split_partial;
+  float split_alpha;
+  const float* split_y;
+  float* split_d;
 };
 
 template <int MODE> struct ConvTraits;
@@ -81,6 +89,7 @@ static inline int nlt_fill_conv_params(ConvP& p, int mode, const float* src0, in
   p.src0 = src0; p.src1 = src1; p.wgt = wgt; p.bias = bias; p.mask_src = mask_src; p.out = out;
   p.n = n; p.h = h; p.w = w; p.c0 = c0; p.c1 = c1; p.ld0 = ld0; p.ld1 = ld1;
   p.cout = cout; p.ldo = ldo; p.ldm = ldm; p.act = act; p.accumulate = accumulate; p.alpha = alpha;
+  p.split_c = 0; p.split_partial = 0; p.split_alpha = 0.f; p.split_y = nullptr; p.split_d = nullptr;
   p.gh = h; p.gw = w; p.oh = h; p.ow = w; p.N = cout;
   if (mode == NLT_CONV_K2S2) { p.gh = p.oh = h / 2; p.gw = p.ow = w / 2; }
   if (mode == NLT_DECONV_K2S2) { p.oh = 2 * h; p.ow = 2 * w; p.N = 4 * cout; }

@@ -339,16 +339,47 @@ __global__ __launch_bounds__(256) void wgrad_walk_kernel(WT w) {
 template <int MODE> __device__ void wgrad_bias_block(const WT& w, int ocq);
 
 template <int MODE>
+__device__ __forceinline__ void wgrad_scatter(const WT& w, long idx, float s) {
+  const ConvP& p = w.c;
+  const int r = idx & 3, ln = (idx >> 2) & 63, ef = (idx >> 8) & 15;
+  const long blk = idx >> 12;
+  const int nb = blk % w.nblocks, kb = blk / w.nblocks;
+  const int kq = kb * 16 + 4 * (ln >> 4) + r;           // D row = k-quad inside the block
+  const int nq = nb * 16 + (ln & 15);                   // D col = n-quad
+  if (kq >= w.kq || nq >= w.nq) return;
+  const int qpt = (p.c0 + p.c1) >> 2;
+  const int tap = kq / qpt;
+  const int c = 4 * (kq - tap * qpt) + (ef >> 2);
+  const int ncol = 4 * nq + (ef & 3);
+  w.dw[keras_widx<MODE>(tap, c, ncol, p.c0 + p.c1, p.cout)] += s;
+}
+
+// FEW = true (<= 8 slices: the mid-network layers, whose 64 x 64 blocks of dW are many and whose slices are few): one
+// thread adds the slices of FOUR consecutive block entries with 16-byte loads, all of them in flight at once -- 1024
+// entries per workgroup.  (The wave-per-slice-group form below gives such a launch 16 384 workgroups of one 4-byte
+// load per thread: 16 us for 12 MB.)  Fixed order: ((s0 + s1) + (s2 + s3)) + ((s4 + s5) + (s6 + s7)).
+template <int MODE, bool FEW>
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(WT w) {
   __shared__ float part[4][64];
-  const ConvP& p = w.c;
-  const int lane = threadIdx.x & 63, g = threadIdx.x >> 6;
   const long per_slice = (long)w.kblocks * w.nblocks * 4096;
-  const long dw_blocks = per_slice / 64;
+  const long dw_blocks = per_slice / (FEW ? 1024 : 64);
   if ((long)blockIdx.x >= dw_blocks) {                                // the trailing cout / 4 workgroups: the bias (no extra launch)
     wgrad_bias_block<MODE>(w, (int)(blockIdx.x - dw_blocks));
     return;
   }
+  if (FEW) {
+    const long idx = ((long)blockIdx.x * 256 + threadIdx.x) * 4;
+    const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+    f32x4 v[8];
+#pragma unroll
+    for (int ms = 0; ms < 8; ++ms)
+      v[ms] = ms < w.msplits ? *reinterpret_cast<const f32x4*>(w.ws + (size_t)ms * per_slice + idx) : z;
+    const f32x4 s = ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
+#pragma unroll
+    for (int r = 0; r < 4; ++r) wgrad_scatter<MODE>(w, idx + r, s[r]);
+    return;
+  }
+  const int lane = threadIdx.x & 63, g = threadIdx.x >> 6;
   const long idx = (long)blockIdx.x * 64 + lane;
   float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
   int ms = g;
@@ -362,18 +393,7 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(WT w) {
   part[g][lane] = (s0 + s1) + (s2 + s3);
   __syncthreads();
   if (g) return;
-  const float s = (part[0][lane] + part[1][lane]) + (part[2][lane] + part[3][lane]);
-  const int r = idx & 3, ln = (idx >> 2) & 63, ef = (idx >> 8) & 15;
-  const long blk = idx >> 12;
-  const int nb = blk % w.nblocks, kb = blk / w.nblocks;
-  const int kq = kb * 16 + 4 * (ln >> 4) + r;           // D row = k-quad inside the block
-  const int nq = nb * 16 + (ln & 15);                   // D col = n-quad
-  if (kq >= w.kq || nq >= w.nq) return;
-  const int qpt = (p.c0 + p.c1) >> 2;
-  const int tap = kq / qpt;
-  const int c = 4 * (kq - tap * qpt) + (ef >> 2);
-  const int ncol = 4 * nq + (ef & 3);
-  w.dw[keras_widx<MODE>(tap, c, ncol, p.c0 + p.c1, p.cout)] += s;
+  wgrad_scatter<MODE>(w, idx, (part[0][lane] + part[1][lane]) + (part[2][lane] + part[3][lane]));
 }
 
 // Bias: one workgroup (of the reduce launch) per quad of output channels; 256 threads share the (slice, ab) terms,
@@ -440,7 +460,11 @@ int run(WT& w, hipStream_t s) {
   else
     hipLaunchKernelGGL(wgrad_tile_kernel<MODE>, dim3((unsigned)groups), dim3(256), 0, s, w);
   const long items = (long)w.kblocks * w.nblocks * 4096;
-  hipLaunchKernelGGL(wgrad_reduce_kernel<MODE>, dim3((unsigned)(items / 64 + (w.db ? w.c.cout / 4 : 0))), dim3(256), 0, s, w);
+  static const bool few_ok = [] { const char* e = getenv("NLT_WGRAD_REDUCE_FEW"); return !(e && e[0] == '0'); }();   // A/B switch
+  if (w.msplits <= 8 && few_ok)
+    hipLaunchKernelGGL((wgrad_reduce_kernel<MODE, true>), dim3((unsigned)(items / 1024 + (w.db ? w.c.cout / 4 : 0))), dim3(256), 0, s, w);
+  else
+    hipLaunchKernelGGL((wgrad_reduce_kernel<MODE, false>), dim3((unsigned)(items / 64 + (w.db ? w.c.cout / 4 : 0))), dim3(256), 0, s, w);
   NLT_CHECK_LAUNCH();
   return NLT_OK;
 }

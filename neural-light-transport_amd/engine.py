@@ -71,6 +71,9 @@ class RenderPlan:
         self.bwd_streams = os.environ.get('NLT_BWD_STREAMS', '1') != '0'
         # launch tape: replay a step's C calls with their resolved arguments instead of re-deriving them (see _capi.py)
         self.use_tape = os.environ.get('NLT_TAPE', '1') != '0'
+        # backward, one observation per frame: the per-level LeakyReLU' / observation-mean adjoint pass folded into the
+        # epilogue of the backward-data launch that completes dfm[l] (0: the separate nlt_level_split_backward launches)
+        self.fold_split = os.environ.get('NLT_FOLD_SPLIT', '1') != '0'
         self._tuning = False
         self.tune_backward = os.environ.get('NLT_TUNE_BWD', '1') != '0'   # plan-time trials for the backward-data launches too
         # 'bf16' (BASELINE config 5): encoder levels >= 3 and the expanding blocks mirroring them run on csrc/conv_bf16.hip with
@@ -739,11 +742,13 @@ class RenderPlan:
                      dpre, ldp, layer.n_ch_out, layer.dkernel, layer.dbias)
 
     def _dgrad(self, label, layer, lo, hi, dpre, ldp, n, oh, ow, out, ldo, mask_src=None, ldm=0, mask_alpha=0.3,
-               accumulate=False, zero_bias=None):
+               accumulate=False, zero_bias=None, split=None):
         """Backward-data of `layer` w.r.t. its input channels [lo,hi): the adjoint conv family on
         the gradient w.r.t. the layer's pre-activation output dpre [n,oh,ow,cout].  mask_src (the
         saved activation the result corresponds to) turns the result into the gradient w.r.t. the
-        PRODUCER's pre-activation."""
+        PRODUCER's pre-activation.  split = (c, obs_y, dobs, alpha_o, has_partial): the target is dfm[l] of a level with one
+        observation per frame -- its observation half leaves the launch as the finished gradient of the observation path's
+        pre-activation (nlt_conv_backward_data), so the level needs no `level_split` pass."""
         packed, ks = layer.packed_adjoint(lo, hi)
         adj = layer.ADJOINT[layer.mode]
         out_px = n * oh * ow * (4 if adj == C.DECONV_K2S2 else 1) // (4 if adj == C.CONV_K2S2 else 1)
@@ -764,13 +769,9 @@ class RenderPlan:
         flops = 2 * rows * taps * layer.n_ch_out * ncols
         if nks > 1:
             self._ran_splitk.add(label)
-            self._launch(label, nbytes, C.conv_forward_splitk, adj, nks, dpre, layer.n_ch_out, ldp, None, 0, 0, n, oh, ow, packed,
-                         zero_bias, hi - lo, out, ldo, act=False, alpha=mask_alpha, tile_hint=tile_hint, mask_src=mask_src, ldm=ldm,
-                         accumulate=accumulate, flops=flops)
-            return
-        self._launch(label, nbytes, C.conv_forward, adj, dpre, layer.n_ch_out, ldp, None, 0, 0, n, oh, ow, ks, packed,
-                     zero_bias, hi - lo, out, ldo, act=False, alpha=mask_alpha, algo=C.ALGO_MFMA, tile_hint=tile_hint,
-                     mask_src=mask_src, ldm=ldm, accumulate=accumulate, flops=flops)
+        self._launch(label, nbytes, C.conv_backward_data, adj, dpre, layer.n_ch_out, ldp, n, oh, ow, packed, zero_bias, hi - lo,
+                     out, ldo, mask_src=mask_src, ldm=ldm, mask_alpha=mask_alpha, accumulate=accumulate, tile_hint=tile_hint,
+                     ksplit=nks, split=split, w_keras=ks, flops=flops)
 
     def backward(self, dpred, base, cvis, lvis, nn_rgb, nn_base, obs_weights=None, generation=None):
         """Gradient of everything `forward` computed, given dpred = dL/d(pred) [N,H,W,3]; uses the
@@ -870,6 +871,18 @@ class RenderPlan:
         if fused:
             hh, ww = h // 2, w // 2
         masked = fused      # g['dec'][j] already holds the gradient w.r.t. the PRE-activation (mask fused into its producer)
+        # One observation per frame (the training configs): the `level_split` pass of every level -- LeakyReLU' of the query
+        # half of dfm[l], the observation mean's adjoint + the observation path's own gradient + its LeakyReLU' -- is the
+        # epilogue of the LAST backward-data launch that writes dfm[l] (level D: the bottleneck's skip half; level l < D:
+        # level l + 1's query stride-2 conv).  That launch has to come after the observation path's own gradient of the
+        # level exists, so a level's observation convs are taken before its query convs.
+        fold = self.fold_split and self.use_obs and obs_weights is None and k == 1
+
+        def split_of(l):
+            (_, _), (_, oact) = o.layers[l].convs()
+            (_, _), (_, qact) = q.layers[l].convs()
+            return dict(mask_src=b['fm'][l], ldm=2 * cl[l], mask_alpha=qact.alpha,
+                        split=(cl[l], b['obs'][l], g['obs'][l], oact.alpha, l < D))
         for j in range(U - 2 if fused else U - 1, -1, -1):
             (da, act_a), (db, act_b) = q.layers[D + 1 + j].convs()
             nl = db.n_ch_out
@@ -899,7 +912,7 @@ class RenderPlan:
             else:
                 self._dgrad(lab + '.s2.dgrad.x', da, 0, cxj, g['dtmp'][j], nl, n, hh, ww, dx, cxj, zero_bias=zb)
             self._dgrad(lab + '.s2.dgrad.skip', da, cxj, cxj + csj, g['dtmp'][j], nl, n, hh, ww, dskip, csj,
-                        accumulate=(j == 0), zero_bias=zb)
+                        accumulate=(j == 0), zero_bias=zb, **(split_of(D) if (fold and j == 0) else {}))
             hh, ww = hh // 2, ww // 2
 
         # every weight gradient of the expanding blocks is queued now: the leading range of the flat gradient
@@ -913,7 +926,9 @@ class RenderPlan:
             (oa, oact_a), (ob, oact_b) = o.layers[l].convs()
             c, cp = cl[l], cl[l - 1]
             lab = 'bwd.L%d' % l
-            if self.use_obs and obs_weights is None:
+            if fold:
+                pass                                                # dfm[l] / dobs[l] arrived finished (see `fold` above)
+            elif self.use_obs and obs_weights is None:
                 # both halves of dfm[l] in one launch: query half -> gradient w.r.t. q.s1's pre-activation (in place);
                 # observation half: the mean's gradient distributed, the obs path's own added, its activation backward
                 self._launch(lab + '.split', 4 * n * hh * ww * c * (3 + 1 + 3 * k), C.level_split_backward, g['fm'][l], b['fm'][l],
@@ -928,6 +943,15 @@ class RenderPlan:
                     self._launch(lab + '.o.mean', 4 * n * hh * ww * c * (1 + 3 * k), C.obs_mean_backward,
                                  g['fm'][l].view(-1)[c:], 2 * c, b['obs'][l], obs_weights, g['obs'][l] if l < D else None,
                                  n, k, hh * ww, c, oact_b.alpha, g['obs'][l])
+            if self.use_obs:
+                # o.s1 / o.s2 (n*k observation frames) -- before the query convs: q.s2's backward-data finishes dobs[l - 1]
+                self._wgrad(lab + '.o.s1.wgrad', ob, b['otmp'][l], c, c, None, 0, 0, n * k, hh, ww, g['obs'][l], c)
+                self._dgrad(lab + '.o.s1.dgrad', ob, 0, c, g['obs'][l], c, n * k, hh, ww, g['otmp'][l], c,
+                            mask_src=b['otmp'][l], ldm=c, mask_alpha=oact_a.alpha, zero_bias=zb)
+                if not (fused and l == 1):
+                    self._wgrad(lab + '.o.s2.wgrad', oa, b['obs'][l - 1], cp, cp, None, 0, 0, n * k, 2 * hh, 2 * ww,
+                                g['otmp'][l], c)
+                    self._dgrad(lab + '.o.s2.dgrad', oa, 0, cp, g['otmp'][l], c, n * k, hh, ww, g['obs'][l - 1], cp, zero_bias=zb)
             # q.s1 / q.s2
             self._wgrad(lab + '.q.s1.wgrad', qb, b['qtmp'][l], c, c, None, 0, 0, n, hh, ww, g['fm'][l], mult * c)
             self._dgrad(lab + '.q.s1.dgrad', qb, 0, c, g['fm'][l], mult * c, n, hh, ww, g['qtmp'][l], c,
@@ -936,16 +960,7 @@ class RenderPlan:
                 self._wgrad(lab + '.q.s2.wgrad', qa, b['fm'][l - 1], mult * cp, mult * cp, None, 0, 0, n, 2 * hh, 2 * ww,
                             g['qtmp'][l], c)
                 self._dgrad(lab + '.q.s2.dgrad', qa, 0, mult * cp, g['qtmp'][l], c, n, hh, ww, g['fm'][l - 1], mult * cp,
-                            accumulate=True, zero_bias=zb)
-            if self.use_obs:
-                # o.s1 / o.s2 (n*k observation frames)
-                self._wgrad(lab + '.o.s1.wgrad', ob, b['otmp'][l], c, c, None, 0, 0, n * k, hh, ww, g['obs'][l], c)
-                self._dgrad(lab + '.o.s1.dgrad', ob, 0, c, g['obs'][l], c, n * k, hh, ww, g['otmp'][l], c,
-                            mask_src=b['otmp'][l], ldm=c, mask_alpha=oact_a.alpha, zero_bias=zb)
-                if not (fused and l == 1):
-                    self._wgrad(lab + '.o.s2.wgrad', oa, b['obs'][l - 1], cp, cp, None, 0, 0, n * k, 2 * hh, 2 * ww,
-                                g['otmp'][l], c)
-                    self._dgrad(lab + '.o.s2.dgrad', oa, 0, cp, g['otmp'][l], c, n * k, hh, ww, g['obs'][l - 1], cp, zero_bias=zb)
+                            accumulate=True, zero_bias=zb, **(split_of(l - 1) if (fold and l > 1) else {}))
             hh, ww = hh * 2, ww * 2
 
         # ---- L0 (both paths)

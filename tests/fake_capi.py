@@ -35,6 +35,29 @@ def conv_forward(mode, src0, c0, ld0, src1, c1, ld1, n, h, w, w_keras, w_packed,
     o.copy_(y)
 
 
+def conv_backward_data(adj_mode, dpre, cpre, ldp, n, h, w, w_packed, zero_bias, cout, out, ldo, mask_src=None, ldm=0,
+                       mask_alpha=0.3, accumulate=False, tile_hint=0, ksplit=1, split=None, w_keras=None):
+    assert ksplit == 1, "split-K is a GPU-only plan choice; the CPU emulation never selects it"
+    x = _view(dpre, n, h, w, cpre, ldp)
+    s, tr = _MODES[adj_mode]
+    y = (T.conv2d_transpose_same if tr else T.conv2d_same)(x, w_keras, zero_bias[:cout], s)
+    oh, ow = y.shape[1:3]
+    o = _view(out, n, oh, ow, cout, ldo)
+    if accumulate:
+        y = y + o
+    nq = cout
+    if split is not None:                                       # observation half of dfm[l] -> finished dobs (k = 1)
+        c, sy, sd, sa, sp = split
+        nq = c
+        d = sd.view(n, oh, ow, c)
+        yo = y[..., c:] + (d if sp else 0)
+        d.copy_(yo * torch.where(sy.view(n, oh, ow, c) > 0, 1.0, sa))
+    yq = y[..., :nq]
+    if mask_src is not None:
+        yq = yq * torch.where(_view(mask_src, n, oh, ow, nq, ldm) > 0, 1.0, mask_alpha)
+    o[..., :nq].copy_(yq)
+
+
 def pack_conv_weights(mode, w_keras, c0, c1, cout):
     return torch.zeros(1)
 
@@ -543,7 +566,7 @@ _FUSED = _FUSED + ('front_pack_l2_weights', 'front2_forward', 'front4_supported'
                   'pixelnorm_forward', 'pixelnorm_backward', 'norm_forward', 'norm_backward', 'pool2x2_forward', 'pool2x2_backward', 'sub_forward', 'finish_pred')
 
 
-_FORWARD = ('conv_forward', 'pack_conv_weights', 'repack_table', 'repack_weights', 'stem_forward', 'obs_mean_forward', 'head_forward', 'warp_forward',
+_FORWARD = ('conv_forward', 'conv_backward_data', 'pack_conv_weights', 'repack_table', 'repack_weights', 'stem_forward', 'obs_mean_forward', 'head_forward', 'warp_forward',
             'resize_bilinear_forward', 'mul_forward')
 
 

@@ -1,6 +1,6 @@
 # PMC passes over the train step's fused-end kernels (front_kernel<false>, back_kernel, back_bwd_kernel, front_bwd_kernel, level split)
 cd "$GRAFT_REPO_ROOT"; mkdir -p gpurun_out; export TMPDIR=/tmp; R="$GRAFT_REPO_ROOT"
-CMD="python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --train-steps 4 --train-loss l2 --tune-cache $R/gpurun_out/tune_fused.json"
+CMD="python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-released-shapes --train-steps 4 --train-loss l2 --tune-cache $R/gpurun_out/tune_fused.json"
 $CMD > /dev/null 2>&1
 cd /tmp
 rm -rf $R/gpurun_out/pmc_tr*
