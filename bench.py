@@ -362,6 +362,37 @@ def bench_config5(args, device):
     return out
 
 
+def bench_f32_split(args, device, native, batches):
+    """`precision = f32x3` beside the headline (VERDICT r02 ruling: reported as a sub-line, the headline stays the native
+    v_mfma_f32 path): the SAME workload, weights and batches with the LDS-tiled encoder convs multiplying fp32 operands as
+    three bf16 terms on the bf16 matrix cores -- 6 term products (`f32x3`) and all 9 (`f32x3_9`, every partial product exact,
+    fp32 accumulate).  rel-L2 of the rendered texels against the native fp32 plan is measured here; against the CPU oracle in
+    tests/test_gpu_tile.py and tests/test_gpu_baseline_sizes.py."""
+    import torch
+    import nlt_amd
+    from nlt_amd.models import get_model_class
+    ref = native.call(batches[0], 'test')[3]['pred'].double()
+    out = {"workload": "the headline's (BASELINE config 3), same weights and batches"}
+    for prec in ('f32x3', 'f32x3_9'):
+        cfg = nlt_amd.make_config(depth=args.depth, uvh=args.uv, uvw=args.uv, imh=args.cam, imw=args.cam, bs=args.frames, precision=prec)
+        model = get_model_class('nlt')(cfg).build(device)
+        model.register_trainable()
+        with torch.no_grad():
+            model.flat_params.copy_(native.flat_params)
+        model.mark_weights_updated()
+        dt = time_forward(model, batches, 50)
+        pred = model.call(batches[0], 'test')[3]['pred'].double()
+        tiled = sorted(l for l, v in model.plan.lds_hints.items())
+        out[prec] = {"ms_per_step": round(1e3 * dt, 4), "Mtexels_per_s": round(args.frames * args.uv * args.uv / dt / 1e6, 1),
+                     "rel_l2_pred_vs_native_fp32_plan": float((pred - ref).norm() / ref.norm()),
+                     "dtype": "f32 storage; LDS-tiled encoder convs as 3 x bf16 terms, %d exact term products, fp32 accumulate "
+                              "(v_mfma_f32_16x16x32_bf16); everything else native fp32" % (9 if prec.endswith('9') else 6),
+                     "launches_on_the_split_kernel": tiled}
+        del model
+        torch.cuda.empty_cache()
+    return out
+
+
 def parity_record(keys):
     """The newest committed HIP-vs-oracle figures for these test ids (profiles/*_parity_sizes.json, written by the -m gpu
     tests under NLT_PARITY_DUMP); bench.py itself never runs the oracle outside its cpu_baseline leg."""
@@ -683,6 +714,8 @@ def main():
         if world == 1 and not args.headline_only and args.uv == 1024:
             out["config5_2048_bf16"] = bench_config5(args, device)
             out["stress_64ch"] = bench_stress_64ch(device)
+            if args.precision == 'fp32' and not args.no_fused:
+                out["config3_f32_split"] = bench_f32_split(args, device, model, batches)
         if released:
             out["released_shapes"] = released
         if train:

@@ -665,6 +665,21 @@ int nlt_conv_tile_forward(int mode, const float* src, int ld, int cin, int frame
                           const float* packed, const float* bias, int cout, int tn,
                           float* out, int ldo, float* mean_out, int ldm, int act, float alpha, void* stream);
 
+/*
+ * `precision = f32x3` form of nlt_conv_tile_forward (csrc/conv_tile3.hip): the same convs with every fp32 operand split exactly
+ * into three bf16 terms (hi + mid + lo) and the term products -- each exact in fp32 -- accumulated in fp32 on
+ * v_mfma_f32_16x16x32_bf16.  nprod = 9: all nine term products (error = fp32 accumulation rounding, as the native fp32 MFMA);
+ * nprod = 6: the three products of relative order 2^-24 dropped.  Same arguments and semantics as nlt_conv_tile_forward;
+ * `packed` = nlt_pack_conv_tile3_weights (nlt_conv_tile3_packed_elems() bf16 elements: the kernel's three terms in fragment order).
+ * An explicit inference / forward mode reported beside the native fp32 path, never instead of it.
+ *   replaces: the same Conv2D (+ LeakyReLU, + tf.reduce_mean over observations) lines as nlt_conv_tile_forward.
+ */
+long nlt_conv_tile3_packed_elems(int mode, int cin, int cout, int tn);
+int nlt_pack_conv_tile3_weights(int mode, const float* w_keras, int cin, int cout, int tn, unsigned short* packed, void* stream);
+int nlt_conv_tile3_forward(int mode, int nprod, const float* src, int ld, int cin, int frames, int kobs, int h, int w,
+                           const unsigned short* packed, const float* bias, int cout, int tn,
+                           float* out, int ldo, float* mean_out, int ldm, int act, float alpha, void* stream);
+
 /* ======================= bf16 channel mix (csrc/chmix_bf16.hip) =======================
  * 1x1 conv with bf16 activations / weights and fp32 accumulation on v_mfma_f32_16x16x32_bf16: the literal dense GEMM
  * of the path, used as the HBM-roofline stress point of BASELINE config 5 (2048^2 UV, bf16; SURVEY.md 8d "x64-ch").

@@ -101,6 +101,10 @@ SIGNATURES = {
     'nlt_pack_conv_tile_weights': (_c_int, [_c_int, _vp, _c_int, _c_int, _c_int, _vp, _vp]),
     'nlt_conv_tile_forward': (_c_int, [_c_int, _vp, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _vp, _vp, _c_int, _c_int,
                                        _vp, _c_int, _vp, _c_int, _c_int, _c_float, _vp]),
+    'nlt_conv_tile3_packed_elems': (_c_long, [_c_int] * 4),
+    'nlt_pack_conv_tile3_weights': (_c_int, [_c_int, _vp, _c_int, _c_int, _c_int, _vp, _vp]),
+    'nlt_conv_tile3_forward': (_c_int, [_c_int, _c_int, _vp, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _vp, _vp, _c_int, _c_int,
+                                        _vp, _c_int, _vp, _c_int, _c_int, _c_float, _vp]),
     'nlt_conv_bf16_packed_elems': (_c_long, [_c_int] * 4),
     'nlt_conv_bf16_pack': (_c_int, [_c_int, _vp, _c_int, _c_int, _c_int, _vp, _vp]),
     'nlt_conv_bf16_forward': (_c_int, [_c_int, _c_int, _vp, _c_int, _c_int, _c_int, _vp, _c_int, _c_int, _c_int,
@@ -721,6 +725,24 @@ def conv_tile_forward(mode, src, ld, cin, frames, kobs, h, w, packed, bias, cout
 
 
 # ---------------------------------------------------------------- bf16 middle of the network
+def pack_conv_tile3_weights(mode, w_keras, cin, cout, tn):
+    n = lib().nlt_conv_tile3_packed_elems(mode, cin, cout, tn)
+    if n <= 0:
+        raise NLTError("nlt_conv_tile3_packed_elems: unsupported (mode %d, cin %d, cout %d, tn %d)" % (mode, cin, cout, tn))
+    out = torch.empty(n, device=w_keras.device, dtype=torch.int16)
+    _check(lib().nlt_pack_conv_tile3_weights(mode, _ptr(_dense(w_keras, 'w_keras')), cin, cout, tn, out.data_ptr(), _stream()),
+           'nlt_pack_conv_tile3_weights')
+    return out
+
+
+def conv_tile3_forward(mode, src, ld, cin, frames, kobs, h, w, packed, bias, cout, tn, out, ldo, mean_out, ldm,
+                       act=True, alpha=0.3, nprod=6):
+    """conv_tile_forward with fp32 operands split into three bf16 terms (precision = f32x3; nprod = 6 or 9 term products)."""
+    _check(lib().nlt_conv_tile3_forward(mode, nprod, _ptr(src), ld, cin, frames, kobs, h, w, packed.data_ptr(), _ptr(bias), cout, tn,
+                                        _ptr(out), ldo, _ptr(mean_out), ldm, 1 if act else 0, float(alpha), _stream()),
+           'nlt_conv_tile3_forward')
+
+
 def conv_bf16_pack(mode, w_keras, c0, c1, cout):
     n = lib().nlt_conv_bf16_packed_elems(mode, c0, c1, cout)
     if n <= 0:

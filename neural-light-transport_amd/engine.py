@@ -77,7 +77,9 @@ class RenderPlan:
         self._tuning = False
         self.tune_backward = os.environ.get('NLT_TUNE_BWD', '1') != '0'   # plan-time trials for the backward-data launches too
         # 'bf16' (BASELINE config 5): encoder levels >= 3 and the expanding blocks mirroring them run on csrc/conv_bf16.hip with
-        # bf16-stored activations (inference, fused plan); everything at full / half / quarter resolution stays fp32
+        # bf16-stored activations (inference, fused plan); everything at full / half / quarter resolution stays fp32.
+        # 'f32x3' / 'f32x3_9': fp32 storage everywhere; the LDS-tiled encoder convs multiply fp32 operands as three bf16 terms
+        # on the bf16 matrix cores (6 / all 9 term products, csrc/conv_tile3.hip) -- forward launches of inference AND training
         self.precision = os.environ.get('NLT_PRECISION', 'fp32')
         self.grad_hook = None           # callable fired by backward() once the expanding blocks' weight gradients are queued
         self.generation = 0             # bumped by every forward: the activations in the plan's buffers belong to that pass
@@ -212,10 +214,17 @@ class RenderPlan:
                 nbytes += 4 * frames * oh * ow * layer.n_ch_out * (kobs + 1)       # what the separate mean launch would move
             flops = 2 * nf * oh * ow * 4 * cin * layer.n_ch_out
             self._ran_lds.add(label)
-            self._launch(label, nbytes, C.conv_tile_forward, layer.mode, src, ld, cin, nf if unfold else frames,
-                         1 if unfold else kobs, h, w, layer.packed_tile(tn), layer.bias.detach(), layer.n_ch_out, tn, out, ldo,
-                         mean_out if fold_mean else None, ldm, act=act is not None,
-                         alpha=act.alpha if act is not None else 0.0, flops=flops)
+            if self.precision in ('f32x3', 'f32x3_9'):
+                # fp32 operands as three bf16 terms on the bf16 matrix cores (csrc/conv_tile3.hip): 6 or all 9 term products
+                self._launch(label, nbytes, C.conv_tile3_forward, layer.mode, src, ld, cin, nf if unfold else frames,
+                             1 if unfold else kobs, h, w, layer.packed_tile3(tn), layer.bias.detach(), layer.n_ch_out, tn, out, ldo,
+                             mean_out if fold_mean else None, ldm, act=act is not None,
+                             alpha=act.alpha if act is not None else 0.0, nprod=9 if self.precision == 'f32x3_9' else 6, flops=flops)
+            else:
+                self._launch(label, nbytes, C.conv_tile_forward, layer.mode, src, ld, cin, nf if unfold else frames,
+                             1 if unfold else kobs, h, w, layer.packed_tile(tn), layer.bias.detach(), layer.n_ch_out, tn, out, ldo,
+                             mean_out if fold_mean else None, ldm, act=act is not None,
+                             alpha=act.alpha if act is not None else 0.0, flops=flops)
             if mean_out is not None and unfold:
                 c = layer.n_ch_out
                 self._launch(label.replace('.s1', '.mean'), 4 * frames * oh * ow * c * (kobs + 1), C.obs_mean_forward,

@@ -103,7 +103,7 @@ class Model(BaseModel):
         self.plan = RenderPlan(self.net['query'], self.net['obs'], self.use_obs)
         # `precision = bf16` (not a reference key; BASELINE config 5): the middle of the network on bf16 MFMA / bf16 storage
         self.plan.precision = config.get('DEFAULT', 'precision', fallback=self.plan.precision)
-        if self.plan.precision not in ('fp32', 'bf16'):
+        if self.plan.precision not in ('fp32', 'bf16', 'f32x3', 'f32x3_9'):
             raise NotImplementedError("precision = %s" % self.plan.precision)
         self.conv_algo = C.ALGO_AUTO
         # hipGraph replay of the inference forward (opt-in: NLT_GRAPH=1 or model.use_graphs = True).  The ~36 launches

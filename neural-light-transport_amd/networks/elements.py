@@ -135,6 +135,15 @@ class Conv2D(Layer):
             ent = cache[(c0, c1)] = (ver, C.conv_bf16_pack(self.mode, self.kernel.detach(), c0, c1, self.n_ch_out))
         return ent[1]
 
+    def packed_tile3(self, tn):
+        """Three-term bf16 fragments of the kernel for csrc/conv_tile3.hip (precision = f32x3); re-packed when the kernel was
+        rewritten (a forward-mode cache like packed_bf16: not part of the one-launch PackRegistry refresh)."""
+        cache = self.__dict__.setdefault('_packed_t3', {})
+        ent, ver = cache.get(tn), self._version()
+        if ent is None or ent[0] != ver:
+            ent = cache[tn] = (ver, C.pack_conv_tile3_weights(self.mode, self.kernel.detach(), self.cin, self.n_ch_out, tn))
+        return ent[1]
+
     ADJOINT = {C.CONV_K2S2: C.DECONV_K2S2, C.CONV_K2S1: C.DECONV_K2S1,
                C.DECONV_K2S2: C.CONV_K2S2, C.DECONV_K2S1: C.CONV_K2S1}
 

@@ -12,12 +12,12 @@ def rel_l2(a, b):
     return float(np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-30))
 
 
-def make_pair(depth=256, uv=64, im=64, loss='l2', seed=0, use_obs=True, skip_connect_base=True, act='leakyrelu'):
+def make_pair(depth=256, uv=64, im=64, loss='l2', seed=0, use_obs=True, skip_connect_base=True, act='leakyrelu', **product_only):
     """(oracle model, product model) sharing the same Keras-layout weights."""
     om = O.OracleModel(depth=depth, uvh=uv, uvw=uv, imh=im, imw=im, loss=loss, seed=seed,
                        use_obs=use_obs, skip_connect_base=skip_connect_base, act=act)
     cfg = nlt_amd.make_config(depth=depth, uvh=uv, uvw=uv, imh=im, imw=im, loss=loss,
-                              use_obs=use_obs, skip_connect_base=skip_connect_base, act=act)
+                              use_obs=use_obs, skip_connect_base=skip_connect_base, act=act, **product_only)
     pm = get_model_class('nlt')(cfg)
     pm.load_weights(om.numpy_weights())
     pm.register_trainable()

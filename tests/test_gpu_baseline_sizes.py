@@ -175,19 +175,23 @@ def _per_tensor(pm, grads):
     return (num / den) ** 0.5, sorted(zip(errs, names), reverse=True)[:8]
 
 
-@pytest.mark.parametrize('loss,alpha,n', [('l2', 0.3, 1), ('barron', 0.3, 1), ('l2', 1.0, 1), ('barron', 1.0, 1), ('l2', 0.3, 4)])
-def test_config4_train_step_1024_per_tensor_gradients(loss, alpha, n):
+@pytest.mark.parametrize('loss,alpha,n,precision', [('l2', 0.3, 1, 'fp32'), ('barron', 0.3, 1, 'fp32'), ('l2', 1.0, 1, 'fp32'),
+                                                    ('barron', 1.0, 1, 'fp32'), ('l2', 0.3, 4, 'fp32'), ('l2', 0.3, 1, 'f32x3'),
+                                                    ('barron', 0.3, 1, 'f32x3_9')])
+def test_config4_train_step_1024_per_tensor_gradients(loss, alpha, n, precision):
     """BASELINE config 4's per-GPU shape (1024^2 UV, 512^2 camera, k = 1; n = 4 frames is exactly what bench.py trains):
     loss and EVERY weight / bias gradient of one train step against the oracle's float64 autograd
     (nlt/trainvali.py:272-281), every tensor <= 1e-5.
 
     alpha = 0.3 is the released LeakyReLU: compared against the float64 oracle evaluated on the HIP forward's own
     activation branches (see GRAD_TOL_TENSOR above); the unconditioned float64 oracle still has to give the same loss and
-    the same flat bucket to 1e-5.  alpha = 1.0 is the kink-free twin and needs no conditioning."""
+    the same flat bucket to 1e-5.  alpha = 1.0 is the kink-free twin and needs no conditioning.
+    precision = f32x3 / f32x3_9: the train FORWARD's LDS-tiled encoder convs on the three-term bf16 split (csrc/conv_tile3.hip;
+    the backward stays native fp32) -- same bars."""
     from gpu_util import hip_activation_masks
     torch.set_num_threads(min(os.cpu_count() or 1, 64))
     uv, cam = 1024, 512
-    om32, pm = make_pair(depth=256, uv=uv, im=cam, loss=loss, seed=41)
+    om32, pm = make_pair(depth=256, uv=uv, im=cam, loss=loss, seed=41, **({} if precision == 'fp32' else {'precision': precision}))
     _set_alpha(om32, pm, alpha)
     pm.build('cuda')
     batch, nn = O.synth_batch(n, uv, uv, cam, cam, cam, cam, k=1, seed=141)
@@ -213,7 +217,9 @@ def test_config4_train_step_1024_per_tensor_gradients(loss, alpha, n):
         recs.append(rec)
         if n > 1:
             break                                           # (the 4-frame float64 oracle pass is the expensive part)
-    _dump('config4_train_1024_%s_alpha%g_n%d' % (loss, alpha, n), recs[-1])
+    if precision != 'fp32':
+        recs[-1]['launches_on_the_split_kernel'] = sorted(pm.plan.lds_hints)
+    _dump('config4_train_1024_%s_alpha%g_n%d%s' % (loss, alpha, n, '' if precision == 'fp32' else '_' + precision), recs[-1])
     for r in recs:
         assert r['flat_rel'] <= GRAD_TOL_FLAT, (loss, r['flat_rel'])
         worst = r['worst_unconditioned'] if alpha == 1.0 else r['worst_hip_masks']

@@ -48,6 +48,79 @@ def test_conv_tile_vs_oracle(mode, cin, cout, tn, h, w, frames, kobs):
     assert rel_l2(mean2.cpu(), ref2) <= 1e-5
 
 
+@pytest.mark.parametrize('nprod', [6, 9])
+@pytest.mark.parametrize('mode,cin,cout,tn,h,w,frames,kobs', [
+    (C.CONV_K2S1, 16, 32, 32, 10, 20, 2, 2), (C.CONV_K2S1, 32, 64, 64, 8, 16, 1, 1), (C.CONV_K2S1, 64, 64, 32, 33, 47, 1, 3),
+    (C.CONV_K2S1, 256, 256, 64, 16, 16, 2, 2), (C.CONV_K2S1, 128, 128, 64, 64, 64, 1, 4),
+    (C.CONV_K2S2, 16, 32, 32, 20, 36, 2, 2), (C.CONV_K2S2, 32, 128, 64, 16, 32, 1, 1), (C.CONV_K2S2, 64, 64, 64, 66, 94, 1, 2),
+    (C.CONV_K2S2, 512, 256, 64, 32, 32, 1, 1)])
+def test_conv_tile3_three_term_bf16_split_vs_float64(nprod, mode, cin, cout, tn, h, w, frames, kobs):
+    """csrc/conv_tile3.hip (precision = f32x3): fp32 operands as three bf16 terms on v_mfma_f32_16x16x32_bf16, against the
+    conv evaluated in FLOAT64 -- beside the native fp32 MFMA kernel's distance to the same float64 result.  Bars: both forms have
+    to be as close to float64 as the native fp32 kernel (x 1.5: all three only round in the fp32 accumulation -- the
+    three products the 6-product form drops are 6e-9 relative, r03 measurement: the two forms agree to 3 digits with each
+    other and sit slightly BELOW the native kernel's error).  Slice strides, partial tiles, the observation mean and the
+    no-activation / mean-only form as in the fp32 test above."""
+    rng = np.random.default_rng(cin + cout + h + kobs)
+    ld = cin + 8
+    src = torch.from_numpy(rng.standard_normal((frames * kobs, h, w, ld)).astype(np.float32))
+    wk = torch.from_numpy((rng.standard_normal((2, 2, cin, cout)) * (1.0 / np.sqrt(4 * cin))).astype(np.float32))
+    bias = torch.from_numpy(rng.standard_normal(cout).astype(np.float32) * 0.1)
+    stride = 2 if mode == C.CONV_K2S2 else 1
+    with torch.no_grad():
+        pre64 = T.conv2d_same(src[..., :cin].double().contiguous(), wk.double(), bias.double(), stride)
+        ref = T.leaky_relu(pre64, 0.3)
+    oh, ow = ref.shape[1:3]
+    E = lambda: torch.full((frames * kobs, oh, ow, cout + 4), float('nan'), device='cuda')
+    out3, out1 = E(), E()
+    mean = torch.full((frames, oh, ow, 2 * cout), float('nan'), device='cuda')
+    C.conv_tile3_forward(mode, src.cuda(), ld, cin, frames, kobs, h, w, C.pack_conv_tile3_weights(mode, wk.cuda(), cin, cout, tn),
+                         bias.cuda(), cout, tn, out3, cout + 4, mean.view(-1)[cout:], 2 * cout, act=True, alpha=0.3, nprod=nprod)
+    C.conv_tile_forward(mode, src.cuda(), ld, cin, frames, kobs, h, w, C.pack_conv_tile_weights(mode, wk.cuda(), cin, cout, tn),
+                        bias.cuda(), cout, tn, out1, cout + 4, None, 0, act=True, alpha=0.3)
+    torch.cuda.synchronize()
+    got = out3[..., :cout].cpu()
+    assert not torch.isnan(got).any() and torch.isnan(out3[..., cout:]).all()
+    e3, e1 = rel_l2(got, ref), rel_l2(out1[..., :cout].cpu(), ref)
+    print("f32x3 nprod=%d: rel-L2 vs float64 %.2e (native fp32 MFMA kernel %.2e)" % (nprod, e3, e1))
+    assert e3 <= 1.5 * e1 + (1e-9 if nprod == 9 else 3e-8), (e3, e1)
+    m = mean[..., cout:].cpu()
+    assert torch.isnan(mean[..., :cout]).all() and rel_l2(m, ref.reshape(frames, kobs, oh, ow, cout).mean(1)) <= 1.5 * e1 + 1e-7
+    mean2 = torch.empty((frames, oh, ow, cout), device='cuda')
+    C.conv_tile3_forward(mode, src.cuda(), ld, cin, frames, kobs, h, w, C.pack_conv_tile3_weights(mode, wk.cuda(), cin, cout, tn),
+                         bias.cuda(), cout, tn, None, 0, mean2, cout, act=False, nprod=nprod)
+    assert rel_l2(mean2.cpu(), pre64.reshape(frames, kobs, oh, ow, cout).mean(1)) <= 1.5 * e1 + 1e-7
+
+
+@pytest.mark.parametrize('precision', ['f32x3', 'f32x3_9'])
+@pytest.mark.parametrize('depth,uv,k,tn,mode', [(256, 128, 3, 64, 'test'), (1024, 256, 1, 64, 'test'), (256, 64, 2, 32, 'train')])
+def test_model_with_three_term_split_encoder_vs_oracle(precision, depth, uv, k, tn, mode):
+    """precision = f32x3 / f32x3_9 end to end: every eligible encoder conv on csrc/conv_tile3.hip, rendered texels against
+    the fp32 oracle (bar 1e-6 -- the native path measures 1e-7) and against the native fp32 plan."""
+    import nlt_amd
+    from nlt_amd.models import get_model_class
+    om, pm = make_pair(depth=depth, uv=uv, im=uv // 2, seed=depth + k + tn)
+    p3 = get_model_class('nlt')(nlt_amd.make_config(depth=depth, uvh=uv, uvw=uv, imh=uv // 2, imw=uv // 2, precision=precision))
+    p3.load_weights(om.numpy_weights())
+    p3.register_trainable()
+    batch, nn = O.synth_batch(1, uv, uv, uv // 2, uv // 2, uv // 2, uv // 2, k=k, seed=30 + k)
+    with torch.no_grad():
+        o_vis = om.call(batch, mode, nn_list=nn)[3]
+    nlev = sum(pm.net['query'].is_contracting) - 1
+    hints = {'L%d.%s.%s' % (l, p, s): tn for l in range(1, nlev + 1) for p in 'qo' for s in ('s1', 's2')}
+    vis = []
+    for m in (pm, p3):
+        m.plan.autotune = False
+        m.plan.lds_hints = dict(hints)
+        vis.append(m.call(to_device_batch(batch, nn), mode)[3])
+    torch.cuda.synchronize()
+    assert 'L3.o.s1' in p3.plan._ran_lds and 'L%d.q.s2' % nlev in p3.plan._ran_lds
+    e_oracle, e_native = rel_l2(vis[1]['pred'].cpu(), o_vis['pred']), rel_l2(vis[1]['pred'].cpu(), vis[0]['pred'].cpu())
+    print("%s depth %d: pred rel-L2 vs fp32 oracle %.2e, vs native fp32 plan %.2e (native vs oracle %.2e)"
+          % (precision, depth, e_oracle, e_native, rel_l2(vis[0]['pred'].cpu(), o_vis['pred'])))
+    assert e_oracle <= 1e-6
+
+
 def test_conv_tile_rejects_what_it_cannot_do():
     x = torch.zeros(1, 8, 8, 24, device='cuda')
     assert not C.conv_tile_supported(C.CONV_K2S1, 24, 32, 32) and not C.conv_tile_supported(C.CONV_K2S1, 32, 48, 32)

@@ -151,6 +151,45 @@ def test_dgrad_is_adjoint_mode_on_same_kernel(mode):
         np.testing.assert_allclose(out.cpu().numpy(), gx.numpy()[..., lo:hi], atol=3e-5 * gx.abs().max().item())
 
 
+@pytest.mark.parametrize('mode,ksplit,partial', [(C.CONV_K2S2, 1, True), (C.CONV_K2S2, 4, True), (C.DECONV_K2S2, 1, False),
+                                                 (C.DECONV_K2S2, 2, True), (C.CONV_K2S1, 1, True)])
+def test_backward_data_with_the_level_split_epilogue(mode, ksplit, partial):
+    """nlt_conv_backward_data: backward-data of a conv whose input is fm[l] = [query c | observation-mean c] (one observation
+    per frame), accumulated on top of what dfm[l] already holds, with the `level_split` work in its epilogue -- query half:
+    times LeakyReLU'(fm y) into dfm[l]; observation half: (+ the observation path's own gradient) times LeakyReLU'(obs y)
+    into dobs -- against the separate steps (torch autograd for the conv's input gradient, the formulas of
+    nlt_level_split_backward); single-pass and split-K."""
+    from nlt_amd.networks.elements import Conv2D
+    rng = np.random.default_rng(mode * 10 + ksplit)
+    k, s, tr = MODES[mode]
+    c, cout, n, h, w = 16, 48, 2, 8, 12
+    cin = 2 * c
+    R = lambda *shape: rng.standard_normal(shape).astype(np.float32)
+    wk = R(*((2, 2, cout, cin) if tr else (2, 2, cin, cout)))
+    x = torch.tensor(R(n, h, w, cin), requires_grad=True)
+    y = (T.conv2d_transpose_same if tr else T.conv2d_same)(x, torch.tensor(wk), torch.zeros(cout), s)
+    dp = R(*y.shape)
+    (gx,) = torch.autograd.grad(y, x, torch.tensor(dp))
+    existing, fm_y, obs_y, dobs0 = R(n, h, w, cin), R(n, h, w, cin), R(n, h, w, c), R(n, h, w, c)
+    aq, ao = 0.3, 0.2
+    tot = gx + torch.tensor(existing)
+    ref_q = tot[..., :c] * torch.where(torch.tensor(fm_y[..., :c]) > 0, 1.0, aq)
+    ref_o = (tot[..., c:] + (torch.tensor(dobs0) if partial else 0)) * torch.where(torch.tensor(obs_y) > 0, 1.0, ao)
+    layer = Conv2D(cout, 2, s, transpose=tr)
+    layer.set_weights(wk, np.zeros(cout, np.float32))
+    packed, ks = layer.packed_adjoint(0, cin)
+    oh, ow = y.shape[1:3]
+    out, dobs = d(existing), d(dobs0)
+    C.conv_backward_data(layer.ADJOINT[mode], d(dp), cout, cout, n, oh, ow, packed, torch.zeros(64, device='cuda'), cin, out, cin,
+                         mask_src=d(fm_y), ldm=cin, mask_alpha=aq, accumulate=True, ksplit=ksplit,
+                         split=(c, d(obs_y), dobs, ao, partial))
+    torch.cuda.synchronize()
+    tol = 3e-5 * float(tot.abs().max())
+    np.testing.assert_allclose(out.cpu().numpy()[..., :c], ref_q.numpy(), atol=tol)
+    np.testing.assert_allclose(dobs.cpu().numpy(), ref_o.numpy(), atol=tol)
+    np.testing.assert_array_equal(out.cpu().numpy()[..., c:], existing[..., c:])     # the observation half of dfm[l] is not rewritten
+
+
 def test_lrelu_and_obs_mean_backward():
     rng = np.random.default_rng(0)
     n, k, hw, c = 2, 3, 35, 16
