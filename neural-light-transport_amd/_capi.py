@@ -101,6 +101,9 @@ SIGNATURES = {
     'nlt_pack_conv_tile_weights': (_c_int, [_c_int, _vp, _c_int, _c_int, _c_int, _vp, _vp]),
     'nlt_conv_tile_forward': (_c_int, [_c_int, _vp, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _vp, _vp, _c_int, _c_int,
                                        _vp, _c_int, _vp, _c_int, _c_int, _c_float, _vp]),
+    'nlt_pack_conv_tile_weights_adjoint': (_c_int, [_c_int, _vp, _c_int, _c_int, _c_int, _c_int, _c_int, _vp, _vp]),
+    'nlt_conv_tile_backward_data': (_c_int, [_c_int, _vp, _c_int, _c_int, _c_int, _c_int, _c_int, _vp, _c_int, _c_int, _vp, _c_int,
+                                             _vp, _c_int, _c_float, _c_int, _vp]),
     'nlt_conv_tile3_packed_elems': (_c_long, [_c_int] * 4),
     'nlt_pack_conv_tile3_weights': (_c_int, [_c_int, _vp, _c_int, _c_int, _c_int, _vp, _vp]),
     'nlt_conv_tile3_forward': (_c_int, [_c_int, _c_int, _vp, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _vp, _vp, _c_int, _c_int,
@@ -725,6 +728,26 @@ def conv_tile_forward(mode, src, ld, cin, frames, kobs, h, w, packed, bias, cout
 
 
 # ---------------------------------------------------------------- bf16 middle of the network
+def pack_conv_tile_weights_adjoint(adj_mode, w_keras, cpre, cout, tn, full, lo):
+    """Tile fragments of the ADJOINT conv family read from the layer's own (contiguous) Keras array: output columns = the layer's
+    input channels [lo, lo + cout) of `full`."""
+    n = lib().nlt_conv_tile_packed_floats(adj_mode, cpre, cout, tn)
+    if n <= 0:
+        raise NLTError("nlt_conv_tile_packed_floats: unsupported (mode %d, cpre %d, cout %d, tn %d)" % (adj_mode, cpre, cout, tn))
+    out = torch.empty(n, device=w_keras.device, dtype=torch.float32)
+    _check(lib().nlt_pack_conv_tile_weights_adjoint(adj_mode, _ptr(_dense(w_keras, 'w_keras')), cpre, cout, tn, full, lo, _ptr(out),
+                                                    _stream()), 'nlt_pack_conv_tile_weights_adjoint')
+    return out
+
+
+def conv_tile_backward_data(adj_mode, dpre, cpre, ldp, n, h, w, packed, cout, tn, out, ldo, mask_src=None, ldm=0, mask_alpha=0.3,
+                            accumulate=False, w_keras=None):
+    """Backward-data on the LDS-tiled kernel (include/nlt_hip.h: nlt_conv_tile_backward_data)."""
+    _check(lib().nlt_conv_tile_backward_data(adj_mode, _ptr(dpre), ldp, cpre, n, h, w, _ptr(packed), cout, tn, _ptr(out), ldo,
+                                             _ptr(mask_src), ldm, float(mask_alpha), 1 if accumulate else 0, _stream()),
+           'nlt_conv_tile_backward_data')
+
+
 def pack_conv_tile3_weights(mode, w_keras, cin, cout, tn):
     n = lib().nlt_conv_tile3_packed_elems(mode, cin, cout, tn)
     if n <= 0:

@@ -27,6 +27,9 @@ constexpr int PL = 160;                      // k2s1 haloed tile: 9 x 17 = 153 t
 template <int MODE> struct TileTraits;
 template <> struct TileTraits<NLT_CONV_K2S1> { static constexpr int STAGE_TAPS = 4, B_UNITS = 153 * 4, B_FLOATS = 4 * PL * 4; };
 template <> struct TileTraits<NLT_CONV_K2S2> { static constexpr int STAGE_TAPS = 2, B_UNITS = 256 * 4, B_FLOATS = 4 * QS2 * 4; };
+// Conv2DTranspose k2s1 ('same': taps (y - a, x - b), zero above / left of the image) = the k2s1 tile with its halo on the top /
+// left: origin (ty0 - 1, tx0 - 1), tap (a, b) reads slot (y + 1 - a, x + 1 - b).  Backward-data of every encoder stride-1 conv.
+template <> struct TileTraits<NLT_DECONV_K2S1> { static constexpr int STAGE_TAPS = 4, B_UNITS = 153 * 4, B_FLOATS = 4 * PL * 4; };
 
 struct TileP {
   const float* src; const float* packed; const float* bias;
@@ -35,6 +38,8 @@ struct TileP {
   int oh, ow, cout, ldo, ldm;
   int tiles_y, tiles_x, ncc;                 // ncc = cin / 16
   int act; float alpha;
+  // backward-data epilogue (nlt_conv_tile_backward_data): v (+= out when accumulate) times LeakyReLU'(mask_src) (slope alpha)
+  const float* mask_src; int ld_mask; int accumulate;
 };
 
 __device__ __forceinline__ int xcd_tile(int b, int nblocks) {
@@ -42,11 +47,11 @@ __device__ __forceinline__ int xcd_tile(int b, int nblocks) {
 }
 
 // packed weights: [g = cout / TN][cc = cin / 16][tap 4][ct TNT][lane 64][s4 4]
-template <int MODE>
-__global__ void pack_tile_kernel(const float* __restrict__ wk, int cin, int cout, int tnt, long total, float* __restrict__ wp) {
+__global__ void pack_tile_kernel(const float* __restrict__ wk, int cin, int cout, int tnt, int full, int lo, int transposed, long total,
+                                 float* __restrict__ wp) {
   const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= total) return;
-  wp[idx] = nlt_tile_fragment(wk, idx, cin, cout, tnt);               // Keras (kh,kw,Cin,Cout), t = a*2+b
+  wp[idx] = nlt_tile_fragment(wk, idx, cin, cout, tnt, full, lo, transposed != 0);   // t = a*2+b
 }
 
 template <int MODE, int TNT>
@@ -66,7 +71,9 @@ __global__ __launch_bounds__(256) void conv_tile_kernel(TileP p) {
   const int ty0 = (tile % p.tiles_y) * TH;
   const int f = tile / p.tiles_y;
   const int g = blockIdx.y;
-  const int stages_per_frame = (MODE == NLT_CONV_K2S1 ? 1 : 2) * p.ncc;
+  constexpr bool K2S1 = MODE == NLT_CONV_K2S1 || MODE == NLT_DECONV_K2S1;   // one stage per 16-channel slab, all 4 taps
+  constexpr bool TR = MODE == NLT_DECONV_K2S1;
+  const int stages_per_frame = (K2S1 ? 1 : 2) * p.ncc;
   const int total_stages = stages_per_frame * p.kobs;
   const long in_frame = (long)p.h * p.w;
 
@@ -83,11 +90,11 @@ __global__ __launch_bounds__(256) void conv_tile_kernel(TileP p) {
     const int u = tid + 256 * i;
     const int q = (u >> 3) & 3, tx = (u >> 5) * 8 + (u & 7);
     b_q[i] = q;
-    if (MODE == NLT_CONV_K2S1) {
+    if (K2S1) {
       const int hy = tx / 17, hx = tx % 17;
-      const int gy = ty0 + hy, gx = tx0 + hx;
+      const int gy = ty0 + hy - (TR ? 1 : 0), gx = tx0 + hx - (TR ? 1 : 0);
       b_st[i] = tx < 153;
-      b_ok[i] = b_st[i] && gy < p.h && gx < p.w;                     // beyond the image: TF's bottom/right zero padding
+      b_ok[i] = b_st[i] && gy >= 0 && gx >= 0 && gy < p.h && gx < p.w;   // beyond the image: TF's zero padding (bottom / right; transposed: top / left)
       b_tex[i] = (long)gy * p.w + gx;
       b_lds[i] = (q * PL + tx) * 4;
     } else {
@@ -103,8 +110,8 @@ __global__ __launch_bounds__(256) void conv_tile_kernel(TileP p) {
   f32x4 ra[NA], rb[NB];
   auto load_stage = [&](int q) {
     const int i = q / stages_per_frame, s = q - i * stages_per_frame;
-    const int cc = MODE == NLT_CONV_K2S1 ? s : (s >> 1);
-    const int a = MODE == NLT_CONV_K2S1 ? 0 : (s & 1);
+    const int cc = K2S1 ? s : (s >> 1);
+    const int a = K2S1 ? 0 : (s & 1);
     const float* ap = p.packed + ((((long)g * p.ncc + cc) * 4 + 2 * a) * TNT) * 256;
 #pragma unroll
     for (int n = 0; n < NA; ++n) ra[n] = *reinterpret_cast<const f32x4*>(ap + (tid + 256 * n) * 4);
@@ -144,8 +151,9 @@ __global__ __launch_bounds__(256) void conv_tile_kernel(TileP p) {
 #pragma unroll
       for (int rt = 0; rt < RT; ++rt) {
         const int y = wm * RT + rt;
-        const int off = MODE == NLT_CONV_K2S1 ? (kk * PL + (y + (tl >> 1)) * 17 + j + (tl & 1)) * 4
-                                              : (kk * QS2 + tl * ODD2 + y * 16 + j) * 4;
+        const int off = TR ? (kk * PL + (y + 1 - (tl >> 1)) * 17 + j + 1 - (tl & 1)) * 4
+                         : K2S1 ? (kk * PL + (y + (tl >> 1)) * 17 + j + (tl & 1)) * 4
+                                : (kk * QS2 + tl * ODD2 + y * 16 + j) * 4;
         bf[rt] = *reinterpret_cast<const f32x4*>(B + off);
       }
 #pragma unroll
@@ -164,11 +172,26 @@ __global__ __launch_bounds__(256) void conv_tile_kernel(TileP p) {
 #pragma unroll
       for (int ct = 0; ct < CT; ++ct) {
         const int oc = (g * TNT + wn * CT + ct) * 16 + 4 * kk;
-        const f32x4 bv = *reinterpret_cast<const f32x4*>(p.bias + oc);
+        const f32x4 bv = p.bias ? *reinterpret_cast<const f32x4*>(p.bias + oc) : (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int rt = 0; rt < RT; ++rt) {
           const int gy = ty0 + wm * RT + rt, gx = tx0 + j;
           f32x4 v = acc[rt][ct] + bv;
+          if (p.mask_src || p.accumulate) {                            // backward-data epilogue
+            if (gy < p.oh && gx < p.ow) {
+              const long ot = ((long)(f * p.kobs + i) * p.oh + gy) * p.ow + gx;
+              f32x4* o = reinterpret_cast<f32x4*>(p.out + ot * p.ldo + oc);
+              if (p.accumulate) v += *o;
+              if (p.mask_src) {
+                const f32x4 mk = *reinterpret_cast<const f32x4*>(p.mask_src + ot * p.ld_mask + oc);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] *= (mk[e] > 0.f) ? 1.f : p.alpha;
+              }
+              *o = v;
+            }
+            acc[rt][ct] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            continue;
+          }
           if (p.act) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : p.alpha * v[e];
@@ -202,22 +225,35 @@ int launch(const TileP& p, hipStream_t s) {
 }  // namespace
 
 extern "C" long nlt_conv_tile_packed_floats(int mode, int cin, int cout, int tn) {
-  if ((mode != NLT_CONV_K2S1 && mode != NLT_CONV_K2S2) || cin <= 0 || cout <= 0) return -1;
+  if ((mode != NLT_CONV_K2S1 && mode != NLT_CONV_K2S2 && mode != NLT_DECONV_K2S1) || cin <= 0 || cout <= 0) return -1;
   if ((cin & 15) || (tn != 32 && tn != 64) || cout % tn) return -1;
   return (long)4 * cin * cout;
 }
 
-extern "C" int nlt_pack_conv_tile_weights(int mode, const float* w_keras, int cin, int cout, int tn, float* packed,
-                                          void* stream) {
+static int pack_tile(int mode, const float* w_keras, int cin, int cout, int tn, int full, int lo, float* packed, void* stream) {
   const long total = nlt_conv_tile_packed_floats(mode, cin, cout, tn);
   if (total <= 0) return NLT_ERR_UNSUPPORTED;
-  if (!w_keras || !packed || !nlt_aligned16(packed)) return NLT_ERR_BAD_ARG;
-  hipStream_t s = static_cast<hipStream_t>(stream);
-  const unsigned blocks = (unsigned)((total + 255) / 256);
-  if (mode == NLT_CONV_K2S1) hipLaunchKernelGGL(pack_tile_kernel<NLT_CONV_K2S1>, dim3(blocks), dim3(256), 0, s, w_keras, cin, cout, tn / 16, total, packed);
-  else hipLaunchKernelGGL(pack_tile_kernel<NLT_CONV_K2S2>, dim3(blocks), dim3(256), 0, s, w_keras, cin, cout, tn / 16, total, packed);
+  if (!w_keras || !packed || !nlt_aligned16(packed) || lo < 0 || lo + cout > full) return NLT_ERR_BAD_ARG;
+  hipLaunchKernelGGL(pack_tile_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream),
+                     w_keras, cin, cout, tn / 16, full, lo, mode == NLT_DECONV_K2S1 ? 1 : 0, total, packed);
   NLT_CHECK_LAUNCH();
   return NLT_OK;
+}
+
+extern "C" int nlt_pack_conv_tile_weights(int mode, const float* w_keras, int cin, int cout, int tn, float* packed,
+                                          void* stream) {
+  return pack_tile(mode, w_keras, cin, cout, tn, cout, 0, packed, stream);
+}
+
+extern "C" int nlt_pack_conv_tile_weights_adjoint(int adj_mode, const float* w_keras, int cpre, int cout, int tn, int full, int lo,
+                                                  float* packed, void* stream) {
+  return pack_tile(adj_mode, w_keras, cpre, cout, tn, full, lo, packed, stream);
+}
+
+static int tile_run(int mode, TileP& p, int tn, hipStream_t s) {
+  if (mode == NLT_CONV_K2S1) return tn == 64 ? launch<NLT_CONV_K2S1, 4>(p, s) : launch<NLT_CONV_K2S1, 2>(p, s);
+  if (mode == NLT_DECONV_K2S1) return tn == 64 ? launch<NLT_DECONV_K2S1, 4>(p, s) : launch<NLT_DECONV_K2S1, 2>(p, s);
+  return tn == 64 ? launch<NLT_CONV_K2S2, 4>(p, s) : launch<NLT_CONV_K2S2, 2>(p, s);
 }
 
 extern "C" int nlt_conv_tile_forward(int mode, const float* src, int ld, int cin, int frames, int kobs, int h, int w,
@@ -236,8 +272,26 @@ extern "C" int nlt_conv_tile_forward(int mode, const float* src, int ld, int cin
   p.ld = ld; p.cin = cin; p.frames = frames; p.kobs = kobs; p.h = h; p.w = w;
   p.oh = mode == NLT_CONV_K2S2 ? h / 2 : h; p.ow = mode == NLT_CONV_K2S2 ? w / 2 : w;
   p.cout = cout; p.ldo = ldo; p.ldm = ldm; p.ncc = cin / 16; p.act = act; p.alpha = alpha;
+  p.mask_src = nullptr; p.ld_mask = 0; p.accumulate = 0;
   p.tiles_y = (p.oh + TH - 1) / TH; p.tiles_x = (p.ow + TW - 1) / TW;
-  hipStream_t s = static_cast<hipStream_t>(stream);
-  if (mode == NLT_CONV_K2S1) return tn == 64 ? launch<NLT_CONV_K2S1, 4>(p, s) : launch<NLT_CONV_K2S1, 2>(p, s);
-  return tn == 64 ? launch<NLT_CONV_K2S2, 4>(p, s) : launch<NLT_CONV_K2S2, 2>(p, s);
+  return tile_run(mode, p, tn, static_cast<hipStream_t>(stream));
+}
+
+extern "C" int nlt_conv_tile_backward_data(int adj_mode, const float* dpre, int ldp, int cpre, int n, int h, int w,
+                                           const float* packed, int cout, int tn, float* out, int ldo,
+                                           const float* mask_src, int ldm, float mask_alpha, int accumulate, void* stream) {
+  if (!dpre || !packed || !out || n <= 0 || h <= 0 || w <= 0 || cpre <= 0 || cout <= 0) return NLT_ERR_BAD_ARG;
+  if (nlt_conv_tile_packed_floats(adj_mode, cpre, cout, tn) <= 0) return NLT_ERR_UNSUPPORTED;
+  if (adj_mode == NLT_CONV_K2S2 && ((h | w) & 1)) return NLT_ERR_UNSUPPORTED;
+  if (ldp < cpre || (ldp & 3) || ldo < cout || (ldo & 3) || (mask_src && (ldm < cout || (ldm & 3)))) return NLT_ERR_BAD_ARG;
+  if (!nlt_aligned16(dpre) || !nlt_aligned16(packed) || !nlt_aligned16(out) || (mask_src && !nlt_aligned16(mask_src))) return NLT_ERR_BAD_ARG;
+  if ((long long)n * h * w * (long long)(ldp > ldo ? ldp : ldo) >= (1ll << 31)) return NLT_ERR_UNSUPPORTED;
+  TileP p;
+  p.src = dpre; p.packed = packed; p.bias = nullptr; p.out = out; p.mean_out = nullptr;
+  p.ld = ldp; p.cin = cpre; p.frames = n; p.kobs = 1; p.h = h; p.w = w;
+  p.oh = adj_mode == NLT_CONV_K2S2 ? h / 2 : h; p.ow = adj_mode == NLT_CONV_K2S2 ? w / 2 : w;
+  p.cout = cout; p.ldo = ldo; p.ldm = 0; p.ld_mask = ldm; p.ncc = cpre / 16; p.act = 0; p.alpha = mask_alpha;
+  p.mask_src = mask_src; p.accumulate = accumulate;
+  p.tiles_y = (p.oh + TH - 1) / TH; p.tiles_x = (p.ow + TW - 1) / TW;
+  return tile_run(adj_mode, p, tn, static_cast<hipStream_t>(stream));
 }

@@ -37,8 +37,15 @@ __device__ __forceinline__ float nlt_mfma_fragment(const float* __restrict__ wk,
   return 0.f;
 }
 
-// LDS-tiled kernel (conv_tile.hip): [g = cout / TN][cc = cin / 16][tap 4][ct TNT][lane 64][s4]; Keras (kh,kw,Cin,Cout)
-__device__ __forceinline__ float nlt_tile_fragment(const float* __restrict__ wk, long idx, int cin, int cout, int tnt) {
+// LDS-tiled kernel (conv_tile.hip): [g = N / TN][cc = K / 16][tap 4][ct TNT][lane 64][s4], K = input channels of the executed
+// conv, N = its output channels.  The Keras array handed in may be a slice [lo, lo + N) of the executed conv's OUTPUT-channel axis
+// (`full` = that axis' extent in memory) and is indexed
+//   normal     (kh,kw,K,N_full): a forward Conv2D, or backward-data of a Conv2DTranspose (its (kh,kw,Cout,Cin) array read as a conv
+//                                from Cout to a slice of Cin);
+//   transposed (kh,kw,N_full,K): a forward Conv2DTranspose, or backward-data of a Conv2D (its (kh,kw,Cin,Cout) array read as a
+//                                transposed conv from Cout to a slice of Cin).
+__device__ __forceinline__ float nlt_tile_fragment(const float* __restrict__ wk, long idx, int cin, int cout, int tnt,
+                                                   int full, int lo, bool transposed) {
   const int s4 = idx & 3, lane = (idx >> 2) & 63;
   long r = idx >> 8;
   const int ct = r % tnt; r /= tnt;
@@ -48,5 +55,5 @@ __device__ __forceinline__ float nlt_tile_fragment(const float* __restrict__ wk,
   const int g = r / ncc;
   const int c = cc * 16 + 4 * (lane >> 4) + s4;
   const int o = (g * tnt + ct) * 16 + (lane & 15);
-  return wk[((long)t * cin + c) * cout + o];
+  return transposed ? wk[((long)t * full + lo + o) * cin + c] : wk[((long)t * cin + c) * full + lo + o];
 }

@@ -74,6 +74,7 @@ class RenderPlan:
         # backward, one observation per frame: the per-level LeakyReLU' / observation-mean adjoint pass folded into the
         # epilogue of the backward-data launch that completes dfm[l] (0: the separate nlt_level_split_backward launches)
         self.fold_split = os.environ.get('NLT_FOLD_SPLIT', '1') != '0'
+        self.tile_dgrad = os.environ.get('NLT_TILE_DGRAD', '1') != '0'   # backward-data launches may go to the LDS-tiled kernel
         self._tuning = False
         self.tune_backward = os.environ.get('NLT_TUNE_BWD', '1') != '0'   # plan-time trials for the backward-data launches too
         # 'bf16' (BASELINE config 5): encoder levels >= 3 and the expanding blocks mirroring them run on csrc/conv_bf16.hip with
@@ -251,6 +252,8 @@ class RenderPlan:
             trials.append(('direct', 0))    # only the 4/8-channel full-resolution layers ever preferred it
         if not backward:
             trials += [('lds', 32), ('lds', 64), ('lds', 256 + 32), ('lds', 256 + 64)]
+        elif self.tile_dgrad:
+            trials += [('lds', 32), ('lds', 64)]                  # backward-data launches on the LDS-tiled kernel
         # split-K: launches with few GEMM rows and a long K (the deep levels; at depth 1024 a 1 x 1-texel level streams 33 MB of
         # weights through 4 rows) need thousands of waves each walking a short K slice to keep HBM busy: up to 128 slices
         mode = os.environ.get('NLT_SPLITK', 'all')                   # 'all' | 'fwd' (forward plans only) | 'off': A/B switch
@@ -284,6 +287,8 @@ class RenderPlan:
             if '.s1' not in label and '.s2' not in label and label != 'L0.q':
                 continue
             t, kind, hint = min(res)
+            if backward and 'dgrad' not in label:
+                continue                                            # (a backward trial pass only chooses backward-data launches)
             if kind == 'direct':
                 self.algo_hints.setdefault(label, C.ALGO_DIRECT)
             elif kind == 'lds':
@@ -776,6 +781,16 @@ class RenderPlan:
             nks = self._trial_splitk if (waves < 4096 and rows * npad * self._trial_splitk <= (1 << 24)) else 1
         taps = 1 if adj == C.DECONV_K2S2 else 4
         flops = 2 * rows * taps * layer.n_ch_out * ncols
+        # LDS-tiled kernel (csrc/conv_tile.hip) for the launches the plan-time trials gave to it: the adjoint families it has
+        # (CONV_K2S1 / CONV_K2S2 of the expanding blocks, the transposed k2s1 of the encoder's stride-1 convs), no split epilogue
+        tn = (self._trial_lds or self.lds_hints.get(label, 0)) & 255
+        if (tn and split is None and adj in (C.CONV_K2S1, C.CONV_K2S2, C.DECONV_K2S1) and layer.n_ch_out % 16 == 0
+                and (hi - lo) % tn == 0 and ldp % 4 == 0 and ldo % 4 == 0 and layer.kernel.is_contiguous()):
+            self._ran_lds.add(label)
+            self._launch(label, nbytes, C.conv_tile_backward_data, adj, dpre, layer.n_ch_out, ldp, n, oh, ow,
+                         layer.packed_adjoint_tile(lo, hi, tn), hi - lo, tn, out, ldo, mask_src=mask_src, ldm=ldm, mask_alpha=mask_alpha,
+                         accumulate=accumulate, w_keras=ks, flops=flops)
+            return
         if nks > 1:
             self._ran_splitk.add(label)
         self._launch(label, nbytes, C.conv_backward_data, adj, dpre, layer.n_ch_out, ldp, n, oh, ow, packed, zero_bias, hi - lo,

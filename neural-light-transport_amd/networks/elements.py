@@ -160,6 +160,14 @@ class Conv2D(Layer):
                                      full=self.cin))
         return buf, ks
 
+    def packed_adjoint_tile(self, lo, hi, tn):
+        """LDS-tile fragments for backward-data w.r.t. forward input channels [lo, hi) (csrc/conv_tile.hip): read in place from
+        the layer's own Keras array (no slice copy), refreshed with every other packed buffer in the one-launch registry pass."""
+        adj = self.ADJOINT[self.mode]
+        return self._cached_pack(('adjtile', lo, hi, tn),
+                                 lambda: C.pack_conv_tile_weights_adjoint(adj, self.kernel.detach(), self.n_ch_out, hi - lo, tn, self.cin, lo),
+                                 dict(kind=C.REPACK_TILE, mode=adj, c0=self.n_ch_out, c1=0, cout=hi - lo, tn=tn, lo=lo, full=self.cin))
+
     def out_hw(self, h, w):
         if self.mode == C.CONV_K2S2:
             return h // 2, w // 2

@@ -151,6 +151,45 @@ def test_dgrad_is_adjoint_mode_on_same_kernel(mode):
         np.testing.assert_allclose(out.cpu().numpy(), gx.numpy()[..., lo:hi], atol=3e-5 * gx.abs().max().item())
 
 
+@pytest.mark.parametrize('mode,cin,cout,h,w,tn', [(C.CONV_K2S1, 64, 32, 19, 37, 32), (C.CONV_K2S1, 128, 64, 16, 32, 64),
+                                                  (C.DECONV_K2S1, 64, 48, 9, 20, 32), (C.DECONV_K2S2, 96, 32, 10, 18, 32),
+                                                  (C.DECONV_K2S2, 128, 16, 8, 16, 64), (C.CONV_K2S1, 32, 256, 8, 8, 32)])
+def test_backward_data_on_the_lds_tiled_kernel(mode, cin, cout, h, w, tn):
+    """nlt_conv_tile_backward_data: the gradient w.r.t. a conv's input channels [lo, hi) on csrc/conv_tile.hip -- the transposed
+    k2s1 mode (halo on the top / left) for Conv2D k2s1 layers, the k2s1 / k2s2 conv modes for Conv2DTranspose layers -- read in
+    place from the layer's Keras array, against torch autograd; plain, with the producer's LeakyReLU' and accumulated."""
+    from nlt_amd.networks.elements import Conv2D
+    rng = np.random.default_rng(mode * 100 + cin)
+    k, s, tr = MODES[mode]
+    n = 2
+    R = lambda *shape: rng.standard_normal(shape).astype(np.float32)
+    wk = R(*((2, 2, cout, cin) if tr else (2, 2, cin, cout)))
+    x = torch.tensor(R(n, h, w, cin), requires_grad=True)
+    y = (T.conv2d_transpose_same if tr else T.conv2d_same)(x, torch.tensor(wk), torch.zeros(cout), s)
+    dp = R(*y.shape)
+    (gx,) = torch.autograd.grad(y, x, torch.tensor(dp))
+    layer = Conv2D(cout, 2, s, transpose=tr)
+    layer.set_weights(wk, np.zeros(cout, np.float32))
+    adj = layer.ADJOINT[mode]
+    oh, ow = y.shape[1:3]
+    tol = 3e-5 * float(gx.abs().max())
+    for lo, hi in ((0, cin), (cin - tn, cin), (tn, 2 * tn) if cin >= 2 * tn else (0, tn)):
+        ld = hi - lo + 4
+        existing, ymask = R(n, h, w, ld), R(n, h, w, hi - lo)
+        packed = layer.packed_adjoint_tile(lo, hi, tn)
+        out = d(existing)
+        C.conv_tile_backward_data(adj, d(dp), cout, cout, n, oh, ow, packed, hi - lo, tn, out, ld)
+        torch.cuda.synchronize()
+        np.testing.assert_allclose(out.cpu().numpy()[..., :hi - lo], gx.numpy()[..., lo:hi], atol=tol)
+        np.testing.assert_array_equal(out.cpu().numpy()[..., hi - lo:], existing[..., hi - lo:])      # the slice only
+        out = d(existing)
+        C.conv_tile_backward_data(adj, d(dp), cout, cout, n, oh, ow, packed, hi - lo, tn, out, ld, mask_src=d(ymask), ldm=hi - lo,
+                                  mask_alpha=0.3, accumulate=True)
+        torch.cuda.synchronize()
+        ref = (gx[..., lo:hi] + torch.tensor(existing[..., :hi - lo])) * torch.where(torch.tensor(ymask) > 0, 1.0, 0.3)
+        np.testing.assert_allclose(out.cpu().numpy()[..., :hi - lo], ref.numpy(), atol=2 * tol)
+
+
 @pytest.mark.parametrize('mode,ksplit,partial', [(C.CONV_K2S2, 1, True), (C.CONV_K2S2, 4, True), (C.DECONV_K2S2, 1, False),
                                                  (C.DECONV_K2S2, 2, True), (C.CONV_K2S1, 1, True)])
 def test_backward_data_with_the_level_split_epilogue(mode, ksplit, partial):
