@@ -496,6 +496,16 @@ int nlt_front4_forward_u8(const unsigned char* diffuse_store, const unsigned cha
                           const float* packed, const float* packed_l2, int add_base, float alpha,
                           float* fm1, float* skip3, float* qtmp2, float* otmp2, int waves_per_simd, void* stream);
 
+/* TRAINING form of nlt_front4_forward: the same launch, which additionally keeps the maps the backward pass reads -- exactly what
+ * nlt_front_forward_train keeps (obs1 [n,k,h/2,w/2,16], qtmp1 [n,h/2,w/2,16], otmp1 [n,k,h/2,w/2,16]) -- while STILL running level
+ * 2's stride-2 convs (qtmp2 / otmp2, which the backward needs as stored activations anyway): the train forward then launches neither
+ * the first-generation front kernel nor L2.q.s2 / L2.o.s2.
+ *   replaces: the same reference lines as nlt_front4_forward, run under the GradientTape of nlt/trainvali.py:272-274. */
+int nlt_front4_forward_train(const float* base, const float* cvis, const float* lvis, const float* nn_rgb,
+                             const float* nn_base, int n, int k, int h, int w, const float* packed,
+                             const float* packed_l2, int add_base, float alpha, float* fm1, float* skip3,
+                             float* qtmp2, float* otmp2, float* obs1, float* qtmp1, float* otmp1, void* stream);
+
 /*
  * One expanding block in one launch (inference): Conv2DTranspose k2s2 (cx + cs -> c) + LeakyReLU on the virtual concat
  * [x | skip], Conv2DTranspose k2s1 (c -> c) + LeakyReLU; the intermediate map stays in LDS.  c = 8 or 16 (the blocks at

@@ -83,6 +83,7 @@ SIGNATURES = {
     'nlt_front2_forward': (_c_int, [_vp] * 5 + [_c_int] * 4 + [_vp, _vp, _c_int, _c_float, _vp, _vp, _vp, _vp, _vp]),
     'nlt_front4_forward': (_c_int, [_vp] * 5 + [_c_int] * 4 + [_vp, _vp, _c_int, _c_float, _vp, _vp, _vp, _vp, _c_int, _vp]),
     'nlt_front4_forward_u8': (_c_int, [_vp] * 6 + [_c_int] * 4 + [_vp, _vp, _c_int, _c_float, _vp, _vp, _vp, _vp, _c_int, _vp]),
+    'nlt_front4_forward_train': (_c_int, [_vp] * 5 + [_c_int] * 4 + [_vp, _vp, _c_int, _c_float] + [_vp] * 7 + [_vp]),
     'nlt_dec_block_forward': (_c_int, [_vp, _c_int, _vp, _c_int, _c_int, _c_int, _c_int, _vp, _vp, _vp, _vp, _c_int, _c_float, _vp, _vp]),
     'nlt_back_forward': (_c_int, [_vp] * 3 + [_c_int] * 3 + [_vp] * 5 + [_c_float, _vp, _vp]),
     'nlt_front_forward_train': (_c_int, [_vp] * 5 + [_c_int] * 4 + [_vp, _c_int, _c_float] + [_vp] * 6),
@@ -879,6 +880,14 @@ def front4_forward_u8(diffuse_store, rgb_store, cvis_store, lvis_store, ids, nn_
                                        _ptr(packed), _ptr(packed_l2), 1 if add_base else 0, float(alpha), _ptr(fm1),
                                        _ptr(skip3), _ptr(qtmp2), _ptr(otmp2), int(waves_per_simd), _stream()),
            'nlt_front4_forward_u8')
+
+
+def front4_forward_train(base, cvis, lvis, nn_rgb, nn_base, n, k, h, w, packed, packed_l2, add_base, alpha, fm1, skip3, qtmp2, otmp2,
+                         obs1, qtmp1, otmp1):
+    """front4_forward that also keeps the level-1 maps the backward pass reads (train mode)."""
+    _check(lib().nlt_front4_forward_train(_ptr(base), _ptr(cvis), _ptr(lvis), _ptr(nn_rgb), _ptr(nn_base), n, k, h, w, _ptr(packed),
+                                          _ptr(packed_l2), 1 if add_base else 0, float(alpha), _ptr(fm1), _ptr(skip3), _ptr(qtmp2),
+                                          _ptr(otmp2), _ptr(obs1), _ptr(qtmp1), _ptr(otmp1), _stream()), 'nlt_front4_forward_train')
 
 
 def dec_block_forward(x, cx, skip, cs, n, h, w, w_s2, b_s2, w_s1, b_s1, c, alpha, out):

@@ -68,11 +68,15 @@ __device__ __forceinline__ f32x4 lrelu4m(f32x4 v, float alpha) {
 // Two waves per SIMD (<= 256 registers).  A leaner variant (weights re-read per observation, query inputs fetched
 // late, 10 KB of LDS, 168 registers, three waves per SIMD) measured SLOWER (0.27 vs 0.25 ms at k = 4, uint8): what
 // limits the kernel is each wave's own MFMA duty cycle, not the number of waves (profiles/README.md r02_a).
-template <bool U8>
+// TRAIN = true additionally keeps what the backward pass reads (the maps nlt_front_forward_train keeps): the level-1
+// stride-2 outputs of both paths (owned texels of the haloed stage-1 tile) and the per-observation level-1 maps.
+struct Front4Keep { float *obs1, *qtmp1, *otmp1; };
+
+template <bool U8, bool TRAIN>
 __global__ __launch_bounds__(64, 2) void front4_kernel(
     Front4In in, int k, int h, int w, int tiles_y, int tiles_x, const float* __restrict__ blob, int add_base, float alpha,
     float* __restrict__ fm1, float* __restrict__ skip3, const float* __restrict__ blob3, float* __restrict__ qtmp2,
-    float* __restrict__ otmp2) {
+    float* __restrict__ otmp2, Front4Keep keep) {
   __shared__ __attribute__((aligned(16))) float lds[W_END];
   const int lane = threadIdx.x;
   const int kk = lane >> 4, j = lane & 15;
@@ -297,6 +301,15 @@ __global__ __launch_bounds__(64, 2) void front4_kernel(
     }
 #pragma unroll
     for (int c = 0; c < NC; ++c) *reinterpret_cast<f32x4*>(ot + (kk * SLOTS + c * 16 + j) * 4) = sv[c];
+    if constexpr (TRAIN) {
+#pragma unroll
+      for (int c = 0; c < NC; ++c)
+        if ((owned_m >> c) & 1) {
+          const int t = c * 16 + j;
+          float* o = keep.otmp1 + ((((long)f * k + i) * h2 + ty0 + t / AW) * w2 + tx0 + t % AW) * 16 + 4 * kk;
+          *reinterpret_cast<f32x4*>(o) = sv[c];
+        }
+    }
     wave_sync();                                                         // every lane has its raw values: the raw tile is free
     // observation i + 1 (loaded an iteration ago) is converted and stored NEXT TO stage 2's MFMAs (same scheduling
     // region, no fence between them): its VALU work fills the matrix pipe's shadow
@@ -311,6 +324,12 @@ __global__ __launch_bounds__(64, 2) void front4_kernel(
     stage2(ao1, bo1, o1);
 #pragma unroll
     for (int r = 0; r < SH; ++r) mean[r] += o1[r];
+    if constexpr (TRAIN) {
+#pragma unroll
+      for (int r = 0; r < SH; ++r)
+        if (ty0 + r < h2 && tx0 + j < w2)
+          *reinterpret_cast<f32x4*>(keep.obs1 + ((((long)f * k + i) * h2 + ty0 + r) * w2 + tx0 + j) * 16 + 4 * kk) = o1[r];
+    }
     wave_sync();                                                         // stage-2 reads of `ot` are done: it becomes the level-1 tile
     // ---- stage 3: level 2's stride-2 conv of this observation's level-1 strip
 #pragma unroll
@@ -370,6 +389,12 @@ __global__ __launch_bounds__(64, 2) void front4_kernel(
         f32x4 v = lrelu4m(acc[c] + bq2, alpha);
         if (!interior && !((inside_m >> (c0 + c)) & 1)) v = zero4;
         *reinterpret_cast<f32x4*>(ot + (kk * SLOTS + (c0 + c) * 16 + j) * 4) = v;
+        if constexpr (TRAIN) {
+          if ((owned_m >> (c0 + c)) & 1) {
+            const int t = (c0 + c) * 16 + j;
+            *reinterpret_cast<f32x4*>(keep.qtmp1 + (((long)f * h2 + ty0 + t / AW) * w2 + tx0 + t % AW) * 16 + 4 * kk) = v;
+          }
+        }
         if ((owned_m >> (c0 + c)) & 1) {                                 // the head's share of the L0 features (+ base)
           float s0 = s0b, s1 = s1b, s2 = s2b;
 #pragma unroll
@@ -434,9 +459,10 @@ __global__ __launch_bounds__(64, 2) void front4_kernel(
   }
 }
 
-template <bool U8>
+template <bool U8, bool TRAIN = false>
 int front4_launch(const Front4In& in, int n, int k, int h, int w, const float* packed, const float* packed_l2, int add_base,
-                  float alpha, float* fm1, float* skip3, float* qtmp2, float* otmp2, int wps, void* stream) {
+                  float alpha, float* fm1, float* skip3, float* qtmp2, float* otmp2, int wps, void* stream,
+                  Front4Keep keep = Front4Keep{nullptr, nullptr, nullptr}) {
   if (!in.base || !in.cvis || !in.lvis || !in.nn_rgb || !in.nn_base || !packed || !packed_l2 || !fm1 || !skip3 || !qtmp2 || !otmp2)
     return NLT_ERR_BAD_ARG;
   if (U8 && (!in.ids || !in.nn_ids)) return NLT_ERR_BAD_ARG;
@@ -454,8 +480,11 @@ int front4_launch(const Front4In& in, int n, int k, int h, int w, const float* p
   const long blocks = (long)n * ty * tx;
   if (blocks >= (1l << 31)) return NLT_ERR_UNSUPPORTED;
   (void)wps;                                                           // one register allocation (2 waves per SIMD); kept in the ABI
-  hipLaunchKernelGGL(front4_kernel<U8>, dim3((unsigned)blocks), dim3(64), 0, static_cast<hipStream_t>(stream),
-                     in, k, h, w, ty, tx, packed, add_base, alpha, fm1, skip3, packed_l2, qtmp2, otmp2);
+  if (TRAIN && (!keep.obs1 || !keep.qtmp1 || !keep.otmp1 || !nlt_aligned16(keep.obs1) || !nlt_aligned16(keep.qtmp1) ||
+                !nlt_aligned16(keep.otmp1)))
+    return NLT_ERR_BAD_ARG;
+  hipLaunchKernelGGL((front4_kernel<U8, TRAIN>), dim3((unsigned)blocks), dim3(64), 0, static_cast<hipStream_t>(stream),
+                     in, k, h, w, ty, tx, packed, add_base, alpha, fm1, skip3, packed_l2, qtmp2, otmp2, keep);
   NLT_CHECK_LAUNCH();
   return NLT_OK;
 }
@@ -478,4 +507,13 @@ extern "C" int nlt_front4_forward_u8(const unsigned char* diffuse_store, const u
                                      void* stream) {
   Front4In in = {diffuse_store, cvis_store, lvis_store, rgb_store, diffuse_store, ids, nn_ids};
   return front4_launch<true>(in, n, k, h, w, packed, packed_l2, add_base, alpha, fm1, skip3, qtmp2, otmp2, waves_per_simd, stream);
+}
+
+extern "C" int nlt_front4_forward_train(const float* base, const float* cvis, const float* lvis, const float* nn_rgb,
+                                        const float* nn_base, int n, int k, int h, int w, const float* packed,
+                                        const float* packed_l2, int add_base, float alpha, float* fm1, float* skip3,
+                                        float* qtmp2, float* otmp2, float* obs1, float* qtmp1, float* otmp1, void* stream) {
+  Front4In in = {base, cvis, lvis, nn_rgb, nn_base, nullptr, nullptr};
+  return front4_launch<false, true>(in, n, k, h, w, packed, packed_l2, add_base, alpha, fm1, skip3, qtmp2, otmp2, 0, stream,
+                                    Front4Keep{obs1, qtmp1, otmp1});
 }

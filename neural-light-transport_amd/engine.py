@@ -62,6 +62,7 @@ class RenderPlan:
         # second-generation front kernel (csrc/front4.hip: barrier-free, one wave per level-1 strip); 0 = first generation
         self.front_v4 = os.environ.get('NLT_FRONT4', '1') != '0'
         self.fuse_train = os.environ.get('NLT_FUSED_TRAIN', '1') != '0'   # fused ends in the train step too (csrc/train_fused.hip)
+XX
         self.two_streams = os.environ.get('NLT_STREAMS', '2') != '1'   # inference: query-path encoder convs on a side stream
         self._side = None               # (side stream, [events]) created on first use
         self._bside = None              # backward: (side stream for the weight gradients, [events], cursor)
@@ -403,7 +404,7 @@ class RenderPlan:
                                                 skip_connect_base, algo, inference))
         # launch tape (second sight of the same inputs records, later sights replay)
         if fused:
-            self._front_weights(dev, l2=inference)   # folded front-kernel weights, refreshed in place OUTSIDE any tape
+            self._front_weights(dev, l2=inference or self.front4_train)   # folded front-kernel weights, refreshed in place OUTSIDE any tape
         tkey = None
         if (self.use_tape and base.is_cuda and self.timer is None and not self._tuning and reg is not None
                 and obs_weights is None and obs_override is None
@@ -561,12 +562,13 @@ class RenderPlan:
         alpha = q.layers[1].convs()[0][1].alpha
         if b['skip3'] is None:
             b['skip3'] = torch.empty((n, h, w, 3), device=dev, dtype=torch.float32)
-        blob, blob_l2 = self._front_weights(dev, l2=not train)
+        blob, blob_l2 = self._front_weights(dev, l2=(not train) or self.front4_train)
         # With k <= 4 the front kernel also runs level 2's stride-2 convs (its 8 x 16 level-1 tile is a 4 x 8 tile of
         # level 2): the per-observation level-1 maps never reach HBM and L2.{q,o}.s2 are not launched.
         v4 = self.front_v4 and 0.0 <= alpha <= 1.0 and (resident is not None or C.front4_supported(base, cvis, lvis, nn_rgb, nn_base))
+        # (training: only the second-generation kernel has a form that also keeps the level-1 maps the backward reads)
         front2 = (self.front_l2 and blob_l2 is not None and (k <= 4 or v4) and h % 4 == 0 and w % 4 == 0 and not self._trial_direct
-                  and not train)
+                  and (not train or (v4 and self.front4_train)))
         if resident is not None and not (front2 and v4 and w % 8 == 0):
             raise C.NLTError("store-resident inputs need the fused front kernel (front4, level-2 fold, w % 8 == 0)")
         nbytes = 4 * n * h * w * ((5 + 3 * k + 16 + 16 * k) + (36 + 20 * k + 8 + 8 * k))     # L0 + L1 (+ means)
@@ -580,6 +582,11 @@ class RenderPlan:
                 self._launch('F.front', nbytes, C.front4_forward_u8, resident.diffuse, resident.rgb, resident.cvis, resident.lvis,
                              resident.ids, resident.nn_ids, n, k, h, w, blob, blob_l2, skip_connect_base, alpha, b['fm'][1],
                              b['skip3'], b['qtmp'][2], b['otmp'][2], flops=flops, moved=moved)
+            elif train:
+                moved += 4 * n * (h // 2) * (w // 2) * 16 * (1 + 2 * k)      # + the three level-1 maps kept for the backward
+                self._launch('F.front', nbytes, C.front4_forward_train, base, cvis, lvis, nn_rgb, nn_base, n, k, h, w, blob, blob_l2,
+                             skip_connect_base, alpha, b['fm'][1], b['skip3'], b['qtmp'][2], b['otmp'][2], b['obs'][1], b['qtmp'][1],
+                             b['otmp'][1], flops=flops, moved=moved)
             elif v4:
                 self._launch('F.front', nbytes, C.front4_forward, base, cvis, lvis, nn_rgb, nn_base, n, k, h, w, blob, blob_l2,
                              skip_connect_base, alpha, b['fm'][1], b['skip3'], b['qtmp'][2], b['otmp'][2],

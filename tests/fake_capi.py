@@ -375,6 +375,14 @@ def front_forward_train(base, cvis, lvis, nn_rgb, nn_base, n, k, h, w, P, add_ba
     otmp1.copy_(torch.stack([lr(T.conv2d_same(o0[:, i], P['woa'], P['boa'], 2)) for i in range(k)], 1))
 
 
+def front4_forward_train(base, cvis, lvis, nn_rgb, nn_base, n, k, h, w, P, P2, add_base, alpha, fm1, skip3, qtmp2, otmp2,
+                         obs1, qtmp1, otmp1):
+    front_forward_train(base, cvis, lvis, nn_rgb, nn_base, n, k, h, w, P, add_base, alpha, fm1, obs1, skip3, qtmp1, otmp1)
+    lr = lambda x: T.leaky_relu(x, alpha)
+    qtmp2.copy_(lr(T.conv2d_same(fm1, P2['wq'], P2['bq'], 2)))
+    otmp2.copy_(torch.stack([lr(T.conv2d_same(obs1[:, i], P2['wo'], P2['bo'], 2)) for i in range(k)], 1))
+
+
 def back_forward_train(x, fm1, skip3, n, h2, w2, w_s2, b_s2, w_s1, b_s1, w_head, alpha, pred, u, v):
     lr = lambda t: T.leaky_relu(t, alpha)
     u.copy_(lr(T.conv2d_transpose_same(torch.cat((x, fm1), -1), w_s2, b_s2, 2)))
@@ -562,7 +570,7 @@ def front4_forward_u8(diffuse_store, rgb_store, cvis_store, lvis_store, ids, nn_
                    qtmp2, otmp2)
 
 
-_FUSED = _FUSED + ('front_pack_l2_weights', 'front2_forward', 'front4_supported', 'front4_forward', 'front4_forward_u8', 'dec_block_forward', 'act_forward', 'act_backward',
+_FUSED = _FUSED + ('front_pack_l2_weights', 'front2_forward', 'front4_supported', 'front4_forward', 'front4_forward_u8', 'front4_forward_train', 'dec_block_forward', 'act_forward', 'act_backward',
                   'pixelnorm_forward', 'pixelnorm_backward', 'norm_forward', 'norm_backward', 'pool2x2_forward', 'pool2x2_backward', 'sub_forward', 'finish_pred')
 
 

@@ -80,6 +80,36 @@ def test_front4_u8_store_is_bit_identical_to_float_on_assembled_batch(n, k, h, w
         assert torch.equal(a, c), (name, float((a - c).abs().max()))
 
 
+@pytest.mark.parametrize('n,k,h,w', [(2, 1, 64, 96), (1, 2, 40, 72), (1, 4, 64, 64), (1, 1, 1024, 1024), (1, 3, 36, 100)])
+def test_front4_train_keeps_the_same_maps_as_the_first_generation_train_kernel(n, k, h, w):
+    """nlt_front4_forward_train: fm1 / skip3 / qtmp2 / otmp2 bit-identical to nlt_front4_forward, and the three maps kept for
+    the backward pass (obs1, qtmp1, otmp1) bit-identical to what nlt_front_forward_train keeps (same folded weights, same
+    MFMA sequences)."""
+    pm, blob, blob_l2 = _weights(seed=k + 10)
+    g = torch.Generator(device='cuda').manual_seed(n * 1000 + k * 100 + h)
+    U = lambda *s: torch.rand(s, device='cuda', generator=g)
+    base, cvis, lvis = U(n, h, w, 3), U(n, h, w, 1), U(n, h, w, 1)
+    nn_rgb, nn_base = U(n, k, h, w, 3), U(n, k, h, w, 3)
+    E = lambda *s: torch.full(s, float('nan'), device='cuda')
+    h2, w2 = h // 2, w // 2
+    inf, tr = _outs(n, k, h, w), _outs(n, k, h, w)
+    keep4 = (E(n, k, h2, w2, 16), E(n, h2, w2, 16), E(n, k, h2, w2, 16))                  # obs1, qtmp1, otmp1
+    C.front4_forward(base, cvis, lvis, nn_rgb, nn_base, n, k, h, w, blob, blob_l2, True, 0.3, *inf)
+    C.front4_forward_train(base, cvis, lvis, nn_rgb, nn_base, n, k, h, w, blob, blob_l2, True, 0.3, *tr, *keep4)
+    fm1, obs1, skip3, qtmp1, otmp1 = E(n, h2, w2, 32), E(n, k, h2, w2, 16), E(n, h, w, 3), E(n, h2, w2, 16), E(n, k, h2, w2, 16)
+    ok_old = w % 8 == 0                                                                   # (the first generation's train form needs w / 2 in fours)
+    if ok_old:
+        C.front_forward_train(base, cvis, lvis, nn_rgb, nn_base, n, k, h, w, blob, True, 0.3, fm1, obs1, skip3, qtmp1, otmp1)
+    torch.cuda.synchronize()
+    for name, a, b in zip(('fm1', 'skip3', 'qtmp2', 'otmp2'), inf, tr):
+        assert torch.equal(a, b), name
+    assert not any(torch.isnan(t).any() for t in keep4)
+    if ok_old:
+        for name, a, b in zip(('obs1', 'qtmp1', 'otmp1'), (obs1, qtmp1, otmp1), keep4):
+            assert torch.equal(a, b), (name, float((a - b).abs().max()))
+        assert torch.equal(fm1, tr[0]) and torch.equal(skip3, tr[1])
+
+
 def test_front4_rejects_what_it_cannot_take():
     pm, blob, blob_l2 = _weights()
     n, k, h, w = 1, 1, 32, 32
