@@ -696,7 +696,8 @@ int nlt_conv_tile_backward_data(int adj_mode, const float* dpre, int ldp, int cp
  * `precision = f32x3` form of nlt_conv_tile_forward (csrc/conv_tile3.hip): the same convs with every fp32 operand split exactly
  * into three bf16 terms (hi + mid + lo) and the term products -- each exact in fp32 -- accumulated in fp32 on
  * v_mfma_f32_16x16x32_bf16.  nprod = 9: all nine term products (error = fp32 accumulation rounding, as the native fp32 MFMA);
- * nprod = 6: the three products of relative order 2^-24 dropped.  Same arguments and semantics as nlt_conv_tile_forward;
+ * nprod = 6: the three products of relative order 2^-24 dropped (nprod = 3 / 1: only the products down to 2^-16 / hi * hi alone --
+ * the precision ladder's lower rungs, for measurement).  Same arguments and semantics as nlt_conv_tile_forward;
  * `packed` = nlt_pack_conv_tile3_weights (nlt_conv_tile3_packed_elems() bf16 elements: the kernel's three terms in fragment order).
  * An explicit inference / forward mode reported beside the native fp32 path, never instead of it.
  *   replaces: the same Conv2D (+ LeakyReLU, + tf.reduce_mean over observations) lines as nlt_conv_tile_forward.

@@ -260,7 +260,9 @@ int launch3(const Tile3P& p, int nprod, hipStream_t s) {
   const long tiles = (long)p.frames * p.tiles_y * p.tiles_x;
   const dim3 grid((unsigned)tiles, (unsigned)(p.cout / (16 * TNT)));
   if (nprod == 9) hipLaunchKernelGGL((conv_tile3_kernel<MODE, TNT, 9>), grid, dim3(256), 0, s, p);
-  else hipLaunchKernelGGL((conv_tile3_kernel<MODE, TNT, 6>), grid, dim3(256), 0, s, p);
+  else if (nprod == 6) hipLaunchKernelGGL((conv_tile3_kernel<MODE, TNT, 6>), grid, dim3(256), 0, s, p);
+  else if (nprod == 3) hipLaunchKernelGGL((conv_tile3_kernel<MODE, TNT, 3>), grid, dim3(256), 0, s, p);   // hi*hi + hi*mid + mid*hi (~2^-16)
+  else hipLaunchKernelGGL((conv_tile3_kernel<MODE, TNT, 1>), grid, dim3(256), 0, s, p);                  // hi*hi: plain bf16 operands
   NLT_CHECK_LAUNCH();
   return NLT_OK;
 }
@@ -287,7 +289,7 @@ extern "C" int nlt_pack_conv_tile3_weights(int mode, const float* w_keras, int c
 extern "C" int nlt_conv_tile3_forward(int mode, int nprod, const float* src, int ld, int cin, int frames, int kobs, int h, int w,
                                       const unsigned short* packed, const float* bias, int cout, int tn,
                                       float* out, int ldo, float* mean_out, int ldm, int act, float alpha, void* stream) {
-  if (!src || !packed || !bias || (!out && !mean_out) || (nprod != 6 && nprod != 9)) return NLT_ERR_BAD_ARG;
+  if (!src || !packed || !bias || (!out && !mean_out) || (nprod != 1 && nprod != 3 && nprod != 6 && nprod != 9)) return NLT_ERR_BAD_ARG;
   if (frames <= 0 || kobs <= 0 || h <= 0 || w <= 0 || cin <= 0 || cout <= 0) return NLT_ERR_BAD_ARG;
   if (nlt_conv_tile3_packed_elems(mode, cin, cout, tn) <= 0) return NLT_ERR_UNSUPPORTED;
   if (mode == NLT_CONV_K2S2 && ((h | w) & 1)) return NLT_ERR_UNSUPPORTED;
