@@ -680,17 +680,22 @@ int nlt_conv_tile_forward(int mode, const float* src, int ld, int cin, int frame
  * gradient w.r.t. its pre-activation output dpre [n,h,w,cpre], as the adjoint conv family adj_mode on the layer's own Keras array:
  *   NLT_CONV_K2S1 / NLT_CONV_K2S2  (the layer is a Conv2DTranspose: its (kh,kw,Cout,Cin) array read as a conv Cout -> Cin slice);
  *   NLT_DECONV_K2S1                (the layer is a Conv2D k2s1: its (kh,kw,Cin,Cout) array read as the transposed conv, halo on
- *                                   the top / left of the tile).
+ *                                   the top / left of the tile);
+ *   NLT_DECONV_K2S2                (the layer is a Conv2D k2s2: a 1x1-conv-shaped GEMM over the tile of dpre texels with N = 4 * cout
+ *                                   columns (a, b, channel) and a scatter store; cpre % 32 == 0, cout % 16 == 0, 4 * cout % tn == 0;
+ *                                   this mode also takes the level-split epilogue arguments of nlt_conv_backward_data).
  * packed = nlt_pack_conv_tile_weights_adjoint(adj_mode, layer array, cpre, cout, tn, full = the array's input-channel extent, lo)
  * (nlt_conv_tile_packed_floats(adj_mode, cpre, cout, tn) floats; cpre % 16 == 0, cout % tn == 0).  Epilogue as
- * nlt_conv_backward_data without the split: v (+= out when accumulate), times LeakyReLU'(mask_src) when mask_src != NULL.
+ * nlt_conv_backward_data (split_c = 0 unless adj_mode is NLT_DECONV_K2S2): v (+= out when accumulate), times LeakyReLU'(mask_src) when mask_src != NULL.
  *   replaces: the input-gradient half of tf.GradientTape.gradient through Conv2D / Conv2DTranspose (nlt/trainvali.py:279).
  */
 int nlt_pack_conv_tile_weights_adjoint(int adj_mode, const float* w_keras, int cpre, int cout, int tn, int full, int lo,
                                        float* packed, void* stream);
 int nlt_conv_tile_backward_data(int adj_mode, const float* dpre, int ldp, int cpre, int n, int h, int w,
                                 const float* packed, int cout, int tn, float* out, int ldo,
-                                const float* mask_src, int ldm, float mask_alpha, int accumulate, void* stream);
+                                const float* mask_src, int ldm, float mask_alpha, int accumulate,
+                                int split_c, const float* split_y, float* split_d, float split_alpha, int split_partial,
+                                void* stream);
 
 /*
  * `precision = f32x3` form of nlt_conv_tile_forward (csrc/conv_tile3.hip): the same convs with every fp32 operand split exactly

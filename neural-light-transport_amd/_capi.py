@@ -104,7 +104,7 @@ SIGNATURES = {
                                        _vp, _c_int, _vp, _c_int, _c_int, _c_float, _vp]),
     'nlt_pack_conv_tile_weights_adjoint': (_c_int, [_c_int, _vp, _c_int, _c_int, _c_int, _c_int, _c_int, _vp, _vp]),
     'nlt_conv_tile_backward_data': (_c_int, [_c_int, _vp, _c_int, _c_int, _c_int, _c_int, _c_int, _vp, _c_int, _c_int, _vp, _c_int,
-                                             _vp, _c_int, _c_float, _c_int, _vp]),
+                                             _vp, _c_int, _c_float, _c_int, _c_int, _vp, _vp, _c_float, _c_int, _vp]),
     'nlt_conv_tile3_packed_elems': (_c_long, [_c_int] * 4),
     'nlt_pack_conv_tile3_weights': (_c_int, [_c_int, _vp, _c_int, _c_int, _c_int, _vp, _vp]),
     'nlt_conv_tile3_forward': (_c_int, [_c_int, _c_int, _vp, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _vp, _vp, _c_int, _c_int,
@@ -742,10 +742,13 @@ def pack_conv_tile_weights_adjoint(adj_mode, w_keras, cpre, cout, tn, full, lo):
 
 
 def conv_tile_backward_data(adj_mode, dpre, cpre, ldp, n, h, w, packed, cout, tn, out, ldo, mask_src=None, ldm=0, mask_alpha=0.3,
-                            accumulate=False, w_keras=None):
-    """Backward-data on the LDS-tiled kernel (include/nlt_hip.h: nlt_conv_tile_backward_data)."""
+                            accumulate=False, split=None, w_keras=None):
+    """Backward-data on the LDS-tiled kernel (include/nlt_hip.h: nlt_conv_tile_backward_data); split as conv_backward_data's
+    (transposed k2s2 mode only)."""
+    sc, sy, sd, sa, sp = split if split is not None else (0, None, None, 0.0, False)
     _check(lib().nlt_conv_tile_backward_data(adj_mode, _ptr(dpre), ldp, cpre, n, h, w, _ptr(packed), cout, tn, _ptr(out), ldo,
-                                             _ptr(mask_src), ldm, float(mask_alpha), 1 if accumulate else 0, _stream()),
+                                             _ptr(mask_src), ldm, float(mask_alpha), 1 if accumulate else 0,
+                                             sc, _ptr(sy), _ptr(sd), float(sa), 1 if sp else 0, _stream()),
            'nlt_conv_tile_backward_data')
 
 

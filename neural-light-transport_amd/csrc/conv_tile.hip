@@ -30,6 +30,10 @@ template <> struct TileTraits<NLT_CONV_K2S2> { static constexpr int STAGE_TAPS =
 // Conv2DTranspose k2s1 ('same': taps (y - a, x - b), zero above / left of the image) = the k2s1 tile with its halo on the top /
 // left: origin (ty0 - 1, tx0 - 1), tap (a, b) reads slot (y + 1 - a, x + 1 - b).  Backward-data of every encoder stride-1 conv.
 template <> struct TileTraits<NLT_DECONV_K2S1> { static constexpr int STAGE_TAPS = 4, B_UNITS = 153 * 4, B_FLOATS = 4 * PL * 4; };
+// Conv2DTranspose k2s2 (each input texel owns a 2 x 2 output block) = a 1x1-conv-shaped GEMM over the 8 x 16 INPUT tile with
+// N = 4 * cout columns (a, b, o) and a scatter store: no halo, no taps -- a stage is TWO 16-channel slabs (the "taps" of the
+// stage loop), 128 slots per channel-quad plane.  Backward-data of every encoder stride-2 conv (with the level-split epilogue).
+template <> struct TileTraits<NLT_DECONV_K2S2> { static constexpr int STAGE_TAPS = 2, B_UNITS = 128 * 4 * 2, B_FLOATS = 2 * 4 * 128 * 4; };
 
 struct TileP {
   const float* src; const float* packed; const float* bias;
@@ -40,6 +44,8 @@ struct TileP {
   int act; float alpha;
   // backward-data epilogue (nlt_conv_tile_backward_data): v (+= out when accumulate) times LeakyReLU'(mask_src) (slope alpha)
   const float* mask_src; int ld_mask; int accumulate;
+  // ... and the level-split part of it (ConvP::split_* in nlt_common.h), transposed k2s2 mode only
+  int split_c, split_partial; float split_alpha; const float* split_y; float* split_d;
 };
 
 __device__ __forceinline__ int xcd_tile(int b, int nblocks) {
@@ -51,7 +57,8 @@ __global__ void pack_tile_kernel(const float* __restrict__ wk, int cin, int cout
                                  float* __restrict__ wp) {
   const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= total) return;
-  wp[idx] = nlt_tile_fragment(wk, idx, cin, cout, tnt, full, lo, transposed != 0);   // t = a*2+b
+  wp[idx] = transposed == 2 ? nlt_tile_fragment_d2(wk, idx, cin, cout, tnt, full, lo)
+                            : nlt_tile_fragment(wk, idx, cin, cout, tnt, full, lo, transposed != 0);   // t = a*2+b
 }
 
 template <int MODE, int TNT>
@@ -73,7 +80,8 @@ __global__ __launch_bounds__(256) void conv_tile_kernel(TileP p) {
   const int g = blockIdx.y;
   constexpr bool K2S1 = MODE == NLT_CONV_K2S1 || MODE == NLT_DECONV_K2S1;   // one stage per 16-channel slab, all 4 taps
   constexpr bool TR = MODE == NLT_DECONV_K2S1;
-  const int stages_per_frame = (K2S1 ? 1 : 2) * p.ncc;
+  constexpr bool D2 = MODE == NLT_DECONV_K2S2;                               // two 16-channel slabs per stage, no taps
+  const int stages_per_frame = D2 ? p.ncc / 2 : (K2S1 ? 1 : 2) * p.ncc;
   const int total_stages = stages_per_frame * p.kobs;
   const long in_frame = (long)p.h * p.w;
 
@@ -90,7 +98,15 @@ __global__ __launch_bounds__(256) void conv_tile_kernel(TileP p) {
     const int u = tid + 256 * i;
     const int q = (u >> 3) & 3, tx = (u >> 5) * 8 + (u & 7);
     b_q[i] = q;
-    if (K2S1) {
+    if (D2) {
+      const int texel = tx & 127, slab = tx >> 7;
+      const int gy = ty0 + (texel >> 4), gx = tx0 + (texel & 15);
+      b_st[i] = true;
+      b_ok[i] = gy < p.h && gx < p.w;
+      b_tex[i] = (long)gy * p.w + gx;
+      b_lds[i] = ((slab * 4 + q) * 128 + texel) * 4;
+      b_q[i] = 4 * slab + q;                                          // channel quad inside the stage's 32 channels
+    } else if (K2S1) {
       const int hy = tx / 17, hx = tx % 17;
       const int gy = ty0 + hy - (TR ? 1 : 0), gx = tx0 + hx - (TR ? 1 : 0);
       b_st[i] = tx < 153;
@@ -110,9 +126,10 @@ __global__ __launch_bounds__(256) void conv_tile_kernel(TileP p) {
   f32x4 ra[NA], rb[NB];
   auto load_stage = [&](int q) {
     const int i = q / stages_per_frame, s = q - i * stages_per_frame;
-    const int cc = K2S1 ? s : (s >> 1);
-    const int a = K2S1 ? 0 : (s & 1);
-    const float* ap = p.packed + ((((long)g * p.ncc + cc) * 4 + 2 * a) * TNT) * 256;
+    const int cc = D2 ? 2 * s : (K2S1 ? s : (s >> 1));
+    const int a = (K2S1 || D2) ? 0 : (s & 1);
+    const float* ap = D2 ? p.packed + (((long)g * p.ncc + cc) * TNT) * 256
+                         : p.packed + ((((long)g * p.ncc + cc) * 4 + 2 * a) * TNT) * 256;
 #pragma unroll
     for (int n = 0; n < NA; ++n) ra[n] = *reinterpret_cast<const f32x4*>(ap + (tid + 256 * n) * 4);
     const float* sp = p.src + ((long)(f * p.kobs + i) * in_frame + (long)a * p.w) * p.ld + cc * 16;
@@ -151,7 +168,8 @@ __global__ __launch_bounds__(256) void conv_tile_kernel(TileP p) {
 #pragma unroll
       for (int rt = 0; rt < RT; ++rt) {
         const int y = wm * RT + rt;
-        const int off = TR ? (kk * PL + (y + 1 - (tl >> 1)) * 17 + j + 1 - (tl & 1)) * 4
+        const int off = D2 ? ((tl * 4 + kk) * 128 + y * 16 + j) * 4
+                         : TR ? (kk * PL + (y + 1 - (tl >> 1)) * 17 + j + 1 - (tl & 1)) * 4
                          : K2S1 ? (kk * PL + (y + (tl >> 1)) * 17 + j + (tl & 1)) * 4
                                 : (kk * QS2 + tl * ODD2 + y * 16 + j) * 4;
         bf[rt] = *reinterpret_cast<const f32x4*>(B + off);
@@ -171,12 +189,29 @@ __global__ __launch_bounds__(256) void conv_tile_kernel(TileP p) {
       const int i = q / stages_per_frame;
 #pragma unroll
       for (int ct = 0; ct < CT; ++ct) {
-        const int oc = (g * TNT + wn * CT + ct) * 16 + 4 * kk;
+        int oc = (g * TNT + wn * CT + ct) * 16 + 4 * kk, ab = 0;
+        if (D2) { ab = oc / p.cout; oc -= ab * p.cout; }                 // column (a, b, o) of the transposed k2s2 GEMM
         const f32x4 bv = p.bias ? *reinterpret_cast<const f32x4*>(p.bias + oc) : (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int rt = 0; rt < RT; ++rt) {
-          const int gy = ty0 + wm * RT + rt, gx = tx0 + j;
+          const int gy = D2 ? 2 * (ty0 + wm * RT + rt) + (ab >> 1) : ty0 + wm * RT + rt;
+          const int gx = D2 ? 2 * (tx0 + j) + (ab & 1) : tx0 + j;
           f32x4 v = acc[rt][ct] + bv;
+          if (D2 && p.split_c && oc >= p.split_c) {                    // observation half of dfm[l]: finished dobs (see ConvP)
+            if (gy < p.oh && gx < p.ow) {
+              const long ot = ((long)f * p.oh + gy) * p.ow + gx;
+              if (p.accumulate) v += *reinterpret_cast<const f32x4*>(p.out + ot * p.ldo + oc);
+              const long at = ot * p.split_c + (oc - p.split_c);
+              f32x4* dd = reinterpret_cast<f32x4*>(p.split_d + at);
+              if (p.split_partial) v += *dd;
+              const f32x4 mk = *reinterpret_cast<const f32x4*>(p.split_y + at);
+#pragma unroll
+              for (int e = 0; e < 4; ++e) v[e] *= (mk[e] > 0.f) ? 1.f : p.split_alpha;
+              *dd = v;
+            }
+            acc[rt][ct] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            continue;
+          }
           if (p.mask_src || p.accumulate) {                            // backward-data epilogue
             if (gy < p.oh && gx < p.ow) {
               const long ot = ((long)(f * p.kobs + i) * p.oh + gy) * p.ow + gx;
@@ -217,7 +252,8 @@ __global__ __launch_bounds__(256) void conv_tile_kernel(TileP p) {
 template <int MODE, int TNT>
 int launch(const TileP& p, hipStream_t s) {
   const long tiles = (long)p.frames * p.tiles_y * p.tiles_x;
-  hipLaunchKernelGGL((conv_tile_kernel<MODE, TNT>), dim3((unsigned)tiles, (unsigned)(p.cout / (16 * TNT))), dim3(256), 0, s, p);
+  const int ncols = MODE == NLT_DECONV_K2S2 ? 4 * p.cout : p.cout;
+  hipLaunchKernelGGL((conv_tile_kernel<MODE, TNT>), dim3((unsigned)tiles, (unsigned)(ncols / (16 * TNT))), dim3(256), 0, s, p);
   NLT_CHECK_LAUNCH();
   return NLT_OK;
 }
@@ -225,6 +261,10 @@ int launch(const TileP& p, hipStream_t s) {
 }  // namespace
 
 extern "C" long nlt_conv_tile_packed_floats(int mode, int cin, int cout, int tn) {
+  if (mode == NLT_DECONV_K2S2) {                                       // K = cin in pairs of 16-channel slabs; N = 4 * cout columns
+    if (cin <= 0 || cout <= 0 || (cin & 31) || (cout & 15) || (tn != 32 && tn != 64) || (4 * cout) % tn) return -1;
+    return (long)4 * cin * cout;
+  }
   if ((mode != NLT_CONV_K2S1 && mode != NLT_CONV_K2S2 && mode != NLT_DECONV_K2S1) || cin <= 0 || cout <= 0) return -1;
   if ((cin & 15) || (tn != 32 && tn != 64) || cout % tn) return -1;
   return (long)4 * cin * cout;
@@ -235,7 +275,7 @@ static int pack_tile(int mode, const float* w_keras, int cin, int cout, int tn, 
   if (total <= 0) return NLT_ERR_UNSUPPORTED;
   if (!w_keras || !packed || !nlt_aligned16(packed) || lo < 0 || lo + cout > full) return NLT_ERR_BAD_ARG;
   hipLaunchKernelGGL(pack_tile_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream),
-                     w_keras, cin, cout, tn / 16, full, lo, mode == NLT_DECONV_K2S1 ? 1 : 0, total, packed);
+                     w_keras, cin, cout, tn / 16, full, lo, mode == NLT_DECONV_K2S2 ? 2 : (mode == NLT_DECONV_K2S1 ? 1 : 0), total, packed);
   NLT_CHECK_LAUNCH();
   return NLT_OK;
 }
@@ -253,6 +293,7 @@ extern "C" int nlt_pack_conv_tile_weights_adjoint(int adj_mode, const float* w_k
 static int tile_run(int mode, TileP& p, int tn, hipStream_t s) {
   if (mode == NLT_CONV_K2S1) return tn == 64 ? launch<NLT_CONV_K2S1, 4>(p, s) : launch<NLT_CONV_K2S1, 2>(p, s);
   if (mode == NLT_DECONV_K2S1) return tn == 64 ? launch<NLT_DECONV_K2S1, 4>(p, s) : launch<NLT_DECONV_K2S1, 2>(p, s);
+  if (mode == NLT_DECONV_K2S2) return tn == 64 ? launch<NLT_DECONV_K2S2, 4>(p, s) : launch<NLT_DECONV_K2S2, 2>(p, s);
   return tn == 64 ? launch<NLT_CONV_K2S2, 4>(p, s) : launch<NLT_CONV_K2S2, 2>(p, s);
 }
 
@@ -273,23 +314,34 @@ extern "C" int nlt_conv_tile_forward(int mode, const float* src, int ld, int cin
   p.oh = mode == NLT_CONV_K2S2 ? h / 2 : h; p.ow = mode == NLT_CONV_K2S2 ? w / 2 : w;
   p.cout = cout; p.ldo = ldo; p.ldm = ldm; p.ncc = cin / 16; p.act = act; p.alpha = alpha;
   p.mask_src = nullptr; p.ld_mask = 0; p.accumulate = 0;
+  p.split_c = 0; p.split_partial = 0; p.split_alpha = 0.f; p.split_y = nullptr; p.split_d = nullptr;
   p.tiles_y = (p.oh + TH - 1) / TH; p.tiles_x = (p.ow + TW - 1) / TW;
   return tile_run(mode, p, tn, static_cast<hipStream_t>(stream));
 }
 
 extern "C" int nlt_conv_tile_backward_data(int adj_mode, const float* dpre, int ldp, int cpre, int n, int h, int w,
                                            const float* packed, int cout, int tn, float* out, int ldo,
-                                           const float* mask_src, int ldm, float mask_alpha, int accumulate, void* stream) {
+                                           const float* mask_src, int ldm, float mask_alpha, int accumulate,
+                                           int split_c, const float* split_y, float* split_d, float split_alpha, int split_partial,
+                                           void* stream) {
   if (!dpre || !packed || !out || n <= 0 || h <= 0 || w <= 0 || cpre <= 0 || cout <= 0) return NLT_ERR_BAD_ARG;
   if (nlt_conv_tile_packed_floats(adj_mode, cpre, cout, tn) <= 0) return NLT_ERR_UNSUPPORTED;
   if (adj_mode == NLT_CONV_K2S2 && ((h | w) & 1)) return NLT_ERR_UNSUPPORTED;
   if (ldp < cpre || (ldp & 3) || ldo < cout || (ldo & 3) || (mask_src && (ldm < cout || (ldm & 3)))) return NLT_ERR_BAD_ARG;
   if (!nlt_aligned16(dpre) || !nlt_aligned16(packed) || !nlt_aligned16(out) || (mask_src && !nlt_aligned16(mask_src))) return NLT_ERR_BAD_ARG;
-  if ((long long)n * h * w * (long long)(ldp > ldo ? ldp : ldo) >= (1ll << 31)) return NLT_ERR_UNSUPPORTED;
+  if ((long long)n * h * w * (adj_mode == NLT_DECONV_K2S2 ? 4 : 1) * (long long)(ldp > ldo ? ldp : ldo) >= (1ll << 31)) return NLT_ERR_UNSUPPORTED;
   TileP p;
   p.src = dpre; p.packed = packed; p.bias = nullptr; p.out = out; p.mean_out = nullptr;
   p.ld = ldp; p.cin = cpre; p.frames = n; p.kobs = 1; p.h = h; p.w = w;
-  p.oh = adj_mode == NLT_CONV_K2S2 ? h / 2 : h; p.ow = adj_mode == NLT_CONV_K2S2 ? w / 2 : w;
+  p.oh = adj_mode == NLT_CONV_K2S2 ? h / 2 : (adj_mode == NLT_DECONV_K2S2 ? 2 * h : h);
+  p.ow = adj_mode == NLT_CONV_K2S2 ? w / 2 : (adj_mode == NLT_DECONV_K2S2 ? 2 * w : w);
+  p.split_c = 0; p.split_partial = 0; p.split_alpha = 0.f; p.split_y = nullptr; p.split_d = nullptr;
+  if (split_c) {
+    if (adj_mode != NLT_DECONV_K2S2 || split_c < 0 || (split_c & 3) || split_c >= cout || !split_y || !split_d ||
+        !nlt_aligned16(split_y) || !nlt_aligned16(split_d))
+      return NLT_ERR_BAD_ARG;
+    p.split_c = split_c; p.split_y = split_y; p.split_d = split_d; p.split_alpha = split_alpha; p.split_partial = split_partial;
+  }
   p.cout = cout; p.ldo = ldo; p.ldm = 0; p.ld_mask = ldm; p.ncc = cpre / 16; p.act = 0; p.alpha = mask_alpha;
   p.mask_src = mask_src; p.accumulate = accumulate;
   p.tiles_y = (p.oh + TH - 1) / TH; p.tiles_x = (p.ow + TW - 1) / TW;

@@ -76,7 +76,7 @@ template <bool U8, bool TRAIN>
 __global__ __launch_bounds__(64, 2) void front4_kernel(
     Front4In in, int k, int h, int w, int tiles_y, int tiles_x, const float* __restrict__ blob, int add_base, float alpha,
     float* __restrict__ fm1, float* __restrict__ skip3, const float* __restrict__ blob3, float* __restrict__ qtmp2,
-    float* __restrict__ otmp2, Front4Keep keep, int variant) {
+    float* __restrict__ otmp2, Front4Keep keep) {
   __shared__ __attribute__((aligned(16))) float lds[W_END];
   const int lane = threadIdx.x;
   const int kk = lane >> 4, j = lane & 15;
@@ -229,9 +229,6 @@ __global__ __launch_bounds__(64, 2) void front4_kernel(
   }
   // a strip whose haloed tile lies inside the image needs no zero-padding masks (wave-uniform)
   const bool interior = ty0 + AH <= h2 && tx0 + AW <= w2;
-  // the strip's 4 x 16 level-1 texels all exist (wave-uniform): its skip3 rows go through LDS (the raw-observation rows are free
-  // by then) and leave as 16-byte stores; rows start 16-byte aligned because w % 4 == 0 and tx0 % 16 == 0
-  const bool skip_rows = variant != 7 && ty0 + SH <= h2 && tx0 + SW <= w2 && (reinterpret_cast<uintptr_t>(skip3) & 15) == 0;
   float xs[NC][3];
 #pragma unroll
   for (int c = 0; c < NC; ++c) xs[c][0] = xs[c][1] = xs[c][2] = 0.f;
@@ -283,7 +280,6 @@ __global__ __launch_bounds__(64, 2) void front4_kernel(
     // ---- stage 1: folded L0 + L1 stride-2 conv of observation i, three column tiles at a time (three independent
     // accumulators keep the matrix pipe issuing; six at once cost 21 more registers)
     f32x4 sv[NC];
-    if (variant == 6) __builtin_amdgcn_s_setprio(1);                     // (experiment: the VALU-dense stage at raised priority)
 #pragma unroll
     for (int c0 = 0; c0 < NC; c0 += 3) {
       f32x4 acc[3] = {zero4, zero4, zero4};
@@ -307,7 +303,6 @@ __global__ __launch_bounds__(64, 2) void front4_kernel(
     }
 #pragma unroll
     for (int c = 0; c < NC; ++c) *reinterpret_cast<f32x4*>(ot + (kk * SLOTS + c * 16 + j) * 4) = sv[c];
-    if (variant == 6) __builtin_amdgcn_s_setprio(0);
     if constexpr (TRAIN) {
 #pragma unroll
       for (int c = 0; c < NC; ++c)
@@ -328,7 +323,6 @@ __global__ __launch_bounds__(64, 2) void front4_kernel(
     }
     // ---- stage 2
     f32x4 o1[SH];
-    if (variant == 5) __builtin_amdgcn_s_setprio(1);                     // (experiment: the MFMA-dense stages at raised priority)
     stage2(ao1, bo1, o1);
 #pragma unroll
     for (int r = 0; r < SH; ++r) mean[r] += o1[r];
@@ -360,7 +354,6 @@ __global__ __launch_bounds__(64, 2) void front4_kernel(
         *reinterpret_cast<f32x4*>(o + 16) = lrelu4m(a3[1] + bo3[1], alpha);
       }
     }
-    if (variant == 5) __builtin_amdgcn_s_setprio(0);
     wave_sync();                                                         // the level-1 tile is consumed: `ot` is free again
   }
 
@@ -414,27 +407,14 @@ __global__ __launch_bounds__(64, 2) void front4_kernel(
           }
           if (add_base) { s0 += raw[c][0]; s1 += raw[c][1]; s2 += raw[c][2]; }
           const int t = (c0 + c) * 16 + j;
-          if (skip_rows) {                                               // full strip: staged, stored row-contiguously below
-            float* sl = lds + W_RO + (2 * (t / AW) + (kk >> 1)) * (6 * SW) + (2 * (t % AW) + (kk & 1)) * 3;
-            sl[0] = s0; sl[1] = s1; sl[2] = s2;
-          } else {
-            float* sk = skip3 + ((long)f * hw + (long)(2 * (ty0 + t / AW) + (kk >> 1)) * w + 2 * (tx0 + t % AW) + (kk & 1)) * 3;
-            sk[0] = s0; sk[1] = s1; sk[2] = s2;
-          }
+          // (staging these rows through LDS for 16-byte stores was built and measured in r03: no change -- the stores are not
+          // what the query path waits for)
+          float* sk = skip3 + ((long)f * hw + (long)(2 * (ty0 + t / AW) + (kk >> 1)) * w + 2 * (tx0 + t % AW) + (kk & 1)) * 3;
+          sk[0] = s0; sk[1] = s1; sk[2] = s2;
         }
       }
     }
     wave_sync();
-    if (skip_rows) {
-      // skip3 of the strip = 8 raw rows x 32 texels x 3 floats = 8 contiguous 384-byte runs: 192 sixteen-byte stores per wave
-      // (3 per lane) instead of 18 four-byte stores per lane scattered at a 24-byte stride
-#pragma unroll
-      for (int pp = 0; pp < 3; ++pp) {
-        const int q = pp * 64 + lane, row = q / (6 * SW / 4), piece = q - row * (6 * SW / 4);
-        const f32x4 v = *reinterpret_cast<const f32x4*>(lds + W_RO + row * (6 * SW) + 4 * piece);
-        *reinterpret_cast<f32x4*>(skip3 + ((long)f * hw + (long)(2 * ty0 + row) * w + 2 * tx0) * 3 + 4 * piece) = v;
-      }
-    }
     f32x4 aq1[4];
 #pragma unroll
     for (int t = 0; t < 4; ++t) aq1[t] = *reinterpret_cast<const f32x4*>(blob + OFF_AQ1 + (t * 64 + lane) * 4);
@@ -503,11 +483,12 @@ int front4_launch(const Front4In& in, int n, int k, int h, int w, const float* p
   const int ty = (h / 2 + SH - 1) / SH, tx = (w / 2 + SW - 1) / SW;
   const long blocks = (long)n * ty * tx;
   if (blocks >= (1l << 31)) return NLT_ERR_UNSUPPORTED;
+  (void)wps;                                                           // one register allocation (2 waves per SIMD); kept in the ABI
   if (TRAIN && (!keep.obs1 || !keep.qtmp1 || !keep.otmp1 || !nlt_aligned16(keep.obs1) || !nlt_aligned16(keep.qtmp1) ||
                 !nlt_aligned16(keep.otmp1)))
     return NLT_ERR_BAD_ARG;
   hipLaunchKernelGGL((front4_kernel<U8, TRAIN>), dim3((unsigned)blocks), dim3(64), 0, static_cast<hipStream_t>(stream),
-                     in, k, h, w, ty, tx, packed, add_base, alpha, fm1, skip3, packed_l2, qtmp2, otmp2, keep, wps);
+                     in, k, h, w, ty, tx, packed, add_base, alpha, fm1, skip3, packed_l2, qtmp2, otmp2, keep);
   NLT_CHECK_LAUNCH();
   return NLT_OK;
 }

@@ -57,3 +57,18 @@ __device__ __forceinline__ float nlt_tile_fragment(const float* __restrict__ wk,
   const int o = (g * tnt + ct) * 16 + (lane & 15);
   return transposed ? wk[((long)t * full + lo + o) * cin + c] : wk[((long)t * cin + c) * full + lo + o];
 }
+
+// Transposed k2s2 mode of the LDS-tiled kernel (a 1x1-conv-shaped GEMM: K = input channels, N = 4 * cout columns (a, b, o)):
+// [g = 4 cout / TN][cc = K / 16][ct TNT][lane 64][s4]; the Keras array is indexed (kh,kw,N_full,K) as for every transposed mode.
+__device__ __forceinline__ float nlt_tile_fragment_d2(const float* __restrict__ wk, long idx, int cin, int cout, int tnt, int full, int lo) {
+  const int s4 = idx & 3, lane = (idx >> 2) & 63;
+  long r = idx >> 8;
+  const int ct = r % tnt; r /= tnt;
+  const int ncc = cin >> 4;
+  const int cc = r % ncc;
+  const int g = r / ncc;
+  const int c = cc * 16 + 4 * (lane >> 4) + s4;
+  const int col = (g * tnt + ct) * 16 + (lane & 15);
+  const int ab = col / cout, o = col - ab * cout;
+  return wk[((long)ab * full + lo + o) * cin + c];
+}

@@ -795,12 +795,17 @@ class RenderPlan:
         # LDS-tiled kernel (csrc/conv_tile.hip) for the launches the plan-time trials gave to it: the adjoint families it has
         # (CONV_K2S1 / CONV_K2S2 of the expanding blocks, the transposed k2s1 of the encoder's stride-1 convs), no split epilogue
         tn = (self._trial_lds or self.lds_hints.get(label, 0)) & 255
-        if (tn and split is None and adj in (C.CONV_K2S1, C.CONV_K2S2, C.DECONV_K2S1) and layer.n_ch_out % 16 == 0
-                and (hi - lo) % tn == 0 and ldp % 4 == 0 and ldo % 4 == 0 and layer.kernel.is_contiguous()):
+        tile_ok = tn and ldp % 4 == 0 and ldo % 4 == 0 and layer.kernel.is_contiguous()
+        if tile_ok and adj == C.DECONV_K2S2:                        # transposed k2s2: a GEMM with 4 (hi - lo) columns; takes the split
+            tile_ok = layer.n_ch_out % 32 == 0 and (hi - lo) % 16 == 0 and (4 * (hi - lo)) % tn == 0
+        elif tile_ok:
+            tile_ok = (split is None and adj in (C.CONV_K2S1, C.CONV_K2S2, C.DECONV_K2S1) and layer.n_ch_out % 16 == 0
+                       and (hi - lo) % tn == 0)
+        if tile_ok:
             self._ran_lds.add(label)
             self._launch(label, nbytes, C.conv_tile_backward_data, adj, dpre, layer.n_ch_out, ldp, n, oh, ow,
                          layer.packed_adjoint_tile(lo, hi, tn), hi - lo, tn, out, ldo, mask_src=mask_src, ldm=ldm, mask_alpha=mask_alpha,
-                         accumulate=accumulate, w_keras=ks, flops=flops)
+                         accumulate=accumulate, split=split, w_keras=ks, flops=flops)
             return
         if nks > 1:
             self._ran_splitk.add(label)

@@ -153,7 +153,9 @@ def test_dgrad_is_adjoint_mode_on_same_kernel(mode):
 
 @pytest.mark.parametrize('mode,cin,cout,h,w,tn', [(C.CONV_K2S1, 64, 32, 19, 37, 32), (C.CONV_K2S1, 128, 64, 16, 32, 64),
                                                   (C.DECONV_K2S1, 64, 48, 9, 20, 32), (C.DECONV_K2S2, 96, 32, 10, 18, 32),
-                                                  (C.DECONV_K2S2, 128, 16, 8, 16, 64), (C.CONV_K2S1, 32, 256, 8, 8, 32)])
+                                                  (C.DECONV_K2S2, 128, 16, 8, 16, 64), (C.CONV_K2S1, 32, 256, 8, 8, 32),
+                                                  (C.CONV_K2S2, 64, 32, 20, 36, 32), (C.CONV_K2S2, 128, 64, 16, 32, 64),
+                                                  (C.CONV_K2S2, 32, 96, 12, 40, 64)])
 def test_backward_data_on_the_lds_tiled_kernel(mode, cin, cout, h, w, tn):
     """nlt_conv_tile_backward_data: the gradient w.r.t. a conv's input channels [lo, hi) on csrc/conv_tile.hip -- the transposed
     k2s1 mode (halo on the top / left) for Conv2D k2s1 layers, the k2s1 / k2s2 conv modes for Conv2DTranspose layers -- read in
@@ -188,6 +190,36 @@ def test_backward_data_on_the_lds_tiled_kernel(mode, cin, cout, h, w, tn):
         torch.cuda.synchronize()
         ref = (gx[..., lo:hi] + torch.tensor(existing[..., :hi - lo])) * torch.where(torch.tensor(ymask) > 0, 1.0, 0.3)
         np.testing.assert_allclose(out.cpu().numpy()[..., :hi - lo], ref.numpy(), atol=2 * tol)
+
+
+@pytest.mark.parametrize('c,cout,h,w,tn,partial', [(16, 32, 16, 32, 64, True), (32, 64, 18, 44, 32, True), (64, 96, 8, 16, 64, False)])
+def test_level_split_epilogue_on_the_lds_tiled_kernel(c, cout, h, w, tn, partial):
+    """The transposed k2s2 mode of csrc/conv_tile.hip with the level-split epilogue (query half x LeakyReLU' into dfm[l],
+    observation half finished into dobs) against nlt_conv_backward_data on the register-tiled kernel, same inputs."""
+    from nlt_amd.networks.elements import Conv2D
+    rng = np.random.default_rng(c + h)
+    n, cin = 2, 2 * c
+    R = lambda *shape: rng.standard_normal(shape).astype(np.float32)
+    wk = R(2, 2, cin, cout)
+    layer = Conv2D(cout, 2, 2)
+    layer.set_weights(wk, np.zeros(cout, np.float32))
+    oh, ow = h // 2, w // 2
+    dp, existing, fm_y, obs_y, dobs0 = R(n, oh, ow, cout), R(n, h, w, cin), R(n, h, w, cin), R(n, h, w, c), R(n, h, w, c)
+    zb = torch.zeros(256, device='cuda')
+    outs = []
+    for tiled in (False, True):
+        out, dobs = d(existing), d(dobs0)
+        kw = dict(mask_src=d(fm_y), ldm=cin, mask_alpha=0.3, accumulate=True, split=(c, d(obs_y), dobs, 0.2, partial))
+        if tiled:
+            C.conv_tile_backward_data(C.DECONV_K2S2, d(dp), cout, cout, n, oh, ow, layer.packed_adjoint_tile(0, cin, tn), cin, tn, out, cin, **kw)
+        else:
+            C.conv_backward_data(C.DECONV_K2S2, d(dp), cout, cout, n, oh, ow, layer.packed_adjoint(0, cin)[0], zb, cin, out, cin, **kw)
+        torch.cuda.synchronize()
+        outs.append((out.cpu().numpy(), dobs.cpu().numpy()))
+    tol = 3e-5 * float(np.abs(outs[0][0]).max())
+    np.testing.assert_allclose(outs[1][0], outs[0][0], atol=tol)
+    np.testing.assert_allclose(outs[1][1], outs[0][1], atol=tol)
+    np.testing.assert_array_equal(outs[1][0][..., c:], existing[..., c:])
 
 
 @pytest.mark.parametrize('mode,ksplit,partial', [(C.CONV_K2S2, 1, True), (C.CONV_K2S2, 4, True), (C.DECONV_K2S2, 1, False),

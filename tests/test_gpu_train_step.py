@@ -213,6 +213,58 @@ def test_overlapped_bucket_collective_runs_on_the_weight_gradient_stream_in_repl
     assert float((p0 - p1).abs().max()) < 2e-5
 
 
+def _two_rank_worker(rank, port, outdir):
+    import os
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    sys.path.insert(0, os.path.dirname(here)); sys.path.insert(0, here)
+    os.environ['MASTER_ADDR'] = '127.0.0.1'; os.environ['MASTER_PORT'] = str(port)
+    import torch
+    import torch.distributed as dist
+    import nlt_amd
+    from nlt_amd import trainvali
+    from oracle import nlt_oracle as O
+    from gpu_util import make_pair, to_device_batch
+    torch.cuda.set_device(0)
+    dist.init_process_group('gloo', rank=rank, world_size=2)
+    out = {}
+    batch, nn = O.synth_batch(4, 128, 128, 64, 64, 64, 64, k=1, seed=77)             # the GLOBAL batch; this rank's half below
+    sl = slice(2 * rank, 2 * rank + 2)
+    shard = tuple(t[sl] if torch.is_tensor(t) else t for t in batch)
+    db = to_device_batch(shard, [(b[sl], r[sl]) for b, r in nn])
+    for overlap in (False, True):
+        _, pm = make_pair(depth=256, uv=128, im=64, loss='l2', seed=21)
+        pm.build('cuda')
+        opt = nlt_amd.optim.AdamAMSGrad(pm, 1e-3)
+        losses = [float(trainvali.distributed_train_step(pm, db, opt, 4, overlap=overlap)[0]) for _ in range(6)]
+        torch.cuda.synchronize()
+        out[overlap] = (losses, pm.flat_params.detach().cpu().clone(), pm.plan.tape_replays)
+    torch.save(out, os.path.join(outdir, 'r%d.pt' % rank))
+    dist.destroy_process_group()
+
+
+def test_two_ranks_on_one_gpu_overlapped_bucket_equals_serial_and_ranks_stay_identical():
+    """Two real processes (one rank each, both on cuda:0, `gloo` carrying the CUDA tensors -- RCCL refuses two ranks on one
+    device) run six data-parallel train steps on the HIP kernels: launch-tape replays, the first gradient range all-reduced
+    from inside the backward plan on the weight-gradient stream.  The collective is a REAL sum here (each rank holds other
+    frames), so a hook fired on the wrong stream -- reading half-accumulated weight gradients -- shows as rank divergence or
+    as a difference between overlap=True and overlap=False.  Ranks must hold bit-identical weights; the two modes agree to
+    the float-atomic noise of the warp adjoint."""
+    import os
+    import tempfile
+    import torch.multiprocessing as mp
+    with tempfile.TemporaryDirectory() as td:
+        port = 29700 + os.getpid() % 200
+        mp.spawn(_two_rank_worker, args=(port, td), nprocs=2, join=True)
+        r = [torch.load(os.path.join(td, 'r%d.pt' % i)) for i in range(2)]
+    for overlap in (False, True):
+        assert r[0][overlap][0] == r[1][overlap][0]                                   # the all-reduced loss
+        assert torch.equal(r[0][overlap][1], r[1][overlap][1])                        # bit-identical weights on both ranks
+    assert r[0][True][2] > 0                                                          # replayed steps were part of it
+    np.testing.assert_allclose(r[0][True][0], r[0][False][0], rtol=2e-5)
+    assert float((r[0][True][1] - r[0][False][1]).abs().max()) < 2e-5
+
+
 @pytest.mark.parametrize('loss', ['l2', 'barron'])
 def test_full_size_gradient_agrees_with_directional_finite_differences(loss):
     """BASELINE config 4's per-GPU shape (1024^2 UV, 512^2 camera; 2 frames here), a size-independent property check

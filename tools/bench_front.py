@@ -30,12 +30,8 @@ def main():
         'front2 (fused.hip)': lambda: C.front2_forward(*fl, n, k, h, w, blob, blob_l2, True, 0.3, *outs),
         'front4 f32 wps2': lambda: C.front4_forward(*fl, n, k, h, w, blob, blob_l2, True, 0.3, *outs, 2),
         'front4 f32 wps3': lambda: C.front4_forward(*fl, n, k, h, w, blob, blob_l2, True, 0.3, *outs, 3),
-        'front4 f32 prio-mfma (5)': lambda: C.front4_forward(*fl, n, k, h, w, blob, blob_l2, True, 0.3, *outs, 5),
-        'front4 f32 prio-valu (6)': lambda: C.front4_forward(*fl, n, k, h, w, blob, blob_l2, True, 0.3, *outs, 6),
-        'front4 f32 scalar skip3 stores (7)': lambda: C.front4_forward(*fl, n, k, h, w, blob, blob_l2, True, 0.3, *outs, 7),
-        'front4 f32 again (0)': lambda: C.front4_forward(*fl, n, k, h, w, blob, blob_l2, True, 0.3, *outs, 0),
+        'front4 u8  wps3': lambda: C.front4_forward_u8(diffuse, rgb, cvis, lvis, ids, nn_ids, n, k, h, w, blob, blob_l2, True, 0.3, *outs, 3),
         'front4 u8  wps2': lambda: C.front4_forward_u8(diffuse, rgb, cvis, lvis, ids, nn_ids, n, k, h, w, blob, blob_l2, True, 0.3, *outs, 2),
-        'front4 u8  scalar skip3 stores (7)': lambda: C.front4_forward_u8(diffuse, rgb, cvis, lvis, ids, nn_ids, n, k, h, w, blob, blob_l2, True, 0.3, *outs, 7),
         'assemble_batch': lambda: C.assemble_batch(diffuse, rgb, cvis, lvis, ids, nn_ids),
     }
     flops = 2 * n * (h // 2) * (w // 2) * ((32 + 64) * 16 + k * (12 + 64) * 16) + 2 * n * h * w * 24 + 2 * n * (h // 4) * (w // 4) * 32 * (128 + 64 * k)
