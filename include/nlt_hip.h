@@ -559,6 +559,27 @@ typedef struct {
 } nlt_repack_desc;
 int nlt_repack_weights(const nlt_repack_desc* descs_device, int n_desc, long total_blocks, void* stream);
 
+/*
+ * Native replay of a recorded launch tape.  A plan issues the same C calls with the same arguments every step; the host mirror
+ * records them once (entry point + resolved arguments) and replays the array with ONE call instead of one ctypes call per launch
+ * (~7 us each from Python: 1.3-1.7 ms per train step, which made the released 512^2 training shape host-bound).
+ * nlt_tape_call: fn = an entry point of this library whose parameters are all integer-class (int, long, pointer) or float, with at
+ * most 32 of the former and 4 of the latter; iargs / fargs = its integer-class / float arguments, each in declaration order (the
+ * x86-64 System V convention assigns the two classes to registers independently).  Calls run in order; the first non-zero status
+ * stops the replay and is returned (failed_index = its position).  nlt_event_record / nlt_stream_wait_event are hipEventRecord /
+ * hipStreamWaitEvent as tape-able entry points (the plan's second-stream hand-overs).
+ *   replaces: nothing in the reference (TF eager re-dispatches every op every step); host-side launch cost only.
+ */
+typedef struct {
+  void* fn;
+  int n_float, reserved;
+  long iargs[32];
+  float fargs[4];
+} nlt_tape_call;
+int nlt_tape_play(const nlt_tape_call* calls, int n, int* failed_index);
+int nlt_event_record(void* event, void* stream);
+int nlt_stream_wait_event(void* stream, void* event);
+
 /* Weight / bias gradient for the NARROW layers (csrc/wgrad_narrow.hip): N = cout (4 * cout for Conv2DTranspose k2s2)
  * <= 32 output columns and K = taps * (c0 + c1) <= 128, modes NLT_CONV_K2S2 / K2S1 / NLT_DECONV_K2S2 / K2S1, any channel
  * count (4-byte operand loads; the MFMA tile is [K index 16] x [output channel 16], so 8 / 16 / 32-channel layers waste

@@ -44,6 +44,9 @@ SIGNATURES = {
     'nlt_conv_backward_weights_tiled': (_c_int, [_c_int, _vp, _c_int, _c_int, _vp, _c_int, _c_int, _c_int, _c_int, _c_int,
                                                  _vp, _c_int, _c_int, _vp, _vp, _vp, _c_long, _vp]),
     'nlt_repack_weights': (_c_int, [_vp, _c_int, _c_long, _vp]),
+    'nlt_tape_play': (_c_int, [_vp, _c_int, _vp]),
+    'nlt_event_record': (_c_int, [_vp, _vp]),
+    'nlt_stream_wait_event': (_c_int, [_vp, _vp]),
     'nlt_wgrad_narrow_workspace_floats': (_c_long, [_c_int] * 7),
     'nlt_conv_backward_weights_narrow': (_c_int, [_c_int, _vp, _c_int, _c_int, _vp, _c_int, _c_int, _c_int, _c_int, _c_int,
                                                  _vp, _c_int, _c_int, _vp, _vp, _vp, _c_long, _vp]),
@@ -202,12 +205,12 @@ def tape_begin():
 
 
 def tape_end(tag=None):
-    """Closes the tape and returns (launch list, allocation epoch it is valid for, caller's validity tag)."""
+    """Closes the tape and returns [launch list, allocation epoch it is valid for, caller's validity tag, native form]."""
     global _tape
     t, _tape = _tape, None
     if _tape_epoch[0] != _alloc_epoch[0]:
         return None                                     # a cached buffer was re-allocated while recording: pointers are stale
-    return t, _alloc_epoch[0], tag
+    return (t, _alloc_epoch[0], tag, [None])
 
 
 def tape_abort():
@@ -219,7 +222,84 @@ def tape_valid(tape, tag=None):
     return tape is not None and tape[1] == _alloc_epoch[0] and tape[2] == tag
 
 
+# Native replay (csrc/tape.hip: nlt_tape_play): the recorded calls of a tape, compiled once into arrays of nlt_tape_call and walked
+# by ONE C call per run of consecutive native entries; what cannot be expressed (a Python hook, an entry with double arguments)
+XX
+
+
+class _TapeCall(ctypes.Structure):
+    _fields_ = [('fn', ctypes.c_void_p), ('n_float', ctypes.c_int), ('reserved', ctypes.c_int), ('iargs', ctypes.c_long * 32),
+                ('fargs', ctypes.c_float * 4)]
+
+
+def _describe(fn, args):
+    """(address, integer-class args, float args) of one recorded step, or None when it has to stay a Python call."""
+    owner = getattr(fn, '__self__', None)
+    if owner is not None:                               # bound methods recorded by record_event / wait_event
+        name = getattr(fn, '__name__', '')
+        if isinstance(owner, torch.cuda.Event) and name == 'record' and len(args) == 1:
+            return (ctypes.cast(_real.nlt_event_record, ctypes.c_void_p).value, [owner.cuda_event, args[0].cuda_stream], [])
+        if isinstance(owner, torch.cuda.Stream) and name == 'wait_event' and len(args) == 1:
+            return (ctypes.cast(_real.nlt_stream_wait_event, ctypes.c_void_p).value, [owner.cuda_stream, args[0].cuda_event], [])
+        return None
+    at = getattr(fn, 'argtypes', None)
+    if at is None or len(at) != len(args):
+        return None
+    ia, fa = [], []
+    for t, a in zip(at, args):
+        if t is _c_float:
+            fa.append(float(a))
+        elif t in (_c_int, _c_long, _vp):
+            ia.append(0 if a is None else int(a))
+        else:
+            return None                                 # doubles, char pointers: not a launching entry of a plan
+    if len(ia) > 32 or len(fa) > 4:
+        return None
+    return (ctypes.cast(fn, ctypes.c_void_p).value, ia, fa)
+
+
+def _compile(calls):
+    """[('native', array, count) | ('py', fn, args)] in order."""
+    segs, run = [], []
+
+    def flush():
+        if run:
+            arr = (_TapeCall * len(run))()
+            for i, (addr, ia, fa) in enumerate(run):
+                arr[i].fn, arr[i].n_float = addr, len(fa)
+                for j, v in enumerate(ia):
+                    arr[i].iargs[j] = v
+                for j, v in enumerate(fa):
+                    arr[i].fargs[j] = v
+            segs.append(('native', arr, len(run)))
+            del run[:]
+    for fn, args in calls:
+        d = _describe(fn, args)
+        if d is None or not d[0]:
+            flush()
+            segs.append(('py', fn, args))
+        else:
+            run.append(d)
+    flush()
+    return segs
+
+
 def replay(tape):
+    if NATIVE_REPLAY and len(tape) > 3 and _real is not None:
+        box = tape[3]
+        if box[0] is None:
+            box[0] = _compile(tape[0])
+        failed = ctypes.c_int(-1)
+        for seg in box[0]:
+            if seg[0] == 'native':
+                rc = _real.nlt_tape_play(seg[1], seg[2], ctypes.byref(failed))
+                if rc:
+                    raise NLTError("replayed launch %d failed: %s" % (failed.value, _real.nlt_status_string(rc).decode()))
+            else:
+                rc = seg[1](*seg[2])
+                if rc:
+                    raise NLTError("replayed launch failed: %s" % lib().nlt_status_string(rc).decode())
+        return
     for fn, args in tape[0]:
         rc = fn(*args)
         if rc:                                          # event helpers return None

@@ -338,7 +338,20 @@ class Model(BaseModel):
                 loss, gt_camspc, d_pred_c = C.l2_train_loss(pred_camspc, rgb_camspc, fg_camspc, global_bs)
             else:
                 gt_camspc = C.mul_forward(rgb_camspc, fg_camspc)
-        if not plain_l2:
+            plain_barron = (not plain_l2 and len(self.wloss) == 1 and self.wloss[0][0] == 1
+                            and type(self.wloss[0][1]).__name__ == 'Barron')
+            if plain_barron:
+                # the released loss (`loss = barron`): value and gradient from the one C call that computes both, the
+                # sum / global batch applied to the per-example gradient rows -- no autograd graph around it (host time:
+                # the released 512^2 training shape is enqueue-bound)
+                per, dunit = C.barron_loss(pred_camspc.contiguous(), gt_camspc, True)
+                loss = per.sum() / global_bs
+                key = (per.shape[0], float(global_bs), str(per.device))
+                inv = getattr(self, '_inv_gbs', None)
+                if inv is None or inv[0] != key:
+                    inv = self._inv_gbs = (key, torch.full((per.shape[0],), 1.0 / global_bs, device=per.device))
+                d_pred_c = C.scale_rows(dunit, inv[1])
+        if not plain_l2 and not plain_barron:
             leaf = pred_camspc.detach().requires_grad_(True)
             with torch.enable_grad():
                 loss = self.compute_loss(leaf, gt_camspc, keep_batch=True).sum() / global_bs

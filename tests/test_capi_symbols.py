@@ -95,3 +95,37 @@ def test_binding_table_matches_the_header_prototypes_argument_for_argument():
             assert kinds[a] == want, (name, p, a)
         want_ret = 'ptr' if '*' in ret else ret
         assert kinds[res] == want_ret, (name, ret, res)
+
+
+def test_native_tape_play_passes_arguments_like_a_direct_call():
+    """nlt_tape_play (csrc/tape.hip) calls an entry point through a generic (32 integer-class, <= 4 float) signature.  Without a
+    GPU the observable is the status code of the argument checks that run before anything is launched: for a 22-parameter entry
+    (integer-class parameters well past the six register slots, two floats in between) every variation has to produce the status
+    the direct ctypes call produces, and a failing call has to stop the replay at its index."""
+    import ctypes
+    L = C.lib()
+    fn = L.nlt_conv_tile_backward_data
+    P = 4096                                            # a non-null, 16-byte aligned fake pointer: checked, never dereferenced here
+
+    def args(cpre=32, cout=32, tn=32, ldp=32, ldo=32, ldm=32, split_c=0, h=8):
+        return (C.CONV_K2S1, P, ldp, cpre, 1, h, 8, P, cout, tn, P, ldo, P, ldm, 0.3, 0, split_c, None, None, 0.2, 0, None)
+    cases = [dict(cpre=24), dict(tn=48), dict(ldp=16), dict(ldo=8), dict(ldm=4), dict(split_c=16), dict(cout=48), dict(h=0)]
+    want = [fn(*args(**kw)) for kw in cases]
+    assert set(want) <= {-1, -2} and -1 in want and -2 in want          # the checks were reached, both kinds
+    calls = [C._describe(fn, args(**kw)) for kw in cases]
+    assert all(c is not None and len(c[1]) == 20 and len(c[2]) == 2 for c in calls)
+    for i, (c, w) in enumerate(zip(calls, want)):
+        arr = (C._TapeCall * 1)()
+        arr[0].fn, arr[0].n_float = c[0], len(c[2])
+        for j, v in enumerate(c[1]):
+            arr[0].iargs[j] = v
+        for j, v in enumerate(c[2]):
+            arr[0].fargs[j] = v
+        failed = ctypes.c_int(-7)
+        assert L.nlt_tape_play(arr, 1, ctypes.byref(failed)) == w and failed.value == 0, (i, cases[i])
+    # a run stops at the first failing call
+    ok = C._describe(L.nlt_stream_wait_event, (None, None))             # hipStreamWaitEvent(NULL, NULL) fails without a device too
+    segs = C._compile([(fn, args(cpre=24))])
+    assert segs[0][0] == 'native' and segs[0][2] == 1 and ok is not None
+    # entries with double parameters stay Python calls
+    assert C._describe(L.nlt_cosine_map, (None,) * 4 + (0.0, 0.0, 0.0, 0, None, None, None)) is None
