@@ -224,7 +224,10 @@ def tape_valid(tape, tag=None):
 
 # Native replay (csrc/tape.hip: nlt_tape_play): the recorded calls of a tape, compiled once into arrays of nlt_tape_call and walked
 # by ONE C call per run of consecutive native entries; what cannot be expressed (a Python hook, an entry with double arguments)
-XX
+# stays a Python step between two runs.  OPT-IN (NLT_NATIVE_REPLAY=1): measured on MI355X boxes it changes nothing -- host enqueue
+# 1.55 -> 1.52 ms per train step at config 4, 1.51 -> 1.48 at the 512^2 shape (r03): the ~9 us per launch are the HIP runtime's own
+# (launch + the second-stream event traffic), not ctypes', and the steps are not host-bound to begin with.
+NATIVE_REPLAY = os.environ.get('NLT_NATIVE_REPLAY', '0') != '0'
 
 
 class _TapeCall(ctypes.Structure):
