@@ -59,3 +59,23 @@ def test_train_steps_with_and_without_the_tape_agree():
     assert r0 >= 6 and r1 == 0                                         # forward + backward tapes from step 3 on
     np.testing.assert_allclose(l0, l1, rtol=2e-5)
     assert float((p0 - p1).abs().max()) < 2e-5                        # float atomics in the warp scatter: not bit-exact
+
+
+def test_native_replay_of_the_tape_matches_the_python_replay(monkeypatch):
+    """NLT_NATIVE_REPLAY=1 (csrc/tape.hip: nlt_tape_play walks the recorded calls in C, the second-stream event hand-overs
+    included): forward and train steps give what the per-call Python replay gives -- the same launches with the same arguments."""
+    from nlt_amd import capi as C
+    batch = to_device_batch(*O.synth_batch(2, 64, 64, 32, 32, 32, 32, k=2, seed=71))
+    res = {}
+    for native in (False, True):
+        monkeypatch.setattr(C, 'NATIVE_REPLAY', native)
+        pm = _model(True, seed=6)
+        fwd = [pm.call(batch, 'test')[0].clone() for _ in range(4)]
+        opt = nlt_amd.optim.AdamAMSGrad(pm, 1e-3)
+        losses = [float(trainvali.distributed_train_step(pm, batch, opt, 2)[0]) for _ in range(5)]
+        torch.cuda.synchronize()
+        assert pm.plan.tape_replays >= 4
+        res[native] = (fwd, losses, pm.flat_params.detach().clone())
+    assert all(torch.equal(a, b) for a, b in zip(res[False][0], res[True][0]))
+    np.testing.assert_allclose(res[True][1], res[False][1], rtol=2e-5)          # (float atomics in the warp adjoint)
+    assert float((res[True][2] - res[False][2]).abs().max()) < 2e-5
