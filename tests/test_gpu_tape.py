@@ -76,6 +76,8 @@ def test_native_replay_of_the_tape_matches_the_python_replay(monkeypatch):
         torch.cuda.synchronize()
         assert pm.plan.tape_replays >= 4
         res[native] = (fwd, losses, pm.flat_params.detach().clone())
-    assert all(torch.equal(a, b) for a, b in zip(res[False][0], res[True][0]))
+    for a, b in zip(res[False][0], res[True][0]):                                # (the two models autotune separately: fp32 re-association)
+        assert float((a - b).norm() / b.norm()) < 1e-5
+    assert all(torch.equal(x, res[True][0][0]) for x in res[True][0][1:])       # native replays = the recorded launches, bit for bit
     np.testing.assert_allclose(res[True][1], res[False][1], rtol=2e-5)          # (float atomics in the warp adjoint)
     assert float((res[True][2] - res[False][2]).abs().max()) < 2e-5
