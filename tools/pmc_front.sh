@@ -25,5 +25,9 @@ for k, r in summary.items():
     if 'SQ_VALU_MFMA_BUSY_CYCLES' in r and 'GRBM_GUI_ACTIVE' in r:
         # GRBM_GUI_ACTIVE is summed over the 8 XCDs; MFMA busy cycles over the 1024 SIMDs
         r['mfma_pipe_utilisation'] = round(r['SQ_VALU_MFMA_BUSY_CYCLES'] / 1024.0 / (r['GRBM_GUI_ACTIVE'] / 8.0), 3)
+    if 'SQ_VALU_MFMA_BUSY_CYCLES' in r and 'SQ_BUSY_CYCLES' in r:
+        # same counter pass: MFMA busy cycles per SIMD / SQ busy cycles per shader engine (32 of them) -- independent of what else
+        # the GRBM pass saw; the GRBM-based figure above is only meaningful when that pass profiled the same dispatches
+        r['mfma_busy_over_sq_busy'] = round(r['SQ_VALU_MFMA_BUSY_CYCLES'] / 1024.0 / (r['SQ_BUSY_CYCLES'] / 32.0), 3)
 json.dump(summary, open('gpurun_out/pmc_sq.json', 'w'), indent=1)
 PY
