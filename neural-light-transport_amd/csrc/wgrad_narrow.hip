@@ -458,30 +458,43 @@ __global__ __launch_bounds__(256) void wgrad_narrowq_kernel(WN w) {
     for (int nt = 0; nt < NT; ++nt) dst[KN + nt * 16 + i] = bsum[nt];
 }
 
-// Pass 2: 16 entries of the [K pad][N pad] block (+ the column sums) per workgroup, the slices dealt to 16 thread groups x 4
-// running sums (64 independent load streams per entry; a serial walk over ~500 slices is pure latency), fixed order.
+// Pass 2: 32 entries of the [K pad][N pad] block (+ the column sums) per workgroup: thread (q, g) adds the slices g, g + 32, ...
+// of the entry QUAD q with 16-byte loads, 8 in flight (whole 128-byte lines per slice; ~2000 slices of 16 KB are 34 MB -- the
+// 4-byte, 4-stream form of round 2 took 15-23 us for them, pure latency), fixed order.
 template <int MODE, int MT, int NT>
 __global__ __launch_bounds__(256) void wgrad_narrow_reduce_kernel(WN w) {
-  __shared__ float part[16][17];
-  constexpr int NC = NT * 16, KN = MT * 16 * NC, PER = KN + NC;
+  __shared__ __attribute__((aligned(16))) float part[32][32];
+  constexpr int NC = NT * 16, KN = MT * 16 * NC, PER = KN + NC;          // PER is a multiple of 16
   const ConvP& p = w.c;
-  const int e = threadIdx.x & 15, g = threadIdx.x >> 4;
-  const int idx = blockIdx.x * 16 + e;                                 // PER is a multiple of 16
-  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  const int q = threadIdx.x & 7, g = threadIdx.x >> 3;
+  const int base = blockIdx.x * 32 + 4 * q;
+  const bool live = base < PER;
+  const f32x4* src = reinterpret_cast<const f32x4*>(w.ws + (live ? base : 0));
+  constexpr size_t stride = PER / 4;
+  f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = s0;
   int ms = g;
-  for (; ms + 48 < w.msplits; ms += 64) {
-    s0 += w.ws[(size_t)ms * PER + idx];
-    s1 += w.ws[(size_t)(ms + 16) * PER + idx];
-    s2 += w.ws[(size_t)(ms + 32) * PER + idx];
-    s3 += w.ws[(size_t)(ms + 48) * PER + idx];
-  }
-  for (; ms < w.msplits; ms += 16) s0 += w.ws[(size_t)ms * PER + idx];
-  part[g][e] = (s0 + s1) + (s2 + s3);
-  __syncthreads();
-  if (g) return;
-  float s = 0.f;
+  for (; ms + 224 < w.msplits; ms += 256) {
+    f32x4 v[8];
 #pragma unroll
-  for (int q = 0; q < 16; ++q) s += part[q][e];
+    for (int j = 0; j < 8; ++j) v[j] = src[(size_t)(ms + 32 * j) * stride];
+    s0 += (v[0] + v[1]) + (v[2] + v[3]);
+    s1 += (v[4] + v[5]) + (v[6] + v[7]);
+  }
+  for (; ms < w.msplits; ms += 32) s0 += src[(size_t)ms * stride];
+  reinterpret_cast<f32x4*>(&part[g][0])[q] = s0 + s1;
+  __syncthreads();
+  if (threadIdx.x >= 32) return;
+  const int e = threadIdx.x;
+  const int idx = blockIdx.x * 32 + e;
+  if (idx >= PER) return;
+  float t[4];
+#pragma unroll
+  for (int a = 0; a < 4; ++a) {
+    t[a] = 0.f;
+#pragma unroll
+    for (int b = 0; b < 8; ++b) t[a] += part[8 * a + b][e];
+  }
+  const float s = (t[0] + t[1]) + (t[2] + t[3]);
   const int cin = p.c0 + p.c1;
   if (idx < KN) {
     const int kidx = idx / NC, n = idx - kidx * NC;
@@ -510,7 +523,7 @@ template <int MODE, int MT, int NT>
 int run_narrow(WN& w, hipStream_t s) {
   constexpr int PER = MT * 16 * NT * 16 + NT * 16;
   hipLaunchKernelGGL((wgrad_narrow_kernel<MODE, MT, NT>), dim3((unsigned)w.msplits), dim3(256), PER * sizeof(float), s, w);
-  hipLaunchKernelGGL((wgrad_narrow_reduce_kernel<MODE, MT, NT>), dim3(PER / 16), dim3(256), 0, s, w);
+  hipLaunchKernelGGL((wgrad_narrow_reduce_kernel<MODE, MT, NT>), dim3((PER + 31) / 32), dim3(256), 0, s, w);
   if (MODE == NLT_DECONV_K2S2 && w.db) hipLaunchKernelGGL((wgrad_narrow_bias_k2s2_kernel<MT, NT>), dim3(1), dim3(64), 0, s, w);
   NLT_CHECK_LAUNCH();
   return NLT_OK;
@@ -531,7 +544,7 @@ int run_narrowq(WN& w, hipStream_t s) {
     hipLaunchKernelGGL((wgrad_narrowq_kernel<MODE, MQ, NT, true>), dim3((unsigned)w.msplits), dim3(256), PER * sizeof(float), s, w);
   else
     hipLaunchKernelGGL((wgrad_narrowq_kernel<MODE, MQ, NT, false>), dim3((unsigned)w.msplits), dim3(256), PER * sizeof(float), s, w);
-  hipLaunchKernelGGL((wgrad_narrow_reduce_kernel<MODE, MT, NT>), dim3(PER / 16), dim3(256), 0, s, w);
+  hipLaunchKernelGGL((wgrad_narrow_reduce_kernel<MODE, MT, NT>), dim3((PER + 31) / 32), dim3(256), 0, s, w);
   if (MODE == NLT_DECONV_K2S2 && w.db) hipLaunchKernelGGL((wgrad_narrow_bias_k2s2_kernel<MT, NT>), dim3(1), dim3(64), 0, s, w);
   NLT_CHECK_LAUNCH();
   return NLT_OK;
@@ -602,7 +615,7 @@ extern "C" int nlt_conv_backward_weights_narrow(int mode,
   long need = 0;
   const int st = prepare_narrow(t, mode, src0, ld0, c0, src1, ld1, c1, n, h, w, dpre, ldp, cout, dw_keras, dbias, &need);
   if (st != NLT_OK) return st;
-  if (workspace_floats < need) return NLT_ERR_BAD_ARG;
+  if (workspace_floats < need || !nlt_aligned16(workspace)) return NLT_ERR_BAD_ARG;
   t.ws = workspace;
   hipStream_t s = static_cast<hipStream_t>(stream);
   const int mt = tiles_m(t.K), nt = t.N <= 16 ? 1 : 2;

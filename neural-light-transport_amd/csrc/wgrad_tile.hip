@@ -334,8 +334,8 @@ __global__ __launch_bounds__(256) void wgrad_walk_kernel(WT w) {
   }
 }
 
-// Pass 2: 64 dW elements of the block layout per workgroup; the slices are dealt to 4 waves x 4 running sums (16
-// independent load streams per element) and combined in a fixed order.
+// Pass 2: 64 dW elements of the block layout per workgroup; the slices are dealt to 16 thread groups (16-byte loads, 8 in
+// flight per thread) and combined in a fixed order.
 template <int MODE> __device__ void wgrad_bias_block(const WT& w, int ocq);
 
 template <int MODE>
@@ -360,7 +360,7 @@ __device__ __forceinline__ void wgrad_scatter(const WT& w, long idx, float s) {
 // load per thread: 16 us for 12 MB.)  Fixed order: ((s0 + s1) + (s2 + s3)) + ((s4 + s5) + (s6 + s7)).
 template <int MODE, bool FEW>
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(WT w) {
-  __shared__ float part[4][64];
+  __shared__ __attribute__((aligned(16))) float part[16][64];
   const long per_slice = (long)w.kblocks * w.nblocks * 4096;
   const long dw_blocks = per_slice / (FEW ? 1024 : 64);
   if ((long)blockIdx.x >= dw_blocks) {                                // the trailing cout / 4 workgroups: the bias (no extra launch)
@@ -379,21 +379,30 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(WT w) {
     for (int r = 0; r < 4; ++r) wgrad_scatter<MODE>(w, idx + r, s[r]);
     return;
   }
-  const int lane = threadIdx.x & 63, g = threadIdx.x >> 6;
-  const long idx = (long)blockIdx.x * 64 + lane;
-  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  // many slices (the shallow levels: few blocks of dW, hundreds of slices): thread (q, g) adds the slices g, g + 16, ... of the
+  // entry QUAD q with 16-byte loads, 8 of them in flight (the 4-byte, 4-stream form of round 2 was pure latency: 23 us for 8 MB)
+  const int q = threadIdx.x & 15, g = threadIdx.x >> 4;
+  const long idx = (long)blockIdx.x * 64 + 4 * q;
+  const f32x4* src = reinterpret_cast<const f32x4*>(w.ws + idx);
+  const size_t stride = (size_t)per_slice / 4;                         // f32x4 per slice
+  f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = s0;
   int ms = g;
-  for (; ms + 12 < w.msplits; ms += 16) {
-    s0 += w.ws[(size_t)ms * per_slice + idx];
-    s1 += w.ws[(size_t)(ms + 4) * per_slice + idx];
-    s2 += w.ws[(size_t)(ms + 8) * per_slice + idx];
-    s3 += w.ws[(size_t)(ms + 12) * per_slice + idx];
+  for (; ms + 112 < w.msplits; ms += 128) {
+    f32x4 v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = src[(size_t)(ms + 16 * j) * stride];
+    s0 += (v[0] + v[1]) + (v[2] + v[3]);
+    s1 += (v[4] + v[5]) + (v[6] + v[7]);
   }
-  for (; ms < w.msplits; ms += 4) s0 += w.ws[(size_t)ms * per_slice + idx];
-  part[g][lane] = (s0 + s1) + (s2 + s3);
+  for (; ms < w.msplits; ms += 16) s0 += src[(size_t)ms * stride];
+  reinterpret_cast<f32x4*>(&part[g][0])[q] = s0 + s1;
   __syncthreads();
-  if (g) return;
-  wgrad_scatter<MODE>(w, idx, (part[0][lane] + part[1][lane]) + (part[2][lane] + part[3][lane]));
+  if (threadIdx.x >= 64) return;
+  const int e = threadIdx.x;
+  float t[4];
+#pragma unroll
+  for (int a = 0; a < 4; ++a) t[a] = (part[4 * a][e] + part[4 * a + 1][e]) + (part[4 * a + 2][e] + part[4 * a + 3][e]);
+  wgrad_scatter<MODE>(w, (long)blockIdx.x * 64 + e, (t[0] + t[1]) + (t[2] + t[3]));
 }
 
 // Bias: one workgroup (of the reduce launch) per quad of output channels; 256 threads share the (slice, ab) terms,
