@@ -61,10 +61,18 @@ __global__ void pack_tile_kernel(const float* __restrict__ wk, int cin, int cout
                             : nlt_tile_fragment(wk, idx, cin, cout, tnt, full, lo, transposed != 0);   // t = a*2+b
 }
 
-template <int MODE, int TNT>
-__global__ __launch_bounds__(256) void conv_tile_kernel(TileP p) {
+// Register budget: the forward modes keep the allocation they were tuned with (<= 225 VGPR + AGPR, 2 workgroups per CU; the
+// mean-free instantiation and a forced 2-waves-per-SIMD allocation were measured on the whole forward pass: 3 workgroups per
+// CU of the query-path launches slow the observation-path launch running beside them, +2 % per step).  The transposed
+// (backward-data) modes and the 128-channel k2s2 tile are compiled for 2 waves per SIMD (the transposed k2s1 tile at 64
+// channels otherwise allocates past 256 registers = one workgroup per CU).
+#ifndef NLT_TILE_MEANFREE
+#define NLT_TILE_MEANFREE 0
+#endif
+template <int MODE, int TNT, bool MEAN>
+__global__ __launch_bounds__(256, (MODE == NLT_DECONV_K2S1 || MODE == NLT_DECONV_K2S2 || TNT == 8) ? 2 : 1) void conv_tile_kernel(TileP p) {
   using TT = TileTraits<MODE>;
-  constexpr int WN = TNT == 4 ? 2 : 1, WM = 4 / WN, RT = TH / WM, CT = 2;
+  constexpr int WN = TNT >= 4 ? 2 : 1, WM = 4 / WN, RT = TH / WM, CT = TNT / WN;   // TNT = 8 (k2s2 only): 4 x 4 tiles per wave
   constexpr int A_FLOATS = TT::STAGE_TAPS * TNT * 256;
   constexpr int A_UNITS = A_FLOATS / 4, NA = A_UNITS / 256, NB = (TT::B_UNITS + 255) / 256;
   constexpr int STAGE = A_FLOATS + TT::B_FLOATS;
@@ -148,11 +156,14 @@ __global__ __launch_bounds__(256) void conv_tile_kernel(TileP p) {
       if (b_st[n]) *reinterpret_cast<f32x4*>(base + A_FLOATS + b_lds[n]) = rb[n];
   };
 
-  f32x4 acc[RT][CT], mean[RT][CT];
+  f32x4 acc[RT][CT], mean[MEAN ? RT : 1][MEAN ? CT : 1];                 // MEAN = false: kobs == 1 and no mean_out (query path, backward-data)
 #pragma unroll
   for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
-    for (int ct = 0; ct < CT; ++ct) { acc[rt][ct] = (f32x4){0.f, 0.f, 0.f, 0.f}; mean[rt][ct] = acc[rt][ct]; }
+    for (int ct = 0; ct < CT; ++ct) {
+      acc[rt][ct] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      if (MEAN) mean[rt][ct] = acc[rt][ct];
+    }
 
   load_stage(0);
   store_stage(0);
@@ -232,11 +243,11 @@ __global__ __launch_bounds__(256) void conv_tile_kernel(TileP p) {
             for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : p.alpha * v[e];
           }
           acc[rt][ct] = (f32x4){0.f, 0.f, 0.f, 0.f};
-          mean[rt][ct] += v;
+          if (MEAN) mean[rt][ct] += v;
           if (gy < p.oh && gx < p.ow) {
             const long ot = ((long)(f * p.kobs + i) * p.oh + gy) * p.ow + gx;
             if (p.out) *reinterpret_cast<f32x4*>(p.out + ot * p.ldo + oc) = v;
-            if (p.mean_out && i == p.kobs - 1) {
+            if (MEAN && p.mean_out && i == p.kobs - 1) {
               const long mt = ((long)f * p.oh + gy) * p.ow + gx;
               *reinterpret_cast<f32x4*>(p.mean_out + mt * p.ldm + oc) = mean[rt][ct] * (1.f / (float)p.kobs);
             }
@@ -253,7 +264,10 @@ template <int MODE, int TNT>
 int launch(const TileP& p, hipStream_t s) {
   const long tiles = (long)p.frames * p.tiles_y * p.tiles_x;
   const int ncols = MODE == NLT_DECONV_K2S2 ? 4 * p.cout : p.cout;
-  hipLaunchKernelGGL((conv_tile_kernel<MODE, TNT>), dim3((unsigned)tiles, (unsigned)(ncols / (16 * TNT))), dim3(256), 0, s, p);
+  const dim3 grid((unsigned)tiles, (unsigned)(ncols / (16 * TNT)));
+  constexpr bool FWD = MODE == NLT_CONV_K2S1 || MODE == NLT_CONV_K2S2;       // (the transposed modes are backward-data only: never a mean)
+  if (FWD && (p.kobs > 1 || p.mean_out || !(NLT_TILE_MEANFREE || TNT == 8))) hipLaunchKernelGGL((conv_tile_kernel<MODE, TNT, FWD>), grid, dim3(256), 0, s, p);
+  else hipLaunchKernelGGL((conv_tile_kernel<MODE, TNT, false>), grid, dim3(256), 0, s, p);
   NLT_CHECK_LAUNCH();
   return NLT_OK;
 }
@@ -266,7 +280,7 @@ extern "C" long nlt_conv_tile_packed_floats(int mode, int cin, int cout, int tn)
     return (long)4 * cin * cout;
   }
   if ((mode != NLT_CONV_K2S1 && mode != NLT_CONV_K2S2 && mode != NLT_DECONV_K2S1) || cin <= 0 || cout <= 0) return -1;
-  if ((cin & 15) || (tn != 32 && tn != 64) || cout % tn) return -1;
+  if ((cin & 15) || (tn != 32 && tn != 64 && !(tn == 128 && mode == NLT_CONV_K2S2)) || cout % tn) return -1;
   return (long)4 * cin * cout;
 }
 
@@ -294,6 +308,7 @@ static int tile_run(int mode, TileP& p, int tn, hipStream_t s) {
   if (mode == NLT_CONV_K2S1) return tn == 64 ? launch<NLT_CONV_K2S1, 4>(p, s) : launch<NLT_CONV_K2S1, 2>(p, s);
   if (mode == NLT_DECONV_K2S1) return tn == 64 ? launch<NLT_DECONV_K2S1, 4>(p, s) : launch<NLT_DECONV_K2S1, 2>(p, s);
   if (mode == NLT_DECONV_K2S2) return tn == 64 ? launch<NLT_DECONV_K2S2, 4>(p, s) : launch<NLT_DECONV_K2S2, 2>(p, s);
+  if (tn == 128) return launch<NLT_CONV_K2S2, 8>(p, s);
   return tn == 64 ? launch<NLT_CONV_K2S2, 4>(p, s) : launch<NLT_CONV_K2S2, 2>(p, s);
 }
 

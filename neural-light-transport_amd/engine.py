@@ -94,6 +94,7 @@ class RenderPlan:
         self._ran_direct = set()
         self._trial_lds = 0             # autotune: try the LDS-tiled kernel with this many output channels per workgroup
         self._ran_lds = set()
+        self.lds_tn128 = os.environ.get('NLT_LDS_TN128', '0') != '0'   # opt-in trials: k2s2 launches with 128 channels per workgroup (faster alone, slower beside the other stream's launch)
         self.lds_hints = {}             # label -> tn (32 / 64) [+256: observations unfolded]: launches that go to csrc/conv_tile.hip
         self._trial_splitk = 0          # autotune: K slices to try on the small deep launches
         self._ran_splitk = set()
@@ -208,6 +209,8 @@ class RenderPlan:
         tn, unfold = hint & 255, bool(hint >> 8)       # +256: observations as separate frames, mean in its own launch
         ok = (tn and obs_weights is None and algo == C.ALGO_AUTO and layer.mode in (C.CONV_K2S2, C.CONV_K2S1)
               and layer.cin == cin and cin % 16 == 0 and layer.n_ch_out % tn == 0)
+        if tn == 128:                                   # 128 output channels per workgroup: stride-2 convs of the native kernel only
+            ok = ok and layer.mode == C.CONV_K2S2 and self.precision not in ('f32x3', 'f32x3_9')
         if ok and unfold and kobs == 1:
             ok = self._trial_lds == 0                   # nothing to unfold here: leave this launch to the other trials
             unfold = False
@@ -257,6 +260,8 @@ class RenderPlan:
             trials.append(('direct', 0))    # only the 4/8-channel full-resolution layers ever preferred it
         if not backward:
             trials += [('lds', 32), ('lds', 64), ('lds', 256 + 32), ('lds', 256 + 64)]
+            if self.lds_tn128:
+                trials += [('lds', 128), ('lds', 256 + 128)]
         elif self.tile_dgrad:
             trials += [('lds', 32), ('lds', 64)]                  # backward-data launches on the LDS-tiled kernel
         # split-K: launches with few GEMM rows and a long K (the deep levels; at depth 1024 a 1 x 1-texel level streams 33 MB of

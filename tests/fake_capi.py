@@ -440,7 +440,7 @@ _FUSED = ('front_pack_weights', 'front_forward', 'back_forward', 'front_forward_
 
 # ------------------------------------------------------------------ LDS-tiled encoder convs (TEST-ONLY emulation)
 def pack_conv_tile_weights(mode, w_keras, cin, cout, tn):
-    assert cin % 16 == 0 and cout % tn == 0 and tn in (32, 64)
+    assert cin % 16 == 0 and cout % tn == 0 and (tn in (32, 64) or (tn == 128 and mode == C.CONV_K2S2))
     return w_keras
 
 

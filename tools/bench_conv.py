@@ -24,6 +24,7 @@ ap.add_argument('--mode', default='s1'); ap.add_argument('--cin', type=int, defa
 ap.add_argument('--h', type=int, default=128); ap.add_argument('--w', type=int, default=128)
 ap.add_argument('--frames', type=int, default=4); ap.add_argument('--kobs', type=int, default=4)
 ap.add_argument('--reps', type=int, default=20)
+ap.add_argument('--no-reg', action='store_true', help='LDS-tiled variants only')
 ap.add_argument('--only', default=None, help='run only this variant (for rocprofv3 --pmc passes), e.g. lds64f')
 a = ap.parse_args()
 names = a.preset.split(',') if a.preset else [None]
@@ -53,16 +54,19 @@ for name in names:
         return e0.elapsed_time(e1) / a.reps
 
     res = {}
-    for tn in (32, 64):
-        if a.cout % tn:
+    for tn in (32, 64, 128):
+        if a.cout % tn or (tn == 128 and a.mode != 's2'):
             continue
-        pk = C.pack_conv_tile_weights(mode, wk, a.cin, a.cout, tn)
+        try:
+            pk = C.pack_conv_tile_weights(mode, wk, a.cin, a.cout, tn)
+        except C.NLTError:
+            continue
         variants = {'lds%df' % tn: lambda pk=pk, tn=tn: C.conv_tile_forward(mode, x, a.cin, a.cin, a.frames, a.kobs, a.h, a.w, pk, bias, a.cout, tn, out, a.cout, mean if a.kobs > 1 else None, a.cout),
                     'lds%du' % tn: lambda pk=pk, tn=tn: C.conv_tile_forward(mode, x, a.cin, a.cin, nf, 1, a.h, a.w, pk, bias, a.cout, tn, out, a.cout, None, 0)}
         for vn, fn in variants.items():
             if a.only is None or a.only == vn:
                 res[vn] = timeit(fn)
-    if a.only is None or a.only.startswith('reg'):
+    if not a.no_reg and (a.only is None or a.only.startswith('reg')):
         pw = C.pack_conv_weights(mode, wk, a.cin, 0, a.cout)
         ntiles = (a.cout + 15) // 16
         for r in (1, 2, 4):
