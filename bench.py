@@ -121,6 +121,7 @@ def parse():
                     help='train step: replay forward + loss + backward as one hipGraph (trainvali.GraphedTrainStep); measured '
                          'slower than eager launches on ROCm 7.0 (5.15 vs 4.75 ms), so off by default')
     ap.add_argument('--headline-only', action='store_true', help='only the timed forward (profiling runs): no loader-inclusive legs, train steps or CPU leg')
+    ap.add_argument('--pipelined', action='store_true', help='with --headline-only: also the several-batches-in-flight sub-line')
     ap.add_argument('--no-released-shapes', action='store_true', help='skip the config 1 / config 2 sub-lines (released .ini shapes)')
     ap.add_argument('--per-op-train', action='store_true', help='per-launch timing table of one train step (stderr)')
     return ap.parse_args()
@@ -152,6 +153,38 @@ def make_loader(args, device, k, mode, seed, loss='l2'):
     ds = get_dataset_class('nlt')(cfg, mode, store, k=k, device=device, ring=nb)
     id_lists = [store['ids'][i * args.frames:(i + 1) * args.frames] for i in range(nb)]
     return cfg, ds, id_lists
+
+
+def bench_pipelined(args, device, model, batches, lanes_list=(2, 3, 4)):
+    """Sub-line: the headline's forward with several batches in flight (nlt_amd.pipeline.RenderPipeline: one lane of render
+    state per batch over the same weights; consecutive batches on consecutive lanes).  Same model, same batches, same
+    number of steps as the headline; every step's full work is inside the timed region.  `ms_per_step` here is elapsed / steps
+    (throughput), not the latency of one batch."""
+    import torch
+    from nlt_amd.pipeline import RenderPipeline
+    out = {"what": "same model, batches and steps as the headline; batch i is queued on lane i % lanes (own plan buffers, launch "
+                   "tapes and HIP streams, shared weights), so the launches of up to `lanes` batches overlap on the GPU",
+           "lanes": {}}
+    ref = model.call(batches[0], 'test')[0].clone()
+    for lanes in lanes_list:
+        pipe = RenderPipeline(model, lanes)
+        for _ in range(3):
+            for t in [pipe.submit(batches[i % len(batches)], 'test') for i in range(2 * lanes)]:
+                t.result()
+        same = bool(torch.equal(pipe.submit(batches[0], 'test').result()[0], ref))
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        tickets = [pipe.submit(batches[i % len(batches)], 'test') for i in range(args.steps)]
+        for t in tickets[-lanes:]:
+            t.result()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        out["lanes"][str(lanes)] = {"ms_per_step": round(1e3 * dt / args.steps, 4),
+                                    "Mtexels_per_s": round(args.frames * args.uv * args.uv * args.steps / dt / 1e6, 1),
+                                    "bit_identical_to_model_call": same}
+    best = max(out["lanes"].items(), key=lambda kv: kv[1]["Mtexels_per_s"])
+    out["best"] = {"lanes": int(best[0]), **best[1]}
+    return out
 
 
 def cpu_baseline_worker(args):
@@ -711,6 +744,8 @@ def main():
         }
         if with_loader:
             out["forward_including_loader"] = with_loader
+        if world == 1 and not args.graph and (args.pipelined or not args.headline_only):
+            out["pipelined"] = bench_pipelined(args, device, model, batches)
         if world == 1 and not args.headline_only and args.uv == 1024:
             out["config5_2048_bf16"] = bench_config5(args, device)
             out["stress_64ch"] = bench_stress_64ch(device)

@@ -48,9 +48,18 @@ def extract_feat(model, datapipe, n_obs_batches=-1):
     return [_mean_over_frames(torch.cat([pb[level] for pb in per_batch], 0), w) for level in range(len(per_batch[0]))]
 
 
-def infer(model, datapipe, feat_agg, on_batch=None):
+def infer(model, datapipe, feat_agg, on_batch=None, lanes=1):
     """nlt_test.py:78-94: renders every test batch with the aggregated observation features; returns the list of
-    `to_vis` dicts (or hands each to `on_batch(i, to_vis)` -- the reference's model.vis_batch slot)."""
+    `to_vis` dicts (or hands each to `on_batch(i, to_vis)` -- the reference's model.vis_batch slot).
+    lanes > 1: that many batches in flight on the GPU (pipeline.RenderPipeline; same results, `datapipe` must keep
+    lanes + 1 batches alive)."""
+    if lanes > 1:
+        from .pipeline import RenderPipeline
+        pipe = RenderPipeline(model, lanes)
+        if on_batch is not None:
+            pipe.render(datapipe, 'test', on_batch=lambda i, r: on_batch(i, r[3]), obs_override=feat_agg)
+            return []
+        return [r[3] for r in pipe.render(datapipe, 'test', obs_override=feat_agg)]
     outs = []
     for i, batch in enumerate(datapipe):
         _, _, _, to_vis = model.call(batch, 'test', obs_override=feat_agg)

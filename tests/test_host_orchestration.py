@@ -211,3 +211,32 @@ def test_nlt_test_orchestration_extract_feat_and_infer(monkeypatch):
     assert not any('.o.' in l or l == 'L0.stem' for l in pm.plan.timer.records)          # no observation launches
     with pytest.raises(ValueError):
         nlt_test.extract_feat(pm, [])
+
+
+def test_render_pipeline_lane_bookkeeping_on_the_host(monkeypatch):
+    """pipeline.RenderPipeline without a GPU (lanes are a launch-scheduling matter; on CPU tensors every lane just calls):
+    batches go round-robin to lanes, a lane is the model's render state only (own plan, shared nets / weights), the
+    lanes copy lane 0's tile choices, results come back in order and equal Model.call's."""
+    fake_capi.install(monkeypatch)
+    from nlt_amd import nlt_test
+    from nlt_amd.pipeline import RenderPipeline
+    om, pm = make(256, 64, 32)
+    data = [O.synth_batch(2, 64, 64, 32, 32, 32, 32, k=1, seed=80 + i) for i in range(5)]
+    batches = [cpu_batch(b, nn) for b, nn in data]
+    ref = [pm.call(b, 'test')[3]['pred'] for b in batches]
+    pm.plan.tile_hints['L3.q.s1'] = 18                          # (as if lane 0's plan-time trials had chosen it)
+    pm.plan.tuned = {'L3.q.s1': [(1.0, 'tile', 18)]}
+    pipe = RenderPipeline(pm, lanes=3)
+    seen = []
+    pipe.render(batches, 'test', on_batch=lambda i, r: seen.append((i, r[3]['pred'])))
+    assert [i for i, _ in seen] == list(range(5))
+    assert all(torch.equal(a, b) for a, (_, b) in zip(ref, seen))
+    l1, l2 = pipe._lanes[1], pipe._lanes[2]
+    assert l1 is not pm and l1.plan is not pm.plan and l2.plan is not l1.plan
+    assert l1.net is pm.net and l1.plan.q is pm.plan.q and l1.plan.o is pm.plan.o
+    assert l1.plan.tile_hints == pm.plan.tile_hints and l1.plan.autotune is False
+    assert pm.plan.generation == 5 + 2 and l1.plan.generation == 2 and l2.plan.generation == 1   # batches 0,3 | 1,4 | 2 (+ the 5 reference calls)
+    out = nlt_test.infer(pm, batches[:3], None, lanes=2)
+    assert len(out) == 3 and torch.equal(out[2]['pred'], ref[2])
+    with pytest.raises(ValueError):
+        RenderPipeline(pm, 0)
