@@ -107,6 +107,7 @@ def parse():
     ap.add_argument('--no-fused', action='store_true', help='layer-by-layer plan (disable csrc/fused.hip) for A/B runs')
     ap.add_argument('--tune-cache', type=str, default=None, help='JSON of tile choices: loaded if present, else written')
     ap.add_argument('--cpu-baseline-worker', action='store_true', help=argparse.SUPPRESS)
+    ap.add_argument('--released-pipelined-worker', action='store_true', help=argparse.SUPPRESS)
     ap.add_argument('--cpu-threads', type=int, default=0, help='host threads for the CPU oracle leg (0 = all)')
     ap.add_argument('--batches', type=int, default=3, help='distinct batches rotated through the timed steps (>= 3)')
     ap.add_argument('--store-frames', type=int, default=16, help='frames of the synthetic uint8 capture store')
@@ -155,7 +156,7 @@ def make_loader(args, device, k, mode, seed, loss='l2'):
     return cfg, ds, id_lists
 
 
-def bench_pipelined(args, device, model, batches, lanes_list=(2, 3, 4)):
+def bench_pipelined(args, device, model, batches, lanes_list=(2, 3, 4, 6)):
     """Sub-line: the headline's forward with several batches in flight (nlt_amd.pipeline.RenderPipeline: one lane of render
     state per batch over the same weights; consecutive batches on consecutive lanes).  Same model, same batches, same
     number of steps as the headline; every step's full work is inside the timed region.  `ms_per_step` here is elapsed / steps
@@ -179,6 +180,8 @@ def bench_pipelined(args, device, model, batches, lanes_list=(2, 3, 4)):
             t.result()
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
+        pipe.close()
+        del pipe, tickets
         out["lanes"][str(lanes)] = {"ms_per_step": round(1e3 * dt / args.steps, 4),
                                     "Mtexels_per_s": round(args.frames * args.uv * args.uv * args.steps / dt / 1e6, 1),
                                     "bit_identical_to_model_call": same}
@@ -467,6 +470,25 @@ def time_forward(model, batches, steps):
     return (time.perf_counter() - t0) / steps
 
 
+def time_pipelined(model, batches, steps, lanes, **mode):
+    """elapsed / steps with `lanes` batches in flight (nlt_amd.pipeline.RenderPipeline)."""
+    import torch
+    from nlt_amd.pipeline import RenderPipeline
+    pipe = RenderPipeline(model, lanes, **mode)
+    for _ in range(3):
+        for t in [pipe.submit(batches[i % len(batches)], 'test') for i in range(2 * lanes)]:
+            t.result()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    tickets = [pipe.submit(batches[i % len(batches)], 'test') for i in range(steps)]
+    for t in tickets[-lanes:]:
+        t.result()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    pipe.close()
+    return dt
+
+
 def bench_released_shapes(args, device, world, rank):
     """The two shapes the reference releases configs for, beside the headline: BASELINE config 2 (dragon_specular.ini: depth
     256, 512^2 UV, bs 4, k = 1, relight only: identity warp) forward AND train step with the released loss (barron), and
@@ -505,6 +527,50 @@ def bench_released_shapes(args, device, world, rank):
         "ms_per_step", "value", "unit", "frac_of_fp32_mfma_peak", "layerwise_flops_per_step_per_gpu", "host_enqueue_ms_per_step",
         "launch_tape_replays", "final_loss")}
     return out
+
+
+def bench_released_pipelined(args, device):
+    """The released shapes at the render loop's own batch size (4 frames) with several batches in flight
+    (nlt_amd.pipeline.RenderPipeline).  At these shapes one batch is a 28-deep chain of 10-30 us launches that leaves most of
+    the chip idle AND costs the host as long to enqueue as the GPU needs to run it, so the lanes replay one hipGraph each
+    (single-stream lanes); `eager_4_lanes` = launch tapes for comparison.  Runs in its own process (released_pipelined_child)."""
+    import torch
+    import nlt_amd
+    from nlt_amd.models import get_model_class
+    out = {"launch": "hipGraph replay per lane (single-stream lanes); eager_4_lanes: launch tapes, two streams per lane"}
+    for name, depth, uv in (("config2_512_depth256", 256, 512), ("config1_256_depth1024", 1024, 256)):
+        cfg = nlt_amd.make_config(depth=depth, uvh=uv, uvw=uv, imh=uv, imw=uv, bs=4)
+        model = get_model_class('nlt')(cfg).build(device)
+        g = torch.Generator(device=device).manual_seed(1234)
+        for v in model.register_trainable() or model.trainable_variables:
+            if v.dim() == 1:
+                v.data.uniform_(-0.1, 0.1, generator=g)
+        batches = identity_batches(4, uv, uv, 1, device)
+        fl = FLOP_PER_TEXEL[depth](1) * 4 * uv * uv
+        d1 = time_forward(model, batches, 120)
+        rec = {"one_batch_at_a_time": {"ms_per_step": round(1e3 * d1, 4), "Mtexels_per_s": round(4 * uv * uv / d1 / 1e6, 1)}}
+        for lanes, mode in ((2, {'graphs': True}), (4, {'graphs': True}), (8, {'graphs': True}), (4, {})):
+            dp = time_pipelined(model, batches, 120, lanes, **mode)
+            rec["%s%d_lanes" % ('' if mode else 'eager_', lanes)] = {
+                "ms_per_step": round(1e3 * dp, 4), "Mtexels_per_s": round(4 * uv * uv / dp / 1e6, 1),
+                "frac_of_fp32_mfma_peak": round(fl / dp / 1e12 / MFMA_F32_PEAK_TFLOPS, 4)}
+        out[name] = rec
+        del model, batches
+        torch.cuda.empty_cache()
+    return out
+
+
+def released_pipelined_child(args):
+    """`bench_released_pipelined` in a fresh process on the same GPU (this process' earlier legs leave dozens of HIP streams and
+    graph pools behind, and the small shapes are sensitive to that: one batch at a time 0.44 ms in a clean process, 0.57 ms
+    at the end of this one), with a hard timeout."""
+    import subprocess
+    cmd = [sys.executable, os.path.abspath(__file__), '--released-pipelined-worker']
+    try:
+        out = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, cwd=ROOT, timeout=240).stdout.decode()
+        return json.loads([l for l in out.splitlines() if l.startswith('{')][-1])
+    except Exception as e:                                         # a sub-line: never take the headline with it
+        return {"error": "%s: %s" % (type(e).__name__, str(e)[:200])}
 
 
 def bench_stress_64ch(device):
@@ -578,6 +644,10 @@ def main():
     args = parse()
     if args.cpu_baseline_worker:
         return cpu_baseline_worker(args)
+    if args.released_pipelined_worker:
+        import torch
+        print(json.dumps(bench_released_pipelined(args, torch.device('cuda', 0))), flush=True)
+        return
     import torch
     import torch.distributed as dist
     world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -744,8 +814,6 @@ def main():
         }
         if with_loader:
             out["forward_including_loader"] = with_loader
-        if world == 1 and not args.graph and (args.pipelined or not args.headline_only):
-            out["pipelined"] = bench_pipelined(args, device, model, batches)
         if world == 1 and not args.headline_only and args.uv == 1024:
             out["config5_2048_bf16"] = bench_config5(args, device)
             out["stress_64ch"] = bench_stress_64ch(device)
@@ -757,6 +825,12 @@ def main():
             out["train_step"] = train[0]
             if len(train) > 1:
                 out["train_step_other_losses"] = train[1:]
+        # several batches in flight: last of the GPU legs (the lanes' streams / graph pools stay with the process and were
+        # measured to perturb legs that run after them: config 5 fp32 1.60 -> 1.70 ms)
+        if world == 1 and not args.graph and (args.pipelined or not args.headline_only):
+            out["pipelined"] = bench_pipelined(args, device, model, batches)
+            if released and args.uv == 1024:
+                out["released_shapes"]["forward_4_frames_pipelined"] = released_pipelined_child(args)
         if world == 1 and not args.no_cpu_baseline and not args.headline_only:
             out["cpu_baseline"] = cpu_baseline(args)
         print(json.dumps(out), flush=True)

@@ -6,6 +6,7 @@ C ABI.  There is NO CPU or torch fallback: if the library is missing or a call r
 non-zero status this raises.
 """
 import ctypes
+import threading
 import os
 
 import torch
@@ -159,9 +160,11 @@ def _load():
 # the whole step at the training shape.  While a tape is open every launching C call is ALSO appended to it as
 # (function, resolved arguments); a later step with the same inputs replays the list with nothing but the ctypes
 # calls.  (hipGraph replay of the same sequence measured slower than eager launches on ROCm 7.0; see DESIGN.md.)
-_tape = None
-_tape_epoch = [0]
+# The open tape belongs to the THREAD that opened it (pipeline.RenderPipeline drives one lane per host thread: a lane that
+# records must not collect another lane's launches).
+_tls = threading.local()
 _alloc_epoch = [0]          # bumped whenever a cached device buffer the C calls point into is re-allocated
+
 
 
 class _TapeLib:
@@ -177,8 +180,9 @@ class _TapeLib:
 
         def recorded(*args):
             rc = fn(*args)
-            if _tape is not None and rc == 0:
-                _tape.append((fn, args))
+            t = getattr(_tls, 'tape', None)
+            if t is not None and rc == 0:
+                t.append((fn, args))
             return rc
         setattr(self, name, recorded)
         return recorded
@@ -189,7 +193,7 @@ _tape_lib = None
 
 def lib():
     global _tape_lib
-    if _tape is None:
+    if getattr(_tls, 'tape', None) is None:
         return _real if _real is not None else _load()
     if _tape_lib is None:
         _tape_lib = _TapeLib(_load())
@@ -197,25 +201,22 @@ def lib():
 
 
 def tape_begin():
-    global _tape
-    if _tape is not None:
+    if getattr(_tls, 'tape', None) is not None:
         raise NLTError("a launch tape is already open")
-    _tape = []
-    _tape_epoch[0] = _alloc_epoch[0]
+    _tls.tape = []
+    _tls.epoch = _alloc_epoch[0]
 
 
 def tape_end(tag=None):
     """Closes the tape and returns [launch list, allocation epoch it is valid for, caller's validity tag, native form]."""
-    global _tape
-    t, _tape = _tape, None
-    if _tape_epoch[0] != _alloc_epoch[0]:
+    t, _tls.tape = _tls.tape, None
+    if _tls.epoch != _alloc_epoch[0]:
         return None                                     # a cached buffer was re-allocated while recording: pointers are stale
     return (t, _alloc_epoch[0], tag, [None])
 
 
 def tape_abort():
-    global _tape
-    _tape = None
+    _tls.tape = None
 
 
 def tape_valid(tape, tag=None):
@@ -288,7 +289,7 @@ def _compile(calls):
 
 
 def replay(tape):
-    if NATIVE_REPLAY and len(tape) > 3 and _real is not None:
+    if (NATIVE_REPLAY or getattr(_tls, 'native_replay', False)) and len(tape) > 3 and _real is not None:
         box = tape[3]
         if box[0] is None:
             box[0] = _compile(tape[0])
@@ -312,20 +313,39 @@ def replay(tape):
 def tape_call(fn, *args):
     """A host-side step that belongs to the plan (a hook): run it now and, while a tape is open, on every replay."""
     fn(*args)
-    if _tape is not None:
-        _tape.append((fn, args))
+    t = getattr(_tls, 'tape', None)
+    if t is not None:
+        t.append((fn, args))
 
 
 def record_event(ev, stream):
     ev.record(stream)
-    if _tape is not None:
-        _tape.append((ev.record, (stream,)))
+    t = getattr(_tls, 'tape', None)
+    if t is not None:
+        t.append((ev.record, (stream,)))
 
 
 def wait_event(stream, ev):
     stream.wait_event(ev)
-    if _tape is not None:
-        _tape.append((stream.wait_event, (ev,)))
+    t = getattr(_tls, 'tape', None)
+    if t is not None:
+        t.append((stream.wait_event, (ev,)))
+
+
+_WS_SCOPE = os.environ.get('NLT_WS_SCOPE', '1') != '0'      # (A/B switch)
+
+
+def set_workspace_scope(token):
+    """Scratch that is cached per stream (the split-K partial sums) is additionally keyed by this token; a plan sets it to its
+    own identity on entry.  Two plans whose launches are CAPTURED on the same capture stream (pipeline.RenderPipeline lanes
+    replaying hipGraphs) would otherwise bake one workspace into both graphs and race on it when the graphs replay side by side."""
+    _tls.scope = token if _WS_SCOPE else 0
+
+
+def set_thread_native_replay(on):
+    """This host thread replays its launch tapes through nlt_tape_play (one C call per run of launches, the interpreter lock
+    released for all of it): what lets the lanes of pipeline.RenderPipeline enqueue in parallel."""
+    _tls.native_replay = bool(on)
 
 
 class NLTError(RuntimeError):
@@ -730,7 +750,7 @@ def conv_forward_splitk(mode, ksplit, src0, c0, ld0, src1, c1, ld1, n, h, w, w_p
     need = lib().nlt_conv_splitk_workspace_floats(mode, n, h, w, cout, ksplit)
     if need <= 0:
         raise NLTError("nlt_conv_splitk_workspace_floats failed")
-    key = (str(src0.device), _stream())          # per stream: the query and observation paths may run concurrently
+    key = (str(src0.device), _stream(), getattr(_tls, 'scope', 0))   # per stream (the query and observation paths run concurrently) and per plan (see set_workspace_scope)
     ws = _splitk_ws.get(key)
     if ws is None or ws.numel() < need:
         ws = torch.empty(need, device=src0.device, dtype=torch.float32)
@@ -752,7 +772,7 @@ def conv_backward_data(adj_mode, dpre, cpre, ldp, n, h, w, w_packed, zero_bias, 
         need = lib().nlt_conv_splitk_workspace_floats(adj_mode, n, h, w, cout, ksplit)
         if need <= 0:
             raise NLTError("nlt_conv_splitk_workspace_floats failed")
-        key = (str(dpre.device), _stream())
+        key = (str(dpre.device), _stream(), getattr(_tls, 'scope', 0))
         ws = _splitk_ws.get(key)
         if ws is None or ws.numel() < need:
             ws = torch.empty(need, device=dpre.device, dtype=torch.float32)

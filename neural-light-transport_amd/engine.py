@@ -391,6 +391,7 @@ class RenderPlan:
         activations a backward pass would need (fm0, obs0, the L1 / last-block intermediates).
         resident = ResidentTexels (datasets/nlt.py): the five float buffers are None and the front kernel reads the
         uint8 capture store itself (inference only; `resident_ok` says when)."""
+        C.set_workspace_scope(id(self))
         if resident is not None:
             return self._forward_resident(resident, skip_connect_base, algo)
         n, h, w, _ = base.shape
@@ -825,6 +826,7 @@ class RenderPlan:
         generation: `plan.generation` right after the forward this backward belongs to -- the plan keeps ONE set of
         activations, so a backward after any other forward (a second micro-batch, a vali / test call) would silently
         pair this pass's inputs with that pass's activations; it raises instead."""
+        C.set_workspace_scope(id(self))
         if generation is not None and generation != self.generation:
             raise RuntimeError("backward() of a forward pass whose activations have been overwritten by a later forward "
                                "(pass %d, the plan now holds pass %d): run each backward before the next forward"

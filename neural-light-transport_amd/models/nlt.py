@@ -109,7 +109,8 @@ class Model(BaseModel):
         # hipGraph replay of the inference forward (opt-in: NLT_GRAPH=1 or model.use_graphs = True).  The ~36 launches
         # of a step cost ~0.6 ms of host time; for small workloads (512^2, k = 1) that is the whole step.
         self.use_graphs = os.environ.get('NLT_GRAPH', '0') == '1'
-        self._graph = None              # {'key', 'hits', 'graph', 'out'}
+        self._graph = None              # {'key', 'hits', 'graph', 'out'}: the entry of `_graphs` used last
+        self._graphs = {}               # input addresses (+ weights version ...) -> entry; a few staging slots' worth
 
     def _init_loss(self):
         wloss = []
@@ -365,8 +366,9 @@ class Model(BaseModel):
     def _render_maybe_graphed(self, base, cvis, lvis, warp, nn_rgb, nn_base, obs_weights, obs_override, want_indices):
         """`_render` (+ the copy of pred) either launched kernel by kernel or, with use_graphs, replayed as one
         hipGraph.  A graph is tied to the ADDRESSES of its inputs: it is captured the second time the same input
-        tensors (and weights version) come back, replayed from then on, and dropped when they change.  Replayed
-        outputs are the graph's own static tensors: consume them before the next call."""
+        tensors (and weights version) come back and replayed from then on; up to 8 such graphs are kept (the slots of a
+        staging ring).  Replayed outputs are the graph's own static tensors: consume them before the next call that
+        replays the same graph."""
         args = (base, cvis, lvis, warp, nn_rgb, nn_base, obs_weights, obs_override, want_indices)
         eager = lambda: self._render(*args) + (None,)
         ok = (self.use_graphs and base.is_cuda and self.plan.timer is None and obs_override is None and obs_weights is None
@@ -376,11 +378,14 @@ class Model(BaseModel):
             return out[:5] + (out[0].clone(),)
         key = (tuple(t.data_ptr() for t in (base, cvis, lvis, warp, nn_rgb, nn_base)), tuple(base.shape), tuple(warp.shape),
                nn_rgb.shape[1], want_indices, self._epoch[0], self.flat_params._version, self.plan.fuse_ends, self.conv_algo)
-        g = self._graph
-        if g is None or g['key'] != key:
-            self._graph = {'key': key, 'hits': 0, 'graph': None, 'out': None}
+        g = self._graphs.get(key)
+        if g is None:
+            if len(self._graphs) >= 8:                           # ever-changing input addresses: forget the oldest
+                self._graphs.pop(next(iter(self._graphs)))
+            self._graph = self._graphs[key] = {'key': key, 'hits': 0, 'graph': None, 'out': None}
             out = eager()                                        # first sight: eager (also runs the plan-time autotune)
             return out[:5] + (out[0].clone(),)
+        self._graph = g
         if g['graph'] is None:                                   # second sight: capture (the capture itself does not execute)
             torch.cuda.synchronize()
             graph = torch.cuda.CUDAGraph()

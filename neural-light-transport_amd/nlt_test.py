@@ -48,14 +48,14 @@ def extract_feat(model, datapipe, n_obs_batches=-1):
     return [_mean_over_frames(torch.cat([pb[level] for pb in per_batch], 0), w) for level in range(len(per_batch[0]))]
 
 
-def infer(model, datapipe, feat_agg, on_batch=None, lanes=1):
+def infer(model, datapipe, feat_agg, on_batch=None, lanes=1, threads=False):
     """nlt_test.py:78-94: renders every test batch with the aggregated observation features; returns the list of
     `to_vis` dicts (or hands each to `on_batch(i, to_vis)` -- the reference's model.vis_batch slot).
     lanes > 1: that many batches in flight on the GPU (pipeline.RenderPipeline; same results, `datapipe` must keep
-    lanes + 1 batches alive)."""
+    lanes + 1 batches alive; threads: one host thread per lane)."""
     if lanes > 1:
         from .pipeline import RenderPipeline
-        pipe = RenderPipeline(model, lanes)
+        pipe = RenderPipeline(model, lanes, threads=threads)
         if on_batch is not None:
             pipe.render(datapipe, 'test', on_batch=lambda i, r: on_batch(i, r[3]), obs_override=feat_agg)
             return []

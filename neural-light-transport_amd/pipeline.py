@@ -14,15 +14,29 @@ choices, deterministic reductions; tests/test_gpu_pipeline.py).
     pred_camspc, _, _, to_vis = tickets[0].result()                 # the caller's stream waits for that batch only
 or  outs = pipe.render(datapipe, 'test', on_batch=...)              # the reference's loop, `lanes` batches in flight
 
+Host side: a forward pass is ~40-60 HIP runtime calls of ~8 us each, i.e. 0.3-0.5 ms of host time per batch -- for the released
+shapes (512^2 / 256^2 UV, 4 frames) as long as the GPU needs for the batch, so lanes driven from ONE thread stay host-bound.
+With threads=True every lane but the first has its own host thread that replays the lane's launch tape through
+nlt_tape_play (one C call per run of launches, interpreter lock released), so the lanes enqueue in parallel.
+
+graphs=True (the released small shapes: 512^2 / 256^2 UV at 4 frames, where even the launch-tape replay is host-bound): every
+lane runs its forward on ONE stream and replays it as a hipGraph per set of input addresses (Model.use_graphs; a single-stream
+chain replays for ~0.07 ms of host time where the two-stream graph and the launch tape both cost 0.3-0.45 ms), and hands out
+copies of the graph's static outputs.  Measured (r03, MI355X, 4 frames per batch): depth 1024 / 256^2 551 -> 1228 Mtexels/s,
+depth 256 / 512^2 2247 -> 3832 Mtexels/s at 4 lanes; the 1024^2 headline shape is GPU-bound and stays on eager launches.
+
 Contract for the inputs: a submitted batch is READ on the lane's stream, so its buffers must stay untouched until that batch's
 ticket has been waited for (`result()`), or until `lanes` further batches have been submitted (submit makes the caller's stream
 wait for the batch issued `lanes` submissions ago): a staging ring (datasets/nlt.py `ring`) needs lanes + 1 slots.
 Weights must not change while batches are in flight (inference); after an update the next submit drains every lane first."""
 import collections
 import copy
+import queue
+import threading
 
 import torch
 
+from . import _capi as C
 from .engine import RenderPlan
 
 _PLAN_SWITCHES = ('precision', 'fuse_ends', 'front_l2', 'fuse_dec', 'front_v4', 'two_streams', 'use_tape', 'lds_tn128')
@@ -37,10 +51,24 @@ def _copy_tuning(dst, src):
 class RenderTicket:
     """One submitted batch.  `result()` orders the caller's current stream after the batch and returns what Model.call returns."""
 
-    def __init__(self, out, done, tensors):
-        self._out, self._done, self._tensors = out, done, tensors
+    def __init__(self):
+        self._out = self._done = self._exc = None
+        self._tensors = []
+        self._queued = threading.Event()             # set once the lane's host thread has issued every launch of the batch
+
+    def _set(self, out, done, exc=None):
+        self._out, self._done, self._exc = out, done, exc
+        self._tensors = _tensors_of(out) if out is not None else []
+        self._queued.set()
+
+    def _done_event(self):
+        self._queued.wait()
+        return self._done
 
     def result(self):
+        self._queued.wait()
+        if self._exc is not None:
+            raise self._exc
         if self._done is not None:
             cur = torch.cuda.current_stream(self._tensors[0].device) if self._tensors else torch.cuda.current_stream()
             cur.wait_event(self._done)
@@ -48,6 +76,13 @@ class RenderTicket:
                 t.record_stream(cur)                 # allocated on the lane's stream, consumed on the caller's
             self._done = None
         return self._out
+
+
+def _own_copies(out, batch):
+    """Model.call's result with every device tensor that is not one of the batch's own buffers cloned."""
+    inputs = {id(t) for t in batch if torch.is_tensor(t)}
+    cp = lambda x: x.clone() if (torch.is_tensor(x) and x.is_cuda and id(x) not in inputs) else x
+    return tuple({k: cp(v) for k, v in x.items()} if isinstance(x, dict) else cp(x) for x in out)
 
 
 def _tensors_of(out):
@@ -61,7 +96,7 @@ def _tensors_of(out):
 
 
 class RenderPipeline:
-    def __init__(self, model, lanes=3):
+    def __init__(self, model, lanes=3, threads=False, graphs=False):
         if lanes < 1:
             raise ValueError("lanes must be >= 1")
         if getattr(model, 'generic', False) and lanes > 1:
@@ -70,20 +105,26 @@ class RenderPipeline:
         self._lanes = [model] + [None] * (lanes - 1)        # lane 0 IS the model: its plan tunes, the others copy its choices
         self._streams = [None] * lanes
         self._tuned_ref = [None] * lanes
-        self._recent = collections.deque()                  # done-events of the last `lanes` submissions
+        self._recent = collections.deque()                  # tickets of the last `lanes` submissions
+        self._graphs = bool(graphs)
+        self._threads = bool(threads) and lanes > 1 and not self._graphs      # (stream capture wants the other host threads quiet)
+        if self._graphs:
+            self._lanes[0] = None                           # every lane a copy: the caller's model keeps its own launch mode
+        self._workers = [None] * lanes                      # (thread, job queue) per lane, started on first use
         self._next = 0
         self._weights = None
 
     # -------------------------------------------------------------- lanes
     def _lane(self, i):
         m = self.model
-        if i == 0:
+        if i == 0 and not self._graphs:
             return m
         lane = self._lanes[i]
         if lane is None:
             lane = copy.copy(m)                             # same nets, flat bucket, pack registry
             lane.plan = RenderPlan(m.net['query'], m.net['obs'], m.use_obs)
-            lane._graph = None
+            lane._graph, lane._graphs = None, {}
+            lane.use_graphs = self._graphs
             self._lanes[i] = lane
         lane.conv_algo, lane.skip_connect_base = m.conv_algo, m.skip_connect_base
         if self._tuned_ref[i] is not getattr(m.plan, 'tuned', None) or lane.plan.precision != m.plan.precision:
@@ -91,6 +132,8 @@ class RenderPipeline:
                 setattr(lane.plan, a, getattr(m.plan, a))
             _copy_tuning(lane.plan, m.plan)                 # lane 0's plan-time trials decide for every lane
             self._tuned_ref[i] = getattr(m.plan, 'tuned', None)
+            if self._graphs:
+                lane.plan.two_streams = False               # a linear chain: the cheap kind of graph to launch
         lane.plan.autotune = False
         return lane
 
@@ -98,38 +141,106 @@ class RenderPipeline:
         fp = getattr(self.model, 'flat_params', None)
         return None if fp is None else (fp._version, getattr(self.model, '_epoch', [0])[0])
 
+    # -------------------------------------------------------------- host threads
+    def _worker(self, i, dev):
+        w = self._workers[i]
+        if w is None:
+            jobs = queue.SimpleQueue()
+
+            def loop():
+                torch.cuda.set_device(dev)
+                C.set_thread_native_replay(True)
+                while True:
+                    job = jobs.get()
+                    if job is None:
+                        return
+                    self._run(*job)
+            th = threading.Thread(target=loop, name='nlt-lane-%d' % i, daemon=True)
+            th.start()
+            w = self._workers[i] = (th, jobs)
+        return w
+
+    def _run(self, lane, stream, ready, batch, mode, kw, ticket):
+        try:
+            with torch.no_grad(), torch.cuda.stream(stream):
+                if ready is not None:
+                    stream.wait_event(ready)                # the batch was assembled on the caller's stream
+                out = lane.call(batch, mode, **kw)
+                if self._graphs:
+                    out = _own_copies(out, batch)           # the graph's static outputs are rewritten by its next replay
+                done = torch.cuda.Event()
+                done.record(stream)
+            ticket._set(out, done)
+        except BaseException as e:                          # surfaces in ticket.result()
+            ticket._set(None, None, e)
+
+    def drain(self):
+        """Host-side wait until every submitted batch has been fully enqueued (not executed)."""
+        for t in list(self._recent):
+            t._queued.wait()
+
+    def close(self):
+        for i, w in enumerate(self._workers):
+            if w is not None:
+                w[1].put(None)
+                w[0].join(timeout=10)
+                self._workers[i] = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
     # -------------------------------------------------------------- submit / collect
     def submit(self, batch, mode='test', **kw):
-        """Queues Model.call(batch, mode, **kw) on the next lane; returns a RenderTicket without waiting for anything."""
+        """Queues Model.call(batch, mode, **kw) on the next lane; returns a RenderTicket without waiting for the GPU."""
+        if mode == 'train':
+            raise ValueError("RenderPipeline renders ('test' / 'vali'); a train step needs the previous step's weights")
         i = self._next % self.n
         probe = next((t for t in batch if torch.is_tensor(t)), None)
         dev = probe.device if probe is not None else getattr(batch[1], 'cvis', torch.empty(0)).device
+        ticket = RenderTicket()
         if dev.type != 'cuda':                              # host tests: lanes are a launch-scheduling matter, nothing to overlap
             self._next += 1
-            return RenderTicket(self._lane(i).call(batch, mode, **kw), None, [])
+            ticket._set(self._lane(i).call(batch, mode, **kw), None)
+            return ticket
         wv = self._weights_version()
-        fresh = wv != self._weights or (i > 0 and self._lanes[i] is None)
+        fresh = wv != self._weights or ((i > 0 or self._graphs) and self._lanes[i] is None)
         if fresh:
             # first batch of this lane / the weights changed: whatever is made once and shared (packed fragments, lane 0's
             # plan-time trials) is made on ONE stream with nothing else in flight, and complete before another lane reads it
+            self.drain()
             torch.cuda.synchronize(dev)
             self._weights = wv
+            if self._graphs and self.model.plan.autotune and not getattr(self.model.plan, 'tuned', None):
+                with torch.no_grad():
+                    self.model.call(batch, mode, **kw)      # the model's own plan runs its plan-time trials; the lanes copy them
+                torch.cuda.synchronize(dev)
         lane = self._lane(i)
         if self._streams[i] is None:
             self._streams[i] = torch.cuda.Stream(device=dev)
         stream, cur = self._streams[i], torch.cuda.current_stream(dev)
         if len(self._recent) >= self.n:
-            cur.wait_event(self._recent.popleft())          # the inputs of the batch `lanes` submissions ago are free again
-        stream.wait_stream(cur)                             # this batch was assembled on the caller's stream
-        with torch.cuda.stream(stream):
-            out = lane.call(batch, mode, **kw)
-            done = torch.cuda.Event()
-            done.record(stream)
-        if fresh:
-            torch.cuda.synchronize(dev)
-        self._recent.append(done)
+            old = self._recent.popleft()._done_event()      # (host: that batch's launches are all queued -- one job per lane)
+            if old is not None:
+                cur.wait_event(old)                         # the inputs of the batch `lanes` submissions ago are free again
+        if fresh or not self._threads or i == 0:            # lane 0 is driven by the caller's thread
+            stream.wait_stream(cur)
+            C.set_thread_native_replay(self._threads)
+            try:
+                self._run(lane, stream, None, batch, mode, kw, ticket)
+            finally:
+                C.set_thread_native_replay(False)
+            if fresh:
+                torch.cuda.synchronize(dev)
+        else:
+            ready = torch.cuda.Event()
+            ready.record(cur)
+            self._worker(i, dev)[1].put((lane, stream, ready, batch, mode, kw, ticket))
+        self._recent.append(ticket)
         self._next += 1
-        return RenderTicket(out, done, _tensors_of(out))
+        return ticket
 
     def render(self, datapipe, mode='test', on_batch=None, **kw):
         """The render loop with `lanes` batches in flight: list of Model.call results in order (or each handed to

@@ -33,20 +33,27 @@ def _same(a, b):
         assert torch.equal(a[3][key], b[3][key]), key
 
 
-@pytest.mark.parametrize('lanes', [2, 3, 4])
+@pytest.mark.parametrize('lanes,kind', [(2, 'plain'), (3, 'plain'), (4, 'plain'), (3, 'threads'), (4, 'threads'),
+                                        (2, 'graphs'), (3, 'graphs')])
 @pytest.mark.parametrize('resident', [False, True])
-def test_pipelined_batches_equal_sequential_calls(lanes, resident):
+def test_pipelined_batches_equal_sequential_calls(lanes, kind, resident):
+    """plain: every lane driven by the caller's thread; threads: one host thread per lane (native tape replay, thread-local
+    launch tapes); graphs: single-stream lanes replaying one hipGraph per (lane, input addresses), outputs handed out as copies."""
     pm, ds, id_lists = _setup()
     batches = [ds.load_batch(ids, resident=resident) for ids in id_lists]
     ref = [pm.call(b, 'test') for b in batches]
     torch.cuda.synchronize()
-    pipe = RenderPipeline(pm, lanes)
+    pipe = RenderPipeline(pm, lanes, threads=kind == 'threads', graphs=kind == 'graphs')
     for rounds in range(3):                                      # eager pass, recorded launch tapes, replays
         tickets = [pipe.submit(b, 'test') for b in batches]
         outs = [t.result() for t in tickets]
         torch.cuda.synchronize()
         for a, b in zip(ref, outs):
             _same(a, b)
+    if kind == 'graphs' and not resident:
+        assert pipe._lanes[0] is not pm and all(len(l._graphs) == len(batches) // lanes and
+                                                all(g['hits'] >= 1 for g in l._graphs.values()) for l in pipe._lanes)
+        assert pm.use_graphs is False and pm.plan.two_streams is True               # the caller's model keeps its launch mode
     assert all(l is not None and l.plan is not pm.plan for l in pipe._lanes[1:])
     assert pipe._lanes[1].plan.lds_hints == pm.plan.lds_hints and pipe._lanes[1].plan.tile_hints == pm.plan.tile_hints
     assert pipe._lanes[1].net is pm.net and pipe._lanes[1].flat_params is pm.flat_params       # one set of weights
@@ -55,6 +62,23 @@ def test_pipelined_batches_equal_sequential_calls(lanes, resident):
     torch.cuda.synchronize()
     for a, b in zip(ref, outs):
         _same(a, b)
+    pipe.close()
+
+
+def test_a_failing_lane_raises_from_the_ticket():
+    pm, ds, id_lists = _setup(frames=4)
+    batches = [ds.load_batch(ids) for ids in id_lists]
+    pipe = RenderPipeline(pm, 2, threads=True)
+    for _ in range(2):
+        [t.result() for t in [pipe.submit(b, 'test') for b in batches]]
+    bad = list(batches[1]); bad[1] = bad[1][:, :-1]                       # a base map of the wrong height
+    good, broken = pipe.submit(batches[0], 'test'), pipe.submit(tuple(bad), 'test')
+    good.result()
+    with pytest.raises(Exception):
+        broken.result()
+    with pytest.raises(ValueError):
+        pipe.submit(batches[0], 'train')
+    pipe.close()
 
 
 def test_pipeline_sees_a_weight_update():
