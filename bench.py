@@ -167,24 +167,43 @@ def bench_pipelined(args, device, model, batches, lanes_list=(2, 3, 4, 6)):
                    "tapes and HIP streams, shared weights), so the launches of up to `lanes` batches overlap on the GPU",
            "lanes": {}}
     ref = model.call(batches[0], 'test')[0].clone()
+    single = time_forward(model, batches, max(20, args.steps // 4))
     for lanes in lanes_list:
         pipe = RenderPipeline(model, lanes)
         for _ in range(3):
             for t in [pipe.submit(batches[i % len(batches)], 'test') for i in range(2 * lanes)]:
                 t.result()
         same = bool(torch.equal(pipe.submit(batches[0], 'test').result()[0], ref))
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        tickets = [pipe.submit(batches[i % len(batches)], 'test') for i in range(args.steps)]
-        for t in tickets[-lanes:]:
-            t.result()
-        torch.cuda.synchronize()
-        dt = time.perf_counter() - t0
+
+        def timed():
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            tickets = [pipe.submit(batches[i % len(batches)], 'test') for i in range(args.steps)]
+            for t in tickets[-lanes:]:
+                t.result()
+            torch.cuda.synchronize()
+            return time.perf_counter() - t0
+        dt = timed()
+        rec = {}
+        if dt / args.steps > 1.15 * single:
+            # seen in the first heavy process on a fresh box: every multi-lane leg 1.8-2x slower than one batch at a time while
+            # every single-lane leg of the process is normal; gone in any process that follows ~20 s of sustained load (DESIGN.md
+            # section 4b).  So: 10 s of the headline's own steps, then measure once more; both figures stay in the line.
+            rec["first_try_ms_per_step"] = round(1e3 * dt / args.steps, 4)
+            rec["re_measured_after"] = "10 s of sustained single-lane steps"
+            t_end = time.perf_counter() + 10.0
+            while time.perf_counter() < t_end:
+                for i in range(50):
+                    model.call(batches[i % len(batches)], 'test')
+                torch.cuda.synchronize()
+            dt = timed()
         pipe.close()
-        del pipe, tickets
-        out["lanes"][str(lanes)] = {"ms_per_step": round(1e3 * dt / args.steps, 4),
-                                    "Mtexels_per_s": round(args.frames * args.uv * args.uv * args.steps / dt / 1e6, 1),
-                                    "bit_identical_to_model_call": same}
+        del pipe
+        rec.update({"ms_per_step": round(1e3 * dt / args.steps, 4),
+                    "Mtexels_per_s": round(args.frames * args.uv * args.uv * args.steps / dt / 1e6, 1),
+                    "bit_identical_to_model_call": same})
+        out["lanes"][str(lanes)] = rec
+    out["one_batch_at_a_time_ms_per_step"] = round(1e3 * single, 4)
     best = max(out["lanes"].items(), key=lambda kv: kv[1]["Mtexels_per_s"])
     out["best"] = {"lanes": int(best[0]), **best[1]}
     return out
@@ -470,23 +489,36 @@ def time_forward(model, batches, steps):
     return (time.perf_counter() - t0) / steps
 
 
-def time_pipelined(model, batches, steps, lanes, **mode):
-    """elapsed / steps with `lanes` batches in flight (nlt_amd.pipeline.RenderPipeline)."""
+def time_pipelined(model, batches, steps, lanes, single=None, **mode):
+    """(elapsed / steps, first try or None) with `lanes` batches in flight (nlt_amd.pipeline.RenderPipeline).  `single` = the
+    one-batch-at-a-time time: a leg that comes out more than 15 % SLOWER than that is the fresh-box state DESIGN.md section 4b
+    describes; it is measured once more after 10 s of sustained single-lane steps and both figures are returned."""
     import torch
     from nlt_amd.pipeline import RenderPipeline
     pipe = RenderPipeline(model, lanes, **mode)
     for _ in range(3):
         for t in [pipe.submit(batches[i % len(batches)], 'test') for i in range(2 * lanes)]:
             t.result()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    tickets = [pipe.submit(batches[i % len(batches)], 'test') for i in range(steps)]
-    for t in tickets[-lanes:]:
-        t.result()
-    torch.cuda.synchronize()
-    dt = (time.perf_counter() - t0) / steps
+
+    def timed():
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        tickets = [pipe.submit(batches[i % len(batches)], 'test') for i in range(steps)]
+        for t in tickets[-lanes:]:
+            t.result()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / steps
+    dt, first = timed(), None
+    if single is not None and dt > 1.15 * single:
+        first = dt
+        t_end = time.perf_counter() + 10.0
+        while time.perf_counter() < t_end:
+            for i in range(50):
+                model.call(batches[i % len(batches)], 'test')
+            torch.cuda.synchronize()
+        dt = timed()
     pipe.close()
-    return dt
+    return dt, first
 
 
 def bench_released_shapes(args, device, world, rank):
@@ -550,10 +582,13 @@ def bench_released_pipelined(args, device):
         d1 = time_forward(model, batches, 120)
         rec = {"one_batch_at_a_time": {"ms_per_step": round(1e3 * d1, 4), "Mtexels_per_s": round(4 * uv * uv / d1 / 1e6, 1)}}
         for lanes, mode in ((2, {'graphs': True}), (4, {'graphs': True}), (8, {'graphs': True}), (4, {})):
-            dp = time_pipelined(model, batches, 120, lanes, **mode)
-            rec["%s%d_lanes" % ('' if mode else 'eager_', lanes)] = {
-                "ms_per_step": round(1e3 * dp, 4), "Mtexels_per_s": round(4 * uv * uv / dp / 1e6, 1),
-                "frac_of_fp32_mfma_peak": round(fl / dp / 1e12 / MFMA_F32_PEAK_TFLOPS, 4)}
+            dp, first = time_pipelined(model, batches, 120, lanes, single=d1, **mode)
+            r = {"ms_per_step": round(1e3 * dp, 4), "Mtexels_per_s": round(4 * uv * uv / dp / 1e6, 1),
+                 "frac_of_fp32_mfma_peak": round(fl / dp / 1e12 / MFMA_F32_PEAK_TFLOPS, 4)}
+            if first is not None:
+                r["first_try_ms_per_step"] = round(1e3 * first, 4)
+                r["re_measured_after"] = "10 s of sustained single-lane steps"
+            rec["%s%d_lanes" % ('' if mode else 'eager_', lanes)] = r
         out[name] = rec
         del model, batches
         torch.cuda.empty_cache()
