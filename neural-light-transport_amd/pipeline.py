@@ -28,7 +28,8 @@ depth 256 / 512^2 2247 -> 3832 Mtexels/s at 4 lanes; the 1024^2 headline shape i
 Contract for the inputs: a submitted batch is READ on the lane's stream, so its buffers must stay untouched until that batch's
 ticket has been waited for (`result()`), or until `lanes` further batches have been submitted (submit makes the caller's stream
 wait for the batch issued `lanes` submissions ago): a staging ring (datasets/nlt.py `ring`) needs lanes + 1 slots.
-Weights must not change while batches are in flight (inference); after an update the next submit drains every lane first."""
+Weights must not change while batches are in flight (inference); after an update the next submit drains every lane first.
+Lane 0 is the model itself (except with graphs=True): do not call the model directly while tickets are outstanding."""
 import collections
 import copy
 import queue
