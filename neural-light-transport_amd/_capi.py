@@ -499,7 +499,7 @@ def conv_backward_weights_tiled(mode, src0, c0, ld0, src1, c1, ld1, n, h, w, dpr
     need = lib().nlt_wgrad_workspace_floats(mode, c0, c1, n, h, w, cout)
     if need <= 0:
         raise NLTError("nlt_wgrad_workspace_floats: unsupported (mode %d, c0 %d, c1 %d, cout %d)" % (mode, c0, c1, cout))
-    key = str(src0.device)
+    key = (str(src0.device), _stream())                 # per stream: the plan may deal weight gradients to two streams
     ws = _wgrad_ws.get(key)
     if ws is None or ws.numel() < need:
         ws = torch.empty(need, device=src0.device, dtype=torch.float32)
@@ -519,7 +519,7 @@ def conv_backward_weights_narrow(mode, src0, c0, ld0, src1, c1, ld1, n, h, w, dp
     need = lib().nlt_wgrad_narrow_workspace_floats(mode, c0, c1, n, h, w, cout)
     if need <= 0:
         raise NLTError("nlt_wgrad_narrow_workspace_floats: unsupported (mode %d, c0 %d, c1 %d, cout %d)" % (mode, c0, c1, cout))
-    ws = _workspace('wgrad_narrow', src0.device, need)
+    ws = _workspace('wgrad_narrow.%d' % _stream(), src0.device, need)
     _check(lib().nlt_conv_backward_weights_narrow(mode, _ptr(src0), ld0, c0, _ptr(src1), ld1, c1, n, h, w, _ptr(dpre), ldp,
                                                   cout, _ptr(dw), _ptr(db), _ptr(ws), ws.numel(), _stream()),
            'nlt_conv_backward_weights_narrow')

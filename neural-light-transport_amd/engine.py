@@ -73,7 +73,7 @@ class RenderPlan:
         self.wgrad_tiled = os.environ.get('NLT_WGRAD', 'tiled') != 'atomic'   # csrc/wgrad_tile.hip vs first-generation csrc/wgrad.hip
         self.wgrad_narrow = os.environ.get('NLT_WGRAD_NARROW', '1') != '0'
         # weight gradients on a side stream, off the backward-data chain (config 4: 5.17 -> 4.63 ms / step)
-        self.bwd_streams = os.environ.get('NLT_BWD_STREAMS', '1') != '0'
+        self.bwd_streams = int(os.environ.get('NLT_BWD_STREAMS', '1'))   # 0: one stream; 1: weight gradients on a side stream; 2: on two, alternately
         # launch tape: replay a step's C calls with their resolved arguments instead of re-deriving them (see _capi.py)
         self.use_tape = os.environ.get('NLT_TAPE', '1') != '0'
         # backward, one observation per frame: the per-level LeakyReLU' / observation-mean adjoint pass folded into the
@@ -731,10 +731,12 @@ class RenderPlan:
         chain -- the critical path -- carries on; `backward` joins the streams at the end."""
         bs = self._bside
         if bs is not None and bs[2] is not None:
-            side, events, cur = bs
+            side, events, cur = bs[:3]
             if cur[0] == len(events):
                 events.append(torch.cuda.Event())
             ev = events[cur[0]]
+            if len(bs) > 3 and bs[3] is not None and cur[0] % 2:            # two weight-gradient streams, dealt alternately
+                side = bs[3]                                                # (scratch is per stream: _capi's wgrad workspaces)
             cur[0] += 1
             C.record_event(ev, torch.cuda.current_stream())
             with torch.cuda.stream(side):
@@ -878,18 +880,23 @@ class RenderPlan:
         concurrent = self.bwd_streams and dpred.is_cuda and self.timer is None
         if concurrent:
             if self._bside is None:
-                self._bside = [torch.cuda.Stream(device=dpred.device), [], None]
+                self._bside = [torch.cuda.Stream(device=dpred.device), [], None,
+                               torch.cuda.Stream(device=dpred.device) if self.bwd_streams > 1 else None]
             self._bside[2] = [0]                                     # event cursor: weight gradients go to the side stream
         try:
             self._backward_plan(dpred, base, cvis, lvis, nn_rgb, nn_base, obs_weights, b, g, n, h, w, k)
         finally:
             if concurrent:
-                side, events, cur = self._bside
+                side, events, cur, side2 = self._bside
                 self._bside[2] = None
-                if cur[0] == len(events):
-                    events.append(torch.cuda.Event())
-                C.record_event(events[cur[0]], side)
-                C.wait_event(torch.cuda.current_stream(), events[cur[0]])   # the optimizer step needs every gradient
+                for sd in (side, side2):
+                    if sd is None:
+                        continue
+                    if cur[0] == len(events):
+                        events.append(torch.cuda.Event())
+                    C.record_event(events[cur[0]], sd)
+                    C.wait_event(torch.cuda.current_stream(), events[cur[0]])   # the optimizer step needs every gradient
+                    cur[0] += 1
 
     def _backward_plan(self, dpred, base, cvis, lvis, nn_rgb, nn_base, obs_weights, b, g, n, h, w, k):
         q, o, D, U, cl = self.q, self.o, self.n_down, self.n_up, b['C']
@@ -965,6 +972,13 @@ class RenderPlan:
         # every weight gradient of the expanding blocks is queued now: the leading range of the flat gradient
         # bucket (models/nlt.py:_flatten) can start its all-reduce while the encoder's backward runs
         bs = self._bside
+        if bs is not None and bs[2] is not None and bs[3] is not None:
+            side, events, cur, side2 = bs                            # (two weight-gradient streams: the hook's stream waits for the other)
+            if cur[0] == len(events):
+                events.append(torch.cuda.Event())
+            C.record_event(events[cur[0]], side2)
+            C.wait_event(side, events[cur[0]])
+            cur[0] += 1
         C.tape_call(self._fire_grad_hook, bs[0] if (bs is not None and bs[2] is not None) else None)
 
         # ---- encoder (contracting blocks), deepest first; hh, ww = dims of level D

@@ -159,13 +159,15 @@ def test_rccl_two_bucket_overlapped_step_equals_the_single_rank_step(monkeypatch
         dist.destroy_process_group()
 
 
-def test_overlapped_bucket_collective_runs_on_the_weight_gradient_stream_in_replayed_steps_too(monkeypatch):
+@pytest.mark.parametrize('wgrad_streams', [1, 2])
+def test_overlapped_bucket_collective_runs_on_the_weight_gradient_stream_in_replayed_steps_too(monkeypatch, wgrad_streams):
     """The first-range gradient collective is started by a hook recorded INSIDE the backward plan.  It has to be queued on
     the stream the expanding blocks' weight-gradient launches run on (the side stream) -- also when the step is a launch-tape
     replay, where no plan is being issued and the side-stream cursor does not exist.  A stand-in collective that is NOT an
     identity (in-place x2 on the stream it is called on, completion = an event on that stream) makes a misplaced hook
     visible: on the main stream it would double half-accumulated sums.  overlap=True must match overlap=False, and every
-    first-range call of an overlapped step must sit on the side stream."""
+    first-range call of an overlapped step must sit on the side stream.  wgrad_streams = 2: the weight gradients dealt to two
+    side streams alternately (NLT_BWD_STREAMS=2); the hook's stream then waits for the other one first."""
     import torch.distributed as dist
 
     class Work:
@@ -191,6 +193,7 @@ def test_overlapped_bucket_collective_runs_on_the_weight_gradient_stream_in_repl
     for overlap in (False, True):
         _, pm = make_pair(depth=256, uv=128, im=64, loss='l2', seed=13)
         pm.build('cuda')
+        pm.plan.bwd_streams = wgrad_streams
         opt = nlt_amd.optim.AdamAMSGrad(pm, 1e-3)
         del calls[:]
         grads = []
@@ -203,7 +206,7 @@ def test_overlapped_bucket_collective_runs_on_the_weight_gradient_stream_in_repl
     assert replays > 0 and bside is not None
     main = torch.cuda.current_stream().cuda_stream
     side = bside[0].cuda_stream
-    assert side != main
+    assert side != main and (bside[3] is not None) == (wgrad_streams == 2)
     first = [st for n, st in c1 if n == split]
     assert len(first) == 8 and all(st == side for st in first), (first, side, main)      # replayed steps included
     assert all(st == main for n, st in c0)                                              # overlap=False: after the backward
