@@ -342,6 +342,12 @@ def set_workspace_scope(token):
     _tls.scope = token if _WS_SCOPE else 0
 
 
+def drop_workspace_scope(token):
+    """Forgets the scratch cached for a plan that is gone (RenderPlan.__del__: the lanes of a closed pipeline)."""
+    for key in [k for k in _splitk_ws if len(k) > 2 and k[2] == token]:
+        del _splitk_ws[key]
+
+
 def set_thread_native_replay(on):
     """This host thread replays its launch tapes through nlt_tape_play (one C call per run of launches, the interpreter lock
     released for all of it): what lets the lanes of pipeline.RenderPipeline enqueue in parallel."""

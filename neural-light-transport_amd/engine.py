@@ -105,6 +105,12 @@ class RenderPlan:
         assert self.n_down == self.n_up
         self._bufs = {}
 
+    def __del__(self):
+        try:
+            C.drop_workspace_scope(id(self))    # split-K scratch cached under this plan's identity (an id may be reused)
+        except Exception:
+            pass
+
     # ------------------------------------------------------------------ buffers
     def _buffers(self, n, k, h, w, device):
         key = (n, k, h, w, str(device), self.precision)
