@@ -448,6 +448,28 @@ def bench_f32_split(args, device, native, batches):
     return out
 
 
+def bench_f32_split_pipelined(args, device, native, batches, lanes=4):
+    """`precision = f32x3` AND several batches in flight: the two sub-line levers together (same weights and batches)."""
+    import torch
+    import nlt_amd
+    from nlt_amd.models import get_model_class
+    cfg = nlt_amd.make_config(depth=args.depth, uvh=args.uv, uvw=args.uv, imh=args.cam, imw=args.cam, bs=args.frames, precision='f32x3')
+    model = get_model_class('nlt')(cfg).build(device)
+    model.register_trainable()
+    with torch.no_grad():
+        model.flat_params.copy_(native.flat_params)
+    model.mark_weights_updated()
+    d1 = time_forward(model, batches, 40)
+    dp, first = time_pipelined(model, batches, max(40, args.steps // 2), lanes, single=d1)
+    rec = {"lanes": lanes, "one_batch_at_a_time_ms_per_step": round(1e3 * d1, 4), "ms_per_step": round(1e3 * dp, 4),
+           "Mtexels_per_s": round(args.frames * args.uv * args.uv / dp / 1e6, 1)}
+    if first is not None:
+        rec["first_try_ms_per_step"] = round(1e3 * first, 4)
+    del model
+    torch.cuda.empty_cache()
+    return rec
+
+
 def parity_record(keys):
     """The newest committed HIP-vs-oracle figures for these test ids (profiles/*_parity_sizes.json, written by the -m gpu
     tests under NLT_PARITY_DUMP); bench.py itself never runs the oracle outside its cpu_baseline leg."""
@@ -864,6 +886,11 @@ def main():
         # measured to perturb legs that run after them: config 5 fp32 1.60 -> 1.70 ms)
         if world == 1 and not args.graph and (args.pipelined or not args.headline_only):
             out["pipelined"] = bench_pipelined(args, device, model, batches)
+            if args.precision == 'fp32' and not args.no_fused and not args.headline_only:
+                try:
+                    out["pipelined"]["f32x3_4_lanes"] = bench_f32_split_pipelined(args, device, model, batches)
+                except Exception as e:                                # a sub-sub-line: never take the line with it
+                    out["pipelined"]["f32x3_4_lanes"] = {"error": "%s: %s" % (type(e).__name__, str(e)[:200])}
             if released and args.uv == 1024:
                 out["released_shapes"]["forward_4_frames_pipelined"] = released_pipelined_child(args)
         if world == 1 and not args.no_cpu_baseline and not args.headline_only:
