@@ -129,3 +129,27 @@ def test_native_tape_play_passes_arguments_like_a_direct_call():
     assert segs[0][0] == 'native' and segs[0][2] == 1 and ok is not None
     # entries with double parameters stay Python calls
     assert C._describe(L.nlt_cosine_map, (None,) * 4 + (0.0, 0.0, 0.0, 0, None, None, None)) is None
+
+
+def test_workspace_scope_and_thread_local_tape_bookkeeping():
+    """Host-side state added for pipeline.RenderPipeline: the open launch tape belongs to the thread that opened it, the
+    split-K scratch cache is keyed per plan (scope token) and forgotten with the plan."""
+    import threading
+    from nlt_amd import capi as C
+    C.tape_begin()
+    seen = []
+
+    def other():
+        seen.append(getattr(C._tls, 'tape', None))          # another thread: no tape open
+        C.tape_begin(); C.tape_call(lambda: None); seen.append(len(C._tls.tape)); C.tape_abort()
+    th = threading.Thread(target=other); th.start(); th.join()
+    C.tape_call(lambda: None)
+    t = C.tape_end('tag')
+    assert seen == [None, 1] and len(t[0]) == 1 and C.tape_valid(t, 'tag') and not C.tape_valid(t, 'other')
+    C.set_workspace_scope(1234)
+    assert C._tls.scope == (1234 if C._WS_SCOPE else 0)
+    C._splitk_ws[('dev', 1, 1234)] = object(); C._splitk_ws[('dev', 1, 99)] = object()
+    C.drop_workspace_scope(1234)
+    assert ('dev', 1, 1234) not in C._splitk_ws and ('dev', 1, 99) in C._splitk_ws
+    del C._splitk_ws[('dev', 1, 99)]
+    C.set_workspace_scope(0)
