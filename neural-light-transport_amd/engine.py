@@ -322,22 +322,30 @@ class RenderPlan:
         for b in self._bufs.values():
             b.pop('tapes', None)
 
-    def save_tuning(self, path):
-        import json
-        with open(path, 'w') as f:
-            json.dump({'tile_hints': self.tile_hints, 'algo_hints': self.algo_hints, 'lds_hints': self.lds_hints,
-                       'splitk_hints': self.splitk_hints}, f)
+    def export_tuning(self):
+        """The plan-time choices (wave tiles, direct / LDS-tiled kernel, split-K slices per launch label) as one dict."""
+        return {'tile_hints': dict(self.tile_hints), 'algo_hints': dict(self.algo_hints), 'lds_hints': dict(self.lds_hints),
+                'splitk_hints': dict(self.splitk_hints)}
 
-    def load_tuning(self, path):
-        """Re-uses tile choices measured by an earlier run (skips the plan-time trials)."""
-        import json
-        with open(path) as f:
-            d = json.load(f)
+    def import_tuning(self, d):
+        """Takes another plan's (or an earlier run's) choices and skips the plan-time trials: two plans with the same
+        choices issue the same kernels with the same summation orders."""
         self.tile_hints.update(d['tile_hints']); self.algo_hints.update(d['algo_hints'])
         self.lds_hints.update(d.get('lds_hints', {}))
         self.splitk_hints.update(d.get('splitk_hints', {}))
         self.autotune = False
         self._drop_tapes()
+
+    def save_tuning(self, path):
+        import json
+        with open(path, 'w') as f:
+            json.dump(self.export_tuning(), f)
+
+    def load_tuning(self, path):
+        """Re-uses tile choices measured by an earlier run (skips the plan-time trials)."""
+        import json
+        with open(path) as f:
+            self.import_tuning(json.load(f))
 
     # ------------------------------------------------------------------ forward
     def can_fuse(self, b, obs_weights, obs_override):

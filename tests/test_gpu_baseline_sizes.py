@@ -80,9 +80,10 @@ def test_config2_512_relight_only_4_frames():
     np.testing.assert_array_equal(vis['pred_camspc'].cpu().numpy(), vis['pred'].cpu().numpy())
 
 
-@pytest.mark.parametrize('n', [1, 2])
+@pytest.mark.parametrize('n', [1, 2, 4])
 def test_config3_1024_k4_random_warp(n):
-    """BASELINE config 3 (the bench workload): depth 256, 1024^2 UV, k = 4 observation maps, 512^2 random fg/bg warp."""
+    """BASELINE config 3 (the bench workload): depth 256, 1024^2 UV, k = 4 observation maps, 512^2 random fg/bg warp.
+    n = 4 is the bench's exact shape (plan-time choices depend on size)."""
     _forward_vs_oracle('config3_1024_k4_n%d' % n, 256, 1024, 512, n, 4, False, seed=3 + n)
 
 
