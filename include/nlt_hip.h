@@ -237,6 +237,15 @@ int nlt_l2_loss_forward(const float* pred, const float* gt, int n, long per_exam
 int nlt_l2_loss_backward(const float* pred, const float* gt, const float* gloss, int n, long per_example,
                          float* dpred, void* stream);
 
+/* losses.L2 with `weights=` (nlt/losses.py:42-43: Keras `sample_weight` on MeanSquaredError(reduction='none')): the per-texel
+ * loss map [n,H,W] (mean over the c channels) is multiplied by weights [n,H,W] before the mean over H,W:
+ * loss[f] = sum_px weights[f,px] * mean_c (gt-pred)^2 / hw.  The host mirror broadcasts the shapes Keras accepts
+ * (scalar, [N,1,1], [N,H,W], [N,H,W,1]) to [n,H,W] first. */
+int nlt_l2_loss_weighted_forward(const float* pred, const float* gt, const float* weights, int n, long hw, int c,
+                                 float* loss, void* stream);
+int nlt_l2_loss_weighted_backward(const float* pred, const float* gt, const float* weights, const float* gloss, int n,
+                                  long hw, int c, float* dpred, void* stream);
+
 /* The l2 train step's loss in one launch (nlt/models/nlt.py:238-245 `gt = rgb_camspc * fg`; losses.L2 keep_batch;
  * trainvali.py:277-278 `sum / global batch`; and the gradient w.r.t. pred): gt = rgb * fg, loss[0] = sum_f mean((pred_f - gt_f)^2)
  * / global_bs, dpred = 2 (pred - gt) / per_example / global_bs.  Same arithmetic as nlt_mul_forward + nlt_l2_loss_forward +

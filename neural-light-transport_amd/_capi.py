@@ -63,6 +63,8 @@ SIGNATURES = {
     'nlt_resize_bilinear_backward': (_c_int, [_vp] + [_c_int] * 6 + [_vp, _vp]),
     'nlt_l2_loss_forward': (_c_int, [_vp, _vp, _c_int, _c_long, _vp, _vp]),
     'nlt_l2_loss_backward': (_c_int, [_vp, _vp, _vp, _c_int, _c_long, _vp, _vp]),
+    'nlt_l2_loss_weighted_forward': (_c_int, [_vp, _vp, _vp, _c_int, _c_long, _c_int, _vp, _vp]),
+    'nlt_l2_loss_weighted_backward': (_c_int, [_vp, _vp, _vp, _vp, _c_int, _c_long, _c_int, _vp, _vp]),
     'nlt_barron_workspace_floats': (_c_long, [_c_int] * 3),
     'nlt_barron_loss': (_c_int, [_vp, _vp, _c_int, _c_int, _c_int, _vp, _vp, _vp, _vp]),
     'nlt_scale_rows': (_c_int, [_vp, _vp, _c_int, _c_long, _vp, _vp]),
@@ -614,6 +616,33 @@ def l2_loss_backward(pred, gt, gloss):
     dpred = torch.empty_like(pred)
     _check(lib().nlt_l2_loss_backward(_ptr(pred), _ptr(gt), _ptr(_dense(gloss, 'gloss')), pred.shape[0],
                                       pred[0].numel(), _ptr(dpred), _stream()), 'nlt_l2_loss_backward')
+    return dpred
+
+
+def l2_loss_weighted_forward(pred, gt, weights):
+    """weights [N,H,W] (already broadcast): loss[f] = mean_hw(weights * mean_c (gt - pred)^2)."""
+    _same_shape(pred, gt, 'l2_loss_weighted_forward')
+    n, c = pred.shape[0], pred.shape[-1]
+    hw = pred[0].numel() // c
+    if weights.numel() != n * hw:
+        raise NLTError("l2_loss_weighted_forward: %d weights for %d texels" % (weights.numel(), n * hw))
+    loss = torch.empty(n, device=pred.device, dtype=torch.float32)
+    _check(lib().nlt_l2_loss_weighted_forward(_ptr(_dense(pred, 'pred')), _ptr(_dense(gt, 'gt')), _ptr(_dense(weights, 'weights')),
+                                              n, hw, c, _ptr(loss), _stream()), 'nlt_l2_loss_weighted_forward')
+    return loss
+
+
+def l2_loss_weighted_backward(pred, gt, weights, gloss):
+    _same_shape(pred, gt, 'l2_loss_weighted_backward')
+    n, c = pred.shape[0], pred.shape[-1]
+    hw = pred[0].numel() // c
+    if gloss.numel() != n or weights.numel() != n * hw:
+        raise NLTError("l2_loss_weighted_backward: %d loss gradients, %d weights for %d examples of %d texels"
+                       % (gloss.numel(), weights.numel(), n, hw))
+    dpred = torch.empty_like(pred)
+    _check(lib().nlt_l2_loss_weighted_backward(_ptr(_dense(pred, 'pred')), _ptr(_dense(gt, 'gt')), _ptr(_dense(weights, 'weights')),
+                                               _ptr(_dense(gloss, 'gloss')), n, hw, c, _ptr(dpred), _stream()),
+           'nlt_l2_loss_weighted_backward')
     return dpred
 
 

@@ -359,6 +359,8 @@ extern "C" int nlt_conv_tile_backward_data(int adj_mode, const float* dpre, int 
   }
   p.cout = cout; p.ldo = ldo; p.ldm = 0; p.ld_mask = ldm; p.ncc = cpre / 16; p.act = 0; p.alpha = mask_alpha;
   p.mask_src = mask_src; p.accumulate = accumulate;
-  p.tiles_y = (p.oh + TH - 1) / TH; p.tiles_x = (p.ow + TW - 1) / TW;
+  // the transposed k2s2 mode tiles the INPUT grid (a workgroup's 8 x 16 input texels own their 16 x 32 outputs)
+  const int gh = adj_mode == NLT_DECONV_K2S2 ? h : p.oh, gw = adj_mode == NLT_DECONV_K2S2 ? w : p.ow;
+  p.tiles_y = (gh + TH - 1) / TH; p.tiles_x = (gw + TW - 1) / TW;
   return tile_run(adj_mode, p, tn, static_cast<hipStream_t>(stream));
 }

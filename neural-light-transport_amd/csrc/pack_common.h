@@ -72,3 +72,29 @@ __device__ __forceinline__ float nlt_tile_fragment_d2(const float* __restrict__ 
   const int ab = col / cout, o = col - ab * cout;
   return wk[((long)ab * full + lo + o) * cin + c];
 }
+
+// Winograd F(2x2, 2x2) kernel (conv_wino.hip): [g = N / TN][c8 = K / 8][position 9 = (xi, nu)][ct TNT][channel quad 2][column 16][e 4]
+// = U = G g G^T of the executed correlation's 2 x 2 taps g, G = [1 0; 1 1; 0 1]: position (xi, nu) sums the taps (a, b) with
+// a in {0} / {0, 1} / {1} for xi = 0 / 1 / 2 and b likewise for nu.  `transposed` (the Conv2DTranspose k2s1 family: a forward
+// Conv2DTranspose or backward-data of a Conv2D) indexes the Keras array as (kh,kw,N_full,K) and FLIPS the taps:
+// y[i,j] = sum_ab x[i-a,j-b] W[a,b] is the correlation of the window starting at (i-1, j-1) with g[a'][b'] = W[1-a'][1-b'].
+__device__ __forceinline__ float nlt_wino_fragment(const float* __restrict__ wk, long idx, int cin, int cout, int tnt,
+                                                   int full, int lo, bool transposed) {
+  const int e = idx & 3, i = (idx >> 2) & 15, q = (idx >> 6) & 1;
+  long r = idx >> 7;
+  const int ct = r % tnt; r /= tnt;
+  const int ps = r % 9; r /= 9;
+  const int nc8 = cin >> 3;
+  const int c8 = r % nc8;
+  const int g = r / nc8;
+  const int c = c8 * 8 + q * 4 + e;
+  const int o = (g * tnt + ct) * 16 + i;
+  const int xi = ps / 3, nu = ps - 3 * xi;
+  float v = 0.f;
+  for (int a = (xi == 2); a <= (xi != 0); ++a)
+    for (int b = (nu == 2); b <= (nu != 0); ++b) {
+      const int t = transposed ? (1 - a) * 2 + (1 - b) : a * 2 + b;
+      v += transposed ? wk[((long)t * full + lo + o) * cin + c] : wk[((long)t * cin + c) * full + lo + o];
+    }
+  return v;
+}

@@ -270,6 +270,38 @@ __global__ __launch_bounds__(256) void l2_fwd_kernel(const float* __restrict__ p
   if (threadIdx.x == 0) atomicAdd(loss + f, (ws[0] + ws[1] + ws[2] + ws[3]) / (float)per);
 }
 
+// Keras `sample_weight` on MeanSquaredError(reduction='none') (nlt/losses.py:42-43): the [N,H,W] per-texel loss (mean over the
+// c channels) times the weight map wt [N,H,W], then the mean over H,W: loss[f] = sum_px wt[px] * (sum_c d^2 / c) / hw
+__global__ __launch_bounds__(256) void l2w_fwd_kernel(const float* __restrict__ pred, const float* __restrict__ gt,
+                                                      const float* __restrict__ wt, long hw, int c, float* loss) {
+  __shared__ float ws[4];
+  const int f = blockIdx.y;
+  float s = 0.f;
+  for (long px = (long)blockIdx.x * blockDim.x + threadIdx.x; px < hw; px += (long)gridDim.x * blockDim.x) {
+    const long e = (f * hw + px) * c;
+    float m = 0.f;
+    for (int ch = 0; ch < c; ++ch) {
+      const float d = gt[e + ch] - pred[e + ch];
+      m += d * d;
+    }
+    s += wt[f * hw + px] * (m / (float)c);
+  }
+  s = wave_sum(s);
+  if ((threadIdx.x & 63) == 0) ws[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) atomicAdd(loss + f, (ws[0] + ws[1] + ws[2] + ws[3]) / (float)hw);
+}
+
+// dpred = gloss[f] * wt[px] * 2 (pred - gt) / (c hw)
+__global__ __launch_bounds__(256) void l2w_bwd_kernel(const float* __restrict__ pred, const float* __restrict__ gt,
+                                                      const float* __restrict__ wt, const float* __restrict__ gloss,
+                                                      long hw, int c, long total, float* __restrict__ dpred) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const long px = i / c;
+  dpred[i] = gloss[px / hw] * wt[px] * 2.f * (pred[i] - gt[i]) / ((float)c * (float)hw);
+}
+
 // dpred = gloss[f] * 2 (pred - gt) / per
 __global__ __launch_bounds__(256) void l2_bwd_kernel(const float* __restrict__ pred, const float* __restrict__ gt,
                                                      const float* __restrict__ gloss, long per, long total,
@@ -502,6 +534,28 @@ extern "C" int nlt_l2_loss_backward(const float* pred, const float* gt, const fl
   const long total = (long)n * per_example;
   hipLaunchKernelGGL(l2_bwd_kernel, dim3(blocks_for(total)), dim3(256), 0, static_cast<hipStream_t>(stream), pred, gt,
                      gloss, per_example, total, dpred);
+  NLT_CHECK_LAUNCH();
+  return NLT_OK;
+}
+
+extern "C" int nlt_l2_loss_weighted_forward(const float* pred, const float* gt, const float* weights, int n, long hw, int c,
+                                            float* loss, void* stream) {
+  if (!pred || !gt || !weights || !loss || n <= 0 || hw <= 0 || c <= 0) return NLT_ERR_BAD_ARG;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  if (hipMemsetAsync(loss, 0, (size_t)n * sizeof(float), s) != hipSuccess) return NLT_ERR_LAUNCH;
+  long bx = (hw + 255) / 256;
+  if (bx > 48) bx = 48;
+  hipLaunchKernelGGL(l2w_fwd_kernel, dim3((unsigned)bx, (unsigned)n), dim3(256), 0, s, pred, gt, weights, hw, c, loss);
+  NLT_CHECK_LAUNCH();
+  return NLT_OK;
+}
+
+extern "C" int nlt_l2_loss_weighted_backward(const float* pred, const float* gt, const float* weights, const float* gloss, int n,
+                                             long hw, int c, float* dpred, void* stream) {
+  if (!pred || !gt || !weights || !gloss || !dpred || n <= 0 || hw <= 0 || c <= 0) return NLT_ERR_BAD_ARG;
+  const long total = (long)n * hw * c;
+  hipLaunchKernelGGL(l2w_bwd_kernel, dim3(blocks_for(total)), dim3(256), 0, static_cast<hipStream_t>(stream), pred, gt, weights,
+                     gloss, hw, c, total, dpred);
   NLT_CHECK_LAUNCH();
   return NLT_OK;
 }

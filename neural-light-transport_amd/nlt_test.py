@@ -51,15 +51,15 @@ def extract_feat(model, datapipe, n_obs_batches=-1):
 def infer(model, datapipe, feat_agg, on_batch=None, lanes=1, threads=False):
     """nlt_test.py:78-94: renders every test batch with the aggregated observation features; returns the list of
     `to_vis` dicts (or hands each to `on_batch(i, to_vis)` -- the reference's model.vis_batch slot).
-    lanes > 1: that many batches in flight on the GPU (pipeline.RenderPipeline; same results, `datapipe` must keep
-    lanes + 1 batches alive; threads: one host thread per lane)."""
+    lanes > 1: that many batches in flight on the GPU (pipeline.RenderPipeline; same results; a `datapipe` that reuses
+    staging buffers needs lanes + 1 slots; threads: one host thread per lane)."""
     if lanes > 1:
         from .pipeline import RenderPipeline
-        pipe = RenderPipeline(model, lanes, threads=threads)
-        if on_batch is not None:
-            pipe.render(datapipe, 'test', on_batch=lambda i, r: on_batch(i, r[3]), obs_override=feat_agg)
-            return []
-        return [r[3] for r in pipe.render(datapipe, 'test', obs_override=feat_agg)]
+        with RenderPipeline(model, lanes, threads=threads) as pipe:      # (lane threads / streams released on the way out)
+            if on_batch is not None:
+                pipe.render(datapipe, 'test', on_batch=lambda i, r: on_batch(i, r[3]), obs_override=feat_agg)
+                return []
+            return [r[3] for r in pipe.render(datapipe, 'test', obs_override=feat_agg)]
     outs = []
     for i, batch in enumerate(datapipe):
         _, _, _, to_vis = model.call(batch, 'test', obs_override=feat_agg)

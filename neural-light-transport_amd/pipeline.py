@@ -25,9 +25,12 @@ chain replays for ~0.07 ms of host time where the two-stream graph and the launc
 copies of the graph's static outputs.  Measured (r03, MI355X, 4 frames per batch): depth 1024 / 256^2 551 -> 1228 Mtexels/s,
 depth 256 / 512^2 2247 -> 3832 Mtexels/s at 4 lanes; the 1024^2 headline shape is GPU-bound and stays on eager launches.
 
-Contract for the inputs: a submitted batch is READ on the lane's stream, so its buffers must stay untouched until that batch's
-ticket has been waited for (`result()`), or until `lanes` further batches have been submitted (submit makes the caller's stream
-wait for the batch issued `lanes` submissions ago): a staging ring (datasets/nlt.py `ring`) needs lanes + 1 slots.
+Contract for the inputs: a submitted batch is READ on the lane's stream.  Its ticket holds a reference to it until `result()`
+and its tensors are `record_stream`ed on the lane's stream, so a loader that hands out fresh tensors per call (tf.data style,
+`ring = 0`) may drop them at once -- the caching allocator will not reuse their blocks early.  What the caller must not do is
+OVERWRITE a submitted batch in place before its ticket has been waited for or `lanes` further batches have been submitted
+(submit makes the caller's stream wait for the batch issued `lanes` submissions ago): a staging ring (datasets/nlt.py `ring`)
+needs lanes + 1 slots.
 Weights must not change while batches are in flight (inference); after an update the next submit drains every lane first.
 Lane 0 is the model itself (except with graphs=True): do not call the model directly while tickets are outstanding."""
 import collections
@@ -52,9 +55,10 @@ def _copy_tuning(dst, src):
 class RenderTicket:
     """One submitted batch.  `result()` orders the caller's current stream after the batch and returns what Model.call returns."""
 
-    def __init__(self):
+    def __init__(self, batch=None):
         self._out = self._done = self._exc = None
         self._tensors = []
+        self._batch = batch                          # kept alive until the batch has been waited for: the lane READS it
         self._queued = threading.Event()             # set once the lane's host thread has issued every launch of the batch
 
     def _set(self, out, done, exc=None):
@@ -76,6 +80,7 @@ class RenderTicket:
             for t in self._tensors:
                 t.record_stream(cur)                 # allocated on the lane's stream, consumed on the caller's
             self._done = None
+        self._batch = None
         return self._out
 
 
@@ -84,6 +89,17 @@ def _own_copies(out, batch):
     inputs = {id(t) for t in batch if torch.is_tensor(t)}
     cp = lambda x: x.clone() if (torch.is_tensor(x) and x.is_cuda and id(x) not in inputs) else x
     return tuple({k: cp(v) for k, v in x.items()} if isinstance(x, dict) else cp(x) for x in out)
+
+
+def _batch_tensors(batch):
+    """Every CUDA tensor a submitted batch is made of (the 11-tuple's tensors; a store-resident batch's id / map tensors)."""
+    found = []
+    for x in batch:
+        if torch.is_tensor(x):
+            found.append(x)
+        elif hasattr(x, '__dict__'):
+            found.extend(v for v in vars(x).values() if torch.is_tensor(v))
+    return [t for t in found if t.is_cuda]
 
 
 def _tensors_of(out):
@@ -106,6 +122,8 @@ class RenderPipeline:
         self._lanes = [model] + [None] * (lanes - 1)        # lane 0 IS the model: its plan tunes, the others copy its choices
         self._streams = [None] * lanes
         self._tuned_ref = [None] * lanes
+        self._switches = [None] * lanes                     # the model plan's switches / hints each lane last copied
+        self._hints = [({}, {}, {}, {})] * lanes
         self._recent = collections.deque()                  # tickets of the last `lanes` submissions
         self._graphs = bool(graphs)
         self._threads = bool(threads) and lanes > 1 and not self._graphs      # (stream capture wants the other host threads quiet)
@@ -121,20 +139,26 @@ class RenderPipeline:
         if i == 0 and not self._graphs:
             return m
         lane = self._lanes[i]
-        if lane is None:
+        new = lane is None
+        if new:
             lane = copy.copy(m)                             # same nets, flat bucket, pack registry
             lane.plan = RenderPlan(m.net['query'], m.net['obs'], m.use_obs)
             lane._graph, lane._graphs = None, {}
             lane.use_graphs = self._graphs
             self._lanes[i] = lane
         lane.conv_algo, lane.skip_connect_base = m.conv_algo, m.skip_connect_base
-        if self._tuned_ref[i] is not getattr(m.plan, 'tuned', None) or lane.plan.precision != m.plan.precision:
-            for a in _PLAN_SWITCHES:
-                setattr(lane.plan, a, getattr(m.plan, a))
+        sw = tuple(getattr(m.plan, a) for a in _PLAN_SWITCHES)
+        hints = (m.plan.tile_hints, m.plan.algo_hints, m.plan.lds_hints, m.plan.splitk_hints)
+        if (new or self._tuned_ref[i] is not getattr(m.plan, 'tuned', None) or self._switches[i] != sw
+                or any(dict(a) != b for a, b in zip(hints, self._hints[i]))):
+            for a in _PLAN_SWITCHES:                        # the model plan's switches and choices, programmatic ones included:
+                setattr(lane.plan, a, getattr(m.plan, a))   # a lane issues exactly the launches Model.call would
             _copy_tuning(lane.plan, m.plan)                 # lane 0's plan-time trials decide for every lane
             self._tuned_ref[i] = getattr(m.plan, 'tuned', None)
-            if self._graphs:
-                lane.plan.two_streams = False               # a linear chain: the cheap kind of graph to launch
+            self._switches[i] = sw
+            self._hints[i] = tuple(dict(a) for a in hints)
+        if self._graphs:
+            lane.plan.two_streams = False                   # a linear chain: the cheap kind of graph to launch
         lane.plan.autotune = False
         return lane
 
@@ -166,7 +190,9 @@ class RenderPipeline:
             with torch.no_grad(), torch.cuda.stream(stream):
                 if ready is not None:
                     stream.wait_event(ready)                # the batch was assembled on the caller's stream
-                out = lane.call(batch, mode, **kw)
+                for t in _batch_tensors(batch):
+                    t.record_stream(stream)                 # a loader that frees the batch early: its blocks are not handed out
+                out = lane.call(batch, mode, **kw)          # again before this lane has read them
                 if self._graphs:
                     out = _own_copies(out, batch)           # the graph's static outputs are rewritten by its next replay
                 done = torch.cuda.Event()
@@ -193,6 +219,13 @@ class RenderPipeline:
         except Exception:
             pass
 
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+        return False
+
     # -------------------------------------------------------------- submit / collect
     def submit(self, batch, mode='test', **kw):
         """Queues Model.call(batch, mode, **kw) on the next lane; returns a RenderTicket without waiting for the GPU."""
@@ -201,7 +234,7 @@ class RenderPipeline:
         i = self._next % self.n
         probe = next((t for t in batch if torch.is_tensor(t)), None)
         dev = probe.device if probe is not None else getattr(batch[1], 'cvis', torch.empty(0)).device
-        ticket = RenderTicket()
+        ticket = RenderTicket(batch)
         if dev.type != 'cuda':                              # host tests: lanes are a launch-scheduling matter, nothing to overlap
             self._next += 1
             ticket._set(self._lane(i).call(batch, mode, **kw), None)
@@ -255,10 +288,15 @@ class RenderPipeline:
                 on_batch(j, r)
             else:
                 outs.append(r)
-        for i, batch in enumerate(datapipe):
-            pending.append((i, self.submit(batch, mode, **kw)))
-            if len(pending) > self.n:
+        try:
+            for i, batch in enumerate(datapipe):
+                pending.append((i, self.submit(batch, mode, **kw)))     # (the ticket keeps its batch alive until collected)
+                if len(pending) > self.n:
+                    collect()
+            while pending:
                 collect()
-        while pending:
-            collect()
+        finally:
+            if pending:                                     # a failing batch: let the queued ones finish before their inputs go
+                self.drain()
+                pending.clear()
         return outs

@@ -152,9 +152,14 @@ def charbonnier_nll(w, scale=BARRON_SCALE, log_z=LOG_Z_ALPHA1):
     return torch.sqrt((w / scale) ** 2 + 1.) - 1. + float(np.log(scale) + log_z)
 
 
-def barron_loss(gt, pred, keep_batch=False):
+def barron_loss(gt, pred, keep_batch=False, weights=None):
     """nlt/losses.py:107-118 -> adaptive.py:453-538 (color_space='YUV',
-    representation='CDF9/7', 5 levels, wavelet_scale_base=1 => rescale is a no-op)."""
+    representation='CDF9/7', 5 levels, wavelet_scale_base=1 => rescale is a no-op).
+    weights: gt and pred alpha-blended against zeros first (losses.py:107-110, nlt/util/img.py:74-89)."""
+    if weights is not None:
+        alpha = torch.as_tensor(weights, dtype=gt.dtype)
+        gt = gt * alpha + torch.zeros_like(gt) * (1 - alpha)
+        pred = pred * alpha + torch.zeros_like(pred) * (1 - alpha)
     x = gt - pred                                       # losses.py:111
     n, h, w, c = x.shape
     x = rgb_to_syuv(x)                                  # adaptive.py:478-479

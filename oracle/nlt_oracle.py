@@ -364,10 +364,19 @@ def parse_loss_and_weight(s):
     return s, 1.
 
 
-def l2_loss(gt, pred, keep_batch=False):
+def l2_loss(gt, pred, keep_batch=False, weights=None):
     """nlt/losses.py:39-53: MeanSquaredError(reduction='none') = mean over C, then
-    mean over H,W (per example) or over everything."""
+    mean over H,W (per example) or over everything.  weights = Keras `sample_weight` (losses.py:42-43): multiplies the
+    [N,H,W] per-texel loss map (losses_utils.compute_weighted_loss: a trailing axis of 1 squeezed, a missing trailing
+    axis added, then an ordinary broadcast); reduction='none' does not renormalise by the weight sum."""
     loss = ((gt - pred) ** 2).mean(-1)
+    if weights is not None:
+        wt = torch.as_tensor(weights, dtype=loss.dtype)
+        if wt.dim() == loss.dim() + 1 and wt.shape[-1] == 1:
+            wt = wt[..., 0]
+        elif wt.dim() == loss.dim() - 1:
+            wt = wt[..., None]
+        loss = loss * wt
     return loss.mean(dim=(1, 2)) if keep_batch else loss.mean()
 
 

@@ -396,6 +396,42 @@ def test_l2_loss_and_scale_rows():
     np.testing.assert_allclose(C.scale_rows(d(pred), d(gl)).cpu().numpy(), pred * gl[:, None, None, None], atol=1e-7)
 
 
+@pytest.mark.parametrize('wshape', [(3, 17, 19), (3, 17, 19, 1), (3, 1, 1), ()])
+@pytest.mark.parametrize('keep_batch', [True, False])
+def test_l2_loss_with_sample_weights(wshape, keep_batch):
+    """losses.L2(weights=) = Keras `sample_weight` on the [N,H,W] loss map (nlt/losses.py:42-43): value and gradient
+    w.r.t. pred against the oracle's float64 autograd, for every weight shape Keras broadcasts."""
+    from nlt_amd import losses
+    rng = np.random.default_rng(31)
+    pred = torch.tensor(rng.random((3, 17, 19, 3), dtype=np.float32), requires_grad=True)
+    gt = torch.tensor(rng.random((3, 17, 19, 3), dtype=np.float32))
+    wt = torch.tensor(rng.random(wshape, dtype=np.float32) if wshape else np.float32(0.625))
+    ref = O.l2_loss(gt.double(), pred.double(), keep_batch, weights=wt.double())
+    (gref,) = torch.autograd.grad(ref.sum(), pred)
+    pg = pred.detach().cuda().requires_grad_(True)
+    got = losses.L2()(gt.cuda(), pg, keep_batch=keep_batch, weights=wt.cuda())
+    (ggot,) = torch.autograd.grad(got.sum(), pg)
+    np.testing.assert_allclose(got.detach().cpu().numpy(), ref.detach().numpy(), rtol=2e-6)
+    assert float((ggot.cpu() - gref).norm() / gref.norm()) < 1e-6
+
+
+def test_barron_loss_with_alpha_blend_weights():
+    """losses.Barron(weights=): gt and pred alpha-blended against zeros before the loss (nlt/losses.py:107-110)."""
+    from nlt_amd import losses
+    rng = np.random.default_rng(32)
+    h, w = 32, 48
+    pred = torch.tensor(rng.random((2, h, w, 3), dtype=np.float32), requires_grad=True)
+    gt = torch.tensor(rng.random((2, h, w, 3), dtype=np.float32))
+    alpha = torch.tensor((rng.random((2, h, w, 1)) > 0.3).astype(np.float32) * rng.random((2, h, w, 1), dtype=np.float32))
+    ref = B.barron_loss(gt.double(), pred.double(), keep_batch=True, weights=alpha.double())
+    (gref,) = torch.autograd.grad(ref.sum(), pred)
+    pg = pred.detach().cuda().requires_grad_(True)
+    got = losses.Barron(w, h)(gt.cuda(), pg, keep_batch=True, weights=alpha.cuda())
+    (ggot,) = torch.autograd.grad(got.sum(), pg)
+    np.testing.assert_allclose(got.detach().cpu().numpy(), ref.detach().numpy(), rtol=2e-5)
+    assert float((ggot.cpu() - gref).norm() / gref.norm()) < 1e-4
+
+
 @pytest.mark.parametrize('h,w', [(64, 64), (32, 48), (83, 71), (17, 17)])
 def test_barron_loss_and_grad(h, w):
     rng = np.random.default_rng(h)
