@@ -553,9 +553,10 @@ int nlt_back_forward(const float* x, const float* fm1, const float* skip3, int n
  *   Cout axis) of an array whose sliced axis has `full` entries -- lo = 0, full = cout for a whole kernel.  This is how
  *   backward-data w.r.t. input channels [lo, hi) of a forward layer reads that layer's own array as the adjoint family.
  * kind NLT_REPACK_TILE: dst = what nlt_pack_conv_tile_weights(mode, src, cin = c0, cout, tn) writes.
+ * kind NLT_REPACK_WINO: dst = what nlt_pack_conv_wino_weights[_adjoint](mode, src, cin = c0, cout, tn, full, lo) writes.
  * first_block: exclusive prefix sum of ceil(total / 256) over the table; total_blocks = its grand total.
  */
-typedef enum { NLT_REPACK_MFMA = 0, NLT_REPACK_TILE = 1 } nlt_repack_kind;
+typedef enum { NLT_REPACK_MFMA = 0, NLT_REPACK_TILE = 1, NLT_REPACK_WINO = 2 } nlt_repack_kind;
 typedef struct {
   const float* src;
   float* dst;
@@ -689,6 +690,33 @@ int nlt_conv_backward_data(int adj_mode, int tile_hint, int ksplit, float* works
                            const float* mask_src, int ldm, float mask_alpha, int accumulate,
                            int split_c, const float* split_y, float* split_d, float split_alpha, int split_partial,
                            void* stream);
+
+/* ======================= Winograd F(2x2, 2x2) stride-1 k2 convs (csrc/conv_wino.hip) =======================
+ * The same results as nlt_conv_forward(NLT_CONV_K2S1 / NLT_DECONV_K2S1) / nlt_conv_tile_forward up to fp32 re-association
+ * (nlt/networks/elements.py:26-39: Conv2D / Conv2DTranspose(kernel 2, stride 1, 'same') + bias [+ LeakyReLU]): a 2 x 2 block of
+ * outputs from 9 instead of 16 products per channel pair (Y = A^T[(G g G^T) (.) (B^T d B)]A), exact fp32 products on
+ * v_mfma_f32_16x16x4_f32, fp32 accumulation.  cin % 8 == 0, cout % tn == 0, tn = 32 | 64.
+ *   replaces: the stride-1 conv of every `Sequential[conv(2,n,s2), ..., conv(2,n,s1), ...]` / `[..., deconv(2,n,s1), ...]` block
+ *             of net['query'] / net['obs'].layers (convnet.py:50-76) as Model._call runs it (nlt.py:154-195).
+ * src [frames*kobs, h, w, ld >= cin]; packed = nlt_pack_conv_wino_weights(mode, Keras array, cin, cout, tn)
+ * (nlt_conv_wino_packed_floats floats); out [frames*kobs, h, w, ldo] (may be NULL when only the mean is wanted);
+ * mean_out [frames, h, w, ldm]: mean over the kobs observation frames of a frame, kept in registers (tn = 32, NLT_CONV_K2S1 only:
+ * kobs > 1 or mean_out with tn = 64 returns NLT_ERR_UNSUPPORTED). */
+long nlt_conv_wino_packed_floats(int mode, int cin, int cout, int tn);
+int nlt_pack_conv_wino_weights(int mode, const float* w_keras, int cin, int cout, int tn, float* packed, void* stream);
+int nlt_conv_wino_forward(int mode, const float* src, int ld, int cin, int frames, int kobs, int h, int w,
+                          const float* packed, const float* bias, int cout, int tn,
+                          float* out, int ldo, float* mean_out, int ldm, int act, float alpha, void* stream);
+/* Backward-data on the Winograd kernel: gradient w.r.t. input channels [lo, lo + cout) of a stride-1 k2 layer from the gradient
+ * dpre [n,h,w,ldp >= cpre] w.r.t. its pre-activation output (GradientTape through Conv2D / Conv2DTranspose, nlt/trainvali.py:279);
+ * adj_mode = the adjoint family (NLT_DECONV_K2S1 for a forward Conv2D, NLT_CONV_K2S1 for a forward Conv2DTranspose), packed =
+ * nlt_pack_conv_wino_weights_adjoint(adj_mode, the layer's own Keras array, cpre, cout, tn, full = its input-channel extent, lo).
+ * Epilogue as nlt_conv_tile_backward_data: out (+= when accumulate), then x LeakyReLU'(mask_src) with slope mask_alpha. */
+int nlt_pack_conv_wino_weights_adjoint(int adj_mode, const float* w_keras, int cpre, int cout, int tn, int full, int lo,
+                                       float* packed, void* stream);
+int nlt_conv_wino_backward_data(int adj_mode, const float* dpre, int ldp, int cpre, int n, int h, int w,
+                                const float* packed, int cout, int tn, float* out, int ldo,
+                                const float* mask_src, int ldm, float mask_alpha, int accumulate, void* stream);
 
 /* ======================= LDS-tiled encoder convs (csrc/conv_tile.hip) =======================
  * Same arithmetic as nlt_conv_forward for mode NLT_CONV_K2S2 / NLT_CONV_K2S1 with a single source (bias +

@@ -109,6 +109,13 @@ SIGNATURES = {
     'nlt_conv_tile_forward': (_c_int, [_c_int, _vp, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _vp, _vp, _c_int, _c_int,
                                        _vp, _c_int, _vp, _c_int, _c_int, _c_float, _vp]),
     'nlt_pack_conv_tile_weights_adjoint': (_c_int, [_c_int, _vp, _c_int, _c_int, _c_int, _c_int, _c_int, _vp, _vp]),
+    'nlt_conv_wino_packed_floats': (_c_long, [_c_int] * 4),
+    'nlt_pack_conv_wino_weights': (_c_int, [_c_int, _vp, _c_int, _c_int, _c_int, _vp, _vp]),
+    'nlt_conv_wino_forward': (_c_int, [_c_int, _vp, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _vp, _vp, _c_int, _c_int,
+                                       _vp, _c_int, _vp, _c_int, _c_int, _c_float, _vp]),
+    'nlt_pack_conv_wino_weights_adjoint': (_c_int, [_c_int, _vp, _c_int, _c_int, _c_int, _c_int, _c_int, _vp, _vp]),
+    'nlt_conv_wino_backward_data': (_c_int, [_c_int, _vp, _c_int, _c_int, _c_int, _c_int, _c_int, _vp, _c_int, _c_int, _vp, _c_int,
+                                             _vp, _c_int, _c_float, _c_int, _vp]),
     'nlt_conv_tile_backward_data': (_c_int, [_c_int, _vp, _c_int, _c_int, _c_int, _c_int, _c_int, _vp, _c_int, _c_int, _vp, _c_int,
                                              _vp, _c_int, _c_float, _c_int, _c_int, _vp, _vp, _c_float, _c_int, _vp]),
     'nlt_conv_tile3_packed_elems': (_c_long, [_c_int] * 4),
@@ -821,7 +828,7 @@ def conv_backward_data(adj_mode, dpre, cpre, ldp, n, h, w, w_packed, zero_bias, 
 
 
 # ---------------------------------------------------------------- one-launch refresh of all packed weights
-REPACK_MFMA, REPACK_TILE = 0, 1
+REPACK_MFMA, REPACK_TILE, REPACK_WINO = 0, 1, 2
 REPACK_FIELDS = [('src', 'u8'), ('dst', 'u8'), ('total', 'i8'), ('first_block', 'i8'), ('kind', 'i4'), ('mode', 'i4'),
                  ('c0', 'i4'), ('c1', 'i4'), ('cout', 'i4'), ('tn', 'i4'), ('lo', 'i4'), ('full', 'i4')]   # = nlt_repack_desc
 
@@ -864,6 +871,40 @@ def conv_tile_forward(mode, src, ld, cin, frames, kobs, h, w, packed, bias, cout
     _check(lib().nlt_conv_tile_forward(mode, _ptr(src), ld, cin, frames, kobs, h, w, _ptr(packed), _ptr(bias), cout, tn,
                                        _ptr(out), ldo, _ptr(mean_out), ldm, 1 if act else 0, float(alpha), _stream()),
            'nlt_conv_tile_forward')
+
+
+# ---------------------------------------------------------------- Winograd stride-1 k2 convs (csrc/conv_wino.hip)
+def conv_wino_supported(mode, cin, cout, tn):
+    return lib().nlt_conv_wino_packed_floats(mode, cin, cout, tn) > 0
+
+
+def pack_conv_wino_weights(mode, w_keras, cin, cout, tn, full=None, lo=0):
+    """G g G^T fragments of a stride-1 k2 kernel; full / lo: the ADJOINT family read from a layer's own array (columns = that
+    layer's input channels [lo, lo + cout) of `full`)."""
+    n = lib().nlt_conv_wino_packed_floats(mode, cin, cout, tn)
+    if n <= 0:
+        raise NLTError("conv_wino: unsupported (mode %d, cin %d, cout %d, tn %d)" % (mode, cin, cout, tn))
+    out = torch.empty(n, device=w_keras.device, dtype=torch.float32)
+    if full is None:
+        _check(lib().nlt_pack_conv_wino_weights(mode, _ptr(_dense(w_keras, 'w_keras')), cin, cout, tn, _ptr(out), _stream()),
+               'nlt_pack_conv_wino_weights')
+    else:
+        _check(lib().nlt_pack_conv_wino_weights_adjoint(mode, _ptr(_dense(w_keras, 'w_keras')), cin, cout, tn, full, lo, _ptr(out),
+                                                        _stream()), 'nlt_pack_conv_wino_weights_adjoint')
+    return out
+
+
+def conv_wino_forward(mode, src, ld, cin, frames, kobs, h, w, packed, bias, cout, tn, out, ldo, mean_out, ldm, act=True, alpha=0.3):
+    _check(lib().nlt_conv_wino_forward(mode, _ptr(src), ld, cin, frames, kobs, h, w, _ptr(packed), _ptr(bias), cout, tn,
+                                       _ptr(out), ldo, _ptr(mean_out), ldm, 1 if act else 0, float(alpha), _stream()),
+           'nlt_conv_wino_forward')
+
+
+def conv_wino_backward_data(adj_mode, dpre, cpre, ldp, n, h, w, packed, cout, tn, out, ldo, mask_src=None, ldm=0, mask_alpha=0.3,
+                            accumulate=False):
+    _check(lib().nlt_conv_wino_backward_data(adj_mode, _ptr(dpre), ldp, cpre, n, h, w, _ptr(packed), cout, tn, _ptr(out), ldo,
+                                             _ptr(mask_src), ldm, float(mask_alpha), 1 if accumulate else 0, _stream()),
+           'nlt_conv_wino_backward_data')
 
 
 # ---------------------------------------------------------------- bf16 middle of the network

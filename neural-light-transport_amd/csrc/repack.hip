@@ -23,7 +23,8 @@ __global__ __launch_bounds__(256) void repack_all_kernel(const nlt_repack_desc* 
   const long idx = ((long)blockIdx.x - e.first_block) * 256 + threadIdx.x;
   if (idx >= e.total) return;
   float v;
-  if (e.kind == NLT_REPACK_TILE && e.mode == NLT_DECONV_K2S2) v = nlt_tile_fragment_d2(e.src, idx, e.c0, e.cout, e.tn >> 4, e.full, e.lo);
+  if (e.kind == NLT_REPACK_WINO) v = nlt_wino_fragment(e.src, idx, e.c0, e.cout, e.tn >> 4, e.full, e.lo, e.mode == NLT_DECONV_K2S1);
+  else if (e.kind == NLT_REPACK_TILE && e.mode == NLT_DECONV_K2S2) v = nlt_tile_fragment_d2(e.src, idx, e.c0, e.cout, e.tn >> 4, e.full, e.lo);
   else if (e.kind == NLT_REPACK_TILE)
     v = nlt_tile_fragment(e.src, idx, e.c0, e.cout, e.tn >> 4, e.full, e.lo, e.mode == NLT_DECONV_K2S1 || e.mode == NLT_DECONV_K2S2);
   else if (e.mode == NLT_CONV1X1) v = frag<NLT_CONV1X1>(e, idx);

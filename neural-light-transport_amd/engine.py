@@ -96,6 +96,11 @@ class RenderPlan:
         self._ran_lds = set()
         self.lds_tn128 = os.environ.get('NLT_LDS_TN128', '0') != '0'   # opt-in trials: k2s2 launches with 128 channels per workgroup (faster alone, slower beside the other stream's launch)
         self.lds_hints = {}             # label -> tn (32 / 64) [+256: observations unfolded]: launches that go to csrc/conv_tile.hip
+        # Winograd F(2x2, 2x2) kernel for the stride-1 k2 convs (csrc/conv_wino.hip: 9/16 of the matrix-pipe work); 0 = never
+        self.use_wino = os.environ.get('NLT_WINO', '1') != '0'
+        self._trial_wino = 0            # autotune: try it with this many output channels per workgroup
+        self._ran_wino = set()
+        self.wino_hints = {}            # label -> tn (32 / 64) [+256: observations unfolded]: launches that go to csrc/conv_wino.hip
         self._trial_splitk = 0          # autotune: K slices to try on the small deep launches
         self._ran_splitk = set()
         self.splitk_hints = {}          # label -> K slices (split-K, csrc/conv_mfma.hip) for launches with few GEMM rows
@@ -173,6 +178,8 @@ class RenderPlan:
         flops = 2 * rows * taps * (c0 + c1) * ncols
         if tile_hint and ((ncols + 15) // 16) % (tile_hint & 15):
             tile_hint = 0                # CT must divide the number of 16-column tiles
+        if c1 == 0 and ok and self._wino(label, layer, act, src0, c0, ld0, n, 1, h, w, out, ldo, None, 0, flops):
+            return
         ks = self.splitk_hints.get(label, 1)
         if self._trial_splitk and ok:
             rt, ct = (tile_hint >> 4, tile_hint & 15) if tile_hint else (1, 1)
@@ -189,6 +196,34 @@ class RenderPlan:
                        layer.packed(c0, c1) if ok else None, layer.bias.detach(), layer.n_ch_out, out, ldo,
                        act=act is not None, alpha=act.alpha if act is not None else 0.0,
                        algo=algo if ok else C.ALGO_DIRECT, tile_hint=tile_hint if ok else 0, flops=flops)
+
+    def _wino(self, label, layer, act, src, cin, ld, frames, kobs, h, w, out, ldo, mean_out, ldm, flops, obs_weights=None):
+        """The launch on the Winograd kernel if the plan (or the running trial) gave it to it; False otherwise.
+        tn = 32 keeps the observation mean in registers; tn = 64 (or +256) runs the observations as frames and the mean in
+        its own launch."""
+        hint = self._trial_wino or self.wino_hints.get(label, 0)
+        tn, unfold = hint & 255, bool(hint >> 8) or (hint & 255) == 64
+        if not (tn and self.use_wino and obs_weights is None and layer.mode in (C.CONV_K2S1, C.DECONV_K2S1) and layer.cin == cin
+                and cin % 8 == 0 and layer.n_ch_out % tn == 0 and ld % 4 == 0 and ldo % 4 == 0):
+            return False
+        if layer.mode == C.DECONV_K2S1 and (kobs > 1 or mean_out is not None):
+            return False
+        if kobs == 1 and mean_out is None:
+            if self._trial_wino >> 8:
+                return False                            # nothing to unfold here: leave this launch to the other trials
+            unfold = False
+        nf = frames * kobs
+        c = layer.n_ch_out
+        fold_mean = mean_out is not None and not unfold
+        nbytes = 4 * nf * h * w * (cin + c) + (4 * frames * h * w * c * (kobs + 1) if fold_mean else 0)
+        self._ran_wino.add(label)
+        self._launch(label, nbytes, C.conv_wino_forward, layer.mode, src, ld, cin, nf if unfold else frames, 1 if unfold else kobs,
+                     h, w, layer.packed_wino(tn), layer.bias.detach(), c, tn, out, ldo, mean_out if fold_mean else None, ldm,
+                     act=act is not None, alpha=act.alpha if act is not None else 0.0, flops=flops)
+        if mean_out is not None and unfold:
+            self._launch(label.replace('.s1', '.mean'), 4 * frames * h * w * c * (kobs + 1), C.obs_mean_forward,
+                         out, None, frames, kobs, h * w, c, mean_out, ldm)
+        return True
 
     def _conv_bf(self, label, layer, act, src0, c0, ld0, src1, c1, ld1, n, h, w, out, ldo):
         """One conv of the bf16 region (csrc/conv_bf16.hip); sources / output fp32 or bf16 as their tensors are."""
@@ -211,7 +246,11 @@ class RenderPlan:
         observations (label + '.mean' when it needs its own launch).  Goes to the LDS-tiled kernel when the plan
         chose it for this launch, else to the register-tiled MFMA / direct kernels."""
         layer.build(cin, src.device)
-        hint = self._trial_lds or self.lds_hints.get(label, 0)
+        if (algo == C.ALGO_AUTO and layer.mode == C.CONV_K2S1 and (self._trial_wino or label in self.wino_hints)
+                and self._wino(label, layer, act, src, cin, ld, frames, kobs, h, w, out, ldo, mean_out, ldm,
+                               2 * frames * kobs * h * w * 4 * cin * layer.n_ch_out, obs_weights)):
+            return
+        hint = self._trial_lds or (0 if self._trial_wino else self.lds_hints.get(label, 0))
         tn, unfold = hint & 255, bool(hint >> 8)       # +256: observations as separate frames, mean in its own launch
         ok = (tn and obs_weights is None and algo == C.ALGO_AUTO and layer.mode in (C.CONV_K2S2, C.CONV_K2S1)
               and layer.cin == cin and cin % 16 == 0 and layer.n_ch_out % tn == 0)
@@ -270,20 +309,23 @@ class RenderPlan:
                 trials += [('lds', 128), ('lds', 256 + 128)]
         elif self.tile_dgrad:
             trials += [('lds', 32), ('lds', 64)]                  # backward-data launches on the LDS-tiled kernel
+        if self.use_wino:                                           # stride-1 k2 launches on the Winograd kernel
+            trials += [('wino', 32), ('wino', 64)] + ([('wino', 256 + 32)] if not backward else [])
         # split-K: launches with few GEMM rows and a long K (the deep levels; at depth 1024 a 1 x 1-texel level streams 33 MB of
         # weights through 4 rows) need thousands of waves each walking a short K slice to keep HBM busy: up to 128 slices
         mode = os.environ.get('NLT_SPLITK', 'all')                   # 'all' | 'fwd' (forward plans only) | 'off': A/B switch
         if mode == 'all' or (mode == 'fwd' and not backward):
             trials += [('splitk', (16 * r + c, ks)) for (r, c) in ((1, 1), (1, 2), (2, 2), (1, 4)) for ks in (4, 8, 16, 32, 64, 128)]
-        saved_lds, saved_sk = dict(self.lds_hints), dict(self.splitk_hints)
+        saved_lds, saved_sk, saved_wino = dict(self.lds_hints), dict(self.splitk_hints), dict(self.wino_hints)
         for kind, hint in trials:
             self.tile_hints = {'*': hint} if kind == 'tile' else ({'*': hint[0]} if kind == 'splitk' else {})
             self.algo_hints = {}
-            self.lds_hints, self.splitk_hints = {}, {}
+            self.lds_hints, self.splitk_hints, self.wino_hints = {}, {}, {}
             self._trial_direct = kind == 'direct'
             self._trial_lds = hint if kind == 'lds' else 0
+            self._trial_wino = hint if kind == 'wino' else 0
             self._trial_splitk = hint[1] if kind == 'splitk' else 0
-            self._ran_direct, self._ran_lds, self._ran_splitk = set(), set(), set()
+            self._ran_direct, self._ran_lds, self._ran_splitk, self._ran_wino = set(), set(), set(), set()
             self.timer = None
             run()
             self.timer = OpTimer()
@@ -294,11 +336,12 @@ class RenderPlan:
                 if label.endswith('.o.s1') and label.replace('.s1', '.mean') in rec:
                     m = rec[label.replace('.s1', '.mean')]
                     t += m[1] / m[0]        # the LDS kernel folds the mean in: compare like with like
-                if kind == 'tile' or label in self._ran_direct or label in self._ran_lds or label in self._ran_splitk:
+                if (kind == 'tile' or label in self._ran_direct or label in self._ran_lds or label in self._ran_splitk
+                        or label in self._ran_wino):
                     results.setdefault(label, []).append((t, kind, hint))
-        self._trial_direct, self._trial_lds, self._trial_splitk = False, 0, 0
+        self._trial_direct, self._trial_lds, self._trial_splitk, self._trial_wino = False, 0, 0, 0
         self.timer, self.tile_hints, self.algo_hints = saved
-        self.lds_hints, self.splitk_hints = saved_lds, saved_sk
+        self.lds_hints, self.splitk_hints, self.wino_hints = saved_lds, saved_sk, saved_wino
         for label, res in results.items():
             if '.s1' not in label and '.s2' not in label and label != 'L0.q':
                 continue
@@ -308,7 +351,11 @@ class RenderPlan:
             if kind == 'direct':
                 self.algo_hints.setdefault(label, C.ALGO_DIRECT)
             elif kind == 'lds':
-                self.lds_hints.setdefault(label, hint)
+                if label not in self.wino_hints:
+                    self.lds_hints.setdefault(label, hint)
+            elif kind == 'wino':
+                if label not in self.lds_hints:
+                    self.wino_hints.setdefault(label, hint)
             elif kind == 'splitk':
                 if label not in self.tile_hints and label not in self.splitk_hints:
                     self.tile_hints[label], self.splitk_hints[label] = hint
@@ -325,7 +372,7 @@ class RenderPlan:
     def export_tuning(self):
         """The plan-time choices (wave tiles, direct / LDS-tiled kernel, split-K slices per launch label) as one dict."""
         return {'tile_hints': dict(self.tile_hints), 'algo_hints': dict(self.algo_hints), 'lds_hints': dict(self.lds_hints),
-                'splitk_hints': dict(self.splitk_hints)}
+                'splitk_hints': dict(self.splitk_hints), 'wino_hints': dict(self.wino_hints)}
 
     def import_tuning(self, d):
         """Takes another plan's (or an earlier run's) choices and skips the plan-time trials: two plans with the same
@@ -333,6 +380,7 @@ class RenderPlan:
         self.tile_hints.update(d['tile_hints']); self.algo_hints.update(d['algo_hints'])
         self.lds_hints.update(d.get('lds_hints', {}))
         self.splitk_hints.update(d.get('splitk_hints', {}))
+        self.wino_hints.update(d.get('wino_hints', {}))
         self.autotune = False
         self._drop_tapes()
 
@@ -633,7 +681,7 @@ class RenderPlan:
         # never waits for the query path; the query convs of a level only need the previous level's observation mean.
         # With two HIP streams the small deep-level launches of one path fill the CUs the other leaves idle.
         concurrent = (self.two_streams and dev.type == 'cuda' and (self.timer is None or getattr(self.timer, 'only', None) is not None)
-                      and not self._trial_lds and not self._trial_splitk and not self._trial_direct)
+                      and not self._trial_lds and not self._trial_splitk and not self._trial_direct and not self._trial_wino)
         if concurrent:
             if self._side is None:
                 self._side = (torch.cuda.Stream(device=dev), [torch.cuda.Event() for _ in range(D + 3)])
@@ -816,7 +864,15 @@ class RenderPlan:
         flops = 2 * rows * taps * layer.n_ch_out * ncols
         # LDS-tiled kernel (csrc/conv_tile.hip) for the launches the plan-time trials gave to it: the adjoint families it has
         # (CONV_K2S1 / CONV_K2S2 of the expanding blocks, the transposed k2s1 of the encoder's stride-1 convs), no split epilogue
-        tn = (self._trial_lds or self.lds_hints.get(label, 0)) & 255
+        wtn = (self._trial_wino or self.wino_hints.get(label, 0)) & 255
+        if (wtn and self.use_wino and split is None and adj in (C.CONV_K2S1, C.DECONV_K2S1) and layer.n_ch_out % 8 == 0
+                and (hi - lo) % wtn == 0 and ldp % 4 == 0 and ldo % 4 == 0 and layer.kernel.is_contiguous()):
+            self._ran_wino.add(label)
+            self._launch(label, nbytes, C.conv_wino_backward_data, adj, dpre, layer.n_ch_out, ldp, n, oh, ow,
+                         layer.packed_adjoint_wino(lo, hi, wtn), hi - lo, wtn, out, ldo, mask_src=mask_src, ldm=ldm,
+                         mask_alpha=mask_alpha, accumulate=accumulate, flops=flops)
+            return
+        tn = (self._trial_lds or (0 if self._trial_wino else self.lds_hints.get(label, 0))) & 255
         tile_ok = tn and ldp % 4 == 0 and ldo % 4 == 0 and layer.kernel.is_contiguous()
         if tile_ok and adj == C.DECONV_K2S2:                        # transposed k2s2: a GEMM with 4 (hi - lo) columns; takes the split
             tile_ok = layer.n_ch_out % 32 == 0 and (hi - lo) % 16 == 0 and (4 * (hi - lo)) % tn == 0

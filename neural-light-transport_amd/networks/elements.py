@@ -126,6 +126,20 @@ class Conv2D(Layer):
                                  dict(kind=C.REPACK_TILE, mode=self.mode, c0=self.cin, c1=0, cout=self.n_ch_out, tn=tn, lo=0,
                                       full=self.n_ch_out))
 
+    def packed_wino(self, tn):
+        """G g G^T fragments of a stride-1 k2 kernel for the Winograd kernel (csrc/conv_wino.hip), re-made on weight change."""
+        return self._cached_pack(('wino', tn),
+                                 lambda: C.pack_conv_wino_weights(self.mode, self.kernel.detach(), self.cin, self.n_ch_out, tn),
+                                 dict(kind=C.REPACK_WINO, mode=self.mode, c0=self.cin, c1=0, cout=self.n_ch_out, tn=tn, lo=0,
+                                      full=self.n_ch_out))
+
+    def packed_adjoint_wino(self, lo, hi, tn):
+        """Winograd fragments for backward-data w.r.t. forward input channels [lo, hi): read in place from the layer's own array."""
+        adj = self.ADJOINT[self.mode]
+        return self._cached_pack(('adjwino', lo, hi, tn),
+                                 lambda: C.pack_conv_wino_weights(adj, self.kernel.detach(), self.n_ch_out, hi - lo, tn, self.cin, lo),
+                                 dict(kind=C.REPACK_WINO, mode=adj, c0=self.n_ch_out, c1=0, cout=hi - lo, tn=tn, lo=lo, full=self.cin))
+
     def packed_bf16(self, c0, c1):
         """bf16 MFMA fragments (csrc/conv_bf16.hip) for a (c0 | c1) input split; re-packed when the kernel was rewritten.
         (Inference path: not part of the one-launch PackRegistry refresh.)"""
