@@ -458,7 +458,40 @@ def conv_tile_forward(mode, src, ld, cin, frames, kobs, h, w, packed, bias, cout
         _view(mean_out, frames, oh, ow, cout, ldm).copy_(y.reshape(frames, kobs, oh, ow, cout).mean(1))
 
 
-_TILE = ('pack_conv_tile_weights', 'conv_tile_forward')
+# ------------------------------------------------------------------ Winograd stride-1 k2 convs (TEST-ONLY emulation)
+def pack_conv_wino_weights(mode, w_keras, cin, cout, tn, full=None, lo=0):
+    assert mode in (C.CONV_K2S1, C.DECONV_K2S1) and cin % 8 == 0 and cout % tn == 0 and tn in (32, 64)
+    if full is None:
+        return w_keras
+    return w_keras[:, :, lo:lo + cout, :] if mode == C.DECONV_K2S1 else w_keras[..., lo:lo + cout]     # adjoint family: a slice
+
+
+def conv_wino_forward(mode, src, ld, cin, frames, kobs, h, w, packed, bias, cout, tn, out, ldo, mean_out, ldm, act=True, alpha=0.3):
+    assert (kobs == 1 and mean_out is None) or (tn == 32 and mode == C.CONV_K2S1), "the in-register mean exists at tn = 32 only"
+    nf = frames * kobs
+    x = _view(src, nf, h, w, cin, ld)
+    y = (T.conv2d_transpose_same if mode == C.DECONV_K2S1 else T.conv2d_same)(x, packed, bias[:cout], 1)
+    if act:
+        y = T.leaky_relu(y, alpha)
+    if out is not None:
+        _view(out, nf, h, w, cout, ldo).copy_(y)
+    if mean_out is not None:
+        _view(mean_out, frames, h, w, cout, ldm).copy_(y.reshape(frames, kobs, h, w, cout).mean(1))
+
+
+def conv_wino_backward_data(adj_mode, dpre, cpre, ldp, n, h, w, packed, cout, tn, out, ldo, mask_src=None, ldm=0, mask_alpha=0.3,
+                            accumulate=False):
+    x = _view(dpre, n, h, w, cpre, ldp)
+    y = (T.conv2d_transpose_same if adj_mode == C.DECONV_K2S1 else T.conv2d_same)(x, packed, torch.zeros(cout), 1)
+    o = _view(out, n, h, w, cout, ldo)
+    if accumulate:
+        y = y + o
+    if mask_src is not None:
+        y = y * torch.where(_view(mask_src, n, h, w, cout, ldm) > 0, 1.0, mask_alpha)
+    o.copy_(y)
+
+
+_TILE = ('pack_conv_tile_weights', 'conv_tile_forward', 'pack_conv_wino_weights', 'conv_wino_forward', 'conv_wino_backward_data')
 
 
 def conv_forward_splitk(mode, ksplit, src0, c0, ld0, src1, c1, ld1, n, h, w, w_packed, bias, cout, out, ldo,

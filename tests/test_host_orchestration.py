@@ -181,6 +181,45 @@ def test_lds_tiled_encoder_launches_fold_the_observation_mean(monkeypatch, fused
     assert 'L1.q.s2' not in pm.plan._ran_lds
 
 
+@pytest.mark.parametrize('fused', [False, True])
+@pytest.mark.parametrize('hint', [32, 64, 256 + 32])
+def test_winograd_launches_of_the_plan(monkeypatch, fused, hint):
+    """Plan with every eligible stride-1 k2 launch given to csrc/conv_wino.hip: same result; the 32-channel form folds the
+    observation mean (no '.o.mean' launch), the 64-channel / unfolded forms run the observations as frames and keep it;
+    the expanding blocks' transposed stride-1 convs go there too."""
+    fake_capi.install(monkeypatch)
+    from nlt_amd.engine import OpTimer
+
+    class Rec(OpTimer):
+        def launch(self, label, nbytes, fn, *a, **kw):
+            self.records[label] = [1, 0.0, nbytes]
+            fn(*a, **kw)
+    om, pm = make(256, 64, 32)
+    pm.plan.fuse_ends = fused
+    batch, nn = O.synth_batch(2, 64, 64, 32, 32, 32, 32, k=3, seed=9)
+    with torch.no_grad():
+        ref = om.call(batch, 'test', nn_list=nn)[3]['pred']
+    labels = ['L%d.%s.%s' % (l, p, s) for l in range(1, 13) for p in 'qo' for s in ('s1', 's2')]
+    pm.plan.wino_hints = {lab: hint for lab in labels}
+    pm.plan.timer = Rec()
+    got = pm.call(cpu_batch(batch, nn), 'test')[3]['pred']
+    assert rel_l2(got, ref) < 1e-5
+    rec = pm.plan.timer.records
+    means = sorted(l for l in rec if l.endswith('.o.mean'))
+    ran = pm.plan._ran_wino
+    assert not any(l.endswith('.s2') for l in ran)
+    eligible = [l for l in range(2, 7) if hint & 255 == 32 or l >= 3]       # level 2 has 32 channels: not a multiple of 64
+    assert ran >= {'L%d.o.s1' % l for l in eligible} | {'L%d.q.s1' % l for l in eligible}
+    assert ('L7.q.s1' in ran) and ('L9.q.s1' in ran) == (hint & 255 == 32)   # expanding blocks: 128 / 64 / 32 channels
+    folded = hint == 32
+    want = [] if fused else ['L1.o.mean']
+    if not folded:
+        want = sorted(want + ['L%d.o.mean' % l for l in eligible])
+    if hint == 64:
+        want = sorted(set(want) | {'L2.o.mean'})                              # level 2 stays on the register-tiled kernel + its mean
+    assert means == want, (means, want)
+
+
 def test_nlt_test_orchestration_extract_feat_and_infer(monkeypatch):
     """nlt/nlt_test.py:78-127: observation features averaged over all training frames, then used as obs_override;
     the observation convs are not launched at all during inference."""

@@ -52,6 +52,27 @@ def test_train_step_matches_oracle(monkeypatch, loss, k, uv, cam, im):
             assert float((po.detach() - c.kernel).abs().max()) < 2e-5
 
 
+def test_train_step_with_the_winograd_launches_of_forward_and_backward_data(monkeypatch):
+    """Every eligible stride-1 k2 launch -- forward convs and their backward-data adjoints (weight slices read in place from the
+    layer's own array, mask / accumulate epilogue) -- given to csrc/conv_wino.hip's entry points: same loss and gradient."""
+    fake_capi.install(monkeypatch)
+    om, pm = make(256, 64, 32, loss='l2')
+    pm.build('cpu'); pm.register_trainable()
+    pm.plan.autotune = False
+    pm.plan._trial_wino = 32
+    batch, nn = O.synth_batch(2, 64, 64, 32, 32, 32, 32, k=1, seed=12)
+    opt_o = O.KerasAdamAMSGrad(om.parameters(), 1e-3)
+    opt_p = nlt_amd.optim.AdamAMSGrad(pm, 1e-3)
+    lo, go = O.train_step(om, opt_o, batch, global_bs=2, nn_list=nn)
+    lp, _ = trainvali.distributed_train_step(pm, cpu_batch(batch, nn), opt_p, global_bs=2)
+    assert abs(float(lp) - float(lo)) <= 1e-5 * max(1.0, abs(float(lo)))
+    ref = flat_oracle_grads(om, pm, go)
+    assert float((pm.flat_params.grad - ref).norm() / ref.norm()) < 2e-4
+    ran = pm.plan._ran_wino
+    assert {'L3.q.s1', 'L3.o.s1', 'L7.q.s1', 'bwd.L3.q.s1.dgrad', 'bwd.L3.o.s1.dgrad', 'bwd.L7.q.s1.dgrad'} <= ran, sorted(ran)
+    assert not any('.s2' in l for l in ran)
+
+
 def test_vali_step_and_no_grad_paths(monkeypatch):
     fake_capi.install(monkeypatch)
     om, pm = make(256, 64, 32, loss='l2')
