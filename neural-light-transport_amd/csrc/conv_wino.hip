@@ -54,7 +54,9 @@ __global__ void pack_wino_kernel(const float* __restrict__ wk, int cin, int cout
   wp[idx] = nlt_wino_fragment(wk, idx, cin, cout, tnt, full, lo, transposed != 0);
 }
 
-template <bool TR, int TNT, bool MEAN>
+// ABL (measurement only, NLT_WINO_ABL): 1 = the window loads of stage 0 are reused for every stage, 2 = likewise the weight
+// loads, 3 = both, 4 = no MFMAs (operands kept live), 5 = no loads and no LDS stores after stage 0 -- wrong results, right timing.
+template <bool TR, int TNT, bool MEAN, int ABL = 0>
 __global__ __launch_bounds__(256, 2) void conv_wino_kernel(WinoP p) {
   constexpr int RT = 2, CT = TNT / 2;                                  // waves 2 (block rows) x 2 (column tiles)
   constexpr int U_SLOTS = 9 * TNT * 2 * 16;
@@ -90,6 +92,7 @@ __global__ __launch_bounds__(256, 2) void conv_wino_kernel(WinoP p) {
   f32x4 rg[9];                                                         // stage in flight: the window (waves 0-1) / 9 weight slots (waves 2-3)
   auto load_stage = [&](int q) {
     const int i = q / p.nc8, c8 = q - i * p.nc8;
+    if (ABL && q > 0 && ((vrole && (ABL == 1 || ABL == 3 || ABL == 5)) || (!vrole && (ABL == 2 || ABL == 3 || ABL == 5)))) return;
     if (vrole) {
       const float* sp = p.src + (long)(f * p.kobs + i) * in_frame * p.ld + c8 * 8 + bq * 4;
 #pragma unroll
@@ -167,7 +170,8 @@ __global__ __launch_bounds__(256, 2) void conv_wino_kernel(WinoP p) {
         for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
           for (int ct = 0; ct < CT; ++ct)
-            acc[ps][rt][ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[ct][s], bf[rt][s], acc[ps][rt][ct], 0, 0, 0);
+            if (ABL == 4) { asm volatile("" :: "v"(af[ct][s]), "v"(bf[rt][s])); acc[ps][rt][ct][0] += 0.f; }
+            else acc[ps][rt][ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[ct][s], bf[rt][s], acc[ps][rt][ct], 0, 0, 0);
     }
     if ((q + 1) % p.nc8 == 0) {                                        // this (observation) frame is complete: A^T M A, epilogue
       const int i = q / p.nc8;
@@ -221,7 +225,7 @@ __global__ __launch_bounds__(256, 2) void conv_wino_kernel(WinoP p) {
         }
       }
     }
-    if (q + 1 < total_stages) store_stage((q + 1) & 1);
+    if (q + 1 < total_stages && !(ABL == 5 && q > 0)) store_stage((q + 1) & 1);
     __syncthreads();
   }
 }
@@ -231,6 +235,16 @@ int launch_wino(const WinoP& p, hipStream_t s) {
   const long tiles = (long)p.frames * p.tiles_y * p.tiles_x;
   const dim3 grid((unsigned)tiles, (unsigned)(p.cout / (16 * TNT)));
   const bool mean = !TR && TNT == 2 && (p.kobs > 1 || p.mean_out);
+  static const int abl = [] { const char* e = getenv("NLT_WINO_ABL"); return e ? atoi(e) : 0; }();
+  if (abl && !TR && TNT == 4) {
+    if (abl == 1) hipLaunchKernelGGL((conv_wino_kernel<TR, TNT, false, (!TR && TNT == 4) ? 1 : 0>), grid, dim3(256), 0, s, p);
+    else if (abl == 2) hipLaunchKernelGGL((conv_wino_kernel<TR, TNT, false, (!TR && TNT == 4) ? 2 : 0>), grid, dim3(256), 0, s, p);
+    else if (abl == 3) hipLaunchKernelGGL((conv_wino_kernel<TR, TNT, false, (!TR && TNT == 4) ? 3 : 0>), grid, dim3(256), 0, s, p);
+    else if (abl == 4) hipLaunchKernelGGL((conv_wino_kernel<TR, TNT, false, (!TR && TNT == 4) ? 4 : 0>), grid, dim3(256), 0, s, p);
+    else hipLaunchKernelGGL((conv_wino_kernel<TR, TNT, false, (!TR && TNT == 4) ? 5 : 0>), grid, dim3(256), 0, s, p);
+    NLT_CHECK_LAUNCH();
+    return NLT_OK;
+  }
   if (mean) hipLaunchKernelGGL((conv_wino_kernel<TR, TNT, !TR && TNT == 2>), grid, dim3(256), 0, s, p);
   else hipLaunchKernelGGL((conv_wino_kernel<TR, TNT, false>), grid, dim3(256), 0, s, p);
   NLT_CHECK_LAUNCH();

@@ -126,8 +126,9 @@ def test_model_call_with_every_stride1_conv_on_the_winograd_kernel(tn, k, uv):
         p_c, _, _, p_vis = pm.call(db, 'test')
         ran |= pm.plan._ran_wino
     torch.cuda.synchronize()
-    assert any('.o.s1' in l for l in ran) and any('.q.s1' in l for l in ran), ran
-    if tn != 256 + 32:
+    assert any('.o.s1' in l for l in ran), ran
+    if tn != 256 + 32:                                      # (+256 = "observations unfolded": a trial of the observation launches only)
+        assert any('.q.s1' in l for l in ran), ran
         assert any(int(l.split('.')[0][1:]) > pm.plan.n_down for l in ran if l.endswith('.q.s1')), ran   # an expanding block's transposed conv
     assert rel_l2(p_vis['pred'].cpu(), o_vis['pred']) <= 2e-6 and rel_l2(p_c.cpu(), o_c) <= 2e-6
 
