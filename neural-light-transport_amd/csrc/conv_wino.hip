@@ -26,6 +26,10 @@
 #include "nlt_common.h"
 #include "pack_common.h"
 
+int nlt_wino2_run(int mode, const float* src, int ld, int cin, int frames, int kobs, int h, int w, const float* packed,
+                  const float* bias, int cout, int tn, float* out, int ldo, float* mean_out, int ldm, int act, float alpha,
+                  const float* mask_src, int ld_mask, int accumulate, hipStream_t s);      // conv_wino2.hip
+
 namespace {
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
@@ -251,7 +255,16 @@ int launch_wino(const WinoP& p, hipStream_t s) {
   return NLT_OK;
 }
 
+// NLT_WINO_V1=1: the first-generation (register-staged) kernel below for every launch (A/B runs); default = conv_wino2.hip
+bool wino_v1() {
+  static const bool v = [] { const char* e = getenv("NLT_WINO_V1"); return e && e[0] == '1'; }();
+  return v;
+}
+
 int wino_run(int mode, const WinoP& p, int tn, hipStream_t s) {
+  if (!wino_v1())
+    return nlt_wino2_run(mode, p.src, p.ld, p.cin, p.frames, p.kobs, p.h, p.w, p.packed, p.bias, p.cout, tn, p.out, p.ldo, p.mean_out,
+                         p.ldm, p.act, p.alpha, p.mask_src, p.ld_mask, p.accumulate, s);
   if (mode == NLT_CONV_K2S1) return tn == 64 ? launch_wino<false, 4>(p, s) : launch_wino<false, 2>(p, s);
   return tn == 64 ? launch_wino<true, 4>(p, s) : launch_wino<true, 2>(p, s);
 }
@@ -301,7 +314,8 @@ extern "C" int nlt_conv_wino_forward(int mode, const float* src, int ld, int cin
   if (rc != NLT_OK) return rc;
   if (mean_out && (ldm < cout || (ldm & 3) || !nlt_aligned16(mean_out))) return NLT_ERR_BAD_ARG;
   if (!nlt_aligned16(bias)) return NLT_ERR_BAD_ARG;
-  if ((kobs > 1 || mean_out) && (tn != 32 || mode != NLT_CONV_K2S1)) return NLT_ERR_UNSUPPORTED;   // the running mean lives in registers: 32-channel form only
+  if ((kobs > 1 || mean_out) && mode != NLT_CONV_K2S1) return NLT_ERR_UNSUPPORTED;
+  if ((kobs > 1 || mean_out) && tn != 32 && wino_v1()) return NLT_ERR_UNSUPPORTED;     // first generation: the running mean fits at 32 channels only
   WinoP p;
   p.src = src; p.packed = packed; p.bias = bias; p.out = out; p.mean_out = mean_out;
   p.ld = ld; p.cin = cin; p.frames = frames; p.kobs = kobs; p.h = h; p.w = w;

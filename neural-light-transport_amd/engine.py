@@ -98,6 +98,7 @@ class RenderPlan:
         self.lds_hints = {}             # label -> tn (32 / 64) [+256: observations unfolded]: launches that go to csrc/conv_tile.hip
         # Winograd F(2x2, 2x2) kernel for the stride-1 k2 convs (csrc/conv_wino.hip: 9/16 of the matrix-pipe work); 0 = never
         self.use_wino = os.environ.get('NLT_WINO', '1') != '0'
+        self.wino_v1 = os.environ.get('NLT_WINO_V1', '0') == '1'       # A/B: the register-staged first generation
         self._trial_wino = 0            # autotune: try it with this many output channels per workgroup
         self._ran_wino = set()
         self.wino_hints = {}            # label -> tn (32 / 64) [+256: observations unfolded]: launches that go to csrc/conv_wino.hip
@@ -199,10 +200,10 @@ class RenderPlan:
 
     def _wino(self, label, layer, act, src, cin, ld, frames, kobs, h, w, out, ldo, mean_out, ldm, flops, obs_weights=None):
         """The launch on the Winograd kernel if the plan (or the running trial) gave it to it; False otherwise.
-        tn = 32 keeps the observation mean in registers; tn = 64 (or +256) runs the observations as frames and the mean in
-        its own launch."""
+        The observation mean stays in the kernel's registers; +256 runs the observations as frames and the mean in its own
+        launch (always so at 64 channels on the first-generation kernel, NLT_WINO_V1=1)."""
         hint = self._trial_wino or self.wino_hints.get(label, 0)
-        tn, unfold = hint & 255, bool(hint >> 8) or (hint & 255) == 64
+        tn, unfold = hint & 255, bool(hint >> 8) or ((hint & 255) == 64 and self.wino_v1)
         if not (tn and self.use_wino and obs_weights is None and layer.mode in (C.CONV_K2S1, C.DECONV_K2S1) and layer.cin == cin
                 and cin % 8 == 0 and layer.n_ch_out % tn == 0 and ld % 4 == 0 and ldo % 4 == 0):
             return False
@@ -310,7 +311,7 @@ class RenderPlan:
         elif self.tile_dgrad:
             trials += [('lds', 32), ('lds', 64)]                  # backward-data launches on the LDS-tiled kernel
         if self.use_wino:                                           # stride-1 k2 launches on the Winograd kernel
-            trials += [('wino', 32), ('wino', 64)] + ([('wino', 256 + 32)] if not backward else [])
+            trials += [('wino', 32), ('wino', 64)] + ([('wino', 256 + 32), ('wino', 256 + 64)] if not backward else [])
         # split-K: launches with few GEMM rows and a long K (the deep levels; at depth 1024 a 1 x 1-texel level streams 33 MB of
         # weights through 4 rows) need thousands of waves each walking a short K slice to keep HBM busy: up to 128 slices
         mode = os.environ.get('NLT_SPLITK', 'all')                   # 'all' | 'fwd' (forward plans only) | 'off': A/B switch

@@ -467,7 +467,7 @@ def pack_conv_wino_weights(mode, w_keras, cin, cout, tn, full=None, lo=0):
 
 
 def conv_wino_forward(mode, src, ld, cin, frames, kobs, h, w, packed, bias, cout, tn, out, ldo, mean_out, ldm, act=True, alpha=0.3):
-    assert (kobs == 1 and mean_out is None) or (tn == 32 and mode == C.CONV_K2S1), "the in-register mean exists at tn = 32 only"
+    assert (kobs == 1 and mean_out is None) or mode == C.CONV_K2S1
     nf = frames * kobs
     x = _view(src, nf, h, w, cin, ld)
     y = (T.conv2d_transpose_same if mode == C.DECONV_K2S1 else T.conv2d_same)(x, packed, bias[:cout], 1)

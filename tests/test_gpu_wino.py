@@ -29,7 +29,7 @@ def test_conv_wino_vs_oracle(cin, cout, tn, h, w, frames, kobs):
         pre64 = T.conv2d_same(src[..., :cin].double().contiguous(), wk.double(), bias.double(), 1)
         ref = T.leaky_relu(pre64, 0.3)
     packed = C.pack_conv_wino_weights(C.CONV_K2S1, wk.cuda(), cin, cout, tn)
-    fold = tn == 32                                                 # the in-register mean exists in the 32-channel form
+    fold = True                                                     # the running observation mean stays in registers in both forms
     out = torch.full((frames * kobs, h, w, cout + 4), float('nan'), device='cuda')        # ldo = cout + 4
     mean = torch.full((frames, h, w, 2 * cout), float('nan'), device='cuda')              # slice [cout, 2cout) of fm
     if fold:
@@ -38,10 +38,6 @@ def test_conv_wino_vs_oracle(cin, cout, tn, h, w, frames, kobs):
     else:
         C.conv_wino_forward(C.CONV_K2S1, src.cuda(), ld, cin, frames * kobs, 1, h, w, packed, bias.cuda(), cout, tn, out, cout + 4,
                             None, 0, act=True, alpha=0.3)
-        if kobs > 1:
-            with pytest.raises(C.NLTError):
-                C.conv_wino_forward(C.CONV_K2S1, src.cuda(), ld, cin, frames, kobs, h, w, packed, bias.cuda(), cout, tn, out, cout + 4,
-                                    mean.view(-1)[cout:], 2 * cout)
     torch.cuda.synchronize()
     got = out[..., :cout].cpu()
     assert not torch.isnan(got).any() and torch.isnan(out[..., cout:]).all()            # nothing written outside the slice
@@ -112,7 +108,7 @@ def _force_wino(pm, tn=32):
     pm.plan._trial_wino = tn
 
 
-@pytest.mark.parametrize('tn,k,uv', [(32, 3, 128), (64, 3, 128), (256 + 32, 3, 128), (32, 1, 64), (64, 1, 64)])
+@pytest.mark.parametrize('tn,k,uv', [(32, 3, 128), (64, 3, 128), (256 + 32, 3, 128), (256 + 64, 3, 128), (32, 1, 64), (64, 1, 64)])
 def test_model_call_with_every_stride1_conv_on_the_winograd_kernel(tn, k, uv):
     om, pm = make_pair(depth=256, uv=uv, im=64, seed=17)
     batch, nn = O.synth_batch(2, uv, uv, 64, 64, 64, 64, k=k, seed=170 + k)
@@ -127,7 +123,7 @@ def test_model_call_with_every_stride1_conv_on_the_winograd_kernel(tn, k, uv):
         ran |= pm.plan._ran_wino
     torch.cuda.synchronize()
     assert any('.o.s1' in l for l in ran), ran
-    if tn != 256 + 32:                                      # (+256 = "observations unfolded": a trial of the observation launches only)
+    if tn < 256:                                            # (+256 = "observations unfolded": a trial of the observation launches only)
         assert any('.q.s1' in l for l in ran), ran
         assert any(int(l.split('.')[0][1:]) > pm.plan.n_down for l in ran if l.endswith('.q.s1')), ran   # an expanding block's transposed conv
     assert rel_l2(p_vis['pred'].cpu(), o_vis['pred']) <= 2e-6 and rel_l2(p_c.cpu(), o_c) <= 2e-6

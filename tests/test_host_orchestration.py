@@ -182,11 +182,11 @@ def test_lds_tiled_encoder_launches_fold_the_observation_mean(monkeypatch, fused
 
 
 @pytest.mark.parametrize('fused', [False, True])
-@pytest.mark.parametrize('hint', [32, 64, 256 + 32])
+@pytest.mark.parametrize('hint', [32, 64, 256 + 32, 256 + 64])
 def test_winograd_launches_of_the_plan(monkeypatch, fused, hint):
-    """Plan with every eligible stride-1 k2 launch given to csrc/conv_wino.hip: same result; the 32-channel form folds the
-    observation mean (no '.o.mean' launch), the 64-channel / unfolded forms run the observations as frames and keep it;
-    the expanding blocks' transposed stride-1 convs go there too."""
+    """Plan with every eligible stride-1 k2 launch given to the Winograd kernels: same result; the observation mean is folded
+    into the launch (no '.o.mean' launch) unless the hint says 'unfolded' (+256: observations as frames, the mean in its own
+    launch); the expanding blocks' transposed stride-1 convs go there too."""
     fake_capi.install(monkeypatch)
     from nlt_amd.engine import OpTimer
 
@@ -211,11 +211,11 @@ def test_winograd_launches_of_the_plan(monkeypatch, fused, hint):
     eligible = [l for l in range(2, 7) if hint & 255 == 32 or l >= 3]       # level 2 has 32 channels: not a multiple of 64
     assert ran >= {'L%d.o.s1' % l for l in eligible} | {'L%d.q.s1' % l for l in eligible}
     assert ('L7.q.s1' in ran) and ('L9.q.s1' in ran) == (hint & 255 == 32)   # expanding blocks: 128 / 64 / 32 channels
-    folded = hint == 32
+    folded = hint < 256
     want = [] if fused else ['L1.o.mean']
     if not folded:
         want = sorted(want + ['L%d.o.mean' % l for l in eligible])
-    if hint == 64:
+    if hint & 255 == 64:
         want = sorted(set(want) | {'L2.o.mean'})                              # level 2 stays on the register-tiled kernel + its mean
     assert means == want, (means, want)
 

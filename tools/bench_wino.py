@@ -49,8 +49,12 @@ for name, c, res, frames, kobs in cases:
     tw64 = tm = float('nan')
     if c % 64 == 0:
         pw6 = C.pack_conv_wino_weights(C.CONV_K2S1, wk, c, c, 64)
-        tw64 = timeit(lambda: C.conv_wino_forward(C.CONV_K2S1, src, c, c, frames * kobs, 1, res, res, pw6, bias, c, 64, out, c, None, 0))
-        tm = tw64 + (timeit(lambda: C.obs_mean_forward(out, None, frames, kobs, res * res, c, mean, c)) if kobs > 1 else 0.0)
+        try:                                                        # second generation: the observation mean folded at 64 channels too
+            tw64 = timeit(lambda: C.conv_wino_forward(C.CONV_K2S1, src, c, c, frames, kobs, res, res, pw6, bias, c, 64, out, c, mean, c))
+            tm = tw64
+        except C.NLTError:                                          # NLT_WINO_V1=1: observations as frames + the mean in its own launch
+            tw64 = timeit(lambda: C.conv_wino_forward(C.CONV_K2S1, src, c, c, frames * kobs, 1, res, res, pw6, bias, c, 64, out, c, None, 0))
+            tm = tw64 + (timeit(lambda: C.obs_mean_forward(out, None, frames, kobs, res * res, c, mean, c)) if kobs > 1 else 0.0)
     print("%-10s %5d %5d | %9.4f %7.1f | %9.4f %7.1f | %9.4f %7.1f %5.2f | %9.4f %7.1f %5.2f | %9.4f"
           % (name, c, res, 1e3 * t1, flops / t1 / 1e12, 1e3 * t9, flops / t9 / 1e12, 1e3 * tw32, flops / tw32 / 1e12, t1 / tw32,
              1e3 * tw64, flops / tw64 / 1e12, t1 / tw64, 1e3 * tm))
