@@ -228,6 +228,18 @@ def tape_abort():
     _tls.tape = None
 
 
+def tape_pause():
+    """Takes the open tape (if any) away for a launch that must NOT be recorded (its arguments change from step to step);
+    hand the return value back to `tape_resume`."""
+    t = getattr(_tls, 'tape', None)
+    _tls.tape = None
+    return t
+
+
+def tape_resume(t):
+    _tls.tape = t
+
+
 def tape_valid(tape, tag=None):
     return tape is not None and tape[1] == _alloc_epoch[0] and tape[2] == tag
 

@@ -47,6 +47,13 @@ struct WinoP {
   const float* mask_src; int ld_mask; int accumulate;      // backward-data epilogue (nlt_conv_wino_backward_data)
 };
 
+// One ds_read_b64, never fused with a neighbour into ds_read2*_b64 (16-lane groups over 32 banks: the 16 blocks of a row, 16
+// bytes apart, collide two by two -- conv_wino2.hip has the measurement).
+__device__ __forceinline__ f32x2 lds_b64(const char* p) {
+  typedef const volatile __attribute__((address_space(3))) f32x2 lds_f32x2;
+  return *(lds_f32x2*)(__attribute__((address_space(3))) void*)p;
+}
+
 __device__ __forceinline__ int xcd_tile_w(int b, int nblocks) {
   return (nblocks & 7) ? b : (b & 7) * (nblocks >> 3) + (b >> 3);
 }
@@ -164,10 +171,10 @@ __global__ __launch_bounds__(256, 2) void conv_wino_kernel(WinoP p) {
       f32x2 bf[RT], af[CT];
 #pragma unroll
       for (int rt = 0; rt < RT; ++rt)
-        bf[rt] = *reinterpret_cast<const f32x2*>(V + ((ps * BY + wm * RT + rt) * 2 * BX) * 16 + frag);
+        bf[rt] = lds_b64(V + ((ps * BY + wm * RT + rt) * 2 * BX) * 16 + frag);
 #pragma unroll
       for (int ct = 0; ct < CT; ++ct)
-        af[ct] = *reinterpret_cast<const f32x2*>(U + ((ps * TNT + wn * CT + ct) * 2 * 16) * 16 + frag);
+        af[ct] = lds_b64(U + ((ps * TNT + wn * CT + ct) * 2 * 16) * 16 + frag);
 #pragma unroll
       for (int s = 0; s < 2; ++s)
 #pragma unroll

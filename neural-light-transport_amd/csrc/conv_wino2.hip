@@ -33,6 +33,7 @@ constexpr int PLANE = 160;                   // slots per (channel quad, x parit
 constexpr int RAW_SLOTS = 4 * PLANE;         // per 8-channel stage
 constexpr int NRP = RAW_SLOTS / 64;          // raw DMA pieces per stage
 constexpr int RAW_DEPTH = 4, PF = 3;         // ring of raw buffers, stages of prefetch
+constexpr int U_DEPTH = 3;                  // ring of weight buffers (requested two stages ahead)
 
 struct Wino2P {
   const float* src; const float* packed; const float* bias; const float* zeros;
@@ -48,6 +49,15 @@ __device__ __forceinline__ int xcd_tile_w2(int b, int nblocks) {
   return (nblocks & 7) ? b : (b & 7) * (nblocks >> 3) + (b >> 3);
 }
 
+// One ds_read_b64 per call, never fused with a neighbour: hipcc merges two 8-byte LDS loads of a lane into ds_read2_b64 /
+// ds_read2st64_b64, which the LDS services 16 lanes at a time over 32 banks (MI355X_MICROARCH.md, LDS table) -- the 16 blocks of
+// a row, 16 bytes apart, then collide two by two (r04 PMC: SQ_LDS_BANK_CONFLICT = half of SQ_LDS_IDX_ACTIVE).  The plain
+// ds_read_b64 covers 32 lanes x 8 bytes = 256 contiguous bytes per LDS cycle: conflict-free in this layout.
+__device__ __forceinline__ f32x2 lds_b64(const char* p) {
+  typedef const volatile __attribute__((address_space(3))) f32x2 lds_f32x2;
+  return *(lds_f32x2*)(lds_void*)p;
+}
+
 __device__ __forceinline__ void dma16(const float* g, f32x4* l) {
   __builtin_amdgcn_global_load_lds((glb_void*)g, (lds_void*)l, 16, 0, 0);
 }
@@ -58,7 +68,7 @@ __global__ __launch_bounds__(256 * WNW, 2) void conv_wino2_kernel(Wino2P p) {
   constexpr int U_SLOTS = 9 * TNT * 2 * 16, NUP = U_SLOTS / 64;
   constexpr int MR = (NRP + NW - 1) / NW, MU = (NUP + NW - 1) / NW;
   constexpr int U_BASE = RAW_DEPTH * RAW_SLOTS;
-  __shared__ f32x4 lds[U_BASE + 2 * U_SLOTS];
+  __shared__ f32x4 lds[U_BASE + U_DEPTH * U_SLOTS];
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -116,10 +126,6 @@ __global__ __launch_bounds__(256 * WNW, 2) void conv_wino2_kernel(Wino2P p) {
 #pragma unroll
       for (int u = 0; u < 4; ++u) mean[ct][u] = (f32x4){0.f, 0.f, 0.f, 0.f};
   }
-  f32x4 bv[CT];
-#pragma unroll
-  for (int ct = 0; ct < CT; ++ct)
-    bv[ct] = p.bias ? *reinterpret_cast<const f32x4*>(p.bias + (g * TNT + wc * CT + ct) * 16 + 4 * kk) : (f32x4){0.f, 0.f, 0.f, 0.f};
 
   // byte offsets of this lane's LDS reads: window texel (r, sx) of block j in row wr -> plane (quad kk >> 1, parity sx & 1),
   // slot (2 wr + r) * 17 + j + (sx >> 1); weight fragment (position, column tile) -> slot ((ps * TNT + ct) * 2 + (kk >> 1)) * 16 + j
@@ -127,59 +133,74 @@ __global__ __launch_bounds__(256 * WNW, 2) void conv_wino2_kernel(Wino2P p) {
   const int wbase = ((kk >> 1) * 2 * PLANE + (2 * wr) * 17 + j) * 16 + half;
   const int abase = U_BASE * 16 + ((wc * CT * 2 + (kk >> 1)) * 16 + j) * 16 + half;
 
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                       // (the bias loads: nothing but DMA pieces on the counter from here)
 #pragma unroll
   for (int s = 0; s < PF; ++s) issue_raw(s);
-  issue_u(0);
-  bool drain = true;                                                     // iteration 0: the weight request is the newest one
+  issue_u(0); issue_u(1);
   int fc = 0, fi = 0;                                                    // stage within the frame, observation frame
-  for (int s = 0; s < total; ++s) {
-    if (drain) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    else if (n_raw == 1) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
-    else if (n_raw == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
-    drain = false;
-    __builtin_amdgcn_s_barrier();
-    asm volatile("" ::: "memory");
-    issue_u((s + 1) & 1);                                                // weights of stage s + 1, then the raw tile of stage s + 3:
-    issue_raw((s + PF) & (RAW_DEPTH - 1));                               // the next wait leaves exactly the latter in flight
+  int ubi = 2, ubr = 0;                                                  // weight ring: next buffer to request into / to read from
+
+  // The fragments of stage s + 1 are READ (LDS -> registers) under the MFMAs of stage s: a stage's reads used to sit between its
+  // barrier and its first MFMA with every wave of the CU at that same point -- the matrix pipe idle for the LDS round trip (r04
+  // PMC: 31 % of the wave cycles parked at waitcnt / barrier).  So a stage's data has to be in LDS one barrier EARLIER: weights
+  // are requested two stages ahead into a ring of three, the raw tile three ahead into four (as before).
+  auto read_frags = [&](int s, f32x2 (&d)[9], f32x2 (&af)[9][CT]) {
     const char* R = reinterpret_cast<const char*>(lds) + (s & (RAW_DEPTH - 1)) * (RAW_SLOTS * 16) + wbase;
-    const char* A = reinterpret_cast<const char*>(lds) + (s & 1) * (U_SLOTS * 16) + abase;
-    // every LDS read of the stage is requested up front (window first, then the weight fragments in the order of their use) and
-    // nothing is scheduled back across the fence: the transform and the first MFMAs wait for the data they need only
-    // (counted lgkmcnt), the rest arrives under them
-    f32x2 d[3][3], af[9][CT];
+    const char* A = reinterpret_cast<const char*>(lds) + ubr * (U_SLOTS * 16) + abase;
+    if (++ubr == U_DEPTH) ubr = 0;
 #pragma unroll
     for (int r = 0; r < 3; ++r)
 #pragma unroll
       for (int sx = 0; sx < 3; ++sx)
-        d[r][sx] = *reinterpret_cast<const f32x2*>(R + ((sx & 1) * PLANE + r * 17 + (sx >> 1)) * 16);
+        d[r * 3 + sx] = lds_b64(R + ((sx & 1) * PLANE + r * 17 + (sx >> 1)) * 16);
 #pragma unroll
     for (int ps = 0; ps < 9; ++ps)
 #pragma unroll
-      for (int ct = 0; ct < CT; ++ct) af[ps][ct] = *reinterpret_cast<const f32x2*>(A + ((ps * TNT + ct) * 2 * 16) * 16);
-    __builtin_amdgcn_sched_barrier(0);
-    f32x2 v[9];
-    {
-      f32x2 e[3][3];
+      for (int ct = 0; ct < CT; ++ct) af[ps][ct] = lds_b64(A + ((ps * TNT + ct) * 2 * 16) * 16);
+  };
+  auto transform = [&](f32x2 (&d)[9]) {                                  // B^T d B in place: rows, then columns
 #pragma unroll
-      for (int sx = 0; sx < 3; ++sx) { e[0][sx] = d[0][sx] - d[1][sx]; e[1][sx] = d[1][sx]; e[2][sx] = d[2][sx] - d[1][sx]; }
+    for (int sx = 0; sx < 3; ++sx) { d[sx] = d[sx] - d[3 + sx]; d[6 + sx] = d[6 + sx] - d[3 + sx]; }
 #pragma unroll
-      for (int x = 0; x < 3; ++x) { v[x * 3] = e[x][0] - e[x][1]; v[x * 3 + 1] = e[x][1]; v[x * 3 + 2] = e[x][2] - e[x][1]; }
+    for (int x = 0; x < 3; ++x) { d[x * 3] = d[x * 3] - d[x * 3 + 1]; d[x * 3 + 2] = d[x * 3 + 2] - d[x * 3 + 1]; }
+  };
+
+  f32x2 v0[9], a0[9][CT], v1[9], a1[9][CT];
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+  read_frags(0, v0, a0);
+  transform(v0);
+  bool drain = false;
+
+  auto stage = [&](int s, f32x2 (&vc)[9], f32x2 (&ac)[9][CT], f32x2 (&vn)[9], f32x2 (&an)[9][CT]) {
+    if (s > 0) {
+      if (drain) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      else if (n_raw == 1) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+      else if (n_raw == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+      drain = false;
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
     }
+    issue_u(ubi);                                                        // weights of stage s + 2, then the raw tile of stage s + 3:
+    if (++ubi == U_DEPTH) ubi = 0;                                       // the next wait leaves exactly the latter in flight
+    issue_raw((s + PF) & (RAW_DEPTH - 1));
+    if (s + 1 < total) read_frags(s + 1, vn, an);
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int ps = 0; ps < 9; ++ps)
 #pragma unroll
       for (int s2 = 0; s2 < 2; ++s2)
 #pragma unroll
         for (int ct = 0; ct < CT; ++ct)
-          acc[ps][ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[ps][ct][s2], v[ps][s2], acc[ps][ct], 0, 0, 0);
+          acc[ps][ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(ac[ps][ct][s2], vc[ps][s2], acc[ps][ct], 0, 0, 0);
     if (++fc == p.nc8) {                                                 // this (observation) frame is complete: A^T M A, epilogue
       const int i = fi++;
       fc = 0;
 #pragma unroll
       for (int ct = 0; ct < CT; ++ct) {
         const int oc = (g * TNT + wc * CT + ct) * 16 + 4 * kk;
+        const f32x4 bias4 = p.bias ? *reinterpret_cast<const f32x4*>(p.bias + oc) : (f32x4){0.f, 0.f, 0.f, 0.f};   // (the wait after an epilogue drains anyway)
         f32x4 r0[3], r1[3];
 #pragma unroll
         for (int nu = 0; nu < 3; ++nu) {
@@ -193,7 +214,7 @@ __global__ __launch_bounds__(256 * WNW, 2) void conv_wino2_kernel(Wino2P p) {
         for (int uv = 0; uv < 4; ++uv) {
           const int gy = ty0 + 2 * wr + (uv >> 1), gx = tx0 + 2 * j + (uv & 1);
           const bool in = gy < p.h && gx < p.w;
-          f32x4 o = y[uv] + bv[ct];
+          f32x4 o = y[uv] + bias4;
           const long ot = ((long)(f * p.kobs + i) * p.h + gy) * p.w + gx;
           if (p.mask_src || p.accumulate) {                              // backward-data epilogue
             if (in) {
@@ -224,6 +245,11 @@ __global__ __launch_bounds__(256 * WNW, 2) void conv_wino2_kernel(Wino2P p) {
       }
       drain = true;                                                      // stores (and mask loads) sit on the VM counter behind the DMA pieces
     }
+    if (s + 1 < total) transform(vn);
+  };
+  for (int s = 0; s < total; s += 2) {
+    stage(s, v0, a0, v1, a1);
+    if (s + 1 < total) stage(s + 1, v1, a1, v0, a0);
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                       // the clamped requests past the last stage
 }

@@ -87,6 +87,7 @@ class RenderPlan:
         # 'f32x3' / 'f32x3_9': fp32 storage everywhere; the LDS-tiled encoder convs multiply fp32 operands as three bf16 terms
         # on the bf16 matrix cores (6 / all 9 term products, csrc/conv_tile3.hip) -- forward launches of inference AND training
         self.precision = os.environ.get('NLT_PRECISION', 'fp32')
+        self._pred_out = None           # this forward's caller-owned output tensor (see `forward`)
         self.grad_hook = None           # callable fired by backward() once the expanding blocks' weight gradients are queued
         self.generation = 0             # bumped by every forward: the activations in the plan's buffers belong to that pass
         self.tape_replays = 0
@@ -447,14 +448,19 @@ class RenderPlan:
                 and 0.0 <= alpha <= 1.0)
 
     def forward(self, base, cvis, lvis, nn_rgb, nn_base, obs_weights=None, obs_override=None,
-                skip_connect_base=True, algo=C.ALGO_AUTO, inference=False, resident=None):
+                skip_connect_base=True, algo=C.ALGO_AUTO, inference=False, resident=None, pred_out=None):
         """base [N,H,W,3], cvis/lvis [N,H,W,1], nn_rgb/nn_base [N,k,H,W,3] -> pred [N,H,W,3]
         (texel (0,0) zeroed, base added).  Returns (pred, buffers).
         inference=True lets the plan use the fused ends (csrc/fused.hip), which do not keep the
         activations a backward pass would need (fm0, obs0, the L1 / last-block intermediates).
         resident = ResidentTexels (datasets/nlt.py): the five float buffers are None and the front kernel reads the
-        uint8 capture store itself (inference only; `resident_ok` says when)."""
+        uint8 capture store itself (inference only; `resident_ok` says when).
+        pred_out [N,H,W,3] (inference, fused ends): the last launch writes the rendered texels THERE instead of the plan's
+        reusable buffer, so the caller can hand them out without a copy (50 MB and 19 us per step at 4 x 1024^2).  That one
+        launch stays out of the launch tape -- its output address changes every step -- and is re-issued after a replay.
+        Returns (pred, buffers); pred is pred_out when it was used."""
         C.set_workspace_scope(id(self))
+        self._pred_out = pred_out
         if resident is not None:
             return self._forward_resident(resident, skip_connect_base, algo)
         n, h, w, _ = base.shape
@@ -474,7 +480,7 @@ class RenderPlan:
         if self.autotune and not b.get(tuned_key) and base.is_cuda:
             b[tuned_key] = True
             self._autotune(lambda: self.forward(base, cvis, lvis, nn_rgb, nn_base, obs_weights, obs_override,
-                                                skip_connect_base, algo, inference))
+                                                skip_connect_base, algo, inference, pred_out=pred_out))
         # launch tape (second sight of the same inputs records, later sights replay)
         if fused:
             self._front_weights(dev, l2=inference or self.front4_train)   # folded front-kernel weights, refreshed in place OUTSIDE any tape
@@ -483,7 +489,7 @@ class RenderPlan:
                 and obs_weights is None and obs_override is None
                 and all(t.is_contiguous() for t in (base, cvis, lvis, nn_rgb, nn_base))):    # (a replay skips the adapters' layout checks)
             tkey = ('fwd', base.data_ptr(), cvis.data_ptr(), lvis.data_ptr(), nn_rgb.data_ptr(), nn_base.data_ptr(),
-                    bool(skip_connect_base), algo, inference, fused, C._stream())
+                    bool(skip_connect_base), algo, inference, fused, C._stream(), pred_out is not None)
             tapes = b.setdefault('tapes', {})
             if len(tapes) > 16:                     # ever-changing input addresses (a loader that allocates per step): forget
                 tapes.clear()
@@ -492,7 +498,7 @@ class RenderPlan:
                 if C.tape_valid(ent, reg.version):
                     C.replay(ent)
                     self.tape_replays += 1
-                    return b['pred'], b
+                    return self._finish_pred(b), b
                 ent = 1
             tapes[tkey] = 1
             if ent == 1:
@@ -528,7 +534,7 @@ class RenderPlan:
         self._front_weights(dev)
         tkey = None
         if self.use_tape and self.timer is None and not self._tuning and reg is not None:
-            tkey = ('fwd_u8',) + res.key() + (bool(skip_connect_base), algo, C._stream())
+            tkey = ('fwd_u8',) + res.key() + (bool(skip_connect_base), algo, C._stream(), self._pred_out is not None)
             tapes = b.setdefault('tapes', {})
             if len(tapes) > 16:
                 tapes.clear()
@@ -537,7 +543,7 @@ class RenderPlan:
                 if C.tape_valid(ent, reg.version):
                     C.replay(ent)
                     self.tape_replays += 1
-                    return b['pred'], b
+                    return self._finish_pred(b), b
                 ent = 1
             tapes[tkey] = 1
             if ent == 1:
@@ -770,11 +776,33 @@ class RenderPlan:
         # last block (40 -> 4 -> 4 at full resolution) + head (36 -> 3) in SURVEY 8d accounting
         nbytes = 4 * n * h * w * ((10 + 4) + (4 + 4) + (36 + 3))
         extra = (b['dtmp'][U - 1], b['dec'][U - 1]) if train else ()
-        self._launch('F.back', nbytes, C.back_forward_train if train else C.back_forward, x, b['fm'][1], b['skip3'], n, hh, ww,
-                     da.kernel.detach(), da.bias.detach(), db.kernel.detach(), db.bias.detach(), head.kernel.detach(), alpha,
-                     b['pred'], *extra, flops=2 * n * hh * ww * 40 * 16 + 2 * n * h * w * (64 + 12),
-                     moved=4 * n * h * w * (10 + 3 + 3 + (8 if train else 0)))
-        return b['pred'], b
+        back_args = (x, b['fm'][1], b['skip3'], n, hh, ww, da.kernel.detach(), da.bias.detach(), db.kernel.detach(), db.bias.detach(),
+                     head.kernel.detach(), alpha)
+        back_kw = dict(flops=2 * n * hh * ww * 40 * 16 + 2 * n * h * w * (64 + 12), moved=4 * n * h * w * (10 + 3 + 3 + (8 if train else 0)))
+
+        def back(pred):
+            self._launch('F.back', nbytes, C.back_forward_train if train else C.back_forward, *back_args, pred, *extra, **back_kw)
+        out = self._pred_out if (not train and not self._tuning) else None
+        if out is None:
+            b['back_call'] = None
+            back(b['pred'])
+            return b['pred'], b
+        # the caller's own output tensor: this launch is not part of the launch tape (its output address differs every step)
+        b['back_call'] = back
+        paused = C.tape_pause()
+        try:
+            back(out)
+        finally:
+            C.tape_resume(paused)
+        return out, b
+
+    def _finish_pred(self, b):
+        """After a tape replay: the launch that was kept out of the tape (see `forward`, pred_out)."""
+        back = b.get('back_call')
+        if back is None or self._pred_out is None:
+            return b['pred']
+        back(self._pred_out)
+        return self._pred_out
 
     # ------------------------------------------------------------------ backward
     def _grad_buffers(self, b):

@@ -51,6 +51,27 @@ def test_forward_replays_match_adapter_launches_and_follow_weight_updates():
     assert a.plan.tape_replays == before + 1
 
 
+def test_rendered_texels_are_handed_out_without_a_copy_and_survive_later_replays():
+    """Inference: the plan's last launch writes `pred` into a tensor of THAT call (it is kept out of the launch tape and re-issued
+    after a replay), so to_vis['pred'] of an earlier call is not overwritten by a later replay of the same tape, and equals what the
+    copying path (NLT_PRED_COPY=1 semantics: plan buffer + clone) returns, bit for bit."""
+    batch = to_device_batch(*O.synth_batch(2, 64, 64, 32, 32, 32, 32, k=2, seed=73))
+    other = to_device_batch(*O.synth_batch(2, 64, 64, 32, 32, 32, 32, k=2, seed=74))
+    a = _model(True)
+    first = a.call(batch, 'test')[3]['pred']
+    keep = first.clone()
+    outs = [a.call(batch, 'test')[3]['pred'] for _ in range(4)]
+    assert a.plan.tape_replays >= 2
+    assert len({t.data_ptr() for t in outs + [first]}) == 5                      # five calls, five tensors
+    assert all(torch.equal(t, keep) for t in outs) and torch.equal(first, keep)
+    (bufs,) = a.plan._bufs.values()
+    assert all(t.data_ptr() != bufs['pred'].data_ptr() for t in outs)            # none of them is the plan's reusable buffer
+    # another batch in between, then the first one again: the earlier results are still intact
+    o2 = a.call(other, 'test')[3]['pred']
+    again = a.call(batch, 'test')[3]['pred']
+    assert torch.equal(again, keep) and torch.equal(outs[0], keep) and not torch.equal(o2, keep)
+
+
 def test_train_steps_with_and_without_the_tape_agree():
     batch = to_device_batch(*O.synth_batch(2, 64, 64, 32, 32, 32, 32, k=2, seed=72))
     res = []
