@@ -100,7 +100,10 @@ def parse():
     ap.add_argument('--k', type=int, default=4, help='neighbour observation maps per frame')
     ap.add_argument('--depth', type=int, default=256)
     ap.add_argument('--algo', type=str, default='auto', choices=['auto', 'direct'])
-    ap.add_argument('--precision', type=str, default='fp32', choices=['fp32', 'bf16'], help='bf16: the middle of the network on bf16 MFMA / bf16 storage (reported as such in dtype)')
+    ap.add_argument('--precision', type=str, default='f32x3_9', choices=['f32x3_9', 'fp32', 'f32x3', 'bf16'],
+                    help='f32x3_9 (default; VERDICT r03 ruling): fp32 storage everywhere, the LDS-tiled encoder convs multiply fp32 operands '
+                         'as three bf16 terms, all 9 exact term products, fp32 accumulate; fp32: every product on v_mfma_f32 (kept in the line '
+                         'as native_fp32); bf16: the middle of the network on bf16 MFMA / bf16 storage (reported as such in dtype)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--graph', action='store_true', help='replay the forward as one hipGraph (model.use_graphs); the dominant '
                     'kernel is then timed in an eager pass of the same steps right after the timed region')
@@ -430,18 +433,26 @@ def bench_config5(args, device):
     return out
 
 
-def bench_f32_split(args, device, native, batches):
-    """`precision = f32x3` beside the headline (VERDICT r02 ruling: reported as a sub-line, the headline stays the native
-    v_mfma_f32 path): the SAME workload, weights and batches with the LDS-tiled encoder convs multiplying fp32 operands as
-    three bf16 terms on the bf16 matrix cores -- 6 term products (`f32x3`) and all 9 (`f32x3_9`, every partial product exact,
-    fp32 accumulate).  rel-L2 of the rendered texels against the native fp32 plan is measured here; against the CPU oracle in
+PRECISION_DTYPE = {
+    'fp32': "f32 (every product on v_mfma_f32_16x16x4_f32 / fp32 VALU)",
+    'f32x3_9': "f32 via 3xbf16 split, 9 exact products, fp32 accumulate (the LDS-tiled encoder convs: fp32 operands as three bf16 terms "
+               "on v_mfma_f32_16x16x32_bf16, every term product exact in fp32); f32 storage everywhere, every other launch native f32",
+    'f32x3': "f32 via 3xbf16 split, 6 of the 9 term products (the three of relative order 2^-24 dropped), fp32 accumulate; f32 storage",
+    'bf16': "bf16 (fp32 accumulate) for the middle of the network, f32 ends",
+}
+
+
+def bench_f32_split(args, device, native, batches, precisions=('f32x3', 'f32x3_9')):
+    """The SAME workload, weights and batches at the other precisions of the plan, beside the headline (VERDICT r03 ruling: the
+    9-product split may be the headline when the native v_mfma_f32 line stays in the JSON as `native_fp32`; the 6-product form stays
+    a sub-line).  rel-L2 of the rendered texels against the headline's plan is measured here; against the CPU oracle in
     tests/test_gpu_tile.py and tests/test_gpu_baseline_sizes.py."""
     import torch
     import nlt_amd
     from nlt_amd.models import get_model_class
     ref = native.call(batches[0], 'test')[3]['pred'].double()
     out = {"workload": "the headline's (BASELINE config 3), same weights and batches"}
-    for prec in ('f32x3', 'f32x3_9'):
+    for prec in precisions:
         cfg = nlt_amd.make_config(depth=args.depth, uvh=args.uv, uvw=args.uv, imh=args.cam, imw=args.cam, bs=args.frames, precision=prec)
         model = get_model_class('nlt')(cfg).build(device)
         model.register_trainable()
@@ -452,10 +463,9 @@ def bench_f32_split(args, device, native, batches):
         pred = model.call(batches[0], 'test')[3]['pred'].double()
         tiled = sorted(l for l, v in model.plan.lds_hints.items())
         out[prec] = {"ms_per_step": round(1e3 * dt, 4), "Mtexels_per_s": round(args.frames * args.uv * args.uv / dt / 1e6, 1),
-                     "rel_l2_pred_vs_native_fp32_plan": float((pred - ref).norm() / ref.norm()),
-                     "dtype": "f32 storage; LDS-tiled encoder convs as 3 x bf16 terms, %d exact term products, fp32 accumulate "
-                              "(v_mfma_f32_16x16x32_bf16); everything else native fp32" % (9 if prec.endswith('9') else 6),
-                     "launches_on_the_split_kernel": tiled}
+                     "rel_l2_pred_vs_the_headline_plan": float((pred - ref).norm() / ref.norm()),
+                     "dtype": PRECISION_DTYPE[prec],
+                     "launches_on_the_lds_tiled_kernel": tiled, "launches_on_the_winograd_kernel": sorted(model.plan.wino_hints)}
         del model
         torch.cuda.empty_cache()
     return out
@@ -862,12 +872,21 @@ def main():
                     "launch_ms": round(dom_ms, 4), "algorithmic_bytes_per_launch": int(dom_bytes)}
         if dom_layerwise != dom_bytes:                          # fused launch: also what it replaces, layer by layer
             roof["layerwise_bytes_replaced"] = int(dom_layerwise)
+        # both roofs of the dominant launch, whichever binds: algorithmic (compulsory) bytes and measured (PMC) bytes over its
+        # duration against the HBM peak; its folded FLOPs against the fp32 matrix peak
+        roof["hbm"] = {"algorithmic_GBps": round(ach, 1), "frac": round(ach / HBM_PEAK_GBS, 4),
+                       "traffic_GBps": round(traffic / (dom_ms * 1e-3) / 1e9, 1) if traffic else None,
+                       "traffic_frac": round(traffic / (dom_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if traffic else None,
+                       "peak_GBps": HBM_PEAK_GBS}
+        if dom_flops:
+            tf_ = dom_flops / (dom_ms * 1e-3) / 1e12
+            roof["mfma"] = {"TFLOPs": round(tf_, 2), "frac": round(tf_ / MFMA_F32_PEAK_TFLOPS, 4), "peak_TFLOPs": MFMA_F32_PEAK_TFLOPS}
         out = {
             "metric": "rendered Mtexels/s at %d^2 UV (full Model.call forward: U-Net + UV->camera warp)" % args.uv,
             "value": round(value, 2), "unit": "Mtexels/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32" if args.precision == 'fp32' else "bf16 (fp32 accumulate) for the middle of the network, f32 ends",
+            "dtype": PRECISION_DTYPE[args.precision],
             "data": "synthetic (seeded random uint8 texel buffers, %s uv2cam map, random-init weights of the released architecture)"
                     % ("chart-structured piecewise-smooth" if args.warp == 'charts' else "per-pixel uniform-random (adversarial)"),
             "config": {"workload": "BASELINE config 3: dragon_specular relight+view-synth, depth0 16/depth %d, "
@@ -887,8 +906,11 @@ def main():
         if world == 1 and not args.headline_only and args.uv == 1024:
             out["config5_2048_bf16"] = bench_config5(args, device)
             out["stress_64ch"] = bench_stress_64ch(device)
-            if args.precision == 'fp32' and not args.no_fused:
-                out["config3_f32_split"] = bench_f32_split(args, device, model, batches)
+            if args.precision in ('fp32', 'f32x3_9') and not args.no_fused:
+                others = bench_f32_split(args, device, model, batches, tuple(p_ for p_ in ('fp32', 'f32x3', 'f32x3_9') if p_ != args.precision))
+                if 'fp32' in others:
+                    out["native_fp32"] = others.pop('fp32')          # every product on v_mfma_f32: the round-1..3 headline
+                out["config3_f32_split"] = others
         if released:
             out["released_shapes"] = released
         if train:
@@ -899,7 +921,7 @@ def main():
         # measured to perturb legs that run after them: config 5 fp32 1.60 -> 1.70 ms)
         if world == 1 and not args.graph and (args.pipelined or not args.headline_only):
             out["pipelined"] = bench_pipelined(args, device, model, batches)
-            if args.precision == 'fp32' and not args.no_fused and not args.headline_only:
+            if args.precision in ('fp32', 'f32x3_9') and not args.no_fused and not args.headline_only:
                 try:
                     out["pipelined"]["f32x3_4_lanes"] = bench_f32_split_pipelined(args, device, model, batches)
                 except Exception as e:                                # a sub-sub-line: never take the line with it
@@ -908,6 +930,19 @@ def main():
                 out["released_shapes"]["forward_4_frames_pipelined"] = released_pipelined_child(args)
         if world == 1 and not args.no_cpu_baseline and not args.headline_only:
             out["cpu_baseline"] = cpu_baseline(args)
+        # what a 2000-byte tail of the line should still show goes last: the two baselines, then a digest of the line
+        for key in ("native_fp32", "cpu_baseline"):
+            if key in out:
+                out[key] = out.pop(key)
+        ts = {t_["loss"]: t_ for t_ in train if isinstance(t_, dict) and "loss" in t_}
+        out["summary"] = {
+            "forward_ms_per_step": out["ms_per_step"], "forward_Mtexels_per_s": out["value"], "forward_dtype": args.precision,
+            "native_fp32_ms_per_step": out.get("native_fp32", {}).get("ms_per_step"),
+            "dominant_kernel": dominant, "dominant_ms": round(dom_ms, 4), "dominant_frac_of_fp32_mfma_peak": roof.get("mfma", {}).get("frac"),
+            "dominant_frac_of_hbm_peak_algorithmic": roof["hbm"]["frac"], "dominant_frac_of_hbm_peak_pmc_traffic": roof["hbm"]["traffic_frac"],
+            "train_step_l2_ms": ts.get("l2", {}).get("ms_per_step"), "train_step_barron_ms": ts.get("barron", {}).get("ms_per_step"),
+            "train_step_l2_host_enqueue_ms": ts.get("l2", {}).get("host_enqueue_ms_per_step"),
+            "cpu_baseline_Mtexels_per_s": out.get("cpu_baseline", {}).get("value"), "cpu_cores": out.get("cpu_baseline", {}).get("cores")}
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()

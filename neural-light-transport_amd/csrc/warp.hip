@@ -66,10 +66,10 @@ __global__ __launch_bounds__(256) void warp_kernel(const float* __restrict__ pre
       vp[t] = (ok && pred) ? pred[tex * 3 + c] : 0.f;
       if (STORE) {
         const unsigned char* bs = static_cast<const unsigned char*>(base_v);
-        vb[t] = (ok && !corner && bs) ? u8_unit(bs[((long)fs * uvh * uvw + in_frame) * 3 + c]) : 0.f;
+        vb[t] = (ok && !corner && bs && base_cam) ? u8_unit(bs[((long)fs * uvh * uvw + in_frame) * 3 + c]) : 0.f;
       } else {
         const float* base = static_cast<const float*>(base_v);
-        vb[t] = (ok && !corner && base) ? base[tex * 3 + c] : 0.f;
+        vb[t] = (ok && !corner && base && base_cam) ? base[tex * 3 + c] : 0.f;   // (a pred-only launch reads no base)
       }
       vg[t] = (ok && !corner) ? 1.f : 0.f;
     }

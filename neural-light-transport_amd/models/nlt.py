@@ -264,23 +264,47 @@ class Model(BaseModel):
         # inference: the plan's last launch writes the rendered texels straight into a tensor of this call (no copy of the
         # plan's reusable buffer afterwards); `_pred_fresh` tells `call` whether that happened
         h_, w_ = (resident.h, resident.w) if resident is not None else base.shape[1:3]
+        timing_all = self.plan.timer is not None and getattr(self.plan.timer, 'only', None) is None     # (per-launch survey: plain path)
         fresh = (torch.empty((n, h_, w_, 3), device=dev, dtype=torch.float32)
-                 if (inference and dev.type == 'cuda' and self.plan.timer is None and os.environ.get('NLT_PRED_COPY', '0') == '0')
+                 if (inference and dev.type == 'cuda' and not timing_all and os.environ.get('NLT_PRED_COPY', '0') == '0')
                  else None)
+        E = lambda: torch.empty((n, hc, wc, 3), device=dev, dtype=torch.float32)
+        pred_camspc, base_camspc, fg_camspc = E(), E(), E()
+        idx = torch.empty((n, hc, wc, 4), device=dev, dtype=torch.int32) if want_indices else None
+
+        def warp(pred_, pc, bc, fc, ix):
+            if resident is not None:
+                # base and the uv2cam map are gathered where they live (uint8 diffuse store, fp16 map store): neither the
+                # float32 base nor a float32 copy of the map is ever written
+                C.warp_forward_store(pred_, resident.diffuse, resident.uv2cam, resident.ids, n, self.uvh, self.uvw, hc, wc, pc, bc, fc, ix)
+            else:
+                C.warp_forward(pred_, base, warp_in, n, self.uvh, self.uvw, hc, wc, pc, bc, fc, ix)
+        warp_in = warp
+        # The base / foreground gathers (two thirds of the resampler's traffic, nlt/models/nlt.py:113-114) and the UV indices do
+        # not depend on the network: inference issues them on a side stream at the START of the pass, beside the front kernel
+        # (which is bound by its own issue latency, not by HBM), and only the gather of `pred` stays behind the last launch.
+        early = (inference and dev.type == 'cuda' and not timing_all and not self.use_graphs
+                 and os.environ.get('NLT_WARP_SPLIT', '1') != '0')
+        if early:
+            ws = getattr(self, '_warp_side', None)
+            if ws is None or ws[0].device != dev:
+                ws = self._warp_side = (torch.cuda.Stream(device=dev), torch.cuda.Event(), torch.cuda.Event())
+            side, ev0, ev1 = ws
+            main = torch.cuda.current_stream(dev)
+            ev0.record(main)                                     # (after the allocations above: the side stream is ordered behind
+            side.wait_event(ev0)                                 #  whatever still uses the blocks they recycled, and behind the loader)
+            with torch.cuda.stream(side):
+                warp(None, None, base_camspc, fg_camspc, idx)
+                ev1.record(side)
         pred, _ = self.plan.forward(base, cvis, lvis, nn_rgb, nn_base, obs_weights=obs_weights,
                                     obs_override=obs_override, skip_connect_base=self.skip_connect_base,
                                     algo=self.conv_algo, inference=inference, resident=resident, pred_out=fresh)
         self._pred_fresh = fresh is not None and pred is fresh
-        E = lambda: torch.empty((n, hc, wc, 3), device=dev, dtype=torch.float32)
-        pred_camspc, base_camspc, fg_camspc = E(), E(), E()
-        idx = torch.empty((n, hc, wc, 4), device=dev, dtype=torch.int32) if want_indices else None
-        if resident is not None:
-            # base and the uv2cam map are gathered where they live (uint8 diffuse store, fp16 map store): neither the float32
-            # base nor a float32 copy of the map is ever written
-            C.warp_forward_store(pred, resident.diffuse, resident.uv2cam, resident.ids, n, self.uvh, self.uvw, hc, wc,
-                                 pred_camspc, base_camspc, fg_camspc, idx)
+        if early:
+            warp(pred, pred_camspc, None, None, None)
+            torch.cuda.current_stream(dev).wait_event(ev1)
         else:
-            C.warp_forward(pred, base, warp, n, self.uvh, self.uvw, hc, wc, pred_camspc, base_camspc, fg_camspc, idx)
+            warp(pred, pred_camspc, base_camspc, fg_camspc, idx)
         if (hc, wc) != (self.imh, self.imw):
             fg_camspc = C.resize_bilinear_forward(fg_camspc, self.imh, self.imw)
             base_camspc = C.resize_bilinear_forward(base_camspc, self.imh, self.imw)

@@ -143,8 +143,18 @@ def test_three_term_split_forward_at_configs_1_2_3(cfg, precision):
     depth, uv, cam, n, k, ident = {1: (1024, 256, 256, 4, 1, True), 2: (256, 512, 512, 4, 1, True), 3: (256, 1024, 512, 2, 4, False)}[cfg]
     pm, _, _ = _forward_vs_oracle('config%d_%s' % (cfg, precision), depth, uv, cam, n, k, ident, seed=cfg, tol=1e-6, precision=precision)
     _dump('config%d_%s_launches_on_the_split_kernel' % (cfg, precision), sorted(pm.plan.lds_hints))
+    _dump('config%d_%s_launches_on_the_winograd_kernel' % (cfg, precision), sorted(pm.plan.wino_hints))
     if cfg == 3:
-        assert pm.plan.lds_hints, "no launch chose the split kernel at the size it is benchmarked at"
+        assert pm.plan.lds_hints or pm.plan.wino_hints, "no launch left the native kernels at the size it is benchmarked at"
+
+
+def test_headline_precision_at_the_bench_shape_and_at_config_5():
+    """The bench's headline plan (precision = f32x3_9: nine exact bf16 term products, fp32 accumulate, + whatever the plan-time
+    trials gave to the Winograd kernel) at the bench's EXACT shape (config 3, 4 frames) and at BASELINE config 5's size (2048^2,
+    k = 1, 2 frames): rendered texels <= 1e-6 rel-L2 against the fp32 oracle, UV gather indices bit-exact (VERDICT r03's
+    conditions for this precision to carry the headline)."""
+    _forward_vs_oracle('config3_1024_k4_n4_f32x3_9', 256, 1024, 512, 4, 4, False, seed=7, tol=1e-6, precision='f32x3_9')
+    _forward_vs_oracle('config5_2048_k1_n2_f32x3_9', 256, 2048, 512, 2, 1, False, seed=52, tol=1e-6, precision='f32x3_9')
 
 
 def _set_alpha(om, pm, alpha):
