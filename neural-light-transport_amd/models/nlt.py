@@ -272,14 +272,13 @@ class Model(BaseModel):
         pred_camspc, base_camspc, fg_camspc = E(), E(), E()
         idx = torch.empty((n, hc, wc, 4), device=dev, dtype=torch.int32) if want_indices else None
 
-        def warp(pred_, pc, bc, fc, ix):
+        def resample(pred_, pc, bc, fc, ix):
             if resident is not None:
                 # base and the uv2cam map are gathered where they live (uint8 diffuse store, fp16 map store): neither the
                 # float32 base nor a float32 copy of the map is ever written
                 C.warp_forward_store(pred_, resident.diffuse, resident.uv2cam, resident.ids, n, self.uvh, self.uvw, hc, wc, pc, bc, fc, ix)
             else:
-                C.warp_forward(pred_, base, warp_in, n, self.uvh, self.uvw, hc, wc, pc, bc, fc, ix)
-        warp_in = warp
+                C.warp_forward(pred_, base, warp, n, self.uvh, self.uvw, hc, wc, pc, bc, fc, ix)
         # The base / foreground gathers (two thirds of the resampler's traffic, nlt/models/nlt.py:113-114) and the UV indices do
         # not depend on the network: inference issues them on a side stream at the START of the pass, beside the front kernel
         # (which is bound by its own issue latency, not by HBM), and only the gather of `pred` stays behind the last launch.
@@ -294,17 +293,17 @@ class Model(BaseModel):
             ev0.record(main)                                     # (after the allocations above: the side stream is ordered behind
             side.wait_event(ev0)                                 #  whatever still uses the blocks they recycled, and behind the loader)
             with torch.cuda.stream(side):
-                warp(None, None, base_camspc, fg_camspc, idx)
+                resample(None, None, base_camspc, fg_camspc, idx)
                 ev1.record(side)
         pred, _ = self.plan.forward(base, cvis, lvis, nn_rgb, nn_base, obs_weights=obs_weights,
                                     obs_override=obs_override, skip_connect_base=self.skip_connect_base,
                                     algo=self.conv_algo, inference=inference, resident=resident, pred_out=fresh)
         self._pred_fresh = fresh is not None and pred is fresh
         if early:
-            warp(pred, pred_camspc, None, None, None)
+            resample(pred, pred_camspc, None, None, None)
             torch.cuda.current_stream(dev).wait_event(ev1)
         else:
-            warp(pred, pred_camspc, base_camspc, fg_camspc, idx)
+            resample(pred, pred_camspc, base_camspc, fg_camspc, idx)
         if (hc, wc) != (self.imh, self.imw):
             fg_camspc = C.resize_bilinear_forward(fg_camspc, self.imh, self.imw)
             base_camspc = C.resize_bilinear_forward(base_camspc, self.imh, self.imw)
