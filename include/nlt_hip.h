@@ -718,6 +718,15 @@ int nlt_conv_wino_backward_data(int adj_mode, const float* dpre, int ldp, int cp
                                 const float* packed, int cout, int tn, float* out, int ldo,
                                 const float* mask_src, int ldm, float mask_alpha, int accumulate, void* stream);
 
+/* Conv2D k2s1 'same' + bias [+ LeakyReLU] [+ observation mean] of the narrow levels (cin = 16 | 32, cout = 32: level 2 of both
+ * paths) with the layer's weights resident in LDS and a whole frame per stage (csrc/conv_c32.hip); arguments and results as
+ * nlt_conv_tile_forward with tn = 32, packed = nlt_pack_conv_tile_weights(NLT_CONV_K2S1, w, cin, 32, 32).
+ *   replaces: the stride-1 conv of `Sequential[conv(2,n,s2), ..., conv(2,n,s1), ...]` at n = 32 (convnet.py:50-59). */
+int nlt_conv_c32_supported(int mode, int cin, int cout);
+int nlt_conv_c32_forward(int mode, const float* src, int ld, int cin, int frames, int kobs, int h, int w,
+                         const float* packed, const float* bias, int cout,
+                         float* out, int ldo, float* mean_out, int ldm, int act, float alpha, void* stream);
+
 /* ======================= LDS-tiled encoder convs (csrc/conv_tile.hip) =======================
  * Same arithmetic as nlt_conv_forward for mode NLT_CONV_K2S2 / NLT_CONV_K2S1 with a single source (bias +
  * optional LeakyReLU), laid out for the MFMA-bound levels: 8 x 16 output tile x tn output channels per

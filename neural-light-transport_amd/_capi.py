@@ -109,6 +109,9 @@ SIGNATURES = {
     'nlt_conv_tile_forward': (_c_int, [_c_int, _vp, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _vp, _vp, _c_int, _c_int,
                                        _vp, _c_int, _vp, _c_int, _c_int, _c_float, _vp]),
     'nlt_pack_conv_tile_weights_adjoint': (_c_int, [_c_int, _vp, _c_int, _c_int, _c_int, _c_int, _c_int, _vp, _vp]),
+    'nlt_conv_c32_supported': (_c_int, [_c_int] * 3),
+    'nlt_conv_c32_forward': (_c_int, [_c_int, _vp, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _vp, _vp, _c_int,
+                                      _vp, _c_int, _vp, _c_int, _c_int, _c_float, _vp]),
     'nlt_conv_wino_packed_floats': (_c_long, [_c_int] * 4),
     'nlt_pack_conv_wino_weights': (_c_int, [_c_int, _vp, _c_int, _c_int, _c_int, _vp, _vp]),
     'nlt_conv_wino_forward': (_c_int, [_c_int, _vp, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _vp, _vp, _c_int, _c_int,
@@ -883,6 +886,17 @@ def conv_tile_forward(mode, src, ld, cin, frames, kobs, h, w, packed, bias, cout
     _check(lib().nlt_conv_tile_forward(mode, _ptr(src), ld, cin, frames, kobs, h, w, _ptr(packed), _ptr(bias), cout, tn,
                                        _ptr(out), ldo, _ptr(mean_out), ldm, 1 if act else 0, float(alpha), _stream()),
            'nlt_conv_tile_forward')
+
+
+def conv_c32_supported(mode, cin, cout):
+    return lib().nlt_conv_c32_supported(mode, cin, cout) > 0
+
+
+def conv_c32_forward(mode, src, ld, cin, frames, kobs, h, w, packed, bias, cout, out, ldo, mean_out, ldm, act=True, alpha=0.3):
+    """Narrow stride-1 conv (cin 16 | 32 -> 32) with LDS-resident weights; packed = pack_conv_tile_weights(mode, w, cin, 32, 32)."""
+    _check(lib().nlt_conv_c32_forward(mode, _ptr(src), ld, cin, frames, kobs, h, w, _ptr(packed), _ptr(bias), cout,
+                                      _ptr(out), ldo, _ptr(mean_out), ldm, 1 if act else 0, float(alpha), _stream()),
+           'nlt_conv_c32_forward')
 
 
 # ---------------------------------------------------------------- Winograd stride-1 k2 convs (csrc/conv_wino.hip)

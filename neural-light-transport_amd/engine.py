@@ -88,6 +88,9 @@ class RenderPlan:
         # on the bf16 matrix cores (6 / all 9 term products, csrc/conv_tile3.hip) -- forward launches of inference AND training
         self.precision = os.environ.get('NLT_PRECISION', 'fp32')
         self._pred_out = None           # this forward's caller-owned output tensor (see `forward`)
+        # callable fired (also on tape replays) when the fused inference pass reaches its expanding blocks: the chip is mostly idle
+        # under that chain of small launches, so Model.call queues the network-independent part of the resampler there
+        self.decoder_hook = None
         self.grad_hook = None           # callable fired by backward() once the expanding blocks' weight gradients are queued
         self.generation = 0             # bumped by every forward: the activations in the plan's buffers belong to that pass
         self.tape_replays = 0
@@ -103,6 +106,11 @@ class RenderPlan:
         self._trial_wino = 0            # autotune: try it with this many output channels per workgroup
         self._ran_wino = set()
         self.wino_hints = {}            # label -> tn (32 / 64) [+256: observations unfolded]: launches that go to csrc/conv_wino.hip
+        # narrow stride-1 convs (cin 16 | 32 -> 32) with LDS-resident weights, a frame per stage (csrc/conv_c32.hip)
+        self.use_c32 = os.environ.get('NLT_C32', '1') != '0'
+        self._trial_c32 = 0             # autotune: 1 = observations folded (mean in registers), 2 = unfolded
+        self._ran_c32 = set()
+        self.c32_hints = {}             # label -> 1 | 2
         self._trial_splitk = 0          # autotune: K slices to try on the small deep launches
         self._ran_splitk = set()
         self.splitk_hints = {}          # label -> K slices (split-K, csrc/conv_mfma.hip) for launches with few GEMM rows
@@ -248,11 +256,26 @@ class RenderPlan:
         observations (label + '.mean' when it needs its own launch).  Goes to the LDS-tiled kernel when the plan
         chose it for this launch, else to the register-tiled MFMA / direct kernels."""
         layer.build(cin, src.device)
+        chint = self._trial_c32 or self.c32_hints.get(label, 0)
+        if (chint and self.use_c32 and algo == C.ALGO_AUTO and obs_weights is None and layer.cin == cin and ld % 4 == 0 and ldo % 4 == 0
+                and C.conv_c32_supported(layer.mode, cin, layer.n_ch_out) and not (chint == 2 and kobs == 1 and self._trial_c32)):
+            unfold = chint == 2 and kobs > 1
+            nf, c = frames * kobs, layer.n_ch_out
+            fold_mean = mean_out is not None and not unfold
+            nbytes = 4 * nf * h * w * (cin + c) + (4 * frames * h * w * c * (kobs + 1) if fold_mean else 0)
+            self._ran_c32.add(label)
+            self._launch(label, nbytes, C.conv_c32_forward, layer.mode, src, ld, cin, nf if unfold else frames, 1 if unfold else kobs, h, w,
+                         layer.packed_tile(32), layer.bias.detach(), c, out, ldo, mean_out if fold_mean else None, ldm,
+                         act=act is not None, alpha=act.alpha if act is not None else 0.0, flops=2 * nf * h * w * 4 * cin * c)
+            if mean_out is not None and unfold:
+                self._launch(label.replace('.s1', '.mean'), 4 * frames * h * w * c * (kobs + 1), C.obs_mean_forward,
+                             out, None, frames, kobs, h * w, c, mean_out, ldm)
+            return
         if (algo == C.ALGO_AUTO and layer.mode == C.CONV_K2S1 and (self._trial_wino or label in self.wino_hints)
                 and self._wino(label, layer, act, src, cin, ld, frames, kobs, h, w, out, ldo, mean_out, ldm,
                                2 * frames * kobs * h * w * 4 * cin * layer.n_ch_out, obs_weights)):
             return
-        hint = self._trial_lds or (0 if self._trial_wino else self.lds_hints.get(label, 0))
+        hint = self._trial_lds or (0 if (self._trial_wino or self._trial_c32) else self.lds_hints.get(label, 0))
         tn, unfold = hint & 255, bool(hint >> 8)       # +256: observations as separate frames, mean in its own launch
         ok = (tn and obs_weights is None and algo == C.ALGO_AUTO and layer.mode in (C.CONV_K2S2, C.CONV_K2S1)
               and layer.cin == cin and cin % 16 == 0 and layer.n_ch_out % tn == 0)
@@ -311,6 +334,8 @@ class RenderPlan:
                 trials += [('lds', 128), ('lds', 256 + 128)]
         elif self.tile_dgrad:
             trials += [('lds', 32), ('lds', 64)]                  # backward-data launches on the LDS-tiled kernel
+        if self.use_c32 and not backward:
+            trials += [('c32', 1), ('c32', 2)]                      # narrow stride-1 launches with LDS-resident weights
         if self.use_wino:                                           # stride-1 k2 launches on the Winograd kernel
             trials += [('wino', 32), ('wino', 64)] + ([('wino', 256 + 32), ('wino', 256 + 64)] if not backward else [])
         # split-K: launches with few GEMM rows and a long K (the deep levels; at depth 1024 a 1 x 1-texel level streams 33 MB of
@@ -318,16 +343,17 @@ class RenderPlan:
         mode = os.environ.get('NLT_SPLITK', 'all')                   # 'all' | 'fwd' (forward plans only) | 'off': A/B switch
         if mode == 'all' or (mode == 'fwd' and not backward):
             trials += [('splitk', (16 * r + c, ks)) for (r, c) in ((1, 1), (1, 2), (2, 2), (1, 4)) for ks in (4, 8, 16, 32, 64, 128)]
-        saved_lds, saved_sk, saved_wino = dict(self.lds_hints), dict(self.splitk_hints), dict(self.wino_hints)
+        saved_lds, saved_sk, saved_wino, saved_c32 = dict(self.lds_hints), dict(self.splitk_hints), dict(self.wino_hints), dict(self.c32_hints)
         for kind, hint in trials:
             self.tile_hints = {'*': hint} if kind == 'tile' else ({'*': hint[0]} if kind == 'splitk' else {})
             self.algo_hints = {}
-            self.lds_hints, self.splitk_hints, self.wino_hints = {}, {}, {}
+            self.lds_hints, self.splitk_hints, self.wino_hints, self.c32_hints = {}, {}, {}, {}
             self._trial_direct = kind == 'direct'
             self._trial_lds = hint if kind == 'lds' else 0
             self._trial_wino = hint if kind == 'wino' else 0
+            self._trial_c32 = hint if kind == 'c32' else 0
             self._trial_splitk = hint[1] if kind == 'splitk' else 0
-            self._ran_direct, self._ran_lds, self._ran_splitk, self._ran_wino = set(), set(), set(), set()
+            self._ran_direct, self._ran_lds, self._ran_splitk, self._ran_wino, self._ran_c32 = set(), set(), set(), set(), set()
             self.timer = None
             run()
             self.timer = OpTimer()
@@ -339,11 +365,11 @@ class RenderPlan:
                     m = rec[label.replace('.s1', '.mean')]
                     t += m[1] / m[0]        # the LDS kernel folds the mean in: compare like with like
                 if (kind == 'tile' or label in self._ran_direct or label in self._ran_lds or label in self._ran_splitk
-                        or label in self._ran_wino):
+                        or label in self._ran_wino or label in self._ran_c32):
                     results.setdefault(label, []).append((t, kind, hint))
-        self._trial_direct, self._trial_lds, self._trial_splitk, self._trial_wino = False, 0, 0, 0
+        self._trial_direct, self._trial_lds, self._trial_splitk, self._trial_wino, self._trial_c32 = False, 0, 0, 0, 0
         self.timer, self.tile_hints, self.algo_hints = saved
-        self.lds_hints, self.splitk_hints, self.wino_hints = saved_lds, saved_sk, saved_wino
+        self.lds_hints, self.splitk_hints, self.wino_hints, self.c32_hints = saved_lds, saved_sk, saved_wino, saved_c32
         for label, res in results.items():
             if '.s1' not in label and '.s2' not in label and label != 'L0.q':
                 continue
@@ -353,11 +379,14 @@ class RenderPlan:
             if kind == 'direct':
                 self.algo_hints.setdefault(label, C.ALGO_DIRECT)
             elif kind == 'lds':
-                if label not in self.wino_hints:
+                if label not in self.wino_hints and label not in self.c32_hints:
                     self.lds_hints.setdefault(label, hint)
             elif kind == 'wino':
-                if label not in self.lds_hints:
+                if label not in self.lds_hints and label not in self.c32_hints:
                     self.wino_hints.setdefault(label, hint)
+            elif kind == 'c32':
+                if label not in self.lds_hints and label not in self.wino_hints:
+                    self.c32_hints.setdefault(label, hint)
             elif kind == 'splitk':
                 if label not in self.tile_hints and label not in self.splitk_hints:
                     self.tile_hints[label], self.splitk_hints[label] = hint
@@ -374,7 +403,7 @@ class RenderPlan:
     def export_tuning(self):
         """The plan-time choices (wave tiles, direct / LDS-tiled kernel, split-K slices per launch label) as one dict."""
         return {'tile_hints': dict(self.tile_hints), 'algo_hints': dict(self.algo_hints), 'lds_hints': dict(self.lds_hints),
-                'splitk_hints': dict(self.splitk_hints), 'wino_hints': dict(self.wino_hints)}
+                'splitk_hints': dict(self.splitk_hints), 'wino_hints': dict(self.wino_hints), 'c32_hints': dict(self.c32_hints)}
 
     def import_tuning(self, d):
         """Takes another plan's (or an earlier run's) choices and skips the plan-time trials: two plans with the same
@@ -383,6 +412,7 @@ class RenderPlan:
         self.lds_hints.update(d.get('lds_hints', {}))
         self.splitk_hints.update(d.get('splitk_hints', {}))
         self.wino_hints.update(d.get('wino_hints', {}))
+        self.c32_hints.update(d.get('c32_hints', {}))
         self.autotune = False
         self._drop_tapes()
 
@@ -489,7 +519,7 @@ class RenderPlan:
                 and obs_weights is None and obs_override is None
                 and all(t.is_contiguous() for t in (base, cvis, lvis, nn_rgb, nn_base))):    # (a replay skips the adapters' layout checks)
             tkey = ('fwd', base.data_ptr(), cvis.data_ptr(), lvis.data_ptr(), nn_rgb.data_ptr(), nn_base.data_ptr(),
-                    bool(skip_connect_base), algo, inference, fused, C._stream(), pred_out is not None)
+                    bool(skip_connect_base), algo, inference, fused, C._stream(), pred_out is not None, self.decoder_hook is not None)
             tapes = b.setdefault('tapes', {})
             if len(tapes) > 16:                     # ever-changing input addresses (a loader that allocates per step): forget
                 tapes.clear()
@@ -534,7 +564,8 @@ class RenderPlan:
         self._front_weights(dev)
         tkey = None
         if self.use_tape and self.timer is None and not self._tuning and reg is not None:
-            tkey = ('fwd_u8',) + res.key() + (bool(skip_connect_base), algo, C._stream(), self._pred_out is not None)
+            tkey = ('fwd_u8',) + res.key() + (bool(skip_connect_base), algo, C._stream(), self._pred_out is not None,
+                                              self.decoder_hook is not None)
             tapes = b.setdefault('tapes', {})
             if len(tapes) > 16:
                 tapes.clear()
@@ -688,7 +719,8 @@ class RenderPlan:
         # never waits for the query path; the query convs of a level only need the previous level's observation mean.
         # With two HIP streams the small deep-level launches of one path fill the CUs the other leaves idle.
         concurrent = (self.two_streams and dev.type == 'cuda' and (self.timer is None or getattr(self.timer, 'only', None) is not None)
-                      and not self._trial_lds and not self._trial_splitk and not self._trial_direct and not self._trial_wino)
+                      and not self._trial_lds and not self._trial_splitk and not self._trial_direct and not self._trial_wino
+                      and not self._trial_c32)
         if concurrent:
             if self._side is None:
                 self._side = (torch.cuda.Stream(device=dev), [torch.cuda.Event() for _ in range(D + 3)])
@@ -741,6 +773,8 @@ class RenderPlan:
         if concurrent:
             C.record_event(ev[D + 1], side)
             C.wait_event(main, ev[D + 1])                              # the decoder needs both halves of every fm[l]
+        if self.decoder_hook is not None and not train and not self._tuning:
+            C.tape_call(self._fire_decoder_hook)
         x, cx = b['fm'][D], 2 * cl[D]
         for j in range(U - 1):
             (da, dact_a), (db, dact_b) = q.layers[D + 1 + j].convs()
@@ -795,6 +829,12 @@ class RenderPlan:
         finally:
             C.tape_resume(paused)
         return out, b
+
+    def _fire_decoder_hook(self):
+        """Runs the CURRENT call's `decoder_hook` (a replayed tape re-invokes this, not the closure it was recorded with)."""
+        hook = self.decoder_hook
+        if hook is not None and not self._tuning:
+            hook()
 
     def _finish_pred(self, b):
         """After a tape replay: the launch that was kept out of the tape (see `forward`, pred_out)."""

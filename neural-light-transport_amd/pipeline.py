@@ -43,13 +43,14 @@ import torch
 from . import _capi as C
 from .engine import RenderPlan
 
-_PLAN_SWITCHES = ('precision', 'fuse_ends', 'front_l2', 'fuse_dec', 'front_v4', 'two_streams', 'use_tape', 'lds_tn128', 'use_wino')
+_PLAN_SWITCHES = ('precision', 'fuse_ends', 'front_l2', 'fuse_dec', 'front_v4', 'two_streams', 'use_tape', 'lds_tn128', 'use_wino', 'use_c32')
 
 
 def _copy_tuning(dst, src):
     dst.tile_hints, dst.algo_hints = dict(src.tile_hints), dict(src.algo_hints)
     dst.lds_hints, dst.splitk_hints = dict(src.lds_hints), dict(src.splitk_hints)
     dst.wino_hints = dict(src.wino_hints)
+    dst.c32_hints = dict(src.c32_hints)
     dst._drop_tapes()
 
 
@@ -124,7 +125,7 @@ class RenderPipeline:
         self._streams = [None] * lanes
         self._tuned_ref = [None] * lanes
         self._switches = [None] * lanes                     # the model plan's switches / hints each lane last copied
-        self._hints = [({}, {}, {}, {}, {})] * lanes
+        self._hints = [({}, {}, {}, {}, {}, {})] * lanes
         self._recent = collections.deque()                  # tickets of the last `lanes` submissions
         self._graphs = bool(graphs)
         self._threads = bool(threads) and lanes > 1 and not self._graphs      # (stream capture wants the other host threads quiet)
@@ -149,7 +150,7 @@ class RenderPipeline:
             self._lanes[i] = lane
         lane.conv_algo, lane.skip_connect_base = m.conv_algo, m.skip_connect_base
         sw = tuple(getattr(m.plan, a) for a in _PLAN_SWITCHES)
-        hints = (m.plan.tile_hints, m.plan.algo_hints, m.plan.lds_hints, m.plan.splitk_hints, m.plan.wino_hints)
+        hints = (m.plan.tile_hints, m.plan.algo_hints, m.plan.lds_hints, m.plan.splitk_hints, m.plan.wino_hints, m.plan.c32_hints)
         if (new or self._tuned_ref[i] is not getattr(m.plan, 'tuned', None) or self._switches[i] != sw
                 or any(dict(a) != b for a, b in zip(hints, self._hints[i]))):
             for a in _PLAN_SWITCHES:                        # the model plan's switches and choices, programmatic ones included:

@@ -491,7 +491,17 @@ def conv_wino_backward_data(adj_mode, dpre, cpre, ldp, n, h, w, packed, cout, tn
     o.copy_(y)
 
 
-_TILE = ('pack_conv_tile_weights', 'conv_tile_forward', 'pack_conv_wino_weights', 'conv_wino_forward', 'conv_wino_backward_data')
+def conv_c32_supported(mode, cin, cout):
+    return mode == C.CONV_K2S1 and cin in (16, 32) and cout == 32
+
+
+def conv_c32_forward(mode, src, ld, cin, frames, kobs, h, w, packed, bias, cout, out, ldo, mean_out, ldm, act=True, alpha=0.3):
+    assert conv_c32_supported(mode, cin, cout)
+    conv_tile_forward(mode, src, ld, cin, frames, kobs, h, w, packed, bias, cout, 32, out, ldo, mean_out, ldm, act, alpha)
+
+
+_TILE = ('pack_conv_tile_weights', 'conv_tile_forward', 'pack_conv_wino_weights', 'conv_wino_forward', 'conv_wino_backward_data',
+         'conv_c32_supported', 'conv_c32_forward')
 
 
 def conv_forward_splitk(mode, ksplit, src0, c0, ld0, src1, c1, ld1, n, h, w, w_packed, bias, cout, out, ldo,

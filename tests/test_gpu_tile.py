@@ -54,6 +54,39 @@ def test_conv_tile_vs_oracle(mode, cin, cout, tn, h, w, frames, kobs):
     assert rel_l2(out3.cpu(), ref) <= 1e-5
 
 
+@pytest.mark.parametrize('cin,h,w,frames,kobs', [(32, 10, 20, 2, 2), (16, 8, 16, 1, 1), (32, 33, 47, 1, 3), (32, 256, 256, 1, 4), (16, 17, 40, 2, 2)])
+def test_conv_c32_vs_oracle(cin, h, w, frames, kobs):
+    """csrc/conv_c32.hip: the narrow stride-1 conv (cin 16 | 32 -> 32) with LDS-resident weights and a frame per stage, against
+    the oracle's Conv2D k2s1 'same' + LeakyReLU: channel-slice strides, ragged tiles, the in-register observation mean, mean only."""
+    cout = 32
+    rng = np.random.default_rng(cin + h + kobs)
+    ld = cin + 8
+    src = torch.from_numpy(rng.standard_normal((frames * kobs, h, w, ld)).astype(np.float32))
+    wk = torch.from_numpy((rng.standard_normal((2, 2, cin, cout)) * (1.0 / np.sqrt(4 * cin))).astype(np.float32))
+    bias = torch.from_numpy(rng.standard_normal(cout).astype(np.float32) * 0.1)
+    with torch.no_grad():
+        pre = T.conv2d_same(src[..., :cin].contiguous(), wk, bias, 1)
+        ref = T.leaky_relu(pre, 0.3)
+    assert C.conv_c32_supported(C.CONV_K2S1, cin, cout) and not C.conv_c32_supported(C.CONV_K2S1, 64, 32)
+    packed = C.pack_conv_tile_weights(C.CONV_K2S1, wk.cuda(), cin, cout, 32)
+    out = torch.full((frames * kobs, h, w, cout + 4), float('nan'), device='cuda')
+    mean = torch.full((frames, h, w, 2 * cout), float('nan'), device='cuda')
+    C.conv_c32_forward(C.CONV_K2S1, src.cuda(), ld, cin, frames, kobs, h, w, packed, bias.cuda(), cout, out, cout + 4,
+                       mean.view(-1)[cout:], 2 * cout, act=True, alpha=0.3)
+    got = out[..., :cout].cpu()
+    assert not torch.isnan(got).any() and torch.isnan(out[..., cout:]).all()
+    assert rel_l2(got, ref) <= 1e-5
+    m = mean[..., cout:].cpu()
+    assert torch.isnan(mean[..., :cout]).all() and not torch.isnan(m).any()
+    assert rel_l2(m, ref.reshape(frames, kobs, h, w, cout).mean(1)) <= 1e-5
+    mean2 = torch.empty((frames, h, w, cout), device='cuda')
+    C.conv_c32_forward(C.CONV_K2S1, src.cuda(), ld, cin, frames, kobs, h, w, packed, bias.cuda(), cout, None, 0, mean2, cout, act=False)
+    assert rel_l2(mean2.cpu(), pre.reshape(frames, kobs, h, w, cout).mean(1)) <= 1e-5
+    out3 = torch.full((frames * kobs, h, w, cout), float('nan'), device='cuda')
+    C.conv_c32_forward(C.CONV_K2S1, src.cuda(), ld, cin, frames * kobs, 1, h, w, packed, bias.cuda(), cout, out3, cout, None, 0)
+    assert rel_l2(out3.cpu(), ref) <= 1e-5
+
+
 @pytest.mark.parametrize('nprod', [6, 9])
 @pytest.mark.parametrize('mode,cin,cout,tn,h,w,frames,kobs', [
     (C.CONV_K2S1, 16, 32, 32, 10, 20, 2, 2), (C.CONV_K2S1, 32, 64, 64, 8, 16, 1, 1), (C.CONV_K2S1, 64, 64, 32, 33, 47, 1, 3),

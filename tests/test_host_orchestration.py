@@ -220,6 +220,30 @@ def test_winograd_launches_of_the_plan(monkeypatch, fused, hint):
     assert means == want, (means, want)
 
 
+@pytest.mark.parametrize('hint', [1, 2])
+def test_narrow_level_launches_of_the_plan(monkeypatch, hint):
+    """Level 2's stride-1 convs (32 -> 32) given to csrc/conv_c32.hip: same result; hint 1 folds the observation mean into the
+    launch, hint 2 runs the observations as frames and keeps the '.o.mean' launch."""
+    fake_capi.install(monkeypatch)
+    from nlt_amd.engine import OpTimer
+
+    class Rec(OpTimer):
+        def launch(self, label, nbytes, fn, *a, **kw):
+            self.records[label] = [1, 0.0, nbytes]
+            fn(*a, **kw)
+    om, pm = make(256, 64, 32)
+    batch, nn = O.synth_batch(2, 64, 64, 32, 32, 32, 32, k=3, seed=9)
+    with torch.no_grad():
+        ref = om.call(batch, 'test', nn_list=nn)[3]['pred']
+    labels = ['L%d.%s.%s' % (l, p, s) for l in range(1, 13) for p in 'qo' for s in ('s1', 's2')]
+    pm.plan.c32_hints = {lab: hint for lab in labels}
+    pm.plan.timer = Rec()
+    got = pm.call(cpu_batch(batch, nn), 'test')[3]['pred']
+    assert rel_l2(got, ref) < 1e-5
+    assert pm.plan._ran_c32 == {'L2.q.s1', 'L2.o.s1'}
+    assert ('L2.o.mean' in pm.plan.timer.records) == (hint == 2)
+
+
 def test_nlt_test_orchestration_extract_feat_and_infer(monkeypatch):
     """nlt/nlt_test.py:78-127: observation features averaged over all training frames, then used as obs_override;
     the observation convs are not launched at all during inference."""

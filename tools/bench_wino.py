@@ -55,6 +55,10 @@ for name, c, res, frames, kobs in cases:
         except C.NLTError:                                          # NLT_WINO_V1=1: observations as frames + the mean in its own launch
             tw64 = timeit(lambda: C.conv_wino_forward(C.CONV_K2S1, src, c, c, frames * kobs, 1, res, res, pw6, bias, c, 64, out, c, None, 0))
             tm = tw64 + (timeit(lambda: C.obs_mean_forward(out, None, frames, kobs, res * res, c, mean, c)) if kobs > 1 else 0.0)
+    if C.conv_c32_supported(C.CONV_K2S1, c, c):
+        pc = C.pack_conv_tile_weights(C.CONV_K2S1, wk, c, c, 32)
+        tc = timeit(lambda: C.conv_c32_forward(C.CONV_K2S1, src, c, c, frames, kobs, res, res, pc, bias, c, out, c, mean, c))
+        print("%-10s conv_c32 (LDS-resident weights, frame per stage): %.4f ms  %.1f TF  %.2fx" % (name, 1e3 * tc, flops / tc / 1e12, t1 / tc))
     print("%-10s %5d %5d | %9.4f %7.1f | %9.4f %7.1f | %9.4f %7.1f %5.2f | %9.4f %7.1f %5.2f | %9.4f"
           % (name, c, res, 1e3 * t1, flops / t1 / 1e12, 1e3 * t9, flops / t9 / 1e12, 1e3 * tw32, flops / tw32 / 1e12, t1 / tw32,
              1e3 * tw64, flops / tw64 / 1e12, t1 / tw64, 1e3 * tm))
