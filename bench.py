@@ -50,6 +50,21 @@ def pmc_traffic(label):
                 return int(rec['hbm_bytes']), os.path.basename(path)
     return None, None
 
+def pmc_cfg5_bytes(prec):
+    """HBM bytes one forward step of BASELINE config 5 (2048^2, 2 frames, k = 1) moves at `prec`, from the newest committed
+    tools/pmc_cfg5.sh summary (profiles/*_pmc_traffic_cfg5_<prec>.json)."""
+    import glob
+    for path in sorted(glob.glob(os.path.join(ROOT, 'profiles', '*_pmc_traffic_cfg5_%s.json' % prec)), reverse=True):
+        try:
+            with open(path) as f:
+                d = json.load(f)
+        except (OSError, ValueError):
+            continue
+        if d.get('hbm_bytes_per_forward_step'):
+            return int(d['hbm_bytes_per_forward_step']), os.path.basename(path)
+    return None, None
+
+
 BYTES_PER_TEXEL = {1: 961.5, 4: 1755.75}   # SURVEY.md 8d, fp32 layer-wise algorithmic bytes
 # SURVEY.md 8d: layer-wise conv FLOP (2 x MAC) per rendered texel of the forward; the obs path adds 4448 per extra neighbour
 FLOP_PER_TEXEL = {256: lambda k: 13464 + 4448 * (k - 1), 1024: lambda k: 17944 + 4448 * (k - 1)}
@@ -369,6 +384,18 @@ def bench_train(args, device, world, rank, n_steps, loss):
         run = run_saved
         comm["ms_per_step_overlapped"] = round(1e3 * el / n_steps, 3)
         comm["ms_per_step_serial"] = round(1e3 * el_serial / n_steps, 3)
+    # per-rank host side of the step (what 8 single-threaded Python ranks on one host have to sustain): this rank's enqueue
+    # time per step and the cores it may run on; gathered on rank 0
+    try:
+        affinity = len(os.sched_getaffinity(0))
+    except (AttributeError, OSError):
+        affinity = os.cpu_count() or 0
+    per_rank = [{"rank": rank, "host_enqueue_ms_per_step": round(1e3 * enq / n_steps, 3), "cpus_allowed": affinity}]
+    if world > 1:
+        gathered = [None] * world
+        dist.all_gather_object(gathered, per_rank[0])
+        per_rank = gathered
+    comm["per_rank_host"] = per_rank
     flops = 3 * FLOP_PER_TEXEL[args.depth](1) * args.frames * args.uv * args.uv      # forward + backward-data + weight gradients
     return {"loss": loss, "comm": comm,
             "layerwise_flops_per_step_per_gpu": int(flops),
@@ -423,6 +450,10 @@ def bench_config5(args, device):
         out[prec] = {"ms_per_step": round(1e3 * dt, 4), "Mtexels_per_s": round(a5.frames * a5.uv * a5.uv / dt / 1e6, 1),
                      "dtype": "f32" if prec == 'fp32' else "bf16 storage + bf16 MFMA (fp32 accumulate) for levels >= 3 and the "
                               "expanding blocks mirroring them; fp32 ends"}
+        hbm, src = pmc_cfg5_bytes(prec)                          # whole-pass HBM bytes of THIS configuration (committed PMC passes)
+        if hbm:
+            out[prec].update({"hbm_bytes_per_step_pmc": hbm, "pmc_source": src,
+                              "frac_of_hbm_peak": round(hbm / dt / 1e9 / HBM_PEAK_GBS, 4)})
         preds[prec] = model.call(batches[0], 'test')[3]['pred'].double()
         del model, batches, ds
         torch.cuda.empty_cache()

@@ -282,10 +282,11 @@ class Model(BaseModel):
         # The base / foreground gathers (two thirds of the resampler's traffic, nlt/models/nlt.py:113-114) and the UV indices do
         # not depend on the network.  Inference queues them on a side stream when the pass reaches its expanding blocks -- a chain
         # of small launches under which the chip is mostly idle -- and only the gather of `pred` stays behind the last launch.
-        # (Beside the front kernel they cost more than they save: it is sensitive to other memory traffic -- 0.264 -> 0.286 ms,
-        # step 1.271 -> 1.302 ms, r04.)  NLT_WARP_SPLIT=0: one launch at the end.
+        # OPT-IN (NLT_WARP_SPLIT=1): measured r04 at the bench shape it gains nothing -- 1.294 vs 1.285 ms with / without, inside the
+        # run-to-run spread; issued at the START of the pass, beside the front kernel, it costs 0.03 ms (that kernel is sensitive
+        # to other memory traffic: 0.264 -> 0.286 ms).
         early = (inference and dev.type == 'cuda' and not timing_all and not self.use_graphs
-                 and os.environ.get('NLT_WARP_SPLIT', '1') != '0')
+                 and os.environ.get('NLT_WARP_SPLIT', '0') != '0')
         fired = []
         if early:
             ws = getattr(self, '_warp_side', None)

@@ -13,7 +13,8 @@ from nlt_amd.engine import OpTimer                               # noqa: E402
 from nlt_amd.models import get_model_class                       # noqa: E402
 
 depth, uv, n, k, cam = (int(x) for x in sys.argv[1:6])
-graph = len(sys.argv) > 6
+graph = len(sys.argv) > 6 and sys.argv[6] == 'graph'
+quiet = len(sys.argv) > 6 and sys.argv[6] == 'quiet'          # (counter passes: no per-launch survey)
 dev = torch.device('cuda')
 pm = get_model_class('nlt')(nlt_amd.make_config(depth=depth, uvh=uv, uvw=uv, imh=cam, imw=cam)).build(dev)
 pm.register_trainable()
@@ -27,14 +28,14 @@ for i in range(9):
     pm.call(batches[i % 3], 'test')
 torch.cuda.synchronize()
 t0 = time.perf_counter()
-steps = 100
+steps = 10 if quiet else 100
 for i in range(steps):
     pm.call(batches[i % 3], 'test')
 torch.cuda.synchronize()
 dt = (time.perf_counter() - t0) / steps
 print("depth %d uv %d frames %d k %d: %.4f ms / step = %.1f Mtexels/s (%s, tape replays %d)"
       % (depth, uv, n, k, 1e3 * dt, n * uv * uv / dt / 1e6, 'hipGraph' if graph else 'eager', pm.plan.tape_replays))
-if not graph:
+if not graph and not quiet:
     t = OpTimer(); pm.plan.timer = t
     for i in range(3):
         pm.call(batches[i % 3], 'test')
