@@ -97,14 +97,20 @@ __global__ void pack_tile3_kernel(const float* __restrict__ wk, int cin, int cou
   wp[idx] = term == 0 ? hi : (term == 1 ? mid : bf16_rne_bits(r2));
 }
 
-template <int MODE, int TNT, int NPROD>
+// KO = observation frames of a tile that share ONE pass over the layer's weights (r04).  The weights are the larger half of what a
+// stage moves (k2s1 at 64 channels: 24.6 KB of term fragments against 9.8 KB of texels; every workgroup of the chip streams them
+// from L2), and the counter passes of r04 show the operand path, not the matrix pipe, bounding these launches.  With KO > 1 the
+// stage order is (channel slab s, observation io) instead of (observation, slab): the slab's weight fragments are staged once and
+// stay in LDS for KO micro-stages, each of which brings only the texel slab of its observation; every observation has its own
+// accumulators (KO x RT x CT), and the frames' epilogues run together after the last slab.  kobs = groups x KO; the mean over
+// all of them stays in registers as before.  KO = 1 is the r03 order.
+template <int MODE, int TNT, int NPROD, int KO>
 __global__ __launch_bounds__(256, 2) void conv_tile3_kernel(Tile3P p) {
   using TT = T3<MODE>;
   constexpr int WN = TNT == 4 ? 2 : 1, WM = 4 / WN, RT = TH / WM, CT = 2;
   constexpr int A_SLOTS = TT::PAIRS * TNT * 3 * 64;                    // 16-byte slots
   constexpr int NA = (A_SLOTS + 255) / 256, NB = (TT::B_UNITS + 255) / 256;      // (k2s2, TN = 32: 384 slots -> the last pass is half full)
-  constexpr int STAGE = A_SLOTS + TT::B_SLOTS;
-  __shared__ u32x4 lds[2 * STAGE];
+  __shared__ u32x4 lds[2 * A_SLOTS + 2 * TT::B_SLOTS];                 // [A of slab parity 0 | 1][B of micro-stage parity 0 | 1]
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int kk = lane >> 4, j = lane & 15;
@@ -114,8 +120,9 @@ __global__ __launch_bounds__(256, 2) void conv_tile3_kernel(Tile3P p) {
   const int ty0 = (tile % p.tiles_y) * TH;
   const int f = tile / p.tiles_y;
   const int g = blockIdx.y;
-  const int stages_per_frame = (MODE == NLT_CONV_K2S1 ? 1 : 2) * p.ncc;
-  const int total_stages = stages_per_frame * p.kobs;
+  const int spf = (MODE == NLT_CONV_K2S1 ? 1 : 2) * p.ncc;             // slabs (stages) per frame
+  const int groups = p.kobs / KO;
+  const int total = spf * p.kobs;                                      // micro-stages
   const long in_frame = (long)p.h * p.w;
 
   // B copy units: unit = (texel, channel half): 8 consecutive lanes take 8 consecutive texels of one half (conflict-free
@@ -146,14 +153,18 @@ __global__ __launch_bounds__(256, 2) void conv_tile3_kernel(Tile3P p) {
 
   u32x4 ra[NA];
   f32x4 rb[NB][2];
-  auto load_stage = [&](int q) {
-    const int i = q / stages_per_frame, s = q - i * stages_per_frame;
+  // micro-stage (group gi, slab s, observation io): texel slab of frame gi * KO + io; weights of slab s (io == 0 only)
+  auto load_a = [&](int s) {
     const int cc = MODE == NLT_CONV_K2S1 ? s : (s >> 1);
     const int a = MODE == NLT_CONV_K2S1 ? 0 : (s & 1);
     const u32x4* ap = reinterpret_cast<const u32x4*>(p.packed) + (((long)g * p.ncc + cc) * 2 + a) * (TNT * 3 * 64);
 #pragma unroll
     for (int n = 0; n < NA; ++n) ra[n] = ap[(A_SLOTS % 256 == 0 || tid + 256 * n < A_SLOTS) ? tid + 256 * n : tid];
-    const float* sp = p.src + ((long)(f * p.kobs + i) * in_frame + (long)a * p.w) * p.ld + cc * 16;
+  };
+  auto load_b = [&](int s, int frame) {
+    const int cc = MODE == NLT_CONV_K2S1 ? s : (s >> 1);
+    const int a = MODE == NLT_CONV_K2S1 ? 0 : (s & 1);
+    const float* sp = p.src + ((long)(f * p.kobs + frame) * in_frame + (long)a * p.w) * p.ld + cc * 16;
 #pragma unroll
     for (int n = 0; n < NB; ++n) {
       const float* q8 = sp + (b_ok[n] ? b_tex[n] : 0) * p.ld + 8 * b_hf[n];
@@ -163,11 +174,14 @@ __global__ __launch_bounds__(256, 2) void conv_tile3_kernel(Tile3P p) {
       rb[n][1] = b_ok[n] ? v1 : z;
     }
   };
-  auto store_stage = [&](int buf) {
-    u32x4* base = lds + buf * STAGE;
+  auto store_a = [&](int buf) {
+    u32x4* base = lds + buf * A_SLOTS;
 #pragma unroll
     for (int n = 0; n < NA; ++n)
       if (A_SLOTS % 256 == 0 || tid + 256 * n < A_SLOTS) base[tid + 256 * n] = ra[n];
+  };
+  auto store_b = [&](int buf) {
+    u32x4* base = lds + 2 * A_SLOTS + buf * TT::B_SLOTS;
 #pragma unroll
     for (int n = 0; n < NB; ++n) {
       if (!b_st[n]) continue;
@@ -176,95 +190,136 @@ __global__ __launch_bounds__(256, 2) void conv_tile3_kernel(Tile3P p) {
       split2(rb[n][0][2], rb[n][0][3], hi[1], mid[1], lo[1]);
       split2(rb[n][1][0], rb[n][1][1], hi[2], mid[2], lo[2]);
       split2(rb[n][1][2], rb[n][1][3], hi[3], mid[3], lo[3]);
-      u32x4* bb = base + A_SLOTS + b_lds[n];
+      u32x4* bb = base + b_lds[n];
       bb[0] = (u32x4){hi[0], hi[1], hi[2], hi[3]};
       bb[2 * BPL] = (u32x4){mid[0], mid[1], mid[2], mid[3]};
       bb[4 * BPL] = (u32x4){lo[0], lo[1], lo[2], lo[3]};
     }
   };
 
-  f32x4 acc[RT][CT], mean[RT][CT];
+  f32x4 acc[KO][RT][CT], mean[RT][CT];
 #pragma unroll
   for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
-    for (int ct = 0; ct < CT; ++ct) { acc[rt][ct] = (f32x4){0.f, 0.f, 0.f, 0.f}; mean[rt][ct] = acc[rt][ct]; }
+    for (int ct = 0; ct < CT; ++ct) {
+      mean[rt][ct] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int io = 0; io < KO; ++io) acc[io][rt][ct] = mean[rt][ct];
+    }
 
-  load_stage(0);
-  store_stage(0);
+  load_a(0);
+  load_b(0, 0);
+  store_a(0);
+  store_b(0);
   __syncthreads();
-  for (int q = 0; q < total_stages; ++q) {
-    if (q + 1 < total_stages) load_stage(q + 1);
-    const u32x4* A = lds + (q & 1) * STAGE;
-    const u32x4* B = A + A_SLOTS;
-    const int s = q % stages_per_frame;
+  int q = 0;                                                            // micro-stage counter (its parity = B buffer)
+  for (int gi = 0; gi < groups; ++gi) {
+    for (int s = 0; s < spf; ++s) {
+      const int sa = (gi * spf + s) & 1;                                // A buffer of this slab
 #pragma unroll
-    for (int pl = 0; pl < TT::PAIRS; ++pl) {
-      bf16x8 bt[3][RT], at[3][CT];
+      for (int io = 0; io < KO; ++io, ++q) {
+        // next micro-stage: (gi, s, io + 1), else (gi, s + 1, 0) -- with the next slab's weights --, else (gi + 1, 0, 0)
+        const bool more = q + 1 < total;
+        const bool new_slab = io + 1 == KO;
+        int ns = s, ngi = gi;
+        if (new_slab) { if (++ns == spf) { ns = 0; ++ngi; } }
+        if (more) {
+          if (new_slab) load_a(ns);
+          load_b(ns, ngi * KO + (new_slab ? 0 : io + 1));
+        }
+        const u32x4* A = lds + sa * A_SLOTS;
+        const u32x4* B = lds + 2 * A_SLOTS + (q & 1) * TT::B_SLOTS;
 #pragma unroll
-      for (int rt = 0; rt < RT; ++rt) {
-        const int y = wm * RT + rt;
-        const int slot = MODE == NLT_CONV_K2S1 ? (kk & 1) * PL + (y + pl) * 17 + j + (kk >> 1)
-                                               : (kk & 1) * QS2 + (kk >> 1) * ODD2 + y * 16 + j;
+        for (int pl = 0; pl < TT::PAIRS; ++pl) {
+          bf16x8 bt[3][RT], at[3][CT];
 #pragma unroll
-        for (int t = 0; t < 3; ++t) bt[t][rt] = __builtin_bit_cast(bf16x8, B[t * 2 * BPL + slot]);
-      }
+          for (int rt = 0; rt < RT; ++rt) {
+            const int y = wm * RT + rt;
+            const int slot = MODE == NLT_CONV_K2S1 ? (kk & 1) * PL + (y + pl) * 17 + j + (kk >> 1)
+                                                   : (kk & 1) * QS2 + (kk >> 1) * ODD2 + y * 16 + j;
 #pragma unroll
-      for (int ct = 0; ct < CT; ++ct)
-#pragma unroll
-        for (int t = 0; t < 3; ++t)
-          at[t][ct] = __builtin_bit_cast(bf16x8, A[((pl * TNT + wn * CT + ct) * 3 + t) * 64 + lane]);
-      // (weight term, texel term), smallest products first; consecutive MFMAs go to different accumulators
-      constexpr int ORDER9[9][2] = {{2, 2}, {2, 1}, {1, 2}, {2, 0}, {0, 2}, {1, 1}, {1, 0}, {0, 1}, {0, 0}};
-#pragma unroll
-      for (int pi = 9 - NPROD; pi < 9; ++pi)
-#pragma unroll
-        for (int rt = 0; rt < RT; ++rt)
+            for (int t = 0; t < 3; ++t) bt[t][rt] = __builtin_bit_cast(bf16x8, B[t * 2 * BPL + slot]);
+          }
 #pragma unroll
           for (int ct = 0; ct < CT; ++ct)
-            acc[rt][ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(at[ORDER9[pi][0]][ct], bt[ORDER9[pi][1]][rt], acc[rt][ct], 0, 0, 0);
-    }
-    if (s == stages_per_frame - 1) {                                  // this observation frame is complete
-      const int i = q / stages_per_frame;
 #pragma unroll
-      for (int ct = 0; ct < CT; ++ct) {
-        const int oc = (g * TNT + wn * CT + ct) * 16 + 4 * kk;
-        const f32x4 bv = *reinterpret_cast<const f32x4*>(p.bias + oc);
+            for (int t = 0; t < 3; ++t)
+              at[t][ct] = __builtin_bit_cast(bf16x8, A[((pl * TNT + wn * CT + ct) * 3 + t) * 64 + lane]);
+          // (weight term, texel term), smallest products first; consecutive MFMAs go to different accumulators
+          constexpr int ORDER9[9][2] = {{2, 2}, {2, 1}, {1, 2}, {2, 0}, {0, 2}, {1, 1}, {1, 0}, {0, 1}, {0, 0}};
 #pragma unroll
-        for (int rt = 0; rt < RT; ++rt) {
-          const int gy = ty0 + wm * RT + rt, gx = tx0 + j;
-          f32x4 v = acc[rt][ct] + bv;
-          if (p.act) {
+          for (int pi = 9 - NPROD; pi < 9; ++pi)
 #pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : p.alpha * v[e];
-          }
-          acc[rt][ct] = (f32x4){0.f, 0.f, 0.f, 0.f};
-          mean[rt][ct] += v;
-          if (gy < p.oh && gx < p.ow) {
-            const long ot = ((long)(f * p.kobs + i) * p.oh + gy) * p.ow + gx;
-            if (p.out) *reinterpret_cast<f32x4*>(p.out + ot * p.ldo + oc) = v;
-            if (p.mean_out && i == p.kobs - 1) {
-              const long mt = ((long)f * p.oh + gy) * p.ow + gx;
-              *reinterpret_cast<f32x4*>(p.mean_out + mt * p.ldm + oc) = mean[rt][ct] * (1.f / (float)p.kobs);
+            for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+              for (int ct = 0; ct < CT; ++ct)
+                acc[io][rt][ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(at[ORDER9[pi][0]][ct], bt[ORDER9[pi][1]][rt], acc[io][rt][ct], 0, 0, 0);
+        }
+        if (s == spf - 1 && io == KO - 1) {                             // the group's KO observation frames are complete
+#pragma unroll
+          for (int e = 0; e < KO; ++e) {
+            const int i = gi * KO + e;
+#pragma unroll
+            for (int ct = 0; ct < CT; ++ct) {
+              const int oc = (g * TNT + wn * CT + ct) * 16 + 4 * kk;
+              const f32x4 bv = *reinterpret_cast<const f32x4*>(p.bias + oc);
+#pragma unroll
+              for (int rt = 0; rt < RT; ++rt) {
+                const int gy = ty0 + wm * RT + rt, gx = tx0 + j;
+                f32x4 v = acc[e][rt][ct] + bv;
+                if (p.act) {
+#pragma unroll
+                  for (int c4 = 0; c4 < 4; ++c4) v[c4] = v[c4] > 0.f ? v[c4] : p.alpha * v[c4];
+                }
+                acc[e][rt][ct] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                mean[rt][ct] += v;
+                if (gy < p.oh && gx < p.ow) {
+                  const long ot = ((long)(f * p.kobs + i) * p.oh + gy) * p.ow + gx;
+                  if (p.out) *reinterpret_cast<f32x4*>(p.out + ot * p.ldo + oc) = v;
+                  if (p.mean_out && i == p.kobs - 1) {
+                    const long mt = ((long)f * p.oh + gy) * p.ow + gx;
+                    *reinterpret_cast<f32x4*>(p.mean_out + mt * p.ldm + oc) = mean[rt][ct] * (1.f / (float)p.kobs);
+                  }
+                }
+              }
             }
           }
         }
+        if (more) {
+          if (new_slab) store_a(sa ^ 1);
+          store_b((q + 1) & 1);
+        }
+        __syncthreads();
       }
     }
-    if (q + 1 < total_stages) store_stage((q + 1) & 1);
-    __syncthreads();
   }
 }
 
-template <int MODE, int TNT>
-int launch3(const Tile3P& p, int nprod, hipStream_t s) {
+template <int MODE, int TNT, int KO>
+int launch3k(const Tile3P& p, int nprod, hipStream_t s) {
   const long tiles = (long)p.frames * p.tiles_y * p.tiles_x;
   const dim3 grid((unsigned)tiles, (unsigned)(p.cout / (16 * TNT)));
-  if (nprod == 9) hipLaunchKernelGGL((conv_tile3_kernel<MODE, TNT, 9>), grid, dim3(256), 0, s, p);
-  else if (nprod == 6) hipLaunchKernelGGL((conv_tile3_kernel<MODE, TNT, 6>), grid, dim3(256), 0, s, p);
-  else if (nprod == 3) hipLaunchKernelGGL((conv_tile3_kernel<MODE, TNT, 3>), grid, dim3(256), 0, s, p);   // hi*hi + hi*mid + mid*hi (~2^-16)
-  else hipLaunchKernelGGL((conv_tile3_kernel<MODE, TNT, 1>), grid, dim3(256), 0, s, p);                  // hi*hi: plain bf16 operands
+  if (nprod == 9) hipLaunchKernelGGL((conv_tile3_kernel<MODE, TNT, 9, KO>), grid, dim3(256), 0, s, p);
+  else if (nprod == 6) hipLaunchKernelGGL((conv_tile3_kernel<MODE, TNT, 6, KO>), grid, dim3(256), 0, s, p);
+  else if (KO > 1) return NLT_ERR_UNSUPPORTED;
+  else if (nprod == 3) hipLaunchKernelGGL((conv_tile3_kernel<MODE, TNT, 3, 1>), grid, dim3(256), 0, s, p);   // hi*hi + hi*mid + mid*hi (~2^-16)
+  else hipLaunchKernelGGL((conv_tile3_kernel<MODE, TNT, 1, 1>), grid, dim3(256), 0, s, p);                  // hi*hi: plain bf16 operands
   NLT_CHECK_LAUNCH();
   return NLT_OK;
+}
+
+// NLT_TILE3_KO: observation frames per pass over the weights (0 = the largest that fits the registers: 4 at 32 channels per
+// workgroup, 2 at 64; 1 = the r03 order) -- A/B switch
+template <int MODE, int TNT>
+int launch3(const Tile3P& p, int nprod, hipStream_t s) {
+  static const int want = [] { const char* e = getenv("NLT_TILE3_KO"); return e ? atoi(e) : 0; }();
+  // (stride-1 conv at 64 channels per workgroup: two sets of 4 x 2 accumulators beside the three-term fragments of 4 rows spill)
+  const int cap = want > 0 ? want : (TNT == 2 ? 4 : (MODE == NLT_CONV_K2S1 ? 1 : 2));
+  if (nprod >= 6) {
+    if (TNT == 2 && cap >= 4 && p.kobs % 4 == 0) return launch3k<MODE, TNT, (TNT == 2 ? 4 : 1)>(p, nprod, s);
+    if (cap >= 2 && p.kobs % 2 == 0) return launch3k<MODE, TNT, 2>(p, nprod, s);
+  }
+  return launch3k<MODE, TNT, 1>(p, nprod, s);
 }
 
 }  // namespace
