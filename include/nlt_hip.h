@@ -587,6 +587,8 @@ typedef struct {
   float fargs[4];
 } nlt_tape_call;
 int nlt_tape_play(const nlt_tape_call* calls, int n, int* failed_index);
+int nlt_event_create(int no_system_fence, void** event);   /* hipEventDisableTiming [| hipEventDisableSystemFence]: same-device stream ordering */
+int nlt_event_destroy(void* event);
 int nlt_event_record(void* event, void* stream);
 int nlt_stream_wait_event(void* stream, void* event);
 

@@ -46,6 +46,8 @@ SIGNATURES = {
                                                  _vp, _c_int, _c_int, _vp, _vp, _vp, _c_long, _vp]),
     'nlt_repack_weights': (_c_int, [_vp, _c_int, _c_long, _vp]),
     'nlt_tape_play': (_c_int, [_vp, _c_int, _vp]),
+    'nlt_event_create': (_c_int, [_c_int, _vp]),
+    'nlt_event_destroy': (_c_int, [_vp]),
     'nlt_event_record': (_c_int, [_vp, _vp]),
     'nlt_stream_wait_event': (_c_int, [_vp, _vp]),
     'nlt_wgrad_narrow_workspace_floats': (_c_long, [_c_int] * 7),
@@ -342,7 +344,35 @@ def tape_call(fn, *args):
         t.append((fn, args))
 
 
+class LightEvent:
+    """A HIP event for ordering two streams of one device: no timing, no system-scope fence at the record (csrc/tape.hip).  Record
+    and wait go through the C ABI, so an open launch tape picks them up like any launch (and replays them natively)."""
+
+    def __init__(self):
+        h = ctypes.c_void_p()
+        _check(_load().nlt_event_create(1, ctypes.byref(h)), 'nlt_event_create')
+        self.handle = h.value
+
+    def __del__(self):
+        try:
+            if self.handle and _real is not None:
+                _real.nlt_event_destroy(self.handle)
+        except Exception:
+            pass
+
+
+LIGHT_EVENTS = os.environ.get('NLT_LIGHT_EVENTS', '1') != '0'
+
+
+def new_event():
+    """Event for the plan's cross-stream hand-overs (NLT_LIGHT_EVENTS=0: an ordinary torch.cuda.Event)."""
+    return LightEvent() if LIGHT_EVENTS else torch.cuda.Event()
+
+
 def record_event(ev, stream):
+    if isinstance(ev, LightEvent):
+        _check(lib().nlt_event_record(ev.handle, stream.cuda_stream), 'nlt_event_record')
+        return
     ev.record(stream)
     t = getattr(_tls, 'tape', None)
     if t is not None:
@@ -350,6 +380,9 @@ def record_event(ev, stream):
 
 
 def wait_event(stream, ev):
+    if isinstance(ev, LightEvent):
+        _check(lib().nlt_stream_wait_event(stream.cuda_stream, ev.handle), 'nlt_stream_wait_event')
+        return
     stream.wait_event(ev)
     t = getattr(_tls, 'tape', None)
     if t is not None:

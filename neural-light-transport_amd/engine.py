@@ -723,7 +723,7 @@ class RenderPlan:
                       and not self._trial_c32)
         if concurrent:
             if self._side is None:
-                self._side = (torch.cuda.Stream(device=dev), [torch.cuda.Event() for _ in range(D + 3)])
+                self._side = (torch.cuda.Stream(device=dev), [C.new_event() for _ in range(D + 3)])
             side, ev = self._side
             main = torch.cuda.current_stream()
             C.record_event(ev[0], main)                             # front kernel done: fm[1], obs[1]
@@ -864,7 +864,7 @@ class RenderPlan:
         if bs is not None and bs[2] is not None:
             side, events, cur = bs[:3]
             if cur[0] == len(events):
-                events.append(torch.cuda.Event())
+                events.append(C.new_event())
             ev = events[cur[0]]
             if len(bs) > 3 and bs[3] is not None and cur[0] % 2:            # two weight-gradient streams, dealt alternately
                 side = bs[3]                                                # (scratch is per stream: _capi's wgrad workspaces)
@@ -1032,7 +1032,7 @@ class RenderPlan:
                     if sd is None:
                         continue
                     if cur[0] == len(events):
-                        events.append(torch.cuda.Event())
+                        events.append(C.new_event())
                     C.record_event(events[cur[0]], sd)
                     C.wait_event(torch.cuda.current_stream(), events[cur[0]])   # the optimizer step needs every gradient
                     cur[0] += 1
@@ -1114,7 +1114,7 @@ class RenderPlan:
         if bs is not None and bs[2] is not None and bs[3] is not None:
             side, events, cur, side2 = bs                            # (two weight-gradient streams: the hook's stream waits for the other)
             if cur[0] == len(events):
-                events.append(torch.cuda.Event())
+                events.append(C.new_event())
             C.record_event(events[cur[0]], side2)
             C.wait_event(side, events[cur[0]])
             cur[0] += 1
