@@ -68,6 +68,7 @@ class RenderPlan:
         # tile spill 46 dwords and the kernel is store-bound at k = 1 anyway (its extra maps are 200 MB per 4 frames)
         self.front4_train = os.environ.get('NLT_FRONT4_TRAIN', '0') != '0'
         self.two_streams = os.environ.get('NLT_STREAMS', '2') != '1'   # inference: query-path encoder convs on a side stream
+        self.lazy_fork = os.environ.get('NLT_LAZY_FORK', '0') != '0'   # ... forked behind level 2's observation conv (see _forward_fused)
         self._side = None               # (side stream, [events]) created on first use
         self._bside = None              # backward: (side stream for the weight gradients, [events], cursor)
         self.wgrad_tiled = os.environ.get('NLT_WGRAD', 'tiled') != 'atomic'   # csrc/wgrad_tile.hip vs first-generation csrc/wgrad.hip
@@ -75,6 +76,9 @@ class RenderPlan:
         # weight gradients on a side stream, off the backward-data chain (config 4: 5.17 -> 4.63 ms / step)
         self.bwd_streams = int(os.environ.get('NLT_BWD_STREAMS', '1'))   # 0: one stream; 1: weight gradients on a side stream; 2: on two, alternately
         # launch tape: replay a step's C calls with their resolved arguments instead of re-deriving them (see _capi.py)
+        # ... handed over in batches of this many behind one event (1: an event per launch, the r03 form)
+        self.wgrad_batch = int(os.environ.get('NLT_WGRAD_BATCH', '3'))
+        self._pending_wgrad = []
         self.use_tape = os.environ.get('NLT_TAPE', '1') != '0'
         # backward, one observation per frame: the per-level LeakyReLU' / observation-mean adjoint pass folded into the
         # epilogue of the backward-data launch that completes dfm[l] (0: the separate nlt_level_split_backward launches)
@@ -726,8 +730,15 @@ class RenderPlan:
                 self._side = (torch.cuda.Stream(device=dev), [C.new_event() for _ in range(D + 3)])
             side, ev = self._side
             main = torch.cuda.current_stream()
-            C.record_event(ev[0], main)                             # front kernel done: fm[1], obs[1]
-            C.wait_event(side, ev[0])
+            # An event record is a marker packet on the recording stream: the next launch behind it starts 4-12 us late (r04
+            # trace: 54 us of such gaps on the observation chain per pass, 46 with events that carry no system-scope fence).
+            # So the query stream is not forked right behind the front kernel (12.6 us before the largest launch of the chain)
+            # but behind level 2's observation conv -- its first wait is ev[2] --, and the record nobody waits for (level D) is
+            # gone.  OPT-IN (NLT_LAZY_FORK=1): measured r04 1.268 / 1.278 vs 1.275 / 1.268 ms -- the gap goes, the query path starts 125 us later, nothing is won.
+            lazy = self.lazy_fork
+            if not lazy:
+                C.record_event(ev[0], main)                         # front kernel done: fm[1], obs[1]
+                C.wait_event(side, ev[0])
         hh, ww = h // 2, w // 2
         bf = self.precision == 'bf16' and not train
         for l in range(2, D + 1):
@@ -762,10 +773,13 @@ class RenderPlan:
 
             obs_path()
             if concurrent:
-                C.record_event(ev[l], main)                         # fm[l]'s observation half is complete
+                if l < D or not lazy or l == 2:
+                    C.record_event(ev[l], main)                     # fm[l]'s observation half is complete
                 with torch.cuda.stream(side):
                     if l > 2:
                         C.wait_event(side, ev[l - 1])
+                    elif lazy:
+                        C.wait_event(side, ev[2])                   # (also orders the side stream behind the front kernel)
                     query_path()
             else:
                 query_path()
@@ -862,6 +876,15 @@ class RenderPlan:
         chain -- the critical path -- carries on; `backward` joins the streams at the end."""
         bs = self._bside
         if bs is not None and bs[2] is not None:
+            if self.wgrad_batch > 1 and (len(bs) <= 3 or bs[3] is None):
+                # every event record is a marker packet on the backward-data chain: the launch behind it starts ~5 us late (r04
+                # trace of the train step: 39 such gaps, 216 us of 3.2 ms).  The weight gradients are off the critical path and
+                # their operands are final when they are queued, so they are handed to the side stream a few at a time behind
+                # ONE event.
+                self._pending_wgrad.append((label, layer, src0, c0, ld0, src1, c1, ld1, n, h, w, dpre, ldp))
+                if len(self._pending_wgrad) >= self.wgrad_batch:
+                    self._flush_wgrads()
+                return
             side, events, cur = bs[:3]
             if cur[0] == len(events):
                 events.append(C.new_event())
@@ -875,6 +898,27 @@ class RenderPlan:
                 self._wgrad_now(label, layer, src0, c0, ld0, src1, c1, ld1, n, h, w, dpre, ldp)
             return
         self._wgrad_now(label, layer, src0, c0, ld0, src1, c1, ld1, n, h, w, dpre, ldp)
+
+    def _flush_wgrads(self):
+        """Queues the weight-gradient launches collected by `_wgrad` on the side stream, behind one event on the current stream."""
+        pend, self._pending_wgrad = self._pending_wgrad, []
+        bs = self._bside
+        if not pend:
+            return
+        if bs is None or bs[2] is None:
+            for a in pend:
+                self._wgrad_now(*a)
+            return
+        side, events, cur = bs[:3]
+        if cur[0] == len(events):
+            events.append(C.new_event())
+        ev = events[cur[0]]
+        cur[0] += 1
+        C.record_event(ev, torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            C.wait_event(side, ev)
+            for a in pend:
+                self._wgrad_now(*a)
 
     def _fire_grad_hook(self, side):
         """Runs `grad_hook` on the stream the expanding blocks' weight gradients were queued on.  `side` is an ARGUMENT
@@ -1022,9 +1066,12 @@ class RenderPlan:
                 self._bside = [torch.cuda.Stream(device=dpred.device), [], None,
                                torch.cuda.Stream(device=dpred.device) if self.bwd_streams > 1 else None]
             self._bside[2] = [0]                                     # event cursor: weight gradients go to the side stream
+        self._pending_wgrad = []
         try:
             self._backward_plan(dpred, base, cvis, lvis, nn_rgb, nn_base, obs_weights, b, g, n, h, w, k)
+            self._flush_wgrads()
         finally:
+            self._pending_wgrad = []
             if concurrent:
                 side, events, cur, side2 = self._bside
                 self._bside[2] = None
@@ -1110,6 +1157,7 @@ class RenderPlan:
 
         # every weight gradient of the expanding blocks is queued now: the leading range of the flat gradient
         # bucket (models/nlt.py:_flatten) can start its all-reduce while the encoder's backward runs
+        self._flush_wgrads()                                        # (the hook needs every expanding block's weight gradient queued)
         bs = self._bside
         if bs is not None and bs[2] is not None and bs[3] is not None:
             side, events, cur, side2 = bs                            # (two weight-gradient streams: the hook's stream waits for the other)
