@@ -76,8 +76,10 @@ class RenderPlan:
         # weight gradients on a side stream, off the backward-data chain (config 4: 5.17 -> 4.63 ms / step)
         self.bwd_streams = int(os.environ.get('NLT_BWD_STREAMS', '1'))   # 0: one stream; 1: weight gradients on a side stream; 2: on two, alternately
         # launch tape: replay a step's C calls with their resolved arguments instead of re-deriving them (see _capi.py)
-        # ... handed over in batches of this many behind one event (1: an event per launch, the r03 form)
-        self.wgrad_batch = int(os.environ.get('NLT_WGRAD_BATCH', '3'))
+        # ... handed over in batches of this many behind one event (1 = an event per launch, the default: batches of 3 / 6 measured
+        # SLOWER in r04 -- 3.22-3.24 -> 3.28 / 3.33 ms l2: the later start of the weight gradients costs more than the ~5 us
+        # marker gaps on the backward-data chain, which mostly sit under the side stream's work anyway)
+        self.wgrad_batch = int(os.environ.get('NLT_WGRAD_BATCH', '1'))
         self._pending_wgrad = []
         self.use_tape = os.environ.get('NLT_TAPE', '1') != '0'
         # backward, one observation per frame: the per-level LeakyReLU' / observation-mean adjoint pass folded into the
