@@ -12,7 +12,7 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'libnlt_hip.so')
+LIB_PATH = os.environ.get('NLT_HIP_LIB') or os.path.join(_HERE, 'libnlt_hip.so')   # NLT_HIP_LIB: A/B of two builds (tools/ab_front.py)
 
 CONV1X1, CONV_K2S2, CONV_K2S1, DECONV_K2S2, DECONV_K2S1 = range(5)
 ALGO_AUTO, ALGO_DIRECT, ALGO_MFMA = range(3)
@@ -91,6 +91,8 @@ SIGNATURES = {
     'nlt_front2_forward': (_c_int, [_vp] * 5 + [_c_int] * 4 + [_vp, _vp, _c_int, _c_float, _vp, _vp, _vp, _vp, _vp]),
     'nlt_front4_forward': (_c_int, [_vp] * 5 + [_c_int] * 4 + [_vp, _vp, _c_int, _c_float, _vp, _vp, _vp, _vp, _c_int, _vp]),
     'nlt_front4_forward_u8': (_c_int, [_vp] * 6 + [_c_int] * 4 + [_vp, _vp, _c_int, _c_float, _vp, _vp, _vp, _vp, _c_int, _vp]),
+    'nlt_front5_forward': (_c_int, [_vp] * 5 + [_c_int] * 4 + [_vp, _vp, _c_int, _c_float, _vp, _vp, _vp, _vp, _c_int, _vp]),
+    'nlt_front5_forward_u8': (_c_int, [_vp] * 6 + [_c_int] * 4 + [_vp, _vp, _c_int, _c_float, _vp, _vp, _vp, _vp, _c_int, _vp]),
     'nlt_front4_forward_train': (_c_int, [_vp] * 5 + [_c_int] * 4 + [_vp, _vp, _c_int, _c_float] + [_vp] * 7 + [_vp]),
     'nlt_dec_block_forward': (_c_int, [_vp, _c_int, _vp, _c_int, _c_int, _c_int, _c_int, _vp, _vp, _vp, _vp, _c_int, _c_float, _vp, _vp]),
     'nlt_back_forward': (_c_int, [_vp] * 3 + [_c_int] * 3 + [_vp] * 5 + [_c_float, _vp, _vp]),
@@ -1121,6 +1123,27 @@ def front4_forward_u8(diffuse_store, rgb_store, cvis_store, lvis_store, ids, nn_
                                        _ptr(packed), _ptr(packed_l2), 1 if add_base else 0, float(alpha), _ptr(fm1),
                                        _ptr(skip3), _ptr(qtmp2), _ptr(otmp2), int(waves_per_simd), _stream()),
            'nlt_front4_forward_u8')
+
+
+def front5_forward(base, cvis, lvis, nn_rgb, nn_base, n, k, h, w, packed, packed_l2, add_base, alpha, fm1, skip3, qtmp2, otmp2,
+                   products=9):
+    """front4_forward with the 16-channel stages on the bf16 matrix cores (three-term split, `products` = 9 or 6)."""
+    for t, nm in ((base, 'base'), (cvis, 'cvis'), (lvis, 'lvis'), (nn_rgb, 'nn_rgb'), (nn_base, 'nn_base')):
+        _dense(t, nm)
+    _check(lib().nlt_front5_forward(_ptr(base), _ptr(cvis), _ptr(lvis), _ptr(nn_rgb), _ptr(nn_base), n, k, h, w,
+                                    _ptr(packed), _ptr(packed_l2), 1 if add_base else 0, float(alpha), _ptr(fm1), _ptr(skip3),
+                                    _ptr(qtmp2), _ptr(otmp2), int(products), _stream()), 'nlt_front5_forward')
+
+
+def front5_forward_u8(diffuse_store, rgb_store, cvis_store, lvis_store, ids, nn_ids, n, k, h, w, packed, packed_l2, add_base,
+                      alpha, fm1, skip3, qtmp2, otmp2, products=9):
+    u8 = torch.uint8
+    _check(lib().nlt_front5_forward_u8(_tptr(diffuse_store, u8, 'diffuse_store'), _tptr(rgb_store, u8, 'rgb_store'),
+                                       _tptr(cvis_store, u8, 'cvis_store'), _tptr(lvis_store, u8, 'lvis_store'),
+                                       _tptr(ids, torch.int32, 'ids'), _tptr(nn_ids, torch.int32, 'nn_ids'), n, k, h, w,
+                                       _ptr(packed), _ptr(packed_l2), 1 if add_base else 0, float(alpha), _ptr(fm1),
+                                       _ptr(skip3), _ptr(qtmp2), _ptr(otmp2), int(products), _stream()),
+           'nlt_front5_forward_u8')
 
 
 def front4_forward_train(base, cvis, lvis, nn_rgb, nn_base, n, k, h, w, packed, packed_l2, add_base, alpha, fm1, skip3, qtmp2, otmp2,

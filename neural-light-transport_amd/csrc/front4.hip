@@ -359,11 +359,22 @@ __global__ __launch_bounds__(64, 2) void front4_kernel(
 
   // ---- query path
   {
+    // The weights of stages 1 and 2 are requested here, level 2's after stage 1, into the registers the observation path's
+    // weights and staging pieces have left: fetched where they are used (r01-r04_a) each stage began with an exposed L2
+    // round trip -- 8 + 4 + 16 of them in a row in stage 3 -- and one strip's query path took as long as 3.8 observations
+    // for 1.5x the MFMAs (r03: k = 1 -> 4: 0.034 ms per observation, 0.128 ms for everything else)
     float aq2[8];
 #pragma unroll
     for (int m = 0; m < 8; ++m) aq2[m] = blob[OFF_AQ2 + m * 64 + lane];
     const f32x4 bq2 = *reinterpret_cast<const f32x4*>(blob + OFF_BQ2 + 4 * kk);
     const float s0b = blob[OFF_BSK], s1b = blob[OFF_BSK + 1], s2b = blob[OFF_BSK + 2];
+    float wsk[24];                                                       // wave-uniform: scalar loads, once (not per column tile)
+#pragma unroll
+    for (int rr = 0; rr < 24; ++rr) wsk[rr] = blob[OFF_WSK + rr];
+    f32x4 aq1[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) aq1[t] = *reinterpret_cast<const f32x4*>(blob + OFF_AQ1 + (t * 64 + lane) * 4);
+    const f32x4 bq1 = *reinterpret_cast<const f32x4*>(blob + OFF_BQ1 + 4 * kk);
     // stage 1 (8 MFMAs per column tile): raw = (base r g b, cvis, lvis, mean raw observation r g b)
 #pragma unroll
     for (int c0 = 0; c0 < NC; c0 += 3) {                                 // three column tiles at a time, as for the observations
@@ -401,9 +412,9 @@ __global__ __launch_bounds__(64, 2) void front4_kernel(
           float s0 = s0b, s1 = s1b, s2 = s2b;
 #pragma unroll
           for (int rr = 0; rr < 8; ++rr) {
-            s0 = fmaf(raw[c][rr], blob[OFF_WSK + rr * 3], s0);
-            s1 = fmaf(raw[c][rr], blob[OFF_WSK + rr * 3 + 1], s1);
-            s2 = fmaf(raw[c][rr], blob[OFF_WSK + rr * 3 + 2], s2);
+            s0 = fmaf(raw[c][rr], wsk[rr * 3], s0);
+            s1 = fmaf(raw[c][rr], wsk[rr * 3 + 1], s1);
+            s2 = fmaf(raw[c][rr], wsk[rr * 3 + 2], s2);
           }
           if (add_base) { s0 += raw[c][0]; s1 += raw[c][1]; s2 += raw[c][2]; }
           const int t = (c0 + c) * 16 + j;
@@ -414,11 +425,15 @@ __global__ __launch_bounds__(64, 2) void front4_kernel(
         }
       }
     }
-    wave_sync();
-    f32x4 aq1[4];
+    // level 2's weights: requested now (stage 1's operands are dead), they arrive under stage 2's 64 MFMAs
+    f32x4 aq3[2][8];                                                     // [row tile][slab * 4 + channel quad]
 #pragma unroll
-    for (int t = 0; t < 4; ++t) aq1[t] = *reinterpret_cast<const f32x4*>(blob + OFF_AQ1 + (t * 64 + lane) * 4);
-    const f32x4 bq1 = *reinterpret_cast<const f32x4*>(blob + OFF_BQ1 + 4 * kk);
+    for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+      for (int c8 = 0; c8 < 8; ++c8) aq3[rt][c8] = *reinterpret_cast<const f32x4*>(blob3 + OFF3_AQ + ((rt * 8 + c8) * 64 + lane) * 4);
+    const f32x4 bq3[2] = {*reinterpret_cast<const f32x4*>(blob3 + OFF3_BQ + 4 * kk),
+                          *reinterpret_cast<const f32x4*>(blob3 + OFF3_BQ + 16 + 4 * kk)};
+    wave_sync();
     f32x4 qv[SH];
     stage2(aq1, bq1, qv);
 #pragma unroll
@@ -445,20 +460,18 @@ __global__ __launch_bounds__(64, 2) void front4_kernel(
 #pragma unroll
       for (int c4 = 0; c4 < 4; ++c4) {
         const f32x4 v = *reinterpret_cast<const f32x4*>(ot + c4 * 256 + l1_rd);
-        const f32x4 w0 = *reinterpret_cast<const f32x4*>(blob3 + OFF3_AQ + ((0 * 8 + slab * 4 + c4) * 64 + lane) * 4);
-        const f32x4 w1 = *reinterpret_cast<const f32x4*>(blob3 + OFF3_AQ + ((1 * 8 + slab * 4 + c4) * 64 + lane) * 4);
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-          a3[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(w0[e], v[e], a3[0], 0, 0, 0);
-          a3[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(w1[e], v[e], a3[1], 0, 0, 0);
+          a3[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(aq3[0][slab * 4 + c4][e], v[e], a3[0], 0, 0, 0);
+          a3[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(aq3[1][slab * 4 + c4][e], v[e], a3[1], 0, 0, 0);
         }
       }
       wave_sync();
     }
     if (in2) {
       float* o = qtmp2 + ((long)f * h4 * w4 + tex2) * 32 + 4 * kk;
-      *reinterpret_cast<f32x4*>(o) = lrelu4m(a3[0] + *reinterpret_cast<const f32x4*>(blob3 + OFF3_BQ + 4 * kk), alpha);
-      *reinterpret_cast<f32x4*>(o + 16) = lrelu4m(a3[1] + *reinterpret_cast<const f32x4*>(blob3 + OFF3_BQ + 16 + 4 * kk), alpha);
+      *reinterpret_cast<f32x4*>(o) = lrelu4m(a3[0] + bq3[0], alpha);
+      *reinterpret_cast<f32x4*>(o + 16) = lrelu4m(a3[1] + bq3[1], alpha);
     }
   }
 }
