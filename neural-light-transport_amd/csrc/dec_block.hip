@@ -15,6 +15,7 @@
 //   stage 2: k2s1 transposed conv from that tile: rows = C output channels (padded to 16 at C = 8), K = 4 taps x C in
 //            16-wide slabs (C = 8: two taps per slab), columns = 16 consecutive output texels of a row.
 #include "nlt_common.h"
+#include <cstdlib>
 
 namespace {
 
@@ -155,6 +156,138 @@ __global__ __launch_bounds__(256) void dec_block_kernel(DecP p) {
   }
 }
 
+// r04: the same block for the widths the U-Net actually has at these two levels -- x = the previous block's 2C channels, skip =
+// [query | mean observation] of the INPUT level = 8C channels, K = 10C -- reorganised around what the r04 trace showed:
+// dec_block_kernel ran at 0.16-0.26 of BOTH roofs (L10 45 us for 14 us of MFMAs and 59 MB) because every wave walked its 2-3 column
+// tiles one after the other, each starting with an exposed HBM round trip for the texels and an L2 round trip for the weight
+// fragments, then one for the bias, with the 10 column tiles dealt 3/3/2/2 to the four waves, and with all 512 workgroups of the
+// launch in lockstep.
+//   * a wave owns HALF of the 4C output columns (row tiles mh * MH ..) of FIVE of the ten column tiles: 20 balanced units,
+//     and its weight fragments (MH x NCH 16-byte registers) are fetched once, not per column tile;
+//   * the texel loads run NPF column tiles ahead of the MFMAs (requested before the weights; one exposed round trip per wave);
+//   * biases and the second conv's fragments are fetched in the prologue, before the barrier.
+// The accumulation order of every output is the one of dec_block_kernel: results are bit-identical.
+template <int C>
+__global__ __launch_bounds__(256, C == 8 ? 4 : 2) void dec_block10_kernel(DecP p) {
+  constexpr int MT = C / 4, MH = MT / 2;          // stage 1: row tiles of the 4C columns (a, b, o); per wave
+  constexpr int K = 10 * C, NCH = K / 16;         // 16-channel chunks of the virtual concat [x 2C | skip 8C]
+  constexpr int NQ = C / 4;                       // channel quads of the intermediate map
+  constexpr int NS = 4 * C / 16;                  // stage 2: 16-wide K slabs
+  constexpr int NI = NT / 2;                      // column tiles per wave
+  constexpr int NPF = C == 8 ? 3 : 2;             // column tiles whose texels are in flight (registers: NPF x NCH x 4)
+  __shared__ __attribute__((aligned(16))) float tile[NQ * FP * 4];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int kk = lane >> 4, j = lane & 15;
+  const int mh = wave & 1, cg = wave >> 1;
+  int t_ = xcd_tile(blockIdx.x, gridDim.x);
+  const int tx0 = (t_ % p.tiles_x) * TW; t_ /= p.tiles_x;
+  const int ty0 = (t_ % p.tiles_y) * TH;
+  const int f = t_ / p.tiles_y;
+  const long hw = (long)p.h * p.w;
+  const f32x4 z4 = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  // texels of column tile cg + 2 i: one 16-byte NHWC load per lane and chunk (permuted K: the lane's 4 channels feed 4 k-steps)
+  auto load_b = [&](int i, f32x4 (&dst)[NCH]) {
+    const int t = (cg + 2 * i) * 16 + j;
+    const bool live = t < HT;
+    const int hy = live ? t / HW : 0, hx = live ? t % HW : 0;
+    const int gy = ty0 - 1 + hy, gx = tx0 - 1 + hx;
+    const bool inside = live && gy >= 0 && gx >= 0 && gy < p.h && gx < p.w;
+    const long tex = (long)f * hw + (inside ? (long)gy * p.w + gx : 0);
+    const float* xp = p.x + tex * (2 * C);
+    const float* sp = p.skip + tex * (8 * C) - 2 * C;                     // indexed by the concat channel
+#pragma unroll
+    for (int ch = 0; ch < NCH; ++ch) {
+      const int c0 = 16 * ch + 4 * kk;                                    // (C = 8: chunk 0 is x for every lane, 2C = 16)
+      dst[ch] = *reinterpret_cast<const f32x4*>(c0 < 2 * C ? xp + c0 : sp + c0);
+    }
+  };
+  f32x4 bq[NPF][NCH];
+#pragma unroll
+  for (int i = 0; i < NPF; ++i) load_b(i, bq[i]);
+  f32x4 a[MH][NCH];
+#pragma unroll
+  for (int m = 0; m < MH; ++m)
+#pragma unroll
+    for (int ch = 0; ch < NCH; ++ch)
+      a[m][ch] = *reinterpret_cast<const f32x4*>(p.w2 + (long)(16 * (mh * MH + m) + j) * K + 16 * ch + 4 * kk);
+  // this lane's 4 consecutive columns of row tile m: col = 16 m + 4 kk = (ab, o0 .. o0 + 3); o0 does not depend on m
+  const int o0 = (4 * kk) % C;
+  const f32x4 bias2 = *reinterpret_cast<const f32x4*>(p.b2 + o0);
+  f32x4 a1[NS];                                                          // stage 2's A fragments: row j = output channel, K slab s
+#pragma unroll
+  for (int s = 0; s < NS; ++s) {
+    const int tap = C >= 16 ? s / (C / 16) : 2 * s + (kk >> 1);
+    const int q = C >= 16 ? (s % (C / 16)) * 4 + kk : (kk & 1);
+    a1[s] = j < C ? *reinterpret_cast<const f32x4*>(p.w1 + ((long)(tap * C + j) * C + 4 * q)) : z4;
+  }
+  const f32x4 bias1 = 4 * kk < C ? *reinterpret_cast<const f32x4*>(p.b1 + 4 * kk) : z4;
+
+  // ---- stage 1
+#pragma unroll
+  for (int i = 0; i < NI; ++i) {
+    f32x4 acc[MH];
+#pragma unroll
+    for (int m = 0; m < MH; ++m) acc[m] = z4;
+#pragma unroll
+    for (int ch = 0; ch < NCH; ++ch)
+#pragma unroll
+      for (int s4 = 0; s4 < 4; ++s4)
+#pragma unroll
+        for (int m = 0; m < MH; ++m) acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[m][ch][s4], bq[i % NPF][ch][s4], acc[m], 0, 0, 0);
+    if (i + NPF < NI) load_b(i + NPF, bq[i % NPF]);
+    const int t = (cg + 2 * i) * 16 + j;
+    const bool live = t < HT;
+    const int hy = live ? t / HW : 0, hx = live ? t % HW : 0;
+    const int gy = ty0 - 1 + hy, gx = tx0 - 1 + hx;
+    const bool inside = live && gy >= 0 && gx >= 0 && gy < p.h && gx < p.w;
+#pragma unroll
+    for (int m = 0; m < MH; ++m) {
+      const int col = 16 * (mh * MH + m) + 4 * kk;
+      const int ab = col / C;
+      f32x4 v = lrelu4(acc[m] + bias2, p.alpha);
+      if (!inside) v = z4;                                               // zero padding above / left of the image
+      const int ly = 2 * hy + (ab >> 1) - 1, lx = 2 * hx + (ab & 1) - 1;
+      if (live && ly >= 0 && lx >= 0) *reinterpret_cast<f32x4*>(tile + ((o0 >> 2) * FP + ly * FW + lx) * 4) = v;
+    }
+  }
+  __syncthreads();
+
+  // ---- stage 2: 16 output rows x 2 segments of 16 texels = 32 column tiles, 8 per wave, 4 accumulators at a time
+  const int H2 = 2 * p.h, W2 = 2 * p.w;
+#pragma unroll
+  for (int g = 0; g < 2; ++g) {
+    f32x4 acc[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) acc[u] = z4;
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+      const int tap = C >= 16 ? s / (C / 16) : 2 * s + (kk >> 1);
+      const int q = C >= 16 ? (s % (C / 16)) * 4 + kk : (kk & 1);
+      f32x4 b[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int ct = wave * 8 + g * 4 + u;                             // column tile -> (output row, 16-texel segment)
+        const int oy = ct >> 1, ox = (ct & 1) * 16 + j;
+        b[u] = *reinterpret_cast<const f32x4*>(tile + (q * FP + (oy + 1 - (tap >> 1)) * FW + ox + 1 - (tap & 1)) * 4);
+      }
+#pragma unroll
+      for (int s4 = 0; s4 < 4; ++s4)
+#pragma unroll
+        for (int u = 0; u < 4; ++u) acc[u] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[s][s4], b[u][s4], acc[u], 0, 0, 0);
+    }
+    if (4 * kk < C) {
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int ct = wave * 8 + g * 4 + u;
+        const int y = 2 * ty0 + (ct >> 1), xg = 2 * tx0 + (ct & 1) * 16 + j;
+        if (y < H2 && xg < W2)
+          *reinterpret_cast<f32x4*>(p.out + (((long)f * H2 + y) * W2 + xg) * C + 4 * kk) = lrelu4(acc[u] + bias1, p.alpha);
+      }
+    }
+  }
+}
+
 }  // namespace
 
 extern "C" int nlt_dec_block_forward(const float* x, int cx, const float* skip, int cs, int n, int h, int w,
@@ -173,8 +306,15 @@ extern "C" int nlt_dec_block_forward(const float* x, int cx, const float* skip, 
   p.tiles_y = (h + TH - 1) / TH; p.tiles_x = (w + TW - 1) / TW;
   const long blocks = (long)n * p.tiles_y * p.tiles_x;
   hipStream_t s = static_cast<hipStream_t>(stream);
-  if (c == 8) hipLaunchKernelGGL(dec_block_kernel<8>, dim3((unsigned)blocks), dim3(256), 0, s, p);
-  else hipLaunchKernelGGL(dec_block_kernel<16>, dim3((unsigned)blocks), dim3(256), 0, s, p);
+  static const bool generic_only = getenv("NLT_DEC_GENERIC") && atoi(getenv("NLT_DEC_GENERIC"));
+  const bool ten = cx == 2 * c && cs == 8 * c && !generic_only;       // the U-Net's widths at these levels: x = 2C, skip = [q | mean obs] of the input level = 8C
+  if (c == 8) {
+    if (ten) hipLaunchKernelGGL(dec_block10_kernel<8>, dim3((unsigned)blocks), dim3(256), 0, s, p);
+    else hipLaunchKernelGGL(dec_block_kernel<8>, dim3((unsigned)blocks), dim3(256), 0, s, p);
+  } else {
+    if (ten) hipLaunchKernelGGL(dec_block10_kernel<16>, dim3((unsigned)blocks), dim3(256), 0, s, p);
+    else hipLaunchKernelGGL(dec_block_kernel<16>, dim3((unsigned)blocks), dim3(256), 0, s, p);
+  }
   NLT_CHECK_LAUNCH();
   return NLT_OK;
 }

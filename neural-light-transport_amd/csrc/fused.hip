@@ -374,22 +374,54 @@ __global__ __launch_bounds__(256) void back_kernel(
   }
   const f32x4 bs2 = *reinterpret_cast<const f32x4*>(b_s2);
 
-  for (int mt = wave; mt < NT; mt += 4) {
+  // r04: every HBM request of the workgroup is issued before the first MFMA -- the texels of the wave's (up to) three column
+  // tiles AND the skip3 rows stage 2 will add -- instead of one exposed round trip per column tile and one more after the barrier
+  // (the kernel ran at 0.50 of the HBM peak with 8 workgroups per CU to cover for that).
+  constexpr int NIT = (NT + 3) / 4;
+  f32x4 bq[NIT][3];
+#pragma unroll
+  for (int it = 0; it < NIT; ++it) {
+    const int mt = wave + 4 * it;
+    const int t = mt * 16 + j;
+    const bool live = mt < NT && t < HT;
+    const int hy = live ? t / HW : 0, hx = live ? t % HW : 0;
+    const int gy = ty0 - 1 + hy, gx = tx0 - 1 + hx;
+    const bool inside = live && gy >= 0 && gx >= 0 && gy < h2 && gx < w2;
+    const long tex = (long)f * hw2 + (inside ? (long)gy * w2 + gx : 0);
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      const int c0 = 16 * c + 4 * kk;                                  // channel of the virtual concat [x 8 | fm1 32]
+      f32x4 b = (f32x4){0.f, 0.f, 0.f, 0.f};
+      if (mt < NT) {                                                   // wave-uniform
+        if (c0 < 8) b = *reinterpret_cast<const f32x4*>(x + tex * 8 + c0);
+        else if (c0 < 40) b = *reinterpret_cast<const f32x4*>(fm1 + tex * 32 + (c0 - 8));
+      }
+      bq[it][c] = b;
+    }
+  }
+  const int h = 2 * h2, w = 2 * w2;
+  float sk[2][3];
+#pragma unroll
+  for (int half = 0; half < 2; ++half) {
+    const int ox = threadIdx.x & 31, oy = (threadIdx.x >> 5) + 8 * half;
+    const int y = 2 * ty0 + oy, xg = 2 * tx0 + ox;
+    const long tex = ((long)f * h + (y < h ? y : 0)) * w + (xg < w ? xg : 0);
+    sk[half][0] = skip3[tex * 3]; sk[half][1] = skip3[tex * 3 + 1]; sk[half][2] = skip3[tex * 3 + 2];
+  }
+#pragma unroll
+  for (int it = 0; it < NIT; ++it) {
+    const int mt = wave + 4 * it;
+    if (mt >= NT) break;
     const int t = mt * 16 + j;
     const bool live = t < HT;
     const int hy = live ? t / HW : 0, hx = live ? t % HW : 0;
     const int gy = ty0 - 1 + hy, gx = tx0 - 1 + hx;
     const bool inside = live && gy >= 0 && gx >= 0 && gy < h2 && gx < w2;
-    const long tex = (long)f * hw2 + (inside ? (long)gy * w2 + gx : 0);
     f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
-      const int c0 = 16 * c + 4 * kk;                                  // channel of the virtual concat [x 8 | fm1 32]
-      f32x4 b = (f32x4){0.f, 0.f, 0.f, 0.f};
-      if (c0 < 8) b = *reinterpret_cast<const f32x4*>(x + tex * 8 + c0);
-      else if (c0 < 40) b = *reinterpret_cast<const f32x4*>(fm1 + tex * 32 + (c0 - 8));
 #pragma unroll
-      for (int s4 = 0; s4 < 4; ++s4) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a2[c][s4], b[s4], acc, 0, 0, 0);
+      for (int s4 = 0; s4 < 4; ++s4) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a2[c][s4], bq[it][c][s4], acc, 0, 0, 0);
     }
     acc = lrelu4(acc + bs2, alpha);
     if (!inside) acc = (f32x4){0.f, 0.f, 0.f, 0.f};                    // zero padding above / left of the image
@@ -400,7 +432,6 @@ __global__ __launch_bounds__(256) void back_kernel(
   }
   __syncthreads();
 
-  const int h = 2 * h2, w = 2 * w2;
 #pragma unroll
   for (int half = 0; half < 2; ++half) {
     const int ox = threadIdx.x & 31, oy = (threadIdx.x >> 5) + 8 * half;
@@ -416,7 +447,7 @@ __global__ __launch_bounds__(256) void back_kernel(
         for (int c = 0; c < 4; ++c) d[o] = fmaf(v[c], w_s1[(t * 4 + o) * 4 + c], d[o]);
     }
     const long tex = ((long)f * h + y) * w + xg;
-    float p0 = skip3[tex * 3], p1 = skip3[tex * 3 + 1], p2 = skip3[tex * 3 + 2];
+    float p0 = sk[half][0], p1 = sk[half][1], p2 = sk[half][2];
     if (vsave)
       *reinterpret_cast<f32x4*>(vsave + tex * 4) = lrelu4((f32x4){d[0], d[1], d[2], d[3]}, alpha);
 #pragma unroll
