@@ -27,13 +27,13 @@ struct C32P {
   int act; float alpha;
 };
 
-__device__ __forceinline__ int xcd_tile_c(int b, int nblocks) {
-  return (nblocks & 7) ? b : (b & 7) * (nblocks >> 3) + (b >> 3);
-}
-
-// NCC = input channels / 16; 32 output channels (TNT = 2 column tiles): waves 4 (rows) x 1, RT = 2, CT = 2
+// NCC = input channels / 16; 32 output channels (TNT = 2 column tiles): waves 4 (rows) x 1, RT = 2, CT = 2.
+// r04_c: PERSISTENT -- two workgroups per CU walk the tiles (an XCD keeps a contiguous run), so the weights go to LDS once per
+// workgroup instead of once per tile (2048 tiles at the bench shape: 4 rounds of prologues, each an exposed L2 + HBM round trip),
+// and the (tile, frame) sequence is one software pipeline: the first frame of the next tile is in flight under the last frame
+// of the current one.
 template <int NCC, bool MEAN>
-__global__ __launch_bounds__(256, 2) void conv_c32_kernel(C32P p) {
+__global__ __launch_bounds__(256, 2) void conv_c32_kernel(C32P p, int ntiles) {
   constexpr int TNT = 2, RT = 2, CT = 2;
   constexpr int NQ = 4 * NCC;                                          // channel quads
   constexpr int A_FLOATS = NCC * 4 * TNT * 256;                        // [cc][tap][ct][lane][4]
@@ -43,29 +43,42 @@ __global__ __launch_bounds__(256, 2) void conv_c32_kernel(C32P p) {
 
   const int tid = threadIdx.x, lane = tid & 63, wm = tid >> 6;
   const int kk = lane >> 4, j = lane & 15;
-  int tile = xcd_tile_c(blockIdx.x, gridDim.x);
-  const int tx0 = (tile % p.tiles_x) * TW; tile /= p.tiles_x;
-  const int ty0 = (tile % p.tiles_y) * TH;
-  const int f = tile / p.tiles_y;
   const long in_frame = (long)p.h * p.w;
+  // this workgroup's tiles: XCD x = blockIdx & 7 owns tiles [x * per, (x + 1) * per), its workgroups take them round-robin
+  const int per = (ntiles + 7) >> 3;
+  const int t_hi = min(((int)(blockIdx.x & 7) + 1) * per, ntiles);
+  const int stride = gridDim.x >> 3;
+  int tile = (blockIdx.x & 7) * per + (blockIdx.x >> 3);
+  if (tile >= t_hi) return;
 
   // B copy units: 8 consecutive lanes copy the same channel quad of 8 consecutive texels (conflict-free ds_write_b128)
   int b_lds[NB], b_q[NB]; long b_tex[NB]; bool b_ok[NB], b_st[NB];
+  int lf = 0;                                                          // frame group of the tile whose frames are being LOADED
 #pragma unroll
   for (int i = 0; i < NB; ++i) {
     const int u = tid + 256 * i;
     const int q = (u >> 3) % NQ, tx = (u / (8 * NQ)) * 8 + (u & 7);
-    const int hy = tx / 17, hx = tx % 17;
-    const int gy = ty0 + hy, gx = tx0 + hx;
     b_q[i] = q;
     b_st[i] = tx < 153;
-    b_ok[i] = b_st[i] && gy < p.h && gx < p.w;                         // beyond the image: TF's zero padding (bottom / right)
-    b_tex[i] = (long)gy * p.w + gx;
     b_lds[i] = (q * PL + tx) * 4;
   }
+  auto load_geom = [&](int t) {
+    const int tx0 = (t % p.tiles_x) * TW; t /= p.tiles_x;
+    const int ty0 = (t % p.tiles_y) * TH;
+    lf = t / p.tiles_y;
+#pragma unroll
+    for (int i = 0; i < NB; ++i) {
+      const int u = tid + 256 * i;
+      const int tx = (u / (8 * NQ)) * 8 + (u & 7);
+      const int hy = tx / 17, hx = tx % 17;
+      const int gy = ty0 + hy, gx = tx0 + hx;
+      b_ok[i] = b_st[i] && gy < p.h && gx < p.w;                       // beyond the image: TF's zero padding (bottom / right)
+      b_tex[i] = (long)gy * p.w + gx;
+    }
+  };
   f32x4 rb[NB];
-  auto load_frame = [&](int i) {
-    const float* sp = p.src + (long)(f * p.kobs + i) * in_frame * p.ld;
+  auto load_frame = [&](int i) {                                       // frame i of the tile being loaded
+    const float* sp = p.src + (long)(lf * p.kobs + i) * in_frame * p.ld;
 #pragma unroll
     for (int n = 0; n < NB; ++n) {
       const f32x4 v = *reinterpret_cast<const f32x4*>(sp + (b_ok[n] ? b_tex[n] : 0) * p.ld + 4 * b_q[n]);
@@ -79,83 +92,103 @@ __global__ __launch_bounds__(256, 2) void conv_c32_kernel(C32P p) {
       if (b_st[n]) *reinterpret_cast<f32x4*>(base + b_lds[n]) = rb[n];
   };
 
-  // weights: once per workgroup
+  // first frame requested, then the weights: once per workgroup
+  load_geom(tile);
+  load_frame(0);
 #pragma unroll
   for (int n = 0; n < NA; ++n)
     *reinterpret_cast<f32x4*>(lds + (tid + 256 * n) * 4) = *reinterpret_cast<const f32x4*>(p.packed + (tid + 256 * n) * 4);
-  load_frame(0);
   store_frame(0);
   __syncthreads();
 
-  f32x4 acc[RT][CT], mean[MEAN ? RT : 1][MEAN ? CT : 1];
-#pragma unroll
-  for (int rt = 0; rt < RT; ++rt)
-#pragma unroll
-    for (int ct = 0; ct < CT; ++ct) {
-      acc[rt][ct] = (f32x4){0.f, 0.f, 0.f, 0.f};
-      if (MEAN) mean[rt][ct] = acc[rt][ct];
-    }
   f32x4 bv[CT];
 #pragma unroll
   for (int ct = 0; ct < CT; ++ct) bv[ct] = *reinterpret_cast<const f32x4*>(p.bias + ct * 16 + 4 * kk);
+  int par = 0;                                                         // B buffer of the frame being computed
 
-  for (int i = 0; i < p.kobs; ++i) {
-    if (i + 1 < p.kobs) load_frame(i + 1);
-    const float* A = lds;
-    const float* B = lds + A_FLOATS + (i & 1) * B_FLOATS;
+  for (;;) {
+    int tt = tile;
+    const int tx0 = (tt % p.tiles_x) * TW; tt /= p.tiles_x;
+    const int ty0 = (tt % p.tiles_y) * TH;
+    const int f = tt / p.tiles_y;
+    const int next = tile + stride;
+    const bool has_next = next < t_hi;
+    f32x4 acc[RT][CT], mean[MEAN ? RT : 1][MEAN ? CT : 1];
 #pragma unroll
-    for (int cc = 0; cc < NCC; ++cc)
+    for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
-      for (int tl = 0; tl < 4; ++tl) {
-        f32x4 bf[RT], af[CT];
+      for (int ct = 0; ct < CT; ++ct) {
+        acc[rt][ct] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        if (MEAN) mean[rt][ct] = acc[rt][ct];
+      }
+
+    for (int i = 0; i < p.kobs; ++i) {
+      const bool more = i + 1 < p.kobs || has_next;                      // a frame follows (of this tile or of the next)
+      if (i + 1 < p.kobs) load_frame(i + 1);
+      else if (has_next) { load_geom(next); load_frame(0); }
+      const float* A = lds;
+      const float* B = lds + A_FLOATS + par * B_FLOATS;
+#pragma unroll
+      for (int cc = 0; cc < NCC; ++cc)
+#pragma unroll
+        for (int tl = 0; tl < 4; ++tl) {
+          f32x4 bf[RT], af[CT];
+#pragma unroll
+          for (int rt = 0; rt < RT; ++rt) {
+            const int y = wm * RT + rt;
+            bf[rt] = *reinterpret_cast<const f32x4*>(B + ((cc * 4 + kk) * PL + (y + (tl >> 1)) * 17 + j + (tl & 1)) * 4);
+          }
+#pragma unroll
+          for (int ct = 0; ct < CT; ++ct) af[ct] = *reinterpret_cast<const f32x4*>(A + (((cc * 4 + tl) * TNT + ct) * 64 + lane) * 4);
+#pragma unroll
+          for (int s4 = 0; s4 < 4; ++s4)
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+              for (int ct = 0; ct < CT; ++ct)
+                acc[rt][ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[ct][s4], bf[rt][s4], acc[rt][ct], 0, 0, 0);
+        }
+#pragma unroll
+      for (int ct = 0; ct < CT; ++ct) {
+        const int oc = ct * 16 + 4 * kk;
 #pragma unroll
         for (int rt = 0; rt < RT; ++rt) {
-          const int y = wm * RT + rt;
-          bf[rt] = *reinterpret_cast<const f32x4*>(B + ((cc * 4 + kk) * PL + (y + (tl >> 1)) * 17 + j + (tl & 1)) * 4);
-        }
+          const int gy = ty0 + wm * RT + rt, gx = tx0 + j;
+          f32x4 v = acc[rt][ct] + bv[ct];
+          if (p.act) {
 #pragma unroll
-        for (int ct = 0; ct < CT; ++ct) af[ct] = *reinterpret_cast<const f32x4*>(A + (((cc * 4 + tl) * TNT + ct) * 64 + lane) * 4);
-#pragma unroll
-        for (int s4 = 0; s4 < 4; ++s4)
-#pragma unroll
-          for (int rt = 0; rt < RT; ++rt)
-#pragma unroll
-            for (int ct = 0; ct < CT; ++ct)
-              acc[rt][ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[ct][s4], bf[rt][s4], acc[rt][ct], 0, 0, 0);
-      }
-#pragma unroll
-    for (int ct = 0; ct < CT; ++ct) {
-      const int oc = ct * 16 + 4 * kk;
-#pragma unroll
-      for (int rt = 0; rt < RT; ++rt) {
-        const int gy = ty0 + wm * RT + rt, gx = tx0 + j;
-        f32x4 v = acc[rt][ct] + bv[ct];
-        if (p.act) {
-#pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : p.alpha * v[e];
-        }
-        acc[rt][ct] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        if (MEAN) mean[rt][ct] += v;
-        if (gy < p.h && gx < p.w) {
-          const long ot = ((long)(f * p.kobs + i) * p.h + gy) * p.w + gx;
-          if (p.out) *reinterpret_cast<f32x4*>(p.out + ot * p.ldo + oc) = v;
-          if (MEAN && p.mean_out && i == p.kobs - 1) {
-            const long mt = ((long)f * p.h + gy) * p.w + gx;
-            *reinterpret_cast<f32x4*>(p.mean_out + mt * p.ldm + oc) = mean[rt][ct] * (1.f / (float)p.kobs);
+            for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : p.alpha * v[e];
+          }
+          acc[rt][ct] = (f32x4){0.f, 0.f, 0.f, 0.f};
+          if (MEAN) mean[rt][ct] += v;
+          if (gy < p.h && gx < p.w) {
+            const long ot = ((long)(f * p.kobs + i) * p.h + gy) * p.w + gx;
+            if (p.out) *reinterpret_cast<f32x4*>(p.out + ot * p.ldo + oc) = v;
+            if (MEAN && p.mean_out && i == p.kobs - 1) {
+              const long mt = ((long)f * p.h + gy) * p.w + gx;
+              *reinterpret_cast<f32x4*>(p.mean_out + mt * p.ldm + oc) = mean[rt][ct] * (1.f / (float)p.kobs);
+            }
           }
         }
       }
+      if (more) store_frame(par ^ 1);
+      __syncthreads();
+      par ^= 1;
     }
-    if (i + 1 < p.kobs) store_frame((i + 1) & 1);
-    __syncthreads();
+    if (!has_next) break;
+    tile = next;
   }
 }
 
 template <int NCC>
 int launch_c32(const C32P& p, hipStream_t s) {
-  const dim3 grid((unsigned)((long)p.frames * p.tiles_y * p.tiles_x));
-  if (p.kobs > 1 || p.mean_out) hipLaunchKernelGGL((conv_c32_kernel<NCC, true>), grid, dim3(256), 0, s, p);
-  else hipLaunchKernelGGL((conv_c32_kernel<NCC, false>), grid, dim3(256), 0, s, p);
+  const long tiles = (long)p.frames * p.tiles_y * p.tiles_x;
+  // two workgroups per CU (57 KB of LDS each); fewer when there are fewer tiles; a multiple of 8 (one run of tiles per XCD)
+  long groups = ((tiles + 7) / 8);
+  if (groups > 64) groups = 64;
+  const dim3 grid((unsigned)(8 * groups));
+  if (p.kobs > 1 || p.mean_out) hipLaunchKernelGGL((conv_c32_kernel<NCC, true>), grid, dim3(256), 0, s, p, (int)tiles);
+  else hipLaunchKernelGGL((conv_c32_kernel<NCC, false>), grid, dim3(256), 0, s, p, (int)tiles);
   NLT_CHECK_LAUNCH();
   return NLT_OK;
 }

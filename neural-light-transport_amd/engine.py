@@ -63,10 +63,10 @@ class RenderPlan:
         self.front_v4 = os.environ.get('NLT_FRONT4', '1') != '0'
         self.fuse_train = os.environ.get('NLT_FUSED_TRAIN', '1') != '0'   # fused ends in the train step too (csrc/train_fused.hip)
         # train forward on the second-generation front kernel (nlt_front4_forward_train: keeps the level-1 maps AND folds level
-        # 2's stride-2 convs, so no front_kernel<false> and no L2.{q,o}.s2 launches).  OPT-IN: measured SLOWER in the step
-        # (3.46 -> 3.53 ms l2, 3.73 -> 3.80 barron on the same box, r03): at 256 registers the three extra 16-byte stores per
-        # tile spill 46 dwords and the kernel is store-bound at k = 1 anyway (its extra maps are 200 MB per 4 frames)
-        self.front4_train = os.environ.get('NLT_FRONT4_TRAIN', '0') != '0'
+        # 2's stride-2 convs, so no front_kernel<false> and no L2.{q,o}.s2 launches).  r03: opt-in, SLOWER in the step (3.46 ->
+        # 3.53 ms l2).  r04: the kernel is persistent (weights once per wave, next strip prefetched) and the step is faster with
+        # it: 3.213 / 3.195 -> 3.173 / 3.173 ms l2 (two pairs, one box), so it is the default; 0 = front_kernel<false>
+        self.front4_train = os.environ.get('NLT_FRONT4_TRAIN', '1') != '0'
         self.two_streams = os.environ.get('NLT_STREAMS', '2') != '1'   # inference: query-path encoder convs on a side stream
         self.lazy_fork = os.environ.get('NLT_LAZY_FORK', '0') != '0'   # ... forked behind level 2's observation conv (see _forward_fused)
         self._side = None               # (side stream, [events]) created on first use
