@@ -111,13 +111,13 @@ __global__ __launch_bounds__(512, 1) void front4_kernel(
   __syncthreads();
 
   // ---- this wave's strips: XCD x = blockIdx & 7 owns a contiguous run of tiles (neighbours share halo lines in its L2);
-  // its waves take them round-robin
+  // its waves take them round-robin (slot = wave * workgroups-per-XCD + workgroup: consecutive slots = consecutive strips)
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int per_xcd = (ntiles + 7) >> 3;
   const int t_lo = (blockIdx.x & 7) * per_xcd;
   const int t_hi = min(t_lo + per_xcd, ntiles);
   const int stride = (gridDim.x >> 3) * NWAVES;
-  int tile = t_lo + (blockIdx.x >> 3) * NWAVES + wv;
+  int tile = t_lo + wv * (int)(gridDim.x >> 3) + (int)(blockIdx.x >> 3);   // wave-major: a small input still puts a wave on every CU
   if (tile >= t_hi) return;
   float* const lds = lds_all + W_WAVES + wv * W_END;
 
@@ -547,10 +547,9 @@ int front4_launch(const Front4In& in, int n, int k, int h, int w, const float* p
   if (TRAIN && (!keep.obs1 || !keep.qtmp1 || !keep.otmp1 || !nlt_aligned16(keep.obs1) || !nlt_aligned16(keep.qtmp1) ||
                 !nlt_aligned16(keep.otmp1)))
     return NLT_ERR_BAD_ARG;
-  // one workgroup per CU; fewer when the input has fewer than 8 strips per workgroup (always a multiple of 8: one run of
-  // tiles per XCD)
+  // one workgroup per CU (always a multiple of 8: one run of tiles per XCD); with fewer than 2048 strips its waves share them out
   const long per_xcd = (tiles + 7) / 8;
-  long groups = (per_xcd + NWAVES - 1) / NWAVES;
+  long groups = per_xcd;                                               // workgroups per XCD: one per CU, fewer only below 32 strips per XCD
   if (groups > 32) groups = 32;
   hipLaunchKernelGGL((front4_kernel<U8, TRAIN>), dim3((unsigned)(8 * groups)), dim3(64 * NWAVES), 0, static_cast<hipStream_t>(stream),
                      in, k, h, w, ty, tx, (int)tiles, packed, add_base, alpha, fm1, skip3, packed_l2, qtmp2, otmp2, keep);

@@ -151,13 +151,13 @@ __global__ __launch_bounds__(512, 1) void front5_kernel(
   __syncthreads();
 
   // ---- this wave's strips: XCD x = blockIdx & 7 owns a contiguous run of tiles (neighbours share halo lines in its L2);
-  // its waves take them round-robin
+  // its waves take them round-robin (slot = wave * workgroups-per-XCD + workgroup: consecutive slots = consecutive strips)
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int per_xcd = (ntiles + 7) >> 3;
   const int t_lo = (blockIdx.x & 7) * per_xcd;
   const int t_hi = min(t_lo + per_xcd, ntiles);
   const int stride = (gridDim.x >> 3) * NWAVES;
-  int tile = t_lo + (blockIdx.x >> 3) * NWAVES + wv;
+  int tile = t_lo + wv * (int)(gridDim.x >> 3) + (int)(blockIdx.x >> 3);   // wave-major: a small input still puts a wave on every CU
   if (tile >= t_hi) return;
 
   float* const wl = lds + W_WAVES + wv * W_WAVE;
@@ -547,9 +547,9 @@ int front5_launch(const Front5In& in, int n, int k, int h, int w, const float* p
   const int ty = (h / 2 + SH - 1) / SH, tx = (w / 2 + SW - 1) / SW;
   const long tiles = (long)n * ty * tx;
   if (tiles >= (1l << 31)) return NLT_ERR_UNSUPPORTED;
-  // one workgroup per CU; fewer when the input has fewer than 8 strips per workgroup (always a multiple of 8: one run per XCD)
+  // one workgroup per CU (always a multiple of 8: one run of tiles per XCD); with fewer than 2048 strips its waves share them out
   const long per_xcd = (tiles + 7) / 8;
-  long groups = (per_xcd + NWAVES - 1) / NWAVES;
+  long groups = per_xcd;                                               // workgroups per XCD: one per CU, fewer only below 32 strips per XCD
   if (groups > 32) groups = 32;
   const dim3 grid((unsigned)(8 * groups));
   hipStream_t s = static_cast<hipStream_t>(stream);

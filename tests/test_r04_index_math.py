@@ -28,7 +28,7 @@ def front_schedule(ntiles, grid, nwaves=8):
         t_lo = (b & 7) * per
         t_hi = min(t_lo + per, ntiles)
         for wv in range(nwaves):
-            tile, seq = t_lo + (b >> 3) * nwaves + wv, []
+            tile, seq = t_lo + wv * (grid >> 3) + (b >> 3), []
             while tile < t_hi:
                 seq.append(tile)
                 tile += stride
@@ -38,7 +38,7 @@ def front_schedule(ntiles, grid, nwaves=8):
 
 def front_grid(tiles, nwaves=8):
     per_xcd = (tiles + 7) // 8
-    return 8 * min(32, (per_xcd + nwaves - 1) // nwaves)
+    return 8 * min(32, per_xcd)
 
 
 @pytest.mark.parametrize('tiles', [1, 2, 7, 8, 9, 63, 64, 65, 255, 256, 257, 1000, 2048, 2049, 16384, 16384 + 13, 4 * 64 * 17])
@@ -67,6 +67,15 @@ def test_front_schedule_takes_every_strip_once_and_keeps_an_xcd_contiguous(tiles
         for r, ts in rounds.items():
             ts = sorted(ts)
             assert ts == list(range(ts[0], ts[0] + len(ts)))
+    # a small input still spreads over the CUs: no workgroup holds two strips while another of its XCD holds none
+    for x in range(8):
+        per_wg = {}
+        for (b, wv), seq in sched.items():
+            if (b & 7) == x:
+                per_wg[b] = per_wg.get(b, 0) + len(seq)
+        assert max(per_wg.values()) - min(per_wg.values()) <= 8
+        if sum(per_wg.values()) >= len(per_wg):                              # the XCD has at least one strip per workgroup
+            assert min(per_wg.values()) >= 1
 
 
 def c32_schedule(ntiles, grid):
