@@ -190,3 +190,41 @@ def test_conv_tile_emulation_matches_oracle(mode, cin, cout, tn, h, w, kobs):
     assert np.abs(out - ref).max() < 1e-4
     m = mean.reshape(frames, oh, ow, ldm)[..., :cout]
     assert np.abs(m - ref.reshape(frames, kobs, oh, ow, cout).mean(1)).max() < 1e-4
+
+
+@pytest.mark.parametrize('h,w,cout,tn', [(8, 16, 16, 64), (9, 17, 16, 32), (20, 12, 32, 64), (5, 40, 8, 32), (16, 32, 16, 64)])
+def test_transposed_k2s2_mode_tiles_the_input_grid_and_writes_every_output_texel_once(h, w, cout, tn):
+    """NLT_DECONV_K2S2 (backward-data of a stride-2 conv = Conv2DTranspose k2s2): the workgroup grid covers the INPUT grid (h x w) in
+    8 x 16 tiles -- nlt_conv_tile_backward_data launched 4x that before r04 (tiles from the 2h x 2w output) -- and the GEMM's 4 * cout
+    columns are (ab, o): row tile (g, wn, ct), lane group kk -> column 16 (g TNT + wn CT + ct) + 4 kk -> (ab, oc), output texel
+    (2 y + ab / 2, 2 x + ab % 2).  Every (output texel, channel quad) must be written by exactly one (workgroup, wave, lane, rt, ct)."""
+    tnt = tn // 16
+    WN = 2 if tnt >= 4 else 1
+    WM = 4 // WN; RT = TH // WM; CT = tnt // WN
+    ncols = 4 * cout
+    assert ncols % tn == 0 or ncols < tn
+    groups = (ncols + tn - 1) // tn
+    tiles_y, tiles_x = (h + TH - 1) // TH, (w + TW - 1) // TW            # input grid (the fixed rule)
+    oh, ow = 2 * h, 2 * w
+    seen = np.zeros((oh, ow, cout // 4), np.int64)
+    for g in range(groups):
+        for ty in range(tiles_y):
+            for tx in range(tiles_x):
+                ty0, tx0 = ty * TH, tx * TW
+                for wave in range(4):
+                    wn, wm = wave % WN, wave // WN
+                    for ct in range(CT):
+                        for kk in range(4):
+                            col = (g * tnt + wn * CT + ct) * 16 + 4 * kk
+                            if col >= ncols:
+                                continue
+                            ab, oc = divmod(col, cout)
+                            assert oc % 4 == 0 and ab < 4
+                            for rt in range(RT):
+                                for j in range(16):
+                                    gy, gx = 2 * (ty0 + wm * RT + rt) + (ab >> 1), 2 * (tx0 + j) + (ab & 1)
+                                    if gy < oh and gx < ow:
+                                        seen[gy, gx, oc // 4] += 1
+    assert (seen == 1).all()
+    # the pre-r04 grid (tiles of the OUTPUT dims) would have launched (about) four times the workgroups for the same writes
+    assert ((oh + TH - 1) // TH) * ((ow + TW - 1) // TW) >= 2 * tiles_y * tiles_x
