@@ -2,14 +2,17 @@
 them (tensorflow==2.2.0, tensorflow-addons==0.10.0, environment.yml:14-16).  Neither wheel can be installed in the
 build image (no network), so this script is committed UNRUN: on any machine that has both,
 
-    python tests/golden/make_tf_golden.py            # writes tests/golden/tf_ops.npz (~60 KB)
+    python tests/golden/make_tf_golden.py            # writes tests/golden/tf_ops.npz (~60 KB) and tests/golden/tf_ckpt/ (~20 KB)
 
 and tests/test_oracle_third_party.py::test_oracle_ops_against_tensorflow_golden then checks oracle/tf_ops.py and
 oracle/nlt_oracle.py against TensorFlow's outputs (it is skipped while the file is absent).  Covered: Conv2D / Conv2DTranspose
 'same' for kernel 1 / 2 and stride 1 / 2 (nlt/networks/elements.py:26-39), LeakyReLU(0.3) (:69-78), tfa.image.resampler incl.
 the (-1, 0) and (W-1, W) border bands, exact integers and fp16-rounded coordinates (nlt/models/nlt.py:112-114), tf.image.resize
 (nlt/util/img.py:115), three Adam(amsgrad=True) steps (nlt/trainvali.py:122-127) and what `clipnorm` does when the loop calls
-tape.gradient + apply_gradients (:279-280)."""
+tape.gradient + apply_gradients (:279-280); and a REAL tensor-bundle checkpoint written by `tf.train.Checkpoint(net=...)` over the
+attribute names the reference's models register (`net_{query,obs}_layer{i}`, nlt/models/base.py:79-101; nlt/trainvali.py:134-141),
+for tests/test_host_ckpt.py::test_reader_against_a_checkpoint_written_by_tensorflow -- the reader (ckpt.py) has so far only met
+bundles written by the test suite's own writer."""
 import os
 
 import numpy as np
@@ -81,13 +84,48 @@ def main():
         res[label] = v.numpy()
     out['clip_p1_applied'], out['clip_p1_if_clipped'] = res['applied'], res['if_clipped']
     # DESIGN.md section 8 claims apply_gradients does NOT clip in TF 2.2 (clipping sits in get_gradients / minimize):
-    out['clip_apply_gradients_clips'] = np.array(False)
-    if np.allclose(res['applied'], res['if_clipped'], rtol=1e-6, atol=1e-9):
+    clipped = bool(np.allclose(res['applied'], res['if_clipped'], rtol=1e-6, atol=1e-9))
+    out['clip_apply_gradients_clips'] = np.array(clipped)
+    if clipped:
         print("NOTE: apply_gradients DID clip here -- DESIGN.md section 8's claim is wrong for this TF build; fix "
               "`clip_apply_gradients_clips` and make clipping the default (mgm_apply = true).")
     path = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'tf_ops.npz')
     np.savez_compressed(path, **out)
     print("wrote", path, "with", len(out), "arrays; tensorflow", tf.__version__, "tensorflow_addons", tfa.__version__)
+
+    # ---- a real checkpoint: plain Conv2D layers and Keras Sequential blocks under the reference's attribute names
+    class Net(tf.keras.Model):
+        pass
+    net = Net()
+    expect = {}
+    conv = lambda cout, k, s: tf.keras.layers.Conv2D(cout, k, strides=s, padding='same')
+    deconv = lambda cout, k, s: tf.keras.layers.Conv2DTranspose(cout, k, strides=s, padding='same')
+    specs = {'query': [('plain', conv(4, 1, 1), 5), ('seq', [conv(6, 2, 2), conv(6, 2, 1)], 4), ('seq', [deconv(4, 2, 2), deconv(4, 2, 1)], 6),
+                       ('plain', conv(3, 1, 1), 8)],
+             'obs': [('plain', conv(4, 1, 1), 3), ('seq', [conv(6, 2, 2), conv(6, 2, 1)], 4)]}
+    for path_name, layers in specs.items():
+        for i, (kind, lay, cin) in enumerate(layers):
+            attr = 'net_%s_layer%d' % (path_name, i)
+            if kind == 'plain':
+                lay.build((None, 8, 8, cin))
+                lay.set_weights([f32(rng.standard_normal(w_.shape)) for w_ in lay.get_weights()])
+                setattr(net, attr, lay)
+                expect['net/%s/kernel/.ATTRIBUTES/VARIABLE_VALUE' % attr] = lay.get_weights()[0]
+                expect['net/%s/bias/.ATTRIBUTES/VARIABLE_VALUE' % attr] = lay.get_weights()[1]
+            else:
+                seq = tf.keras.Sequential([lay[0], tf.keras.layers.LeakyReLU(), lay[1], tf.keras.layers.LeakyReLU()])
+                seq.build((None, 8, 8, cin))
+                for j, l_ in enumerate(lay):
+                    l_.set_weights([f32(rng.standard_normal(w_.shape)) for w_ in l_.get_weights()])
+                    expect['net/%s/layer_with_weights-%d/kernel/.ATTRIBUTES/VARIABLE_VALUE' % (attr, j)] = l_.get_weights()[0]
+                    expect['net/%s/layer_with_weights-%d/bias/.ATTRIBUTES/VARIABLE_VALUE' % (attr, j)] = l_.get_weights()[1]
+                setattr(net, attr, seq)
+    ckdir = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'tf_ckpt')
+    os.makedirs(ckdir, exist_ok=True)
+    prefix = tf.train.Checkpoint(step=tf.Variable(7), net=net).save(os.path.join(ckdir, 'ckpt'))
+    np.savez_compressed(os.path.join(ckdir, 'expected.npz'), prefix=np.array(os.path.basename(prefix)),
+                        **{k.replace('/', '|'): v for k, v in expect.items()})
+    print("wrote", prefix, "(+ expected.npz) with", len(expect), "variables")
 
 
 if __name__ == '__main__':

@@ -163,3 +163,25 @@ def test_import_refuses_norm_layer_variables_and_half_written_convs(tmp_path):
     write_bundle(str(tmp_path / 'half'), t)
     with pytest.raises(ValueError, match='net_query_layer1.*bias'):
         ckpt.reference_weights(str(tmp_path / 'half'))
+
+
+def test_reader_against_a_checkpoint_written_by_tensorflow():
+    """tests/golden/make_tf_golden.py (run where tensorflow==2.2.0 exists) saves `tf.train.Checkpoint(step, net)` over the
+    reference's attribute names; the reader must find every variable under its key, bit for bit.  Skipped while the files are
+    absent (no TensorFlow in the build image): until then the reader has only met this file's own writer."""
+    import os
+    ckdir = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'tf_ckpt')
+    exp_path = os.path.join(ckdir, 'expected.npz')
+    if not os.path.exists(exp_path):
+        pytest.skip("tests/golden/tf_ckpt/ not generated (needs tensorflow==2.2.0; see tests/golden/make_tf_golden.py)")
+    exp = np.load(exp_path)
+    prefix = os.path.join(ckdir, str(exp['prefix']))
+    got = ckpt.read_bundle(prefix)
+    keys = [k for k in exp.files if k != 'prefix']
+    assert keys
+    for k in keys:
+        key = k.replace('|', '/')
+        assert key in got, key
+        np.testing.assert_array_equal(got[key], exp[k])
+    w = ckpt.reference_weights(prefix)
+    assert len(w['query']) == 4 and len(w['obs']) == 2 and len(w['query'][1]) == 2
