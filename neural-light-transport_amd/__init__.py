@@ -16,7 +16,7 @@ def make_config(**overrides):
     cfg = ConfigParser()
     d = dict(imh=512, imw=512, uvh=512, uvw=512, use_obs=True, skip_connect_base=True, depth0=16, depth=256,
              kernel=2, stride=2, norm='None', act='leakyrelu', pool='None', loss='l2', lr=1e-3, mgm=-1, bs=4,
-             model='nlt')
+             model='nlt', linear_space=False)
     d.update(overrides)
     for k, v in d.items():
         cfg.set('DEFAULT', k, str(v))

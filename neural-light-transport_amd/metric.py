@@ -7,6 +7,15 @@ import torch
 from . import _capi as C
 
 
+DEVICE = 'cuda'
+
+
+def _on_device(x):
+    if torch.is_tensor(x):
+        return x if x.device.type == torch.device(DEVICE).type else x.to(DEVICE)
+    return torch.from_numpy(np.ascontiguousarray(x)).to(DEVICE)
+
+
 class PSNR:
     """xm.metric.PSNR (metric.py:105-151): Peak Signal-to-Noise Ratio in dB on luma (0.2126 r + 0.7152 g + 0.0722 b for
     3-channel inputs), float64 arithmetic, optional H x W logical mask.  `dtype` fixes the dynamic range the way
@@ -23,7 +32,10 @@ class PSNR:
             raise NotImplementedError(self.dtype.kind)
 
     def __call__(self, im1, im2, mask=None):
-        """im1, im2: [H,W] / [H,W,1] / [H,W,3] torch CUDA tensors (float32 storage) in [0, drange] -> float dB."""
+        """im1, im2: [H,W] / [H,W,1] / [H,W,3] torch CUDA tensors (float32 storage) in [0, drange] -> float dB.
+        NumPy arrays / host tensors (what the reference's vis_batch hands over) go up to `DEVICE` first: the sums are
+        always the kernel's."""
+        im1, im2 = _on_device(im1), _on_device(im2)
         if tuple(im1.shape) != tuple(im2.shape):
             raise AssertionError("The two images are not even of the same shape")
         if im1.dim() == 3 and im1.shape[2] not in (1, 3):

@@ -3,6 +3,10 @@
 `compute_loss`); tensors are torch CUDA tensors instead of TF eager tensors.
 """
 import os
+import pickle
+import warnings
+from glob import glob
+from os.path import dirname, exists, join
 
 import numpy as np
 import torch
@@ -13,6 +17,7 @@ from .. import metric
 from ..datasets.nlt import ResidentTexels
 from ..engine import RenderPlan
 from ..networks import convnet
+from ..util import vis as V
 from .base import Model as BaseModel
 
 
@@ -533,3 +538,97 @@ class Model(BaseModel):
         for weight, loss_func in self.wloss:
             loss = loss + weight * loss_func(gt, pred, **kwargs)
         return loss
+
+    def vis_batch(self, data_dict, outdir, mode, dump_raw_to=None,
+                  text_loc_ratio=0.05, text_size_ratio=0.05, text_color=(1, 1, 1)):
+        """nlt/models/nlt.py:207-272: per sample `<i>_{base,pred,nn[,gt]}.png` (clip to [0,1], linear -> sRGB when
+        `linear_space`, x255 truncated), the two labelled animated PNGs, `<i>_metadata.json` (ids; PSNR of prediction and
+        diffuse base against the ground truth outside test mode -- on the CLIPPED LINEAR values, as the reference), and
+        optionally the raw dict as a pickle (arrays as NumPy: there is no tf.Tensor to pickle here).
+        One device -> host copy per map; the arithmetic that decides the bytes is float32 NumPy like the reference's;
+        the PSNR sums run on the device when the maps live there (`metric.PSNR`, float64)."""
+        is_linear = self.config.getboolean('DEFAULT', 'linear_space')
+        self._validate_mode(mode)
+        ids = [V.to_str(x) for x in data_dict['id']]
+        nn_ids = [V.to_str(x) for x in data_dict['nn_id']]
+        keys = ('base_camspc', 'pred_camspc', 'nn_camspc') + (() if mode == 'test' else ('gt_camspc',))
+        host = {k: np.clip(V.to_numpy(data_dict[k]), 0, 1) for k in keys}
+        bases, preds, nns, gts = host['base_camspc'], host['pred_camspc'], host['nn_camspc'], host.get('gt_camspc')
+        # the clipped maps where the PSNR kernel can read them without a second trip over PCIe
+        dev = {k: (data_dict[k].detach().clamp(0, 1) if torch.is_tensor(data_dict[k]) and data_dict[k].is_cuda else None) for k in keys}
+        for i in range(len(ids)):
+            base, pred, nn = bases[i], preds[i], nns[i]
+            gt = None if gts is None else gts[i]
+            if is_linear:
+                base, pred, nn = V.linear2srgb(base), V.linear2srgb(pred), V.linear2srgb(nn)
+                gt = None if gt is None else V.linear2srgb(gt)
+            imgs = {'base': V.write_arr(base, join(outdir, '%d_base.png' % i)),
+                    'pred': V.write_arr(pred, join(outdir, '%d_pred.png' % i))}
+            V.write_arr(nn, join(outdir, '%d_nn.png' % i))
+            imgs['gt'] = None if gt is None else V.write_arr(gt, join(outdir, '%d_gt.png' % i))
+            hw = base.shape[:2]
+            label_loc = (int(text_loc_ratio * hw[1]), int(text_loc_ratio * hw[0]))
+            font_size = int(text_size_ratio * hw[0])
+            V.make_apng((imgs['base'], imgs['pred']), labels=('Diffuse Base', 'Prediction'), label_top_left_xy=label_loc,
+                        font_size=font_size, font_color=text_color, outpath=join(outdir, '%d_base-vs-pred.apng' % i))
+            if imgs['gt'] is not None:
+                V.make_apng((imgs['gt'], imgs['pred']), labels=('Ground Truth', 'Prediction'), label_top_left_xy=label_loc,
+                            font_size=font_size, font_color=text_color, outpath=join(outdir, '%d_gt-vs-pred.apng' % i))
+        for i, id_ in enumerate(ids):
+            metadata = {'id': id_, 'nn_id': nn_ids[i]}
+            if gts is not None:
+                gt, pred, base = (dev[k][i] if dev[k] is not None else host[k][i] for k in ('gt_camspc', 'pred_camspc', 'base_camspc'))
+                metadata['pred_psnr'] = self.psnr(gt, pred)
+                metadata['base_psnr'] = self.psnr(gt, base)
+            V.write_json(metadata, join(outdir, '%d_metadata.json' % i))
+        if dump_raw_to is not None:
+            raw = {k: (V.to_numpy(v) if hasattr(v, 'detach') else v) for k, v in data_dict.items()}
+            os.makedirs(dirname(dump_raw_to) or '.', exist_ok=True)
+            with open(dump_raw_to, 'wb') as h:
+                pickle.dump(raw, h)
+
+    def compile_batch_vis(self, batch_vis_dirs, outpref, mode, fps=6, file_explorer=''):
+        """nlt/models/nlt.py:274-285: train / vali -> `<outpref>.html` (one table row per sample), test -> the frames in id
+        order as `<outpref>.mp4` where an encoder exists and `<outpref>.apng` + `.frames.json` always.  Returns the link the
+        reference logs to TensorBoard (`file_explorer` + path; the reference hard-codes its lab's file server there)."""
+        self._validate_mode(mode)
+        if mode in ('train', 'vali'):
+            outpath = outpref + '.html'
+            self._compile_into_webpage(batch_vis_dirs, outpath, title="NLT (%s)" % mode)
+        else:
+            outpath = outpref + '.mp4'
+            self._compile_into_video(batch_vis_dirs, outpath, fps=fps)
+        return file_explorer + outpath
+
+    @staticmethod
+    def _compile_into_webpage(batch_dirs, out_html, title=None):
+        page = V.Page()
+        if title is not None:
+            page.add_header(title)
+        n_rows = 0
+        for batch_dir in batch_dirs:
+            for metadata_path in sorted(glob(join(batch_dir, '?_metadata.json'))):
+                pref = metadata_path[:-len('metadata.json')]
+                page.add_row([str(V.read_json(metadata_path)), pref + 'base-vs-pred.apng', pref + 'gt-vs-pred.apng', pref + 'nn.png'],
+                             ['text', 'image', 'image', 'image'],
+                             captions=["Metadata", "Prediction vs. Diffuse Base", "Prediction vs. Ground Truth", "Nearest Neighbor"])
+                n_rows += 1
+        assert n_rows > 0, "No row"
+        page.save(out_html)
+
+    @staticmethod
+    def _compile_into_video(batch_dirs, out_mp4, fps=12):
+        from ..datasets.nlt import read_png
+        frames, paths = {}, {}
+        for batch_dir in batch_dirs:
+            for metadata_path in glob(join(batch_dir, '?_metadata.json')):
+                pred_path = metadata_path[:-len('metadata.json')] + 'pred.png'
+                if not exists(pred_path):
+                    warnings.warn("Skipping because of missing file:\n\t%s" % pred_path)
+                    continue
+                id_ = V.read_json(metadata_path)['id']
+                frames[id_], paths[id_] = read_png(pred_path), pred_path
+        order = sorted(frames)
+        written = V.write_frames([frames[k] for k in order], out_mp4, fps=fps)
+        stem = out_mp4[:-len('.mp4')]
+        V.write_json({'fps': fps, 'ids': order, 'frames': [paths[k] for k in order], 'written': written}, stem + '.frames.json')

@@ -6,9 +6,14 @@ features (`obs_override`).  Unlike the reference, which still pushes a placehold
 observation network on every test batch and throws the result away (nlt/models/nlt.py:154-155,172-173), the
 plan skips the observation convs entirely when an override is given, and the running average never
 concatenates all frames' features (nlt_test.py:116-121 keeps every frame of every level alive)."""
+import logging
+from os.path import join
+
 import torch
 
 from . import _capi as C
+
+logger = logging.getLogger('nlt_test')
 
 
 def _obs_features(model, x):
@@ -48,23 +53,32 @@ def extract_feat(model, datapipe, n_obs_batches=-1):
     return [_mean_over_frames(torch.cat([pb[level] for pb in per_batch], 0), w) for level in range(len(per_batch[0]))]
 
 
-def infer(model, datapipe, feat_agg, on_batch=None, lanes=1, threads=False):
-    """nlt_test.py:78-94: renders every test batch with the aggregated observation features; returns the list of
-    `to_vis` dicts (or hands each to `on_batch(i, to_vis)` -- the reference's model.vis_batch slot).
+def infer(model, datapipe, feat_agg, outroot=None, report_every=10, on_batch=None, lanes=1, threads=False):
+    """nlt_test.py:78-94: renders every test batch with the aggregated observation features and visualises it into
+    `<outroot>/batch<i:09d>` (`model.vis_batch(to_vis, outdir, 'test')`, as the reference).  outroot = None: nothing is
+    written; the `to_vis` dicts are returned (or handed to `on_batch(i, to_vis)`; with outroot AND on_batch both happen).
     lanes > 1: that many batches in flight on the GPU (pipeline.RenderPipeline; same results; a `datapipe` that reuses
-    staging buffers needs lanes + 1 slots; threads: one host thread per lane)."""
+    staging buffers needs lanes + 1 slots; threads: one host thread per lane) -- the PNG encoding of batch i then runs on
+    the host while batches i + 1 ... are on the GPU."""
+    outs, done = [], [0]
+
+    def sink(i, to_vis):
+        if outroot is not None:
+            model.vis_batch(to_vis, join(outroot, 'batch{i:09d}'.format(i=i)), 'test')
+        if on_batch is not None:
+            on_batch(i, to_vis)
+        elif outroot is None:
+            outs.append(to_vis)
+        done[0] += 1
+        if done[0] % report_every == 0:
+            logger.info("Done inferring %d batches", done[0])
+
     if lanes > 1:
         from .pipeline import RenderPipeline
         with RenderPipeline(model, lanes, threads=threads) as pipe:      # (lane threads / streams released on the way out)
-            if on_batch is not None:
-                pipe.render(datapipe, 'test', on_batch=lambda i, r: on_batch(i, r[3]), obs_override=feat_agg)
-                return []
-            return [r[3] for r in pipe.render(datapipe, 'test', obs_override=feat_agg)]
-    outs = []
+            pipe.render(datapipe, 'test', on_batch=lambda i, r: sink(i, r[3]), obs_override=feat_agg)
+        return outs
     for i, batch in enumerate(datapipe):
         _, _, _, to_vis = model.call(batch, 'test', obs_override=feat_agg)
-        if on_batch is not None:
-            on_batch(i, to_vis)
-        else:
-            outs.append(to_vis)
+        sink(i, to_vis)
     return outs

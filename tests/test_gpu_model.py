@@ -153,3 +153,52 @@ def test_nlt_test_orchestration_extract_feat_and_infer():
         assert rel_l2(a.cpu(), r) <= TOL
     out = nlt_test.infer(pm, [to_device_batch(test_b, test_nn)], agg)
     assert rel_l2(out[0]['pred'].cpu(), ref) <= TOL
+
+
+@pytest.mark.parametrize('mode', ['test', 'vali'])
+def test_vis_batch_on_device_maps(tmp_path, mode):
+    """nlt/models/nlt.py:207-272 with the maps in HBM: PNG bytes = oracle denormalize_float of the clipped maps, the PSNR
+    in the metadata = the device kernel's float64 sums = the oracle's PSNR."""
+    import json
+    from nlt_amd.datasets.nlt import read_png
+    from oracle import buffers as OB, metric as OM
+    om, pm = make_pair(depth=256, uv=64, im=64, seed=21)
+    batch, nn = O.synth_batch(2, 64, 64, 64, 64, 64, 64, k=1, seed=22)
+    b = list(to_device_batch(batch, nn))
+    b[0], b[7] = [b'cam0_light0', b'cam0_light1'], ['nn_a', 'nn_b']
+    _, _, _, to_vis = pm.call(tuple(b), mode)
+    pm.vis_batch(to_vis, str(tmp_path), mode)
+    for i in range(2):
+        for name in ('base', 'pred', 'nn') + (('gt',) if mode != 'test' else ()):
+            want = OB.denormalize_float(np.clip(to_vis[name + '_camspc'][i].cpu().numpy(), 0, 1))
+            np.testing.assert_array_equal(read_png(os.path.join(str(tmp_path), '%d_%s.png' % (i, name))), want)
+        md = json.load(open(os.path.join(str(tmp_path), '%d_metadata.json' % i)))
+        assert md['id'] == 'cam0_light%d' % i and md['nn_id'] == 'nn_' + 'ab'[i]
+        if mode != 'test':
+            gt, pred, base = (np.clip(to_vis[k][i].cpu().numpy(), 0, 1) for k in ('gt_camspc', 'pred_camspc', 'base_camspc'))
+            assert md['pred_psnr'] == pytest.approx(OM.psnr(gt, pred), rel=1e-9)
+            assert md['base_psnr'] == pytest.approx(OM.psnr(gt, base), rel=1e-9)
+            assert pm.psnr(gt, pred) == pytest.approx(md['pred_psnr'], rel=1e-12)       # host arrays go up to the device
+    link = pm.compile_batch_vis([str(tmp_path)], str(tmp_path / 'all'), mode)
+    assert os.path.exists(str(tmp_path / 'all') + ('.apng' if mode == 'test' else '.html')) and link.startswith(str(tmp_path))
+
+
+def test_infer_writes_batches_like_the_reference(tmp_path):
+    from nlt_amd import nlt_test
+    from nlt_amd.datasets.nlt import read_png
+    from oracle import buffers as OB
+    om, pm = make_pair(depth=256, uv=64, im=32, seed=15)
+    train = [O.synth_batch(2, 64, 64, 32, 32, 32, 32, k=1, seed=62)]
+    agg = nlt_test.extract_feat(pm, [to_device_batch(b, nn) for b, nn in train])
+    tests = []
+    for j in range(3):
+        tb = list(to_device_batch(*O.synth_batch(2, 64, 64, 32, 32, 32, 32, k=1, seed=70 + j)))
+        tb[0], tb[7] = ['t%d_%d' % (j, i) for i in range(2)], ['n%d_%d' % (j, i) for i in range(2)]
+        tests.append(tuple(tb))
+    ref = nlt_test.infer(pm, tests, agg)
+    for lanes, tag in ((1, 'a'), (2, 'b')):
+        nlt_test.infer(pm, tests, agg, str(tmp_path / tag), lanes=lanes)
+        for j in range(3):
+            for i in range(2):
+                want = OB.denormalize_float(np.clip(ref[j]['pred_camspc'][i].cpu().numpy(), 0, 1))
+                np.testing.assert_array_equal(read_png(str(tmp_path / tag / ('batch%09d' % j) / ('%d_pred.png' % i))), want)
