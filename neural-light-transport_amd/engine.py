@@ -531,7 +531,7 @@ class RenderPlan:
                 tapes.clear()
             ent = tapes.get(tkey, 0)
             if isinstance(ent, tuple):
-                if C.tape_valid(ent, reg.version):
+                if self._replayable(b, ent, reg):
                     C.replay(ent)
                     self.tape_replays += 1
                     return self._finish_pred(b), b
@@ -577,7 +577,7 @@ class RenderPlan:
                 tapes.clear()
             ent = tapes.get(tkey, 0)
             if isinstance(ent, tuple):
-                if C.tape_valid(ent, reg.version):
+                if self._replayable(b, ent, reg):
                     C.replay(ent)
                     self.tape_replays += 1
                     return self._finish_pred(b), b
@@ -834,11 +834,12 @@ class RenderPlan:
             self._launch('F.back', nbytes, C.back_forward_train if train else C.back_forward, *back_args, pred, *extra, **back_kw)
         out = self._pred_out if (not train and not self._tuning) else None
         if out is None:
-            b['back_call'] = None
+            # (leaves `back_infer` alone: a train forward, a timed survey or a copy-out pass over these buffers must not
+            # take the closure away from the inference tapes recorded with pred_out -- they would hand out a stale b['pred'])
             back(b['pred'])
             return b['pred'], b
         # the caller's own output tensor: this launch is not part of the launch tape (its output address differs every step)
-        b['back_call'] = back
+        b['back_infer'] = back
         paused = C.tape_pause()
         try:
             back(out)
@@ -854,11 +855,15 @@ class RenderPlan:
 
     def _finish_pred(self, b):
         """After a tape replay: the launch that was kept out of the tape (see `forward`, pred_out)."""
-        back = b.get('back_call')
-        if back is None or self._pred_out is None:
+        if self._pred_out is None:
             return b['pred']
-        back(self._pred_out)
+        b['back_infer'](self._pred_out)         # (`_replayable` made sure it exists)
         return self._pred_out
+
+    def _replayable(self, b, ent, reg):
+        """A recorded forward tape may be replayed: still valid, and -- when this call brought its own output tensor -- the
+        launch that was kept out of it is at hand (written only by a pred_out pass over these buffers)."""
+        return C.tape_valid(ent, reg.version) and (self._pred_out is None or b.get('back_infer') is not None)
 
     # ------------------------------------------------------------------ backward
     def _grad_buffers(self, b):

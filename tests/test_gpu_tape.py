@@ -108,3 +108,37 @@ def test_native_replay_of_the_tape_matches_the_python_replay(monkeypatch):
     assert all(torch.equal(x, res[True][0][0]) for x in res[True][0][1:])       # native replays = the recorded launches, bit for bit
     np.testing.assert_allclose(res[True][1], res[False][1], rtol=1e-4)          # (float atomics in the warp adjoint)
     assert float((res[True][2] - res[False][2]).abs().max()) < 1e-4
+
+
+@pytest.mark.parametrize('disturb', ['train_forward', 'copy_out', 'timer'])
+def test_inference_tapes_survive_a_pass_that_does_not_bring_its_own_output(monkeypatch, disturb):
+    """(advisor r04, high) An inference tape recorded with a caller-owned output keeps its last launch outside the tape.  A later
+    pass over the same buffers WITHOUT such an output -- a train forward, the copying path, a per-launch survey -- used to clear
+    that launch's closure, and the next replay handed out the plan's buffer still holding that other pass's texels."""
+    from nlt_amd.engine import OpTimer
+    batch = to_device_batch(*O.synth_batch(2, 64, 64, 32, 32, 32, 32, k=2, seed=75))
+    fresh = to_device_batch(*O.synth_batch(2, 64, 64, 32, 32, 32, 32, k=2, seed=76))
+    a = _model(True)
+    ref = _model(False, like=a)
+    for _ in range(3):
+        a.call(batch, 'test')
+    assert a.plan.tape_replays >= 1
+    if disturb == 'train_forward':
+        with torch.enable_grad():
+            a.call(batch, 'train')
+    elif disturb == 'copy_out':
+        monkeypatch.setenv('NLT_PRED_COPY', '1')
+        a.call(batch, 'test')
+        monkeypatch.setenv('NLT_PRED_COPY', '0')
+    else:
+        a.plan.timer = OpTimer()
+        a.call(batch, 'test')
+        a.plan.timer = None
+    for t, s in zip(batch, fresh):                                      # new contents at the SAME addresses: the tape key recurs
+        if torch.is_tensor(t):
+            t.copy_(s)
+    want = ref.call(batch, 'test')
+    before = a.plan.tape_replays
+    got = a.call(batch, 'test')
+    assert torch.equal(got[3]['pred'], want[3]['pred']) and torch.equal(got[0], want[0])
+    assert a.plan.tape_replays == before + 1                          # ... and it still is a replay
