@@ -119,10 +119,10 @@ def test_inference_tapes_survive_a_pass_that_does_not_bring_its_own_output(monke
     batch = to_device_batch(*O.synth_batch(2, 64, 64, 32, 32, 32, 32, k=2, seed=75))
     fresh = to_device_batch(*O.synth_batch(2, 64, 64, 32, 32, 32, 32, k=2, seed=76))
     a = _model(True)
-    ref = _model(False, like=a)
     for _ in range(3):
         a.call(batch, 'test')
     assert a.plan.tape_replays >= 1
+    ref = _model(False, like=a)
     if disturb == 'train_forward':
         with torch.enable_grad():
             a.call(batch, 'train')
@@ -140,5 +140,6 @@ def test_inference_tapes_survive_a_pass_that_does_not_bring_its_own_output(monke
     want = ref.call(batch, 'test')
     before = a.plan.tape_replays
     got = a.call(batch, 'test')
-    assert torch.equal(got[3]['pred'], want[3]['pred']) and torch.equal(got[0], want[0])
+    close = lambda x, y: float((x - y).norm() / y.norm()) < 1e-6      # (a stale buffer is another batch's texels: O(1) away)
+    assert close(got[3]['pred'], want[3]['pred']) and close(got[0], want[0])
     assert a.plan.tape_replays == before + 1                          # ... and it still is a replay
