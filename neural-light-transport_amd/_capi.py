@@ -183,6 +183,10 @@ _alloc_epoch = [0]          # bumped whenever a cached device buffer the C calls
 
 
 
+# int-returning entry points that answer a question instead of launching: a 0 from them is "no", not "launched"
+_NOT_LAUNCHES = frozenset(('nlt_conv_c32_supported',))
+
+
 class _TapeLib:
     """Stand-in for the CDLL while a tape is open: launching entry points (int status) are recorded after they ran."""
 
@@ -191,8 +195,8 @@ class _TapeLib:
 
     def __getattr__(self, name):
         fn = getattr(self._real, name)
-        if SIGNATURES[name][0] is not _c_int:
-            return fn                                   # size queries etc.: pure, not part of the step
+        if SIGNATURES[name][0] is not _c_int or name in _NOT_LAUNCHES:
+            return fn                                   # size / capability queries: pure, not part of the step
 
         def recorded(*args):
             rc = fn(*args)

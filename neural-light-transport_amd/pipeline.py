@@ -146,6 +146,7 @@ class RenderPipeline:
             lane = copy.copy(m)                             # same nets, flat bucket, pack registry
             lane.plan = RenderPlan(m.net['query'], m.net['obs'], m.use_obs)
             lane._graph, lane._graphs = None, {}
+            lane._warp_side = None                          # (NLT_WARP_SPLIT: side stream + events are per lane, never shared)
             lane.use_graphs = self._graphs
             self._lanes[i] = lane
         lane.conv_algo, lane.skip_connect_base = m.conv_algo, m.skip_connect_base
