@@ -985,7 +985,7 @@ class RenderPlan:
         # LDS-tiled kernel (csrc/conv_tile.hip) for the launches the plan-time trials gave to it: the adjoint families it has
         # (CONV_K2S1 / CONV_K2S2 of the expanding blocks, the transposed k2s1 of the encoder's stride-1 convs), no split epilogue
         wtn = (self._trial_wino or self.wino_hints.get(label, 0)) & 255
-        if (wtn and self.use_wino and algo == C.ALGO_AUTO and split is None and adj in (C.CONV_K2S1, C.DECONV_K2S1) and layer.n_ch_out % 8 == 0
+        if (wtn and self.use_wino and split is None and adj in (C.CONV_K2S1, C.DECONV_K2S1) and layer.n_ch_out % 8 == 0
                 and (hi - lo) % wtn == 0 and ldp % 4 == 0 and ldo % 4 == 0 and layer.kernel.is_contiguous()):
             self._ran_wino.add(label)
             self._launch(label, nbytes, C.conv_wino_backward_data, adj, dpre, layer.n_ch_out, ldp, n, oh, ow,
