@@ -371,10 +371,14 @@ def bench_train(args, device, world, rank, n_steps, loss):
     el_same, _, _ = timed(True)
     # what a multi-GPU run has to document about itself: the collective library's own world size, the two all-reduce
     # ranges, and the step with the first range issued from inside the backward plan (overlap) vs after it (serial)
+    rg = list(model.bucket_ranges)
     comm = {"rccl_world": dist.get_world_size() if (world > 1 and dist.is_initialized()) else 1,
-            "allreduce_floats": [int(model.bucket_split), int(model.flat_params.numel() - model.bucket_split)],
-            "allreduce_MB": [round(4e-6 * model.bucket_split, 2), round(4e-6 * (model.flat_params.numel() - model.bucket_split), 2)],
-            "backend": "nccl (RCCL over xGMI)" if world > 1 else "none (single rank: no collective is issued)"}
+            "allreduce_ranges": ["expanding blocks (issued inside the backward)", "encoder levels D..3 (issued inside the backward)",
+                                 "levels 2..0 + head (after the backward)"],
+            "allreduce_floats": [int(rg[i + 1] - rg[i]) for i in range(len(rg) - 1)],
+            "allreduce_MB": [round(4e-6 * (rg[i + 1] - rg[i]), 2) for i in range(len(rg) - 1)],
+            "backend": "nccl (RCCL over xGMI)" if world > 1 else "none (single rank: no collective is issued)",
+            "scaling_curve": "never measured on hardware: no multi-GPU node was available to rounds 1-5 (SCALE_r01..r04 skipped)"}
     if world > 1 and not args.train_graph:
         run_serial = lambda b: trainvali.distributed_train_step(model, b, opt, gbs, overlap=False)
         for i in range(len(batches)):
@@ -384,6 +388,19 @@ def bench_train(args, device, world, rank, n_steps, loss):
         run = run_saved
         comm["ms_per_step_overlapped"] = round(1e3 * el / n_steps, 3)
         comm["ms_per_step_serial"] = round(1e3 * el_serial / n_steps, 3)
+        # the same step on every rank at once WITHOUT the collectives (forward + loss + backward + Adam on the local gradient):
+        # what the all-reduces cost beyond what the backward hides.  Last: it lets the ranks' weights drift apart.
+        def run_local(b):
+            out_ = model.train_forward_backward(b, gbs)
+            opt.step(model.flat_grads)
+            return out_
+        for i in range(len(batches)):
+            run_local(batches[i])
+        run_saved, run = run, run_local
+        el_local, _, _ = timed(False)
+        run = run_saved
+        comm["ms_per_step_no_collective"] = round(1e3 * el_local / n_steps, 3)
+        comm["exposed_ms"] = round(1e3 * (el - el_local) / n_steps, 3)
     # per-rank host side of the step (what 8 single-threaded Python ranks on one host have to sustain): this rank's enqueue
     # time per step and the cores it may run on; gathered on rank 0
     try:
@@ -873,6 +890,8 @@ def main():
 
     train = []
     n_train = max(50, args.steps // 2) if args.train_steps < 0 else args.train_steps
+    if world > 1:
+        n_train = args.steps            # the data-parallel line IS the train step: exactly --steps timed steps
     if n_train > 0 and not args.headline_only:
         for loss in args.train_loss.split(','):
             train.append(bench_train(args, device, world, rank, n_train, loss))
@@ -944,6 +963,23 @@ def main():
                 out["config3_f32_split"] = others
         if released:
             out["released_shapes"] = released
+        if world > 1 and train:
+            # N > 1: what shards with a collective is BASELINE config 4's train step (frames data-parallel, RCCL gradient
+            # all-reduce) -- that is the line the scaling curve is drawn on.  The collective-free forward (replicas: scales
+            # by construction) moves to a sub-line.
+            t0_ = train[0]
+            out["forward_replicas"] = {k_: out[k_] for k_ in ("metric", "value", "unit", "ms_per_step", "steps", "dtype")}
+            out["forward_replicas"]["note"] = "N independent replicas of the inference forward, no collective: not a scaling result"
+            out["metric"] = ("rendered Mtexels/s at %d^2 UV, data-parallel TRAIN step (BASELINE config 4: forward + %s loss + backward + "
+                             "RCCL all-reduce of the %d-float gradient bucket in 3 ranges + Adam-AMSGrad)"
+                             % (args.uv, t0_["loss"], sum(t0_["comm"]["allreduce_floats"])))
+            out["value"], out["ms_per_step"], out["steps"] = t0_["value"], t0_["ms_per_step"], t0_["steps"]
+            out["dtype"] = "f32 (native v_mfma_f32 forward and backward, fp32 gradients and all-reduce)"
+            out["config"]["workload"] = t0_["workload"]
+            out["config"]["k"] = 1
+            out["config"]["global_batch"] = t0_["global_batch"]
+            out["config"]["parallelism"] = "dp%d (frames sharded; gradient all-reduce over RCCL/xGMI, ranges 0-1 overlapped with the backward)" % world
+            out["config"]["scaling_curve"] = t0_["comm"]["scaling_curve"]
         if train:
             out["train_step"] = train[0]
             if len(train) > 1:

@@ -97,7 +97,8 @@ class RenderPlan:
         # callable fired (also on tape replays) when the fused inference pass reaches its expanding blocks: the chip is mostly idle
         # under that chain of small launches, so Model.call queues the network-independent part of the resampler there
         self.decoder_hook = None
-        self.grad_hook = None           # callable fired by backward() once the expanding blocks' weight gradients are queued
+        self.grad_hook = None           # grad_hook(i): fired by backward() once range i of the gradient bucket has its weight gradients queued
+        self.grad_mid_level = 0         # encoder level that closes range 1 (0: no such range); set by Model._flatten
         self.generation = 0             # bumped by every forward: the activations in the plan's buffers belong to that pass
         self.tape_replays = 0
         self._trial_direct = False
@@ -927,8 +928,22 @@ class RenderPlan:
             for a in pend:
                 self._wgrad_now(*a)
 
-    def _fire_grad_hook(self, side):
-        """Runs `grad_hook` on the stream the expanding blocks' weight gradients were queued on.  `side` is an ARGUMENT
+    def _grad_range_done(self, i):
+        """Range i of the flat gradient bucket (models/nlt.py:_flatten: 0 = expanding blocks, 1 = encoder levels D .. grad_mid_level)
+        has all its weight-gradient launches queued: fire the hook on their stream."""
+        self._flush_wgrads()
+        bs = self._bside
+        if bs is not None and bs[2] is not None and bs[3] is not None:
+            side, events, cur, side2 = bs                            # (two weight-gradient streams: the hook's stream waits for the other)
+            if cur[0] == len(events):
+                events.append(C.new_event())
+            C.record_event(events[cur[0]], side2)
+            C.wait_event(side, events[cur[0]])
+            cur[0] += 1
+        C.tape_call(self._fire_grad_hook, bs[0] if (bs is not None and bs[2] is not None) else None, i)
+
+    def _fire_grad_hook(self, side, i=0):
+        """Runs `grad_hook(i)` on the stream the expanding blocks' weight gradients were queued on.  `side` is an ARGUMENT
         of the recorded call (not looked up in `_bside`, whose cursor only exists while a plan is being issued): a
         launch-tape replay re-invokes this with the same stream the recorded wgrad launches keep, so the collective the
         hook starts is ordered after them -- on the main stream it would race the side stream's accumulation.
@@ -938,9 +953,9 @@ class RenderPlan:
             return
         if side is not None:
             with torch.cuda.stream(side):
-                hook()
+                hook(i)
         else:
-            hook()
+            hook(i)
 
     def _wgrad_now(self, label, layer, src0, c0, ld0, src1, c1, ld1, n, h, w, dpre, ldp):
         oh, ow = layer.out_hw(h, w)
@@ -1164,16 +1179,7 @@ class RenderPlan:
 
         # every weight gradient of the expanding blocks is queued now: the leading range of the flat gradient
         # bucket (models/nlt.py:_flatten) can start its all-reduce while the encoder's backward runs
-        self._flush_wgrads()                                        # (the hook needs every expanding block's weight gradient queued)
-        bs = self._bside
-        if bs is not None and bs[2] is not None and bs[3] is not None:
-            side, events, cur, side2 = bs                            # (two weight-gradient streams: the hook's stream waits for the other)
-            if cur[0] == len(events):
-                events.append(C.new_event())
-            C.record_event(events[cur[0]], side2)
-            C.wait_event(side, events[cur[0]])
-            cur[0] += 1
-        C.tape_call(self._fire_grad_hook, bs[0] if (bs is not None and bs[2] is not None) else None)
+        self._grad_range_done(0)
 
         # ---- encoder (contracting blocks), deepest first; hh, ww = dims of level D
         for l in range(D, 0, -1):
@@ -1217,6 +1223,10 @@ class RenderPlan:
                 self._dgrad(lab + '.q.s2.dgrad', qa, 0, mult * cp, g['qtmp'][l], c, n, hh, ww, g['fm'][l - 1], mult * cp,
                             accumulate=True, zero_bias=zb, **(split_of(l - 1) if (fold and l > 1) else {}))
             hh, ww = hh * 2, ww * 2
+            if l == self.grad_mid_level and l > 1:
+                # levels D .. l of both paths -- the bulk of the bucket -- are queued: the second range goes out while
+                # the wide, cheap-in-parameters levels below still run
+                self._grad_range_done(1)
 
         # ---- L0 (both paths)
         q0, o0 = q.layers[0], o.layers[0]

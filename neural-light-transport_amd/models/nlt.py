@@ -167,26 +167,37 @@ class Model(BaseModel):
         with a matching flat gradient bucket; layers keep views.  One bucket = one RCCL all-reduce
         and one fused Adam launch per step."""
         convs = self._conv_layers()
-        # Slot ORDER inside the bucket: the query net's expanding blocks first, everything else after them.  The backward
-        # pass finishes those weight gradients first (it walks head -> decoder -> encoder), so the bucket's leading
-        # `bucket_split` floats can be all-reduced while the encoder's backward is still running
-        # (trainvali.distributed_train_step); the second collective covers the rest.  Two fixed, contiguous ranges.
-        # (The 1x1 head stays in the second range: the fused training path adds its skip rows at the very end.)
-        q = self.net['query']
-        late = set()
+        # Slot ORDER inside the bucket = the order in which the backward pass FINISHES the weight gradients (it walks head ->
+        # expanding blocks -> encoder, deepest level first), cut into three fixed contiguous ranges (`bucket_ranges`):
+        #   0  the query net's expanding blocks                                   (3.3 MB at depth 256)
+        #   1  encoder levels D .. M of both paths, deepest first; M = min(3, D)  (10.0 MB: the 64..256-channel levels)
+        #   2  everything else: levels M-1 .. 0 and the 1x1 head                  (0.1 MB; the fused training path adds the
+        #      head's skip rows and level 1's stride-2 gradients at the very end)
+        # Range 0 is all-reduced while the encoder's backward runs, range 1 while the wide shallow levels and the fused front
+        # backward run (trainvali.distributed_train_step); only range 2 is exposed behind the backward.
+        q, o = self.net['query'], self.net['obs']
+        late, mid = [], []
         for layer, is_c in zip(q.layers, q.is_contracting):
             if not is_c and not hasattr(layer, 'set_weights'):
-                late.update(id(c) for c in _convs_of(layer))
-        order = [c for c in convs if id(c) in late] + [c for c in convs if id(c) not in late]
+                late += _convs_of(layer)
+        D = sum(1 for layer, is_c in zip(q.layers, q.is_contracting) if is_c and not hasattr(layer, 'set_weights'))
+        M = min(3, D)
+        self.plan.grad_mid_level = M if D >= 2 else 0
+        if self.plan.grad_mid_level:
+            for l in range(D, M - 1, -1):
+                mid += _convs_of(q.layers[l]) + (_convs_of(o.layers[l]) if l < len(o.layers) else [])
+        taken = {id(c) for c in late + mid}
         where, off = {}, 0
-        self.bucket_split = 0               # (a query net without expanding Sequential blocks: one range)
-        for c in order:
-            for name in ('kernel', 'bias'):
-                t = getattr(c, name)
-                where[(id(c), name)] = (off, t.numel(), tuple(t.shape))
-                off += (t.numel() + 3) // 4 * 4
-            if id(c) in late:
-                self.bucket_split = off
+        ends = []
+        for group in (late, mid, [c for c in convs if id(c) not in taken]):
+            for c in group:
+                for name in ('kernel', 'bias'):
+                    t = getattr(c, name)
+                    where[(id(c), name)] = (off, t.numel(), tuple(t.shape))
+                    off += (t.numel() + 3) // 4 * 4
+            ends.append(off)
+        self.bucket_ranges = [0] + ends     # range i = [bucket_ranges[i], bucket_ranges[i + 1]) floats; an absent group: empty
+        self.bucket_split = ends[0]         # (the leading range alone: what rounds 1-4 overlapped)
         slots = [where[(id(c), name)] for c in convs for name in ('kernel', 'bias')]
         flat = torch.zeros(off, device=device, dtype=torch.float32)
         it = iter(slots)

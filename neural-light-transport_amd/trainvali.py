@@ -66,11 +66,12 @@ def distributed_train_step(model, batch, optimizer, global_bs, group=None, overl
     """batch = this rank's shard of the global batch.  Returns (loss summed over ranks, to_vis).
 
     One rank: per-example loss -> sum / global batch -> autograd backward -> fused Adam.
-    Several ranks: the gradient sum is TWO all-reduces of fixed contiguous ranges of the flat bucket (so every rank adds the
-    same numbers in the same order: bit-identical weights).  The first -- the expanding blocks, whose gradients the
-    backward pass finishes first -- is issued from inside the backward plan as soon as those weight-gradient launches are
-    queued (on their stream), and runs over xGMI while the encoder's backward occupies the CUs; the second follows the
-    backward.  overlap=False issues both after the backward (same result)."""
+    Several ranks: the gradient sum is THREE all-reduces of fixed contiguous ranges of the flat bucket, cut in the order
+    the backward pass finishes them (`Model.bucket_ranges`: expanding blocks | encoder levels D .. 3 | the rest), so every
+    rank adds the same numbers in the same order: bit-identical weights.  The first two are issued from inside the backward
+    plan as soon as their weight-gradient launches are queued (on their stream) and run over xGMI while the rest of the
+    backward occupies the CUs; only the last (0.1 MB of 13.5) follows the backward.  overlap=False issues all three after
+    the backward (same result)."""
     assert model.trainable_registered, "Register the trainable layers before using `trainable_variables`"
     world = _world(group)
     if world == 1 and not AUTOGRAD_STEP and not getattr(model, 'generic', False):     # (branch configs run layer by layer through autograd)
@@ -108,17 +109,21 @@ def distributed_train_step(model, batch, optimizer, global_bs, group=None, overl
             w.wait()
         optimizer.step(grad)
         return loss, to_vis
-    grad, split = model.flat_grads, model.bucket_split
-    works = []
+    grad, r = model.flat_grads, model.bucket_ranges
+    works, sent = [], set()
+
+    def reduce_range(i):
+        if i not in sent and r[i + 1] > r[i]:
+            works.append(dist.all_reduce(grad[r[i]:r[i + 1]], op=dist.ReduceOp.SUM, group=group, async_op=True))
+        sent.add(i)
     if overlap:
-        model.plan.grad_hook = lambda: works.append(dist.all_reduce(grad[:split], op=dist.ReduceOp.SUM, group=group, async_op=True))
+        model.plan.grad_hook = reduce_range
     try:
         loss, to_vis = model.train_forward_backward(batch, global_bs)    # gradients land in the flat bucket (no autograd copy)
     finally:
         model.plan.grad_hook = None
-    if not works:
-        works.append(dist.all_reduce(grad[:split], op=dist.ReduceOp.SUM, group=group, async_op=True))
-    works.append(dist.all_reduce(grad[split:], op=dist.ReduceOp.SUM, group=group, async_op=True))
+    for i in range(len(r) - 1):                                         # whatever the backward did not send, in range order
+        reduce_range(i)
     loss = loss.clone()
     works.append(dist.all_reduce(loss, op=dist.ReduceOp.SUM, group=group, async_op=True))
     for w in works:

@@ -50,7 +50,9 @@ def _worker(rank, world, port, outdir, mode):
     shard = tuple(t[sl] if torch.is_tensor(t) else t for t in batch)
     nn_s = [(b[sl], r[sl]) for b, r in nn]
     opt = nlt_amd.optim.AdamAMSGrad(pm, 1e-3)
-    fired = []
+    fired, trace = [], []
+    wgrad_now = pm.plan._wgrad_now
+    pm.plan._wgrad_now = lambda label, *a, **kw: (trace.append(label), wgrad_now(label, *a, **kw))[1]
     if mode == 'graphed':
         step = trainvali.GraphedTrainStep(pm, opt, gbs, warmup=0)         # off the GPU: degrades to the eager step
         run = lambda: step(cpu_batch(shard, nn_s))
@@ -60,6 +62,7 @@ def _worker(rank, world, port, outdir, mode):
 
             def spy(t, *a, **kw):                                         # order and sizes of the collectives
                 fired.append(t.numel())
+                trace.append(t.numel())
                 return real(t, *a, **kw)
             dist.all_reduce = spy
             try:
@@ -74,7 +77,7 @@ def _worker(rank, world, port, outdir, mode):
     base = pm.flat_params.data_ptr()
     offs = [((v.data_ptr() - base) // 4, v.numel()) for c in pm._conv_layers() for v in (c.kernel, c.bias)]
     torch.save({'losses': losses, 'vali': float(lv), 'params': pm.flat_params.detach().clone(),
-                'grad': pm.flat_params.grad.clone(), 'offs': offs, 'fired': fired, 'split': pm.bucket_split},
+                'grad': pm.flat_params.grad.clone(), 'offs': offs, 'fired': fired, 'split': pm.bucket_split, 'ranges': list(pm.bucket_ranges), 'trace': trace},
                os.path.join(outdir, 'r%d.pt' % rank))
     dist.destroy_process_group()
 
@@ -95,9 +98,29 @@ def test_data_parallel_train_step(world, mode):
     if mode == 'branch':
         assert r[0]['fired'] == [r[0]['params'].numel(), 1] * 2      # layer-by-layer configs: the whole bucket at once
     elif mode != 'graphed':
-        # per step: the bucket's leading range (expanding blocks), the rest, the scalar loss -- in this order
-        n, split = r[0]['params'].numel(), r[0]['split']
-        assert 0 < split < n and r[0]['fired'] == [split, n - split, 1] * 2
+        # per step: the bucket's three ranges in backward-completion order (expanding blocks | encoder levels 6..3 | the rest),
+        # then the scalar loss
+        n, split, rg = r[0]['params'].numel(), r[0]['split'], r[0]['ranges']
+        assert rg[0] == 0 and rg[1] == split and rg[-1] == n and len(rg) == 4 and rg == sorted(rg)
+        sizes = [rg[i + 1] - rg[i] for i in range(3)]
+        assert all(x > 0 for x in sizes) and r[0]['fired'] == (sizes + [1]) * 2
+        assert sizes[2] < 0.02 * n < sizes[0] < sizes[1]               # what stays exposed behind the backward is the small tail
+        # every slot lies inside exactly one range, and the ranges hold what their names say
+        for off, cnt in r[0]['offs']:
+            assert sum(rg[i] <= off and off + cnt <= rg[i + 1] for i in range(3)) == 1
+        # WHERE in the backward the collectives start (one step's trace: weight-gradient labels and collective sizes)
+        tr = r[0]['trace']
+        step = tr[:tr.index(1) + 1]                                     # up to and including the loss all-reduce of step 0
+        at = [step.index(x) for x in sizes]
+        lev = lambda lab: int(lab.split('.')[1][1:])
+        before = lambda i: [lev(x) for x in step[:at[i]] if isinstance(x, str) and x.endswith('.wgrad')]
+        after = lambda i: [lev(x) for x in step[at[i]:] if isinstance(x, str) and x.endswith('.wgrad')]
+        if mode == 'overlap':
+            assert set(before(0)) >= {7, 8, 9, 10, 11} and min(before(0)) >= 7 and max(after(0)) <= 6   # (the last block: fused end)
+            assert set(before(1)) >= {3, 4, 5, 6} and all(l < 3 for l in after(1)) and after(1)       # range 1 leaves mid-backward
+            assert at[2] > max(i for i, x in enumerate(step) if isinstance(x, str))               # range 2 behind the backward
+        else:
+            assert at[0] > max(i for i, x in enumerate(step) if isinstance(x, str))
     # ... and they equal the single-process oracle on the full batch
     gbs = GLOBAL[world]
     om = (O.OracleModel(depth=32, uvh=64, uvw=64, imh=32, imw=32, seed=1, loss='l2', norm='layer') if mode == 'branch' else

@@ -160,7 +160,9 @@ def test_overlapped_bucket_collective_runs_on_the_weight_gradient_stream_in_repl
     first = [st for n, st in c1 if n == split]
     assert len(first) == 8 and all(st == side for st in first), (first, side, main)      # replayed steps included
     assert all(st == main for n, st in c0)                                              # overlap=False: after the backward
-    assert len(c0) == len(c1) == 8 * 3
+    assert len(c0) == len(c1) == 8 * 4                                                  # three gradient ranges + the loss
+    mid = [st for n, st in c1 if n == pm.bucket_ranges[2] - pm.bucket_ranges[1]]
+    assert len(mid) == 8 and all(st == side for st in mid)                              # the second range: from inside the backward too
     # A misplaced hook doubles half-accumulated sums: an O(1) error.  What two CORRECT runs differ by is the float-atomic
     # noise of the resampler adjoint (~1e-7 of the gradient at step 0), which Adam's m / sqrt(v) then carries into the
     # weights of the later steps: step 0 is bounded tightly, the replayed steps by a drift-aware bound.
