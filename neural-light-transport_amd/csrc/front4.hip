@@ -76,9 +76,26 @@ template <bool U8> struct Staged;
 template <> struct Staged<false> { f32x4 v[10]; };
 template <> struct Staged<true> { uint2 v[6]; };
 
-// LeakyReLU for 0 <= alpha <= 1 (checked by the launcher): max(v, alpha * v), bit-identical to the select form
-__device__ __forceinline__ f32x4 lrelu4m(f32x4 v, float alpha) {
-  return (f32x4){fmaxf(v[0], alpha * v[0]), fmaxf(v[1], alpha * v[1]), fmaxf(v[2], alpha * v[2]), fmaxf(v[3], alpha * v[3])};
+// LeakyReLU for 0 <= alpha <= 1 (checked by the launcher): max(v, alpha * v), bit-identical to the select form.  r05: the
+// products as <2 x float> multiplies (v_pk_mul_f32) and the maximum as v_med3_f32(v, alpha v, FLT_MAX) (= max for every finite value): 1.5 instead of 2 VALU
+// instructions per value (fmaxf() on an MFMA result costs a third: the compiler quiets the operand first).
+// NO inline-asm VALU in this kernel: the hazard recognizer pads MFMA -> VALU read / write distances with s_nop only for
+// instructions it can see, and a v_max_f32 / v_pk_add_f32 written as asm landed inside an MFMA's write-back window in one
+// build of the uint8 variant (obs texels wrong by 1e-1; which build depends on register allocation).
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f32x4 lrelu4m(f32x4 v, f32x2 alpha2) {
+  const f32x2 plo = (f32x2){v[0], v[1]} * alpha2, phi = (f32x2){v[2], v[3]} * alpha2;
+  const float top = 3.4028234663852886e38f;   // FLT_MAX, not +inf: med3 with an infinity is folded back into the quieting max
+  return (f32x4){__builtin_amdgcn_fmed3f(v[0], plo[0], top), __builtin_amdgcn_fmed3f(v[1], plo[1], top),
+                 __builtin_amdgcn_fmed3f(v[2], phi[0], top), __builtin_amdgcn_fmed3f(v[3], phi[1], top)};
+}
+
+// a - b as two packed operations
+__device__ __forceinline__ f32x4 sub4(f32x4 a, f32x4 b) {
+  const f32x2 m1 = (f32x2){-1.f, -1.f};                 // fma(b, -1, a) = a - b, one rounding: v_pk_fma_f32
+  const f32x2 lo = __builtin_elementwise_fma((f32x2){b[0], b[1]}, m1, (f32x2){a[0], a[1]});
+  const f32x2 hi = __builtin_elementwise_fma((f32x2){b[2], b[3]}, m1, (f32x2){a[2], a[3]});
+  return (f32x4){lo[0], lo[1], hi[0], hi[1]};
 }
 
 // Two waves per SIMD (<= 256 registers).  A leaner variant (weights re-read per observation, query inputs fetched
@@ -100,6 +117,7 @@ __global__ __launch_bounds__(512, 1) void front4_kernel(
   const int h2 = h >> 1, w2 = w >> 1;
   const long hw = (long)h * w;
   const f32x4 zero4 = (f32x4){0.f, 0.f, 0.f, 0.f};
+  const f32x2 alpha2 = (f32x2){alpha, alpha};
 
   // ---- the query path's level-2 and stride-1 fragments and all biases: once per workgroup (128 registers of every wave otherwise)
 #pragma unroll
@@ -128,7 +146,8 @@ __global__ __launch_bounds__(512, 1) void front4_kernel(
   // Loads are unconditional: wave-uniform frame pointer + 32-bit lane offset.  A piece that lies beyond the image's
   // bottom / right edge (or a lane without a piece) reads the frame's first bytes instead: whatever it delivers only
   // reaches stage-1 texels outside the image, whose outputs are forced to zero (`inside_m`), so no select is needed.
-  unsigned g3[P3], g1[P1];                                               // element offset inside a frame
+  unsigned g3[P3], g1[P1];                                               // BYTE offset inside a frame (32 bits: the load takes
+                                                                         // it as the VGPR offset of an SGPR base -- no address VALU)
   int lf = 0;                                                            // sample (frame of the batch) of that strip
   // (`opaque`: the lane-only parts of these index computations are loop invariants; hoisted out of the strip loop they
   // would occupy ~40 registers of a kernel that has none to spare -- recomputing them per strip is ~100 VALU instructions)
@@ -144,7 +163,7 @@ __global__ __launch_bounds__(512, 1) void front4_kernel(
       const int r = item / N3, i = item - r * N3;
       const int gy = 2 * ty0 + r;
       const bool ok = item < XH * N3 && gy < h && 3 * (2 * tx0) + E3 * i < 3 * w;
-      g3[p] = ok ? (unsigned)((gy * w + 2 * tx0) * 3 + E3 * i) : 0u;
+      g3[p] = ok ? (unsigned)((gy * w + 2 * tx0) * 3 + E3 * i) * (U8 ? 1u : 4u) : 0u;
     }
 #pragma unroll
     for (int p = 0; p < P1; ++p) {
@@ -152,7 +171,7 @@ __global__ __launch_bounds__(512, 1) void front4_kernel(
       const int r = item / N1, i = item - r * N1;
       const int gy = 2 * ty0 + r;
       const bool ok = item < XH * N1 && gy < h && 2 * tx0 + E1 * i < w;
-      g1[p] = ok ? (unsigned)(gy * w + 2 * tx0 + E1 * i) : 0u;
+      g1[p] = ok ? (unsigned)(gy * w + 2 * tx0 + E1 * i) * (U8 ? 1u : 4u) : 0u;
     }
   };
   Staged<U8> st;
@@ -160,25 +179,25 @@ __global__ __launch_bounds__(512, 1) void front4_kernel(
 #pragma unroll
     for (int p = 0; p < P3; ++p) {
       if constexpr (U8) st.v[at + p] = *reinterpret_cast<const uint2*>(static_cast<const unsigned char*>(arr) + frame * hw * 3 + g3[p]);
-      else st.v[at + p] = *reinterpret_cast<const f32x4*>(static_cast<const float*>(arr) + frame * hw * 3 + g3[p]);
+      else st.v[at + p] = *reinterpret_cast<const f32x4*>(static_cast<const unsigned char*>(arr) + frame * hw * 12 + g3[p]);
     }
   };
   auto ld1 = [&](const void* arr, long frame, int at) {
 #pragma unroll
     for (int p = 0; p < P1; ++p) {
       if constexpr (U8) st.v[at + p] = *reinterpret_cast<const uint2*>(static_cast<const unsigned char*>(arr) + frame * hw + g1[p]);
-      else st.v[at + p] = *reinterpret_cast<const f32x4*>(static_cast<const float*>(arr) + frame * hw + g1[p]);
+      else st.v[at + p] = *reinterpret_cast<const f32x4*>(static_cast<const unsigned char*>(arr) + frame * hw * 4 + g1[p]);
     }
   };
   auto load_obs = [&](int i) {                                           // observation i of the strip being loaded
     long fr;
     if constexpr (U8) fr = in.nn_ids[lf * k + i]; else fr = (long)lf * k + i;
-    if (fr < 0) {                                                        // a missing neighbour (wave-uniform): zeros
+    if constexpr (U8) {                                                  // (float batches have every neighbour: the assembler wrote zeros)
+      if (fr < 0) {                                                      // a missing neighbour (wave-uniform): zeros
 #pragma unroll
-      for (int p = 0; p < 2 * P3; ++p) {
-        if constexpr (U8) st.v[p] = make_uint2(0u, 0u); else st.v[p] = zero4;
+        for (int p = 0; p < 2 * P3; ++p) st.v[p] = make_uint2(0u, 0u);
+        return;
       }
-      return;
     }
     ld3(in.nn_rgb, fr, 0);
     ld3(in.nn_base, fr, P3);
@@ -204,7 +223,7 @@ __global__ __launch_bounds__(512, 1) void front4_kernel(
         *reinterpret_cast<f32x4*>(dst + item * 8) = lo;
         *reinterpret_cast<f32x4*>(dst + item * 8 + 4) = hi;
       } else {
-        *reinterpret_cast<f32x4*>(dst + item * 4) = sub ? st.v[p] - st.v[P3 + p] : st.v[p];
+        *reinterpret_cast<f32x4*>(dst + item * 4) = sub ? sub4(st.v[p], st.v[P3 + p]) : st.v[p];
       }
     }
   };
@@ -270,7 +289,7 @@ __global__ __launch_bounds__(512, 1) void front4_kernel(
   // stage 2: L1 stride-1 conv of the haloed tile in `ot` (TF 'same': taps (y + a, x + b)), four rows side by side
   auto stage2 = [&](const f32x4 (&a)[4], f32x4 bias, f32x4 (&out)[SH]) {
     const float* tilep = ot + kk * SLOTS * 4;
-    f32x4 acc[SH] = {zero4, zero4, zero4, zero4};
+    f32x4 acc[SH] = {bias, bias, bias, bias};                            // r05: the bias is the chain's initial value (no add)                            // r05: the bias is the chain's initial value (no add)
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
       f32x4 b[SH];
@@ -282,7 +301,7 @@ __global__ __launch_bounds__(512, 1) void front4_kernel(
         for (int r = 0; r < SH; ++r) acc[r] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[t][s4], b[r][s4], acc[r], 0, 0, 0);
     }
 #pragma unroll
-    for (int r = 0; r < SH; ++r) out[r] = lrelu4m(acc[r] + bias, alpha);
+    for (int r = 0; r < SH; ++r) out[r] = lrelu4m(acc[r], alpha2);
   };
 
   // ---- prologue: item 0 of the first strip into LDS, item 1 in flight
@@ -331,8 +350,8 @@ __global__ __launch_bounds__(512, 1) void front4_kernel(
       f32x4 sv[NC];
 #pragma unroll
       for (int c0 = 0; c0 < NC; c0 += 3) {
-        f32x4 acc[3] = {zero4, zero4, zero4};
         const f32x4 b2 = bias4(B_O2);
+        f32x4 acc[3] = {b2, b2, b2};
         float d[3][3];
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
@@ -346,10 +365,14 @@ __global__ __launch_bounds__(512, 1) void front4_kernel(
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
           xs[c0 + c][0] += d[c][0]; xs[c0 + c][1] += d[c][1]; xs[c0 + c][2] += d[c][2];
-          f32x4 v = lrelu4m(acc[c] + b2, alpha);
-          if (!interior && !((inside_m >> (c0 + c)) & 1)) v = zero4;       // beyond the image: the stride-1 conv's zero padding
-          sv[c0 + c] = v;
+          sv[c0 + c] = lrelu4m(acc[c], alpha2);
         }
+      }
+      if (!interior) {                                                     // beyond the image: the stride-1 conv's zero padding.
+        asm volatile("" ::: "memory");                                     // A BRANCH (wave-uniform, border strips only), not 24 selects in every strip
+#pragma unroll
+        for (int c = 0; c < NC; ++c)
+          if (!((inside_m >> c) & 1)) sv[c] = zero4;
       }
 #pragma unroll
       for (int c = 0; c < NC; ++c) *reinterpret_cast<f32x4*>(ot + (kk * SLOTS + c * 16 + j) * 4) = sv[c];
@@ -387,8 +410,7 @@ __global__ __launch_bounds__(512, 1) void front4_kernel(
       for (int r = 0; r < SH; ++r) *reinterpret_cast<f32x4*>(ot + l1_wr(r)) = o1[r];
       wave_sync();
       {
-        f32x4 a3[2] = {zero4, zero4};
-        const f32x4 b3[2] = {bias4(B_O3), bias4(B_O3 + 16)};               // requested ahead of the MFMAs, not inside the branch below
+        f32x4 a3[2] = {bias4(B_O3), bias4(B_O3 + 16)};                     // the biases: initial values of the two chains
 #pragma unroll
         for (int c4 = 0; c4 < 4; ++c4) {
           const f32x4 v = *reinterpret_cast<const f32x4*>(ot + c4 * 256 + l1_rd);
@@ -400,8 +422,8 @@ __global__ __launch_bounds__(512, 1) void front4_kernel(
         }
         if (in2) {
           float* o = otmp2 + (((long)f * k + i) * h4 * w4 + tex2) * 32 + 4 * kk;
-          *reinterpret_cast<f32x4*>(o) = lrelu4m(a3[0] + b3[0], alpha);
-          *reinterpret_cast<f32x4*>(o + 16) = lrelu4m(a3[1] + b3[1], alpha);
+          *reinterpret_cast<f32x4*>(o) = lrelu4m(a3[0], alpha2);
+          *reinterpret_cast<f32x4*>(o + 16) = lrelu4m(a3[1], alpha2);
         }
       }
       wave_sync();                                                         // the level-1 tile is consumed: `ot` is free again
@@ -416,8 +438,8 @@ __global__ __launch_bounds__(512, 1) void front4_kernel(
       // stage 1 (8 MFMAs per column tile): raw = (base r g b, cvis, lvis, mean raw observation r g b)
 #pragma unroll
       for (int c0 = 0; c0 < NC; c0 += 3) {                                 // three column tiles at a time, as for the observations
-        f32x4 acc[3] = {zero4, zero4, zero4};
         const f32x4 b2 = bias4(B_Q2);
+        f32x4 acc[3] = {b2, b2, b2};
         float raw[3][8];
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
@@ -438,8 +460,11 @@ __global__ __launch_bounds__(512, 1) void front4_kernel(
           for (int c = 0; c < 3; ++c) acc[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(aq2[m], raw[c][m], acc[c], 0, 0, 0);
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
-          f32x4 v = lrelu4m(acc[c] + b2, alpha);
-          if (!interior && !((inside_m >> (c0 + c)) & 1)) v = zero4;
+          f32x4 v = lrelu4m(acc[c], alpha2);
+          if (!interior) {
+            asm volatile("" ::: "memory");
+            if (!((inside_m >> (c0 + c)) & 1)) v = zero4;
+          }
           *reinterpret_cast<f32x4*>(ot + (kk * SLOTS + (c0 + c) * 16 + j) * 4) = v;
           if constexpr (TRAIN) {
             if ((owned_m >> (c0 + c)) & 1) {
@@ -492,8 +517,7 @@ __global__ __launch_bounds__(512, 1) void front4_kernel(
       wave_sync();
       // stage 3, query (2,2,32,32): slab 0 = q1 (c8 0..3), slab 1 = mean o1 (c8 4..7), accumulated in this order; fragments
       // from the workgroup's LDS copy
-      f32x4 a3[2] = {zero4, zero4};
-      const f32x4 b3[2] = {bias4(B_Q3), bias4(B_Q3 + 16)};
+      f32x4 a3[2] = {bias4(B_Q3), bias4(B_Q3 + 16)};
 #pragma unroll
       for (int slab = 0; slab < 2; ++slab) {
 #pragma unroll
@@ -514,8 +538,8 @@ __global__ __launch_bounds__(512, 1) void front4_kernel(
       }
       if (in2) {
         float* o = qtmp2 + ((long)f * h4 * w4 + tex2) * 32 + 4 * kk;
-        *reinterpret_cast<f32x4*>(o) = lrelu4m(a3[0] + b3[0], alpha);
-        *reinterpret_cast<f32x4*>(o + 16) = lrelu4m(a3[1] + b3[1], alpha);
+        *reinterpret_cast<f32x4*>(o) = lrelu4m(a3[0], alpha2);
+        *reinterpret_cast<f32x4*>(o + 16) = lrelu4m(a3[1], alpha2);
       }
     }
     if (!has_next) break;

@@ -79,9 +79,11 @@ __device__ __forceinline__ void wave_sync5() {      // orders this wave's LDS tr
 
 // two floats -> their bf16 roundings (nearest even), packed (low half = a)
 __device__ __forceinline__ unsigned cvt_pk_bf16_5(float a, float b) {
-  unsigned r;
-  asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
-  return r;
+  // (a conversion the compiler can see -- one v_cvt_pk_bf16_f32 -- not inline asm: the hazard recognizer pads MFMA -> VALU
+  // read / write distances only for instructions it knows, r05)
+  typedef float f32x2_ __attribute__((ext_vector_type(2)));
+  typedef __bf16 bf16x2_ __attribute__((ext_vector_type(2)));
+  return __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2_){a, b}, bf16x2_));
 }
 
 // four floats -> the three bf16 terms of each, packed in element order: t[term] = 4 bf16

@@ -97,6 +97,7 @@ class RenderPlan:
         # callable fired (also on tape replays) when the fused inference pass reaches its expanding blocks: the chip is mostly idle
         # under that chain of small launches, so Model.call queues the network-independent part of the resampler there
         self.decoder_hook = None
+        self.prune_packs = os.environ.get('NLT_PRUNE_PACKS', '1') != '0'   # retire fragment buffers only plan-time trials read
         self.grad_hook = None           # grad_hook(i): fired by backward() once range i of the gradient bucket has its weight gradients queued
         self.grad_mid_level = 0         # encoder level that closes range 1 (0: no such range); set by Model._flatten
         self.generation = 0             # bumped by every forward: the activations in the plan's buffers belong to that pass
@@ -402,6 +403,9 @@ class RenderPlan:
         self.tuned = {**getattr(self, 'tuned', {}), **results}
         self._tuning = False
         self._drop_tapes()
+        reg = getattr(self.q.layers[0], '_registry', None)
+        if reg is not None and self.prune_packs:
+            reg.begin_census()              # which of the candidates' fragment buffers does the chosen plan read?
 
     def _drop_tapes(self):
         for b in self._bufs.values():
@@ -508,6 +512,8 @@ class RenderPlan:
             self.generation += 1
         reg = getattr(self.q.layers[0], '_registry', None)
         if reg is not None:
+            if not self._tuning:
+                reg.tick()
             reg.refresh_if_stale()          # all packed fragments, one launch, before any stream is forked
         fused = (inference or self.fuse_train) and self.can_fuse(b, obs_weights, obs_override)
         if fused and not inference and w % 8:                           # the training ends: w/2 in groups of 4 texels
@@ -561,6 +567,8 @@ class RenderPlan:
             self.generation += 1
         reg = getattr(self.q.layers[0], '_registry', None)
         if reg is not None:
+            if not self._tuning:
+                reg.tick()
             reg.refresh_if_stale()
         if not self.can_fuse(b, None, None):
             raise C.NLTError("this network / plan cannot take store-resident inputs: materialise the batch")
@@ -1045,6 +1053,8 @@ class RenderPlan:
         q, o, D, U, cl = self.q, self.o, self.n_down, self.n_up, b['C']
         zb = g['zero_bias']
         reg = getattr(self.q.layers[0], '_registry', None)
+        if reg is not None and not self._tuning:
+            reg.tick()
         if self.autotune and self.tune_backward and dpred.is_cuda and not b.get('tuned_bwd') and not self._tuning:
             # plan-time choice of the backward-data launches' wave tiles / split-K (the same trial machinery as the forward).
             # The trial passes accumulate into the weight-gradient bucket: it is cleared again before the real pass.

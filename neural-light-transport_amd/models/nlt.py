@@ -182,7 +182,7 @@ class Model(BaseModel):
                 late += _convs_of(layer)
         D = sum(1 for layer, is_c in zip(q.layers, q.is_contracting) if is_c and not hasattr(layer, 'set_weights'))
         M = min(3, D)
-        self.plan.grad_mid_level = M if D >= 2 else 0
+        self.plan.grad_mid_level = M if (D >= 2 and os.environ.get('NLT_GRAD_RANGES', '3') != '2') else 0   # (2: the r01-r04 split, A/B)
         if self.plan.grad_mid_level:
             for l in range(D, M - 1, -1):
                 mid += _convs_of(q.layers[l]) + (_convs_of(o.layers[l]) if l < len(o.layers) else [])

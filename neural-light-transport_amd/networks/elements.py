@@ -100,10 +100,13 @@ class Conv2D(Layer):
         the model in ONE launch when the layer belongs to a PackRegistry, by re-running `make` otherwise."""
         ent = self._packed.get(key)
         ver = self._version()
+        reg = self._registry
+        if reg is not None:
+            reg.touch(self, key)
         if ent is not None and ent[0] == ver:
             return ent[1]
-        reg = self._registry
         if ent is not None and reg is not None and reg.owns(self, key):
+            reg.activate(self, key)          # (a buffer the census had retired: back into the one-launch refresh)
             reg.refresh()
             return self._packed[key][1]
         buf = make()
@@ -214,9 +217,50 @@ class PackRegistry:
         self.state_fn = state_fn     # () -> hashable that changes whenever any kernel of the model is rewritten
         self.state = None
         self.version = 0             # bumped when the SET of buffers changes (recorded launch tapes point at them)
+        # r05: the plan-time trials pack a fragment layout for every candidate kernel of every layer (201 buffers, 118 MB at
+        # depth 256) and the step keeps 60-odd of them: the refresh launch cost 0.12 ms per train step.  After a plan has been
+        # (re-)tuned a CENSUS runs over its next passes; buffers nothing asked for go INACTIVE: kept, not refreshed, hence
+        # stale -- whoever asks for one later re-activates it (`_cached_pack`), and recorded tapes (which hold buffer
+        # addresses and would read a stale one without asking) are invalidated by the version bump.
+        self.inactive = set()
+        self.used = None             # keys asked for since the census began (None: no census running)
+        self.ticks_left = 0
 
     def owns(self, layer, key):
         return (id(layer), key) in self.entries
+
+    def touch(self, layer, key):
+        if self.used is not None:
+            self.used.add((id(layer), key))
+
+    def begin_census(self, passes=4):
+        """Called when a plan's choices have just been made: the next `passes` plan passes (forward / backward, whichever
+        come) say which buffers the chosen kernels read."""
+        self.used, self.ticks_left = set(), passes
+
+    def tick(self):
+        """One plan pass (forward or backward, any kind) begins."""
+        if self.used is None:
+            return
+        if self.ticks_left <= 0:
+            self.prune()
+        self.ticks_left -= 1
+
+    def prune(self):
+        if self.used is None:
+            return
+        drop = [k for k in self.entries if k not in self.used and k not in self.inactive]
+        self.used = None
+        if drop:
+            self.inactive.update(drop)
+            self.table = None
+            self.version += 1
+
+    def activate(self, layer, key):
+        k = (id(layer), key)
+        if k in self.inactive:
+            self.inactive.discard(k)
+            self.table = None
 
     def add(self, layer, key, buf, desc):
         self.entries[(id(layer), key)] = (layer, key, buf, desc)
@@ -227,23 +271,25 @@ class PackRegistry:
 
     def drop(self, layer):
         self.entries = {k: v for k, v in self.entries.items() if v[0] is not layer}
+        self.inactive = {k for k in self.inactive if k in self.entries}
         self.table = None
         self.version += 1
 
     def prepare(self):
         """Builds the device descriptor table (a host-to-device copy: must not happen inside a graph capture)."""
-        if self.table is None and self.entries:
-            ents = list(self.entries.values())
+        if self.table is None and len(self.entries) > len(self.inactive):
+            ents = [v for k, v in self.entries.items() if k not in self.inactive]
             rows = [dict(d, src=layer.kernel, dst=buf) for layer, _, buf, d in ents]
             self.table = C.repack_table(rows, ents[0][2].device)
 
     def refresh(self):
-        if not self.entries:
+        if len(self.entries) <= len(self.inactive):
             return
         self.prepare()
         C.repack_weights(*self.table)
-        for layer, key, buf, _ in self.entries.values():
-            layer._packed[key] = (layer._version(), buf)
+        for k, (layer, key, buf, _) in self.entries.items():
+            if k not in self.inactive:
+                layer._packed[key] = (layer._version(), buf)
         if self.state_fn is not None:
             self.state = self.state_fn()
 

@@ -181,6 +181,7 @@ class GraphedTrainStep:
                     self.static[i] = batch[i].clone()
                 reg = getattr(self.model, 'pack_registry', None)
                 if reg is not None:                      # the refresh of the packed weights must be IN the graph, its
+                    reg.prune()                          # (a running census of used fragment buffers ends here, not mid-capture)
                     reg.prepare()                        # descriptor upload must not
                     reg.state = None
                 if self.model.plan._front_blob is not None:

@@ -1,7 +1,8 @@
-"""-m gpu: second-generation front kernel (csrc/front4.hip) -- float inputs against front_kernel<true> (bit-identical
-by construction: same folded weights, same MFMA sequences), uint8-store inputs against the float kernel on
-nlt_assemble_batch's output (bit-identical: the uint8 -> float32 conversion is exact), and the whole Model.call with
-the plan switch on / off."""
+"""-m gpu: second-generation front kernel (csrc/front4.hip) -- float inputs against front_kernel<true> (same folded
+weights, same MFMA sequences; since r05 the biases are the accumulators' initial values instead of a separate add, so the
+two kernels differ by that re-association: <= 5e-7 rel-L2, r04 review item 5), uint8-store inputs against the float kernel
+on nlt_assemble_batch's output (bit-identical: the uint8 -> float32 conversion is exact), the train form against the
+inference form (bit-identical), and the whole Model.call with the plan switch on / off."""
 import numpy as np
 import pytest
 import torch
@@ -11,6 +12,11 @@ from oracle import nlt_oracle as O
 from gpu_util import make_pair, to_device_batch
 
 pytestmark = pytest.mark.gpu
+REASSOC = 5e-7          # bias-first vs bias-last accumulation of the same exact fp32 products
+
+
+def close(a, b, tol=REASSOC):
+    return float((a.double() - b.double()).norm()) <= tol * float(b.double().norm()) + 1e-30
 
 
 def _weights(seed=0):
@@ -28,7 +34,7 @@ def _outs(n, k, h, w):
 
 @pytest.mark.parametrize('n,k,h,w', [(2, 1, 64, 96), (1, 2, 40, 72), (2, 4, 64, 64), (1, 3, 32, 32), (1, 4, 1024, 1024), (1, 4, 36, 100),
                                      (1, 6, 64, 64), (3, 1, 8, 8), (1, 2, 4, 4)])
-def test_front4_float_is_bit_identical_to_front2(n, k, h, w):
+def test_front4_float_matches_front2(n, k, h, w):
     """csrc/front4.hip (one wave per 4 x 16 strip, no workgroup barrier) against front_kernel<true>; k > 4 (which
     front_kernel<true> does not take) against the layer-by-layer plan instead."""
     pm, blob, blob_l2 = _weights(seed=k)
@@ -49,7 +55,7 @@ def test_front4_float_is_bit_identical_to_front2(n, k, h, w):
             ref[3][:, i] = r1[3][:, 0]
             fm_sum += r1[0]
         torch.cuda.synchronize()
-        assert torch.equal(ref[3], got[3])
+        assert close(got[3], ref[3])
         assert not torch.isnan(got[0]).any() and not torch.isnan(got[1]).any() and not torch.isnan(got[2]).any()
         mean_ref = fm_sum[..., 16:] / k                                   # mean of the observations' level-1 maps
         assert float((mean_ref - got[0][..., 16:]).abs().max()) <= 1e-5 * float(mean_ref.abs().max())
@@ -57,7 +63,8 @@ def test_front4_float_is_bit_identical_to_front2(n, k, h, w):
     torch.cuda.synchronize()
     for name, a, b in zip(('fm1', 'skip3', 'qtmp2', 'otmp2'), ref, got):
         assert not torch.isnan(b).any(), name
-        assert torch.equal(a, b), (name, float((a - b).abs().max()))
+        assert close(b, a), (name, float((a - b).abs().max()))
+        assert float((a - b).abs().max()) <= 2e-6 * float(a.abs().max())          # ... and no single texel is off by more than a few ulps
 
 
 @pytest.mark.parametrize('n,k,h,w', [(2, 1, 64, 96), (3, 4, 64, 64), (1, 2, 40, 72), (2, 4, 512, 512), (1, 7, 32, 64)])
@@ -83,8 +90,8 @@ def test_front4_u8_store_is_bit_identical_to_float_on_assembled_batch(n, k, h, w
 @pytest.mark.parametrize('n,k,h,w', [(2, 1, 64, 96), (1, 2, 40, 72), (1, 4, 64, 64), (1, 1, 1024, 1024), (1, 3, 36, 100)])
 def test_front4_train_keeps_the_same_maps_as_the_first_generation_train_kernel(n, k, h, w):
     """nlt_front4_forward_train: fm1 / skip3 / qtmp2 / otmp2 bit-identical to nlt_front4_forward, and the three maps kept for
-    the backward pass (obs1, qtmp1, otmp1) bit-identical to what nlt_front_forward_train keeps (same folded weights, same
-    MFMA sequences)."""
+    the backward pass (obs1, qtmp1, otmp1) equal to what nlt_front_forward_train keeps up to the bias re-association (same
+    folded weights, same MFMA sequences)."""
     pm, blob, blob_l2 = _weights(seed=k + 10)
     g = torch.Generator(device='cuda').manual_seed(n * 1000 + k * 100 + h)
     U = lambda *s: torch.rand(s, device='cuda', generator=g)
@@ -106,8 +113,8 @@ def test_front4_train_keeps_the_same_maps_as_the_first_generation_train_kernel(n
     assert not any(torch.isnan(t).any() for t in keep4)
     if ok_old:
         for name, a, b in zip(('obs1', 'qtmp1', 'otmp1'), (obs1, qtmp1, otmp1), keep4):
-            assert torch.equal(a, b), (name, float((a - b).abs().max()))
-        assert torch.equal(fm1, tr[0]) and torch.equal(skip3, tr[1])
+            assert close(b, a), (name, float((a - b).abs().max()))
+        assert close(tr[0], fm1) and torch.equal(skip3, tr[1])                          # (skip3: VALU in both, no bias chain)
 
 
 def test_front4_rejects_what_it_cannot_take():
@@ -139,7 +146,7 @@ def test_model_call_same_result_with_either_front_kernel():
         out = pm.call(db, 'test')
         torch.cuda.synchronize()
         res.append((out[0].clone(), out[3]['pred'].clone()))
-    assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1])
+    assert close(res[1][0], res[0][0], 1e-6) and close(res[1][1], res[0][1], 1e-6)
 
 
 def test_model_call_on_a_store_resident_batch_equals_the_eager_float_batch():

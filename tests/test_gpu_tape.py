@@ -82,7 +82,8 @@ def test_train_steps_with_and_without_the_tape_agree():
         losses = [float(trainvali.distributed_train_step(pm, batch, opt, 2)[0]) for _ in range(6)]
         res.append((losses, pm.flat_params.detach().clone(), pm.plan.tape_replays))
     (l0, p0, r0), (l1, p1, r1) = res
-    assert r0 >= 6 and r1 == 0                                         # forward + backward tapes from step 3 on
+    assert r0 >= 4 and r1 == 0                                         # forward + backward tapes from step 3 on (re-recorded once more when
+                                                                        # the fragment-buffer census retires the trial candidates' buffers)
     np.testing.assert_allclose(l0, l1, rtol=1e-4)
     assert float((p0 - p1).abs().max()) < 1e-4                        # float atomics in the warp scatter, carried through six Adam steps
 

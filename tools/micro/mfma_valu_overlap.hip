@@ -16,8 +16,13 @@ __global__ __launch_bounds__(512, 1) void body(float* out, int iters, float seed
   const int wave = threadIdx.x >> 6;
   f32x4 acc[4];
   for (int i = 0; i < 4; ++i) acc[i] = (f32x4){seed, seed, seed, seed};
-  float v[8];
-  for (int i = 0; i < 8; ++i) v[i] = seed + i;
+  // r05 (r04 review, item 8): the MFMA operands live in registers of their own (`mb`); the VALU chain owns `v`.  The r04 form fed
+  // v[m & 7] to the fp32 MFMA as its B operand while the interleaved v_fma_f32 wrote the same registers -- a RAW / WAR dependence
+  // between the two instruction streams, which is why its "interleaved" fp32 figure (1901) exceeded MFMA alone + VALU alone.
+  float v[8], mb[8];
+  for (int i = 0; i < 8; ++i) { v[i] = seed + i; mb[i] = seed - 0.5f * i; }
+#pragma unroll
+  for (int i = 0; i < 8; ++i) asm volatile("" : "+v"(mb[i]));            // opaque: stays in 8 distinct registers
   bf16x8 a, b;
   for (int i = 0; i < 8; ++i) { a[i] = (__bf16)(seed + i); b[i] = (__bf16)(seed - i); }
   const bool do_m = SPLITROLE == 0 || ((wave >> 2) & 1) == 0;
@@ -28,7 +33,7 @@ __global__ __launch_bounds__(512, 1) void body(float* out, int iters, float seed
 #pragma unroll
       for (int m = 0; m < (SPLITROLE ? 2 * NM : NM); ++m) {
         if (KIND == 0) acc[m & 3] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, acc[m & 3], 0, 0, 0);
-        else acc[m & 3] = __builtin_amdgcn_mfma_f32_16x16x4f32(seed, v[m & 7], acc[m & 3], 0, 0, 0);
+        else acc[m & 3] = __builtin_amdgcn_mfma_f32_16x16x4f32(seed, mb[m & 7], acc[m & 3], 0, 0, 0);
         if (SPLITROLE == 0 && NV > 0) {                                      // interleave: NV / NM VALU ops behind each MFMA
 #pragma unroll
           for (int q = 0; q < (NM ? NV / NM : 0); ++q) { const int r = (m * (NV / (NM ? NM : 1)) + q) & 7; asm volatile("v_fma_f32 %0, %0, %1, %0" : "+v"(v[r]) : "v"(seed)); }
@@ -43,7 +48,7 @@ __global__ __launch_bounds__(512, 1) void body(float* out, int iters, float seed
   }
   float s = 0.f;
   for (int i = 0; i < 4; ++i) s += acc[i][0] + acc[i][1] + acc[i][2] + acc[i][3];
-  for (int i = 0; i < 8; ++i) s += v[i];
+  for (int i = 0; i < 8; ++i) s += v[i] + mb[i];
   if (s == 12345.678f) out[threadIdx.x] = s;
 }
 
