@@ -61,36 +61,19 @@ __global__ __launch_bounds__(256) void back_bwd_kernel(
   accbh[0] = accbh[1] = accbh[2] = 0.f;
   f32x4 accw2[3] = {(f32x4){0.f, 0.f, 0.f, 0.f}, (f32x4){0.f, 0.f, 0.f, 0.f}, (f32x4){0.f, 0.f, 0.f, 0.f}};
 
-  // ---- r05: the loads of a tile are issued one tile AHEAD.  (r02_c moved every global load of a tile in front of its first
-  // barrier: 0.28 -> 0.17 ms; what remained is that nothing was in flight during phases 2 and 3 -- 63 KB per tile requested in
-  // one burst, then three phases of LDS / MFMA work with an idle memory pipe, 3.2 TB/s.)  Group A = (v, dpred, u with its halo),
-  // consumed by phase 1, is requested for the NEXT tile right behind phase 1's barrier; group B = (x | fm1), consumed by phase
-  // 3, right behind phase 3.  Same registers (each group is dead when its successor is requested), same arithmetic.
-  // Group B carries no select: lane constant base pointers pick x or fm1 by channel, texels beyond the image read texel 0 and
-  // meet du = 0 in the A operand; columns >= 40 of the 48 are never stored.
-  f32x4 pv[3], pu[3];
-  float pg[3][3];
-  bool in_v[3], in_u[3];
-  float pb[8][3];                                                      // phase 3a's B operands (x | fm1 channels 16 mt + j of texel (gi, kk))
-  f32x4 pxv[2];                                                        // phase 3b: x at channels 4 kk (kk < 2) of texel (ty0 + wave + 4 r, tx0 + j)
-  const int na = j >> 3, nb = (j >> 2) & 1, no = j & 3;
-  const float* pb_base[3];
-  int pb_ld[3];
-#pragma unroll
-  for (int mt = 0; mt < 3; ++mt) {
-    const int c = 16 * mt + j;
-    pb_base[mt] = c < 8 ? x + c : (c < 40 ? fm1 + (c - 8) : x);
-    pb_ld[mt] = (c >= 8 && c < 40) ? 32 : 8;
-  }
-  auto geom = [&](long t, int& tx0, int& ty0, int& f) {
-    tx0 = (int)(t % tiles_x) * BTW;
-    const long tr = t / tiles_x;
-    ty0 = (int)(tr % tiles_y) * BTH; f = (int)(tr / tiles_y);
-  };
-  auto load_a = [&](long t) {
-    int tx0, ty0, f;
-    geom(t, tx0, ty0, f);
+  for (long tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
+    const int tx0 = (int)(tile % tiles_x) * BTW;
+    const long tr = tile / tiles_x;
+    const int ty0 = (int)(tr % tiles_y) * BTH, f = (int)(tr / tiles_y);
     const int Y0 = 2 * ty0, X0 = 2 * tx0;
+
+    // ---- every global load of the tile is issued HERE, before the first barrier: the three phases used to fetch their own
+    // operands one after the other, and with two workgroups per CU the kernel spent 74 % of its wave-cycles waiting for
+    // memory (PMC: SQ_WAIT_ANY) at 2 TB/s.  (v, dpred) -> phase 1; the u tile with its top / left halo -> LDS -> phase 2 and
+    // the dW_s1 MFMAs; x | fm1 -> phase 3.
+    f32x4 pv[3], pu[3];
+    float pg[3][3];
+    bool in_v[3], in_u[3];
 #pragma unroll
     for (int it = 0; it < 3; ++it) {
       const int e = threadIdx.x + 256 * it;
@@ -106,11 +89,8 @@ __global__ __launch_bounds__(256) void back_bwd_kernel(
       const long texu = in_u[it] ? ((long)f * h + yu) * w + xu : 0;
       pu[it] = *reinterpret_cast<const f32x4*>(u + texu * 4);
     }
-  };
-  auto load_b = [&](long t, bool first) {                              // first: the 24 phase-3a operands; else phase 3b's two
-    int tx0, ty0, f;
-    geom(t, tx0, ty0, f);
-    if (first) {
+    float pb[8][3];                                                    // phase 3a's B operands (x | fm1 channels 16 mt + j of texel (gi, kk))
+    const int na = j >> 3, nb = (j >> 2) & 1, no = j & 3;
 #pragma unroll
     for (int g8 = 0; g8 < 8; ++g8) {
       const int gi = wave + 4 * g8;
@@ -119,10 +99,14 @@ __global__ __launch_bounds__(256) void back_bwd_kernel(
       const bool inside = gy < h2 && gx < w2;
       const long tex2 = inside ? ((long)f * h2 + gy) * w2 + gx : 0;
 #pragma unroll
-      for (int mt = 0; mt < 3; ++mt) pb[g8][mt] = pb_base[mt][tex2 * pb_ld[mt]];
+      for (int mt = 0; mt < 3; ++mt) {
+        const int c = 16 * mt + j;
+        const float vx = x[tex2 * 8 + (c < 8 ? c : 0)];
+        const float vf = fm1[tex2 * 32 + ((c >= 8 && c < 40) ? c - 8 : 0)];
+        pb[g8][mt] = !inside ? 0.f : (c < 8 ? vx : (c < 40 ? vf : 0.f));
+      }
     }
-      return;
-    }
+    f32x4 pxv[2];                                                      // phase 3b: x at channels 4 kk (kk < 2) of texel (ty0 + wave + 4 r, tx0 + j)
 #pragma unroll
     for (int r = 0; r < 2; ++r) {
       const int gy = ty0 + wave + 4 * r, gx = tx0 + j;
@@ -130,14 +114,6 @@ __global__ __launch_bounds__(256) void back_bwd_kernel(
       const long tex2 = inside ? ((long)f * h2 + gy) * w2 + gx : 0;
       pxv[r] = *reinterpret_cast<const f32x4*>(x + tex2 * 8 + (kk < 2 ? 4 * kk : 0));
     }
-  };
-  if ((long)blockIdx.x < tiles) { load_a(blockIdx.x); load_b(blockIdx.x, true); load_b(blockIdx.x, false); }
-
-  for (long tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
-    int tx0, ty0, f;
-    geom(tile, tx0, ty0, f);
-    const int Y0 = 2 * ty0, X0 = 2 * tx0;
-    const long next = tile + gridDim.x;
 
     // ---- phase 1
 #pragma unroll
@@ -170,7 +146,6 @@ __global__ __launch_bounds__(256) void back_bwd_kernel(
       *reinterpret_cast<f32x4*>(utile + e * 4) = in_u[it] ? pu[it] : (f32x4){0.f, 0.f, 0.f, 0.f};
     }
     __syncthreads();
-    if (next < tiles) load_a(next);                                    // in flight under phases 2 and 3
 
     // ---- phase 2
 #pragma unroll
@@ -223,7 +198,6 @@ __global__ __launch_bounds__(256) void back_bwd_kernel(
 #pragma unroll
       for (int mt = 0; mt < 3; ++mt) accw2[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, pb[g8][mt], accw2[mt], 0, 0, 0);
     }
-    if (next < tiles) load_b(next, true);                              // (ahead of phase 3b's stores: a wait behind a store drains everything)
     // ---- phase 3b: d_in = W_s2^T du, 16 texels (one tile row) per MFMA column block
     for (int ii = wave; ii < BTH; ii += 4) {
       const int gy = ty0 + ii, gx = tx0 + j;
@@ -248,7 +222,6 @@ __global__ __launch_bounds__(256) void back_bwd_kernel(
         }
       }
     }
-    if (next < tiles) load_b(next, false);
     __syncthreads();
   }
 

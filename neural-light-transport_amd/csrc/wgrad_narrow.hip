@@ -564,6 +564,234 @@ int dispatch(WN& w, int mt, int nt, hipStream_t s) {
   return NLT_ERR_UNSUPPORTED;
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// r05: the stride-1 k2 layers with 16 / 32 channels in and out (levels 1 and 2 of both paths, the 16- and 32-channel expanding
+// blocks: the five weight gradients that stream 134 MB each) as an LDS-TILED kernel.  The walking kernel above forms the four
+// tap-shifted A operands with four overlapping global reads per texel (L1 / L2 traffic 4x the unique bytes, B from 64-byte
+// halves of 128-byte lines): 72-84 us per launch against a 27 us HBM floor.  Here a workgroup stages a 4 x 64 (32 channels: 4 x 32)
+// texel tile of dP and the haloed (+1 row, +1 column) tile of X in LDS ONCE (16-byte coalesced loads, every HBM byte read 1.0x / 1.27x), the next tile's loads
+// are in flight in registers while the current tile's MFMAs read their operands from LDS, and the weight-gradient block stays in
+// registers across the workgroup's tiles.  Wave r owns tile row r; per 4-texel step and tap: A[cin][texel] = X(y + a, x + b)
+// (transposed family: X(y - a, x - b)), B[texel][cout] = dP(y, x); rows of D = cin, columns = cout.  Same [K][N] workspace
+// block per workgroup, same fixed-order reduce pass (wgrad_narrow_reduce_kernel) as the kernels above: deterministic.
+// 32 channels: texel pitch 32 floats would put lanes kk and kk + 1 of a ds_read_b32 on the same banks, so odd texels store
+// their channel halves swapped (c ^ 16).
+constexpr int S1_TH = 4, S1_XR = S1_TH + 1;
+
+template <int C> struct S1T {
+  static constexpr int TW = C == 16 ? 64 : 32;                          // tile width: 10 float4 of prefetch per thread either way
+  static constexpr int XW = TW + 1;                                     // (32 channels x 64 texels: 241 registers, one wave per SIMD)
+  static constexpr int Q = C / 4;                                       // float4 per texel
+  static constexpr int NX = (S1_XR * XW * Q + 255) / 256;               // X-tile float4 per thread: 6
+  static constexpr int ND = S1_TH * TW * Q / 256;                       // dP-tile float4 per thread: 4
+  static constexpr int XF = S1_XR * XW * C, DF = S1_TH * TW * C;        // floats: 37 KB of LDS per workgroup
+  static constexpr int T = C / 16;                                      // 16-row / 16-column MFMA tiles
+};
+
+template <int MODE, int C>
+__global__ __launch_bounds__(256) void wgrad_s1t_kernel(WN w, int tiles_x, int tiles_y, int ntiles) {
+  using TT = S1T<C>;
+  constexpr int Q = TT::Q, NX = TT::NX, ND = TT::ND, T = TT::T, S1_TW = TT::TW, S1_XW = TT::XW;
+  constexpr int NC = C, KN = 4 * C * NC, PER = KN + NC;
+  extern __shared__ __attribute__((aligned(16))) float s1_lds[];
+  float* const xs = s1_lds;
+  float* const ds = s1_lds + TT::XF;
+  const ConvP& p = w.c;
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int i = lane & 15, kk = lane >> 4;
+  constexpr int OFF = MODE == NLT_DECONV_K2S1 ? -1 : 0;                 // tile origin of X relative to the dP tile
+  const f32x4 zero4 = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  // ---- per-thread staging geometry (tile independent): float4 q -> (row, column, channel quad)
+  int xr[NX], xc[NX], xg[NX], xl[NX];
+#pragma unroll
+  for (int it = 0; it < NX; ++it) {
+    const int q = tid + 256 * it;
+    const bool live = q < S1_XR * S1_XW * Q;
+    const int tex = live ? q / Q : 0, cq = q - tex * Q;
+    xr[it] = live ? tex / S1_XW : -4096;                               // (a dead slot never passes the bounds test)
+    xc[it] = tex - (live ? tex / S1_XW : 0) * S1_XW;
+    xg[it] = (xr[it] * p.w + xc[it]) * p.ld0 + 4 * cq;
+    const int c0 = 4 * cq;
+    xl[it] = tex * C + (C == 32 ? (c0 ^ ((tex & 1) << 4)) : c0);
+  }
+  int dr[ND], dc[ND], dg[ND], dl[ND];
+#pragma unroll
+  for (int it = 0; it < ND; ++it) {
+    const int q = tid + 256 * it;
+    const int tex = q / Q, cq = q - tex * Q;
+    dr[it] = tex / S1_TW; dc[it] = tex - dr[it] * S1_TW;
+    dg[it] = (dr[it] * p.w + dc[it]) * w.ldp + 4 * cq;
+    const int c0 = 4 * cq;
+    dl[it] = tex * C + (C == 32 ? (c0 ^ ((tex & 1) << 4)) : c0);
+  }
+  f32x4 px[NX], pd[ND];
+  auto request = [&](int tile) {
+    const int tx = tile % tiles_x, r2 = tile / tiles_x;
+    const int ty = r2 % tiles_y, f = r2 / tiles_y;
+    const int y0 = ty * S1_TH, x0 = tx * S1_TW;
+    const long xbase = ((long)(f * p.h + y0 + OFF) * p.w + x0 + OFF) * p.ld0;
+    const long dbase = ((long)(f * p.h + y0) * p.w + x0) * w.ldp;
+#pragma unroll
+    for (int it = 0; it < NX; ++it) {
+      const int gy = y0 + OFF + xr[it], gx = x0 + OFF + xc[it];
+      const bool ok = (unsigned)gy < (unsigned)p.h && (unsigned)gx < (unsigned)p.w;
+      const f32x4 v = *reinterpret_cast<const f32x4*>(p.src0 + (ok ? xbase + xg[it] : 0));
+      px[it] = ok ? v : zero4;
+    }
+#pragma unroll
+    for (int it = 0; it < ND; ++it) {
+      const bool ok = y0 + dr[it] < p.h && x0 + dc[it] < p.w;
+      const f32x4 v = *reinterpret_cast<const f32x4*>(w.dp + (ok ? dbase + dg[it] : 0));
+      pd[it] = ok ? v : zero4;
+    }
+  };
+
+  f32x4 acc[4][T][T];
+#pragma unroll
+  for (int t = 0; t < 4; ++t)
+#pragma unroll
+    for (int mt = 0; mt < T; ++mt)
+#pragma unroll
+      for (int nt = 0; nt < T; ++nt) acc[t][mt][nt] = zero4;
+  f32x4 bsum = zero4;                                                   // column sums of dP: this thread's channel quad (tid % Q)
+
+  // LDS read offsets of this lane (texel = step * 4 + kk of row wv)
+  int a_off[4], sw_a[T], sw_b[T];
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    const int a = t >> 1, b = t & 1;
+    const int ry = MODE == NLT_DECONV_K2S1 ? wv + 1 - a : wv + a, cx = MODE == NLT_DECONV_K2S1 ? kk + 1 - b : kk + b;
+    a_off[t] = ry * S1_XW + cx;                                        // texel index inside the X tile at step 0
+  }
+  const int b_tex = wv * S1_TW + kk;
+
+  int tile = blockIdx.x;
+  if (tile < ntiles) request(tile);
+  for (; tile < ntiles; tile += gridDim.x) {
+    // ---- registers -> LDS
+#pragma unroll
+    for (int it = 0; it < NX; ++it)
+      if (xr[it] >= 0) *reinterpret_cast<f32x4*>(xs + xl[it]) = px[it];
+#pragma unroll
+    for (int it = 0; it < ND; ++it) {
+      *reinterpret_cast<f32x4*>(ds + dl[it]) = pd[it];
+      bsum += pd[it];
+    }
+    __syncthreads();
+    const int next = tile + gridDim.x;
+    if (next < ntiles) request(next);                                  // in flight under this tile's MFMAs
+    // ---- 16 steps of 4 texels
+#pragma unroll 4
+    for (int st = 0; st < S1_TW / 4; ++st) {
+      float bv[T];
+      const int bt = b_tex + 4 * st;
+#pragma unroll
+      for (int nt = 0; nt < T; ++nt) {
+        const int c = 16 * nt + i;
+        bv[nt] = ds[bt * C + (C == 32 ? (c ^ ((bt & 1) << 4)) : c)];
+      }
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const int at = a_off[t] + 4 * st;
+#pragma unroll
+        for (int mt = 0; mt < T; ++mt) {
+          const int c = 16 * mt + i;
+          const float av = xs[at * C + (C == 32 ? (c ^ ((at & 1) << 4)) : c)];
+#pragma unroll
+          for (int nt = 0; nt < T; ++nt) acc[t][mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv[nt], acc[t][mt][nt], 0, 0, 0);
+        }
+      }
+    }
+    __syncthreads();                                                   // the tile is consumed: LDS may be overwritten
+  }
+  (void)sw_a; (void)sw_b;
+
+  // ---- the four waves' blocks, added in wave order (fixed -> deterministic), then the workgroup's block to the workspace
+  float* const xch = s1_lds;                                           // [K][NC] + column sums
+  for (int src = 1; src < 4; ++src) {
+    if (wv == src) {
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int mt = 0; mt < T; ++mt)
+#pragma unroll
+          for (int nt = 0; nt < T; ++nt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) xch[(t * C + 16 * mt + 4 * kk + r) * NC + 16 * nt + i] = acc[t][mt][nt][r];
+    }
+    __syncthreads();
+    if (wv == 0) {
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int mt = 0; mt < T; ++mt)
+#pragma unroll
+          for (int nt = 0; nt < T; ++nt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[t][mt][nt][r] += xch[(t * C + 16 * mt + 4 * kk + r) * NC + 16 * nt + i];
+    }
+    __syncthreads();
+  }
+  float* dst = w.ws + (size_t)blockIdx.x * PER;
+  if (wv == 0) {
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+      for (int mt = 0; mt < T; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < T; ++nt)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) dst[(t * C + 16 * mt + 4 * kk + r) * NC + 16 * nt + i] = acc[t][mt][nt][r];
+  }
+  // column sums: thread t holds the sums of channel quad t % Q over its texels; added over the 256 / Q threads of a quad in thread order
+  *reinterpret_cast<f32x4*>(xch + KN + 4 * tid) = bsum;                 // (K * NC <= the X tile: room for 1024 floats behind it)
+  __syncthreads();
+  if (tid < C) {
+    const int quad = tid >> 2, e = tid & 3;
+    float s = 0.f;
+    for (int t = quad; t < 256; t += Q) s += xch[KN + 4 * t + e];
+    dst[KN + tid] = s;
+  }
+}
+
+// which launches the LDS-tiled form takes, and with how many (persistent) workgroups = slices of the reduce pass
+inline bool s1t_ok(int mode, int c0, int c1, int ld0, int ldp, int cout, int h, int wd, const float* src0, const float* dpre) {
+  const char* e = getenv("NLT_WGRAD_S1T");                              // (read per call: A/B runs and the parity test flip it in-process)
+  if ((e && e[0] == '0') || nlt_wgrad_generic_only()) return false;
+  if (mode != NLT_CONV_K2S1 && mode != NLT_DECONV_K2S1) return false;
+  if (c1 != 0 || c0 != cout || (cout != 16 && cout != 32)) return false;
+  if ((ld0 & 3) || (ldp & 3) || h < S1_TH || wd < 8) return false;
+  if (src0 && (!nlt_aligned16(src0) || !nlt_aligned16(dpre))) return false;
+  return true;
+}
+
+inline int s1t_blocks(int n, int h, int wd, int cout) {
+  const int tw = cout == 16 ? S1T<16>::TW : S1T<32>::TW;
+  const long tiles = (long)n * ((h + S1_TH - 1) / S1_TH) * ((wd + tw - 1) / tw);
+  const long cap = cout == 16 ? 768 : 512;                            // what is resident at once: 3 / 2 workgroups per CU (148 / 216 registers)
+  return (int)(tiles < cap ? tiles : cap);
+}
+
+template <int MODE, int C>
+int run_s1t(WN& w, hipStream_t s) {
+  using TT = S1T<C>;
+  constexpr int MT = 4 * C / 16, NT = C / 16;
+  const int ty = (w.c.h + S1_TH - 1) / S1_TH, tx = (w.c.w + TT::TW - 1) / TT::TW;
+  const int ntiles = w.c.n * ty * tx;
+  const size_t lds = (size_t)(TT::XF + TT::DF) * sizeof(float);
+  static bool attr = [] {
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_s1t_kernel<MODE, C>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                               (int)((TT::XF + TT::DF) * sizeof(float))) == hipSuccess;
+  }();
+  if (!attr) return NLT_ERR_LAUNCH;
+  hipLaunchKernelGGL((wgrad_s1t_kernel<MODE, C>), dim3((unsigned)w.msplits), dim3(256), lds, s, w, tx, ty, ntiles);
+  hipLaunchKernelGGL((wgrad_narrow_reduce_kernel<MODE, MT, NT>), dim3((MT * 16 * NT * 16 + NT * 16 + 31) / 32), dim3(256), 0, s, w);
+  NLT_CHECK_LAUNCH();
+  return NLT_OK;
+}
+
 int tiles_m(int K) { return K <= 32 ? 2 : (K <= 64 ? 4 : 8); }
 
 int prepare_narrow(WN& w, int mode, const float* src0, int ld0, int c0, const float* src1, int ld1, int c1, int n, int h, int wd,
@@ -589,8 +817,14 @@ int prepare_narrow(WN& w, int mode, const float* src0, int ld0, int c0, const fl
   rows = (rows + unit - 1) / unit * unit;
   w.msplits = (int)((w.c.M + rows - 1) / rows);
   w.rows_per_split = (int)rows;
+  long slices = w.msplits;
+  if (s1t_ok(mode, c0, c1, ld0, ldp, cout, h, wd, src0, dpre)) {          // LDS-tiled form: one slice per persistent workgroup
+    w.msplits = s1t_blocks(n, h, wd, cout);
+    w.rows_per_split = 0;
+    if (w.msplits > slices || src0) slices = w.msplits;                  // (the size query has no pointers to check: room for either form)
+  }
   const int mt = w.K <= 64 ? 4 : 8, nt = w.N <= 16 ? 1 : 2;               // (the quad-A form pads K to 64 / 128)
-  *ws_floats = ((long)w.msplits + 1) * (mt * 16 * nt * 16 + nt * 16);
+  *ws_floats = (slices + 1) * (mt * 16 * nt * 16 + nt * 16);
   return NLT_OK;
 }
 
@@ -618,6 +852,10 @@ extern "C" int nlt_conv_backward_weights_narrow(int mode,
   if (workspace_floats < need || !nlt_aligned16(workspace)) return NLT_ERR_BAD_ARG;
   t.ws = workspace;
   hipStream_t s = static_cast<hipStream_t>(stream);
+  if (t.rows_per_split == 0) {                                          // (prepare_narrow chose the LDS-tiled form)
+    if (mode == NLT_CONV_K2S1) return cout == 16 ? run_s1t<NLT_CONV_K2S1, 16>(t, s) : run_s1t<NLT_CONV_K2S1, 32>(t, s);
+    return cout == 16 ? run_s1t<NLT_DECONV_K2S1, 16>(t, s) : run_s1t<NLT_DECONV_K2S1, 32>(t, s);
+  }
   const int mt = tiles_m(t.K), nt = t.N <= 16 ? 1 : 2;
   const bool quads = !(c0 & 3) && !(c1 & 3) && !(ld0 & 3) && (c1 == 0 || !(ld1 & 3)) && nlt_aligned16(src0) &&
                      (c1 == 0 || nlt_aligned16(src1));

@@ -65,7 +65,8 @@ def test_wgrad_mfma_shapes(mode, c0, c1, cout, algo):
 
 NARROW = [(C.CONV_K2S1, 16, 0, 16), (C.CONV_K2S1, 32, 0, 32), (C.CONV_K2S2, 32, 0, 32), (C.CONV_K2S2, 16, 0, 32),
           (C.CONV_K2S2, 32, 0, 16), (C.DECONV_K2S1, 8, 0, 8), (C.DECONV_K2S1, 16, 0, 16), (C.DECONV_K2S1, 4, 0, 4),
-          (C.DECONV_K2S2, 16, 64, 8), (C.DECONV_K2S2, 8, 32, 4), (C.CONV_K2S1, 5, 0, 7), (C.CONV_K2S2, 3, 6, 12)]
+          (C.DECONV_K2S2, 16, 64, 8), (C.DECONV_K2S2, 8, 32, 4), (C.CONV_K2S1, 5, 0, 7), (C.CONV_K2S2, 3, 6, 12),
+          (C.DECONV_K2S1, 32, 0, 32)]
 
 
 @pytest.mark.parametrize('mode,c0,c1,cout', NARROW)
@@ -73,6 +74,26 @@ def test_wgrad_narrow_layers(mode, c0, c1, cout):
     """csrc/wgrad_narrow.hip: the released net's 8/16/32-column layers (+ odd channel counts), ragged leading dims."""
     wgrad_case(mode, 2, 12, 20, c0, c1, cout, 'narrow', pad0=4, pad1=8 if c1 else 0, padp=4, seed=60 + cout)
     wgrad_case(mode, 1, 8, 8, c0, c1, cout, 'narrow', seed=61)               # a single partial step per wave
+
+
+@pytest.mark.parametrize('mode', [C.CONV_K2S1, C.DECONV_K2S1])
+@pytest.mark.parametrize('c', [16, 32])
+def test_wgrad_lds_tiled_stride1_layers(mode, c, monkeypatch):
+    """r05, wgrad_s1t_kernel (the 16 / 32-channel stride-1 layers through LDS tiles): many tiles per persistent workgroup, widths
+    that are not a multiple of the tile, heights that are not a multiple of 4, dP as a channel slice of a wider map (the
+    interleaved [query | observation-mean] gradient), and agreement with the row-walking kernel it replaces."""
+    wgrad_case(mode, 3, 38, 200, c, 0, c, 'narrow', padp=c, seed=70 + c)            # dP leading dimension 2c, 3 x 10 x 4|7 tiles
+    wgrad_case(mode, 2, 5, 9, c, 0, c, 'narrow', pad0=4, seed=71)                    # one clipped tile, ragged X rows
+    x = torch.randn(5, 260, 132, c, device='cuda'); dp = torch.randn(5, 260, 132, 2 * c, device='cuda')   # > 768 tiles
+    res = []
+    for form in ('1', '0'):
+        dw = torch.zeros((2, 2, c, c), device='cuda'); db = torch.zeros(c, device='cuda')
+        monkeypatch.setenv('NLT_WGRAD_S1T', form)                                # '0': the row-walking kernel
+        C.conv_backward_weights_narrow(mode, x, c, c, None, 0, 0, 5, 260, 132, dp, 2 * c, c, dw, db)
+        res.append((dw.cpu().numpy(), db.cpu().numpy()))
+    scale = np.abs(res[1][0]).max()
+    np.testing.assert_allclose(res[0][0], res[1][0], atol=2e-5 * scale)
+    np.testing.assert_allclose(res[0][1], res[1][1], atol=2e-5 * np.abs(res[1][1]).max())
 
 
 def test_wgrad_narrow_many_row_slices_is_deterministic_accumulates_and_rejects_wide_layers():

@@ -19,6 +19,8 @@ dev = torch.device('cuda')
 pm = get_model_class('nlt')(nlt_amd.make_config(depth=depth, uvh=uv, uvw=uv, imh=cam, imw=cam)).build(dev)
 pm.register_trainable()
 pm.use_graphs = graph
+if os.environ.get('ONE_STREAM') == '1':
+    pm.plan.two_streams = False
 batches = [bench.synth_device_batch(n, uv, cam, k, dev, seed=i) for i in range(3)]
 if cam == uv:                                                    # relight only: identity warp
     jj, ii = torch.meshgrid(torch.arange(cam, device=dev), torch.arange(cam, device=dev), indexing='xy')
