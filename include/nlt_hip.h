@@ -679,6 +679,15 @@ int nlt_back_backward(const float* x, const float* fm1, const float* u, const fl
                       int n, int h2, int w2, const float* w_s2, const float* w_s1, const float* w_head,
                       float alpha, float* dx, float* dfm1, float* dw_s2, float* db_s2, float* dw_s1,
                       float* db_s1, float* dw_head, float* db_head, float* workspace, void* stream);
+/* The same pass in two launches (r05): parts = 1 -> dx and dfm1 only (the backward-data chain, nlt/trainvali.py:279, continues
+ * behind it; the weight-gradient pointers and the workspace may be NULL), parts = 2 -> the weight / bias gradient sums only (dx /
+ * dfm1 may be NULL; meant for the weight-gradient stream), parts = 3 -> nlt_back_backward.  Both halves recompute the two
+ * intermediate gradients from (v, dpred, u); the results are those of the one-launch form up to fp32 re-association (<= 1e-6).
+ * Measured slower inside the train step than the one-launch form (the second launch competes with the chain): opt-in. */
+int nlt_back_backward_parts(const float* x, const float* fm1, const float* u, const float* v, const float* dpred,
+                            int n, int h2, int w2, const float* w_s2, const float* w_s1, const float* w_head,
+                            float alpha, float* dx, float* dfm1, float* dw_s2, float* db_s2, float* dw_s1,
+                            float* db_s1, float* dw_head, float* db_head, float* workspace, int parts, void* stream);
 
 /* nlt_conv_forward on the MFMA path with the K loop split into `ksplit` slices run by different waves (for
  * the deep levels: a few hundred texels x thousands of input channels would otherwise occupy a fraction of the

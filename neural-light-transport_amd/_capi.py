@@ -102,6 +102,7 @@ SIGNATURES = {
     'nlt_front_backward': (_c_int, [_vp] * 5 + [_c_int] * 4 + [_vp] * 21),
     'nlt_back_backward_workspace_floats': (_c_long, [_c_int] * 3),
     'nlt_back_backward': (_c_int, [_vp] * 5 + [_c_int] * 3 + [_vp] * 3 + [_c_float] + [_vp] * 10),
+    'nlt_back_backward_parts': (_c_int, [_vp] * 5 + [_c_int] * 3 + [_vp] * 3 + [_c_float] + [_vp] * 9 + [_c_int, _vp]),
     'nlt_conv_splitk_workspace_floats': (_c_long, [_c_int] * 6),
     'nlt_conv_forward_splitk': (_c_int, [_c_int, _c_int, _c_int, _vp, _vp, _c_int, _c_int, _vp, _c_int, _c_int,
                                          _c_int, _c_int, _c_int, _vp, _vp, _c_int, _vp, _c_int, _c_int, _c_float,
@@ -1211,6 +1212,23 @@ def back_backward(x, fm1, u, v, dpred, n, h2, w2, w_s2, w_s1, w_head, alpha, dx,
     wts = [_ptr(_dense(t, 'weight')) for t in (w_s2, w_s1, w_head)]
     outs = [_ptr(_dense(t, 'grad')) for t in (dx, dfm1, dw_s2, db_s2, dw_s1, db_s1, dw_head, db_head)]
     _check(lib().nlt_back_backward(*ins, n, h2, w2, *wts, float(alpha), *outs, _ptr(ws), _stream()), 'nlt_back_backward')
+
+
+def back_backward_parts(parts, x, fm1, u, v, dpred, n, h2, w2, w_s2, w_s1, w_head, alpha, dx, dfm1, dw_s2, db_s2, dw_s1, db_s1,
+                        dw_head, db_head):
+    """`back_backward` as two launches: parts = 1 writes dx / dfm1 (the chain continues behind it), parts = 2 accumulates the
+    weight / bias gradients (for the weight-gradient stream: its workspace is per stream)."""
+    ws = None
+    if parts & 2:
+        need = lib().nlt_back_backward_workspace_floats(n, h2, w2)
+        if need <= 0:
+            raise NLTError("nlt_back_backward_workspace_floats(%d,%d,%d) failed" % (n, h2, w2))
+        ws = _workspace('back_bwd.%d' % _stream(), x.device, need)
+    ins = [_ptr(_dense(t, nm)) for t, nm in ((x, 'x'), (fm1, 'fm1'), (u, 'u'), (v, 'v'), (dpred, 'dpred'))]
+    wts = [_ptr(_dense(t, 'weight')) for t in (w_s2, w_s1, w_head)]
+    outs = [_ptr(_dense(t, 'grad')) if t is not None else None for t in (dx, dfm1, dw_s2, db_s2, dw_s1, db_s1, dw_head, db_head)]
+    _check(lib().nlt_back_backward_parts(*ins, n, h2, w2, *wts, float(alpha), *outs, _ptr(ws), int(parts), _stream()),
+           'nlt_back_backward_parts')
 
 
 # ---------------------------------------------------------------- texel-buffer assembly

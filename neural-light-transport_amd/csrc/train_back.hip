@@ -27,6 +27,12 @@ __device__ __forceinline__ float wave_sum(float v) {
   return v;
 }
 
+// PARTS (r05): 3 = everything (one launch, the r01-r04 form); 1 = backward-DATA only (dx, dfm1: what the backward chain waits
+// for); 2 = the weight / bias gradient sums only.  Split, the chain's launch drops the 24 x | fm1 operand loads, every
+// accumulator and the workspace hand-off (fewer registers: three workgroups per CU instead of two), and the sums run beside
+// the next backward-data launches on the weight-gradient stream; both halves recompute dv and du from (v, dpred, u), the
+// cheap part.
+template <int PARTS>
 __global__ __launch_bounds__(256) void back_bwd_kernel(
     const float* __restrict__ x, const float* __restrict__ fm1, const float* __restrict__ u, const float* __restrict__ v,
     const float* __restrict__ dpred, int h2, int w2, int tiles_y, int tiles_x, long tiles,
@@ -40,13 +46,14 @@ __global__ __launch_bounds__(256) void back_bwd_kernel(
   const int kk = lane >> 4, j = lane & 15;
   const int h = 2 * h2, w = 2 * w2;
 
+  constexpr bool DG = (PARTS & 1) != 0, WG = (PARTS & 2) != 0;
   float wa[3][4];                                                      // dgrad A operands: W_s2[n = 4 kk + ks][c = 16 mt + j]
 #pragma unroll
   for (int mt = 0; mt < 3; ++mt)
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
       const int c = 16 * mt + j;
-      wa[mt][ks] = c < 40 ? w_s2[(4 * kk + ks) * 40 + c] : 0.f;
+      wa[mt][ks] = (DG && c < 40) ? w_s2[(4 * kk + ks) * 40 + c] : 0.f;
     }
   float wh[12];
 #pragma unroll
@@ -91,6 +98,7 @@ __global__ __launch_bounds__(256) void back_bwd_kernel(
     }
     float pb[8][3];                                                    // phase 3a's B operands (x | fm1 channels 16 mt + j of texel (gi, kk))
     const int na = j >> 3, nb = (j >> 2) & 1, no = j & 3;
+    if constexpr (WG) {
 #pragma unroll
     for (int g8 = 0; g8 < 8; ++g8) {
       const int gi = wave + 4 * g8;
@@ -106,13 +114,16 @@ __global__ __launch_bounds__(256) void back_bwd_kernel(
         pb[g8][mt] = !inside ? 0.f : (c < 8 ? vx : (c < 40 ? vf : 0.f));
       }
     }
+    }
     f32x4 pxv[2];                                                      // phase 3b: x at channels 4 kk (kk < 2) of texel (ty0 + wave + 4 r, tx0 + j)
+    if constexpr (DG) {
 #pragma unroll
     for (int r = 0; r < 2; ++r) {
       const int gy = ty0 + wave + 4 * r, gx = tx0 + j;
       const bool inside = gy < h2 && gx < w2 && kk < 2;
       const long tex2 = inside ? ((long)f * h2 + gy) * w2 + gx : 0;
       pxv[r] = *reinterpret_cast<const f32x4*>(x + tex2 * 8 + (kk < 2 ? 4 * kk : 0));
+    }
     }
 
     // ---- phase 1
@@ -132,7 +143,7 @@ __global__ __launch_bounds__(256) void back_bwd_kernel(
           const float dl = wh[o * 3] * g[0] + wh[o * 3 + 1] * g[1] + wh[o * 3 + 2] * g[2];
           d[o] = vv[o] > 0.f ? dl : alpha * dl;
         }
-        if (ly < BFH && lx < BFW) {
+        if (WG && ly < BFH && lx < BFW) {
 #pragma unroll
           for (int c = 0; c < 4; ++c) {
 #pragma unroll
@@ -169,14 +180,14 @@ __global__ __launch_bounds__(256) void back_bwd_kernel(
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
           dp[c] = u0[c] > 0.f ? du[c] : alpha * du[c];
-          accb2[c] += dp[c];
+          if (WG) accb2[c] += dp[c];
         }
       }
       *reinterpret_cast<f32x4*>(dup + e * 4) = dp;
     }
     // dW_s1[t][o][c] += sum_texels u(y - a, x - b)[c] dv(y, x)[o]: rows (t, c) = lane & 15, columns o = lane & 15 (< 4), K = 4
     // texels per MFMA; the wave takes a quarter of the tile (dv is zero outside the image, so clipped tiles need no mask)
-    {
+    if constexpr (WG) {
       const int ta = (j >> 3) & 1, tb = (j >> 2) & 1, cc = j & 3;
 #pragma unroll 4
       for (int m = 0; m < 32; ++m) {
@@ -190,6 +201,7 @@ __global__ __launch_bounds__(256) void back_bwd_kernel(
     __syncthreads();
 
     // ---- phase 3a: dW_s2^T, rows n = (a, b, o), columns c, K = half-resolution texels
+    if constexpr (WG) {
 #pragma unroll
     for (int g8 = 0; g8 < 8; ++g8) {
       const int gi = wave + 4 * g8;
@@ -198,7 +210,9 @@ __global__ __launch_bounds__(256) void back_bwd_kernel(
 #pragma unroll
       for (int mt = 0; mt < 3; ++mt) accw2[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, pb[g8][mt], accw2[mt], 0, 0, 0);
     }
+    }
     // ---- phase 3b: d_in = W_s2^T du, 16 texels (one tile row) per MFMA column block
+    if constexpr (DG) {
     for (int ii = wave; ii < BTH; ii += 4) {
       const int gy = ty0 + ii, gx = tx0 + j;
       const bool inside = gy < h2 && gx < w2;
@@ -222,8 +236,10 @@ __global__ __launch_bounds__(256) void back_bwd_kernel(
         }
       }
     }
+    }
     __syncthreads();
   }
+  if constexpr (!WG) return;
 
   // ---- block partial sums -> workspace
   float* r = red[wave];
@@ -297,25 +313,48 @@ extern "C" long nlt_back_backward_workspace_floats(int n, int h2, int w2) {
   return back_bwd_blocks(n, h2, w2) * BB_TOT;
 }
 
-extern "C" int nlt_back_backward(const float* x, const float* fm1, const float* u, const float* v, const float* dpred,
-                                 int n, int h2, int w2, const float* w_s2, const float* w_s1, const float* w_head,
-                                 float alpha, float* dx, float* dfm1, float* dw_s2, float* db_s2, float* dw_s1,
-                                 float* db_s1, float* dw_head, float* db_head, float* workspace, void* stream) {
-  if (!x || !fm1 || !u || !v || !dpred || !w_s2 || !w_s1 || !w_head || !dx || !dfm1 || !dw_s2 || !db_s2 || !dw_s1 || !db_s1 ||
-      !dw_head || !db_head || !workspace)
-    return NLT_ERR_BAD_ARG;
+namespace {
+int back_backward_launch(const float* x, const float* fm1, const float* u, const float* v, const float* dpred,
+                         int n, int h2, int w2, const float* w_s2, const float* w_s1, const float* w_head,
+                         float alpha, float* dx, float* dfm1, float* dw_s2, float* db_s2, float* dw_s1,
+                         float* db_s1, float* dw_head, float* db_head, float* workspace, int parts, void* stream) {
+  if (parts < 1 || parts > 3) return NLT_ERR_BAD_ARG;
+  if (!x || !fm1 || !u || !v || !dpred || !w_s2 || !w_s1 || !w_head) return NLT_ERR_BAD_ARG;
+  if ((parts & 1) && (!dx || !dfm1)) return NLT_ERR_BAD_ARG;
+  if ((parts & 2) && (!dw_s2 || !db_s2 || !dw_s1 || !db_s1 || !dw_head || !db_head || !workspace)) return NLT_ERR_BAD_ARG;
   if (n <= 0 || h2 <= 0 || w2 <= 0) return NLT_ERR_BAD_ARG;
-  if (!nlt_aligned16(u) || !nlt_aligned16(v) || !nlt_aligned16(dx) || !nlt_aligned16(dfm1)) return NLT_ERR_BAD_ARG;
+  if (!nlt_aligned16(u) || !nlt_aligned16(v) || ((parts & 1) && (!nlt_aligned16(dx) || !nlt_aligned16(dfm1)))) return NLT_ERR_BAD_ARG;
   if ((long long)n * h2 * w2 * 4 * 8 >= (1ll << 31)) return NLT_ERR_UNSUPPORTED;
   hipStream_t s = static_cast<hipStream_t>(stream);
   const int ty = (h2 + BTH - 1) / BTH, tx = (w2 + BTW - 1) / BTW;
   const long tiles = (long)n * ty * tx;
   const int blocks = (int)back_bwd_blocks(n, h2, w2);
-  hipLaunchKernelGGL(back_bwd_kernel, dim3(blocks), dim3(256), 0, s, x, fm1, u, v, dpred, h2, w2, ty, tx, tiles, w_s2, w_s1,
-                     w_head, alpha, dx, dfm1, workspace);
+#define NLT_BB(P_) hipLaunchKernelGGL(back_bwd_kernel<P_>, dim3(blocks), dim3(256), 0, s, x, fm1, u, v, dpred, h2, w2, ty, tx, tiles, \
+                                      w_s2, w_s1, w_head, alpha, dx, dfm1, workspace)
+  if (parts == 3) NLT_BB(3); else if (parts == 1) NLT_BB(1); else NLT_BB(2);
+#undef NLT_BB
   NLT_CHECK_LAUNCH();
-  BackBwdOut out = {dw_s2, db_s2, dw_s1, db_s1, dw_head, db_head};
-  hipLaunchKernelGGL(back_bwd_reduce_kernel, dim3((BB_TOT + 15) / 16), dim3(256), 0, s, workspace, blocks, out);
-  NLT_CHECK_LAUNCH();
+  if (parts & 2) {
+    BackBwdOut out = {dw_s2, db_s2, dw_s1, db_s1, dw_head, db_head};
+    hipLaunchKernelGGL(back_bwd_reduce_kernel, dim3((BB_TOT + 15) / 16), dim3(256), 0, s, workspace, blocks, out);
+    NLT_CHECK_LAUNCH();
+  }
   return NLT_OK;
+}
+}  // namespace
+
+extern "C" int nlt_back_backward(const float* x, const float* fm1, const float* u, const float* v, const float* dpred,
+                                 int n, int h2, int w2, const float* w_s2, const float* w_s1, const float* w_head,
+                                 float alpha, float* dx, float* dfm1, float* dw_s2, float* db_s2, float* dw_s1,
+                                 float* db_s1, float* dw_head, float* db_head, float* workspace, void* stream) {
+  return back_backward_launch(x, fm1, u, v, dpred, n, h2, w2, w_s2, w_s1, w_head, alpha, dx, dfm1, dw_s2, db_s2, dw_s1, db_s1, dw_head,
+                              db_head, workspace, 3, stream);
+}
+
+extern "C" int nlt_back_backward_parts(const float* x, const float* fm1, const float* u, const float* v, const float* dpred,
+                                       int n, int h2, int w2, const float* w_s2, const float* w_s1, const float* w_head,
+                                       float alpha, float* dx, float* dfm1, float* dw_s2, float* db_s2, float* dw_s1,
+                                       float* db_s1, float* dw_head, float* db_head, float* workspace, int parts, void* stream) {
+  return back_backward_launch(x, fm1, u, v, dpred, n, h2, w2, w_s2, w_s1, w_head, alpha, dx, dfm1, dw_s2, db_s2, dw_s1, db_s1, dw_head,
+                              db_head, workspace, parts, stream);
 }

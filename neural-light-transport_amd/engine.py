@@ -94,9 +94,14 @@ class RenderPlan:
         # on the bf16 matrix cores (6 / all 9 term products, csrc/conv_tile3.hip) -- forward launches of inference AND training
         self.precision = os.environ.get('NLT_PRECISION', 'fp32')
         self._pred_out = None           # this forward's caller-owned output tensor (see `forward`)
+        self._pred_slot = 'back_infer'
         # callable fired (also on tape replays) when the fused inference pass reaches its expanding blocks: the chip is mostly idle
         # under that chain of small launches, so Model.call queues the network-independent part of the resampler there
         self.decoder_hook = None
+        # F.back.bwd as a backward-data launch on the chain + a weight-gradient launch on the side stream: built and measured in r05
+        # -- 3.16 vs 3.06 ms per l2 step, two A/B pairs on one box: the second launch re-reads (v, dpred, u) beside the chain's
+        # full-resolution launches and costs more than the 0.05 ms the lighter first launch saves.  Opt-in.
+        self.split_back_bwd = os.environ.get('NLT_SPLIT_BACK_BWD', '0') == '1'
         self.prune_packs = os.environ.get('NLT_PRUNE_PACKS', '1') != '0'   # retire fragment buffers only plan-time trials read
         self.grad_hook = None           # grad_hook(i): fired by backward() once range i of the gradient bucket has its weight gradients queued
         self.grad_mid_level = 0         # encoder level that closes range 1 (0: no such range); set by Model._flatten
@@ -502,6 +507,7 @@ class RenderPlan:
         Returns (pred, buffers); pred is pred_out when it was used."""
         C.set_workspace_scope(id(self))
         self._pred_out = pred_out
+        self._pred_slot = 'back_infer' if inference else 'back_train'
         if resident is not None:
             return self._forward_resident(resident, skip_connect_base, algo)
         n, h, w, _ = base.shape
@@ -841,14 +847,15 @@ class RenderPlan:
 
         def back(pred):
             self._launch('F.back', nbytes, C.back_forward_train if train else C.back_forward, *back_args, pred, *extra, **back_kw)
-        out = self._pred_out if (not train and not self._tuning) else None
+        out = self._pred_out if not self._tuning else None
         if out is None:
-            # (leaves `back_infer` alone: a train forward, a timed survey or a copy-out pass over these buffers must not
-            # take the closure away from the inference tapes recorded with pred_out -- they would hand out a stale b['pred'])
+            # (leaves the closures alone: a timed survey or a copy-out pass over these buffers must not take them away from
+            # the tapes recorded with pred_out -- they would hand out a stale b['pred'])
             back(b['pred'])
             return b['pred'], b
-        # the caller's own output tensor: this launch is not part of the launch tape (its output address differs every step)
-        b['back_infer'] = back
+        # the caller's own output tensor: this launch is not part of the launch tape (its output address differs every step).
+        # One closure per kind of pass: the train forward's last launch also keeps two maps for the backward.
+        b['back_train' if train else 'back_infer'] = back
         paused = C.tape_pause()
         try:
             back(out)
@@ -866,13 +873,13 @@ class RenderPlan:
         """After a tape replay: the launch that was kept out of the tape (see `forward`, pred_out)."""
         if self._pred_out is None:
             return b['pred']
-        b['back_infer'](self._pred_out)         # (`_replayable` made sure it exists)
+        b[self._pred_slot](self._pred_out)      # (`_replayable` made sure it exists)
         return self._pred_out
 
     def _replayable(self, b, ent, reg):
         """A recorded forward tape may be replayed: still valid, and -- when this call brought its own output tensor -- the
         launch that was kept out of it is at hand (written only by a pred_out pass over these buffers)."""
-        return C.tape_valid(ent, reg.version) and (self._pred_out is None or b.get('back_infer') is not None)
+        return C.tape_valid(ent, reg.version) and (self._pred_out is None or b.get(self._pred_slot) is not None)
 
     # ------------------------------------------------------------------ backward
     def _grad_buffers(self, b):
@@ -1130,10 +1137,27 @@ class RenderPlan:
         if fused:
             # last expanding block + head in one launch (csrc/train_back.hip); the head's skip rows are F.front.bwd's
             (da, act_a), (db, _) = q.layers[D + U].convs()
-            self._launch('F.back.bwd', 4 * n * h * w * (4 + 4 + 3 + 20), C.back_backward, b['dec'][U - 2], b['fm'][1],
-                         b['dtmp'][U - 1], b['dec'][U - 1], dpred, n, h // 2, w // 2, da.kernel.detach(), db.kernel.detach(),
-                         head.kernel.detach(), act_a.alpha, g['dec'][U - 2], g['fm'][1], da.dkernel, da.dbias, db.dkernel,
-                         db.dbias, head.dkernel, head.dbias)
+            bb_in = (b['dec'][U - 2], b['fm'][1], b['dtmp'][U - 1], b['dec'][U - 1], dpred, n, h // 2, w // 2, da.kernel.detach(),
+                     db.kernel.detach(), head.kernel.detach(), act_a.alpha)
+            bb_w = (da.dkernel, da.dbias, db.dkernel, db.dbias, head.dkernel, head.dbias)
+            bs = self._bside
+            if self.split_back_bwd and bs is not None and bs[2] is not None and not self._tuning:
+                # r05: the chain waits for dx / dfm1 only -- a launch without the x | fm1 operand loads and the accumulators
+                # (112 registers: four workgroups per CU); the weight / bias sums go to the weight-gradient stream like every
+                # other weight gradient (they recompute dv / du from the same three maps)
+                self._launch('F.back.bwd', 4 * n * h * w * (4 + 4 + 3 + 10), C.back_backward_parts, 1, *bb_in, g['dec'][U - 2], g['fm'][1],
+                             None, None, None, None, None, None)
+                side, events, cur = bs[:3]
+                if cur[0] == len(events):
+                    events.append(C.new_event())
+                ev = events[cur[0]]
+                cur[0] += 1
+                C.record_event(ev, torch.cuda.current_stream())
+                with torch.cuda.stream(side):
+                    C.wait_event(side, ev)
+                    self._launch('F.back.wgrad', 4 * n * h * w * (4 + 4 + 3 + 10), C.back_backward_parts, 2, *bb_in, None, None, *bb_w)
+            else:
+                self._launch('F.back.bwd', 4 * n * h * w * (4 + 4 + 3 + 20), C.back_backward, *bb_in, g['dec'][U - 2], g['fm'][1], *bb_w)
         else:
             self._launch('bwd.head', 4 * n * h * w * (2 * (cx + cs) + 3), C.head_backward, x_last, cx, cx, b['fm'][0], cs, cs,
                          head.kernel.detach(), dpred, n, h, w, g['dec'][U - 1], cx, g['fm'][0], cs, head.dkernel, head.dbias)

@@ -277,13 +277,13 @@ class Model(BaseModel):
             n, hc, wc, dev = resident.n, resident.hc, resident.wc, resident.cvis.device
         else:
             (n, hc, wc, _), dev = warp.shape, base.device
-        # inference: the plan's last launch writes the rendered texels straight into a tensor of this call (no copy of the
-        # plan's reusable buffer afterwards); `_pred_fresh` tells `call` whether that happened
+        # the plan's last launch writes the rendered texels straight into a tensor of this call when it runs the fused ends (no
+        # copy of the plan's reusable buffer afterwards); `_pred_fresh` tells the caller whether that happened
         h_, w_ = (resident.h, resident.w) if resident is not None else base.shape[1:3]
         timing_all = self.plan.timer is not None and getattr(self.plan.timer, 'only', None) is None     # (per-launch survey: plain path)
         fresh = (torch.empty((n, h_, w_, 3), device=dev, dtype=torch.float32)
-                 if (inference and dev.type == 'cuda' and not timing_all and os.environ.get('NLT_PRED_COPY', '0') == '0')
-                 else None)
+                 if (dev.type == 'cuda' and not timing_all and os.environ.get('NLT_PRED_COPY', '0') == '0')
+                 else None)                                      # (train forwards too since r05: their last launch takes it as well)
         E = lambda: torch.empty((n, hc, wc, 3), device=dev, dtype=torch.float32)
         pred_camspc, base_camspc, fg_camspc = E(), E(), E()
         idx = torch.empty((n, hc, wc, 4), device=dev, dtype=torch.int32) if want_indices else None
@@ -392,6 +392,8 @@ class Model(BaseModel):
         with torch.no_grad():
             pred, pred_camspc, base_camspc, fg_camspc, _ = self._render(base, cvis, lvis, warp, nn_rgb, nn_base, None, None,
                                                                         False, inference=False)
+            # (the fused train forward wrote `pred` into a tensor of this call: no 50 MB copy of the plan's buffer at the step's end)
+            pred_vis = pred if self._pred_fresh else pred.clone()
             gen = self.plan.generation
             plain_l2 = len(self.wloss) == 1 and self.wloss[0][0] == 1 and type(self.wloss[0][1]).__name__ == 'L2'
             if plain_l2:
@@ -419,7 +421,7 @@ class Model(BaseModel):
                 (d_pred_c,) = torch.autograd.grad(loss, leaf)
         with torch.no_grad():
             self._render_backward(d_pred_c, (base, cvis, lvis, warp, nn_rgb, nn_base, None), gen)
-            to_vis = {'id': id_, 'nn_id': nn_id, 'base_camspc': base_camspc, 'pred': pred.clone(), 'pred_camspc': pred_camspc,
+            to_vis = {'id': id_, 'nn_id': nn_id, 'base_camspc': base_camspc, 'pred': pred_vis, 'pred_camspc': pred_camspc,
                       'nn_camspc': nn_rgb_camspc, 'gt': rgb, 'gt_camspc': gt_camspc}
         return loss.detach(), to_vis
 
