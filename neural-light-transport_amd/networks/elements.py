@@ -249,8 +249,8 @@ class PackRegistry:
     def prune(self):
         if self.used is None:
             return
-        drop = [k for k in self.entries if k not in self.used and k not in self.inactive]
-        self.used = None
+        used, self.used = self.used, None                    # (closed first: lanes on other host threads keep touching / adding)
+        drop = [k for k in list(self.entries) if k not in used and k not in self.inactive]
         if drop:
             self.inactive.update(drop)
             self.table = None
