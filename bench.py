@@ -377,7 +377,8 @@ def bench_train(args, device, world, rank, n_steps, loss):
                                  "levels 2..0 + head (after the backward)"],
             "allreduce_floats": [int(rg[i + 1] - rg[i]) for i in range(len(rg) - 1)],
             "allreduce_MB": [round(4e-6 * (rg[i + 1] - rg[i]), 2) for i in range(len(rg) - 1)],
-            "backend": "nccl (RCCL over xGMI)" if world > 1 else "none (single rank: no collective is issued)",
+            "backend": ("nccl (RCCL over xGMI)" if os.environ.get('NLT_BENCH_BACKEND', 'nccl') == 'nccl' else os.environ['NLT_BENCH_BACKEND'])
+                       if world > 1 else "none (single rank: no collective is issued)",
             "scaling_curve": "never measured on hardware: no multi-GPU node was available to rounds 1-5 (SCALE_r01..r04 skipped)"}
     if world > 1 and not args.train_graph:
         run_serial = lambda b: trainvali.distributed_train_step(model, b, opt, gbs, overlap=False)
@@ -783,11 +784,19 @@ def main():
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     if world != args.gpus and world > 1:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    # NLT_BENCH_BACKEND=gloo + NLT_BENCH_SHARE_GPU=1: a DRY RUN of the multi-rank line on a one-GPU box (every rank on cuda:0,
+    # collectives through the host) -- exercises the N > 1 code path, measures nothing; the line says so (`config.dry_run`).
+    backend = os.environ.get('NLT_BENCH_BACKEND', 'nccl')
+    if os.environ.get('NLT_BENCH_SHARE_GPU', '0') == '1':
+        local_rank = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     device = torch.device('cuda', local_rank)
     if world > 1:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        dist.init_process_group('nccl', device_id=device)
+        if backend == 'nccl':
+            dist.init_process_group('nccl', device_id=device)
+        else:
+            dist.init_process_group(backend)
 
     import nlt_amd
     from nlt_amd import capi
@@ -980,6 +989,8 @@ def main():
             out["config"]["global_batch"] = t0_["global_batch"]
             out["config"]["parallelism"] = "dp%d (frames sharded; gradient all-reduce over RCCL/xGMI, ranges 0-1 overlapped with the backward)" % world
             out["config"]["scaling_curve"] = t0_["comm"]["scaling_curve"]
+            if backend != 'nccl' or os.environ.get('NLT_BENCH_SHARE_GPU', '0') == '1':
+                out["config"]["dry_run"] = "backend %s, ranks share GPUs: a code-path check, NOT a measurement" % backend
         if train:
             out["train_step"] = train[0]
             if len(train) > 1:
