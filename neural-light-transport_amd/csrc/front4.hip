@@ -26,8 +26,8 @@
 //     in registers, so no strip starts with a wait.
 // The arithmetic of a strip is unchanged (tests/test_gpu_front4.py: still bit-identical to front_kernel<true>).
 //
-// U8 = true reads the resident uint8 capture store (nlt/datasets/nlt.py:131-136,173-181) and converts in registers:
-// see u8_unit.
+// U8 = true reads the resident uint8 capture store (nlt/datasets/nlt.py:131-136,173-181) and feeds the byte values themselves:
+// see u8x4_unit.
 #include "front_common.h"
 
 namespace {
@@ -59,9 +59,15 @@ struct Front4In {
   const int *ids, *nn_ids;                              // U8 only: frame of each sample [n], of each observation [n,k] (-1: zeros)
 };
 
-// u8_unit (nlt_common.h): float32(float64(u) / 255.0), `_load_data`'s normalize_uint + astype(float32)
+// r05 (r04 review item 5): the uint8-store variant stages the raw BYTE values (v_cvt_f32_ubyteN: one instruction, exact) instead of
+// `_load_data`'s float32(float64(u) / 255) (u8_unit: four instructions per byte, 192 per observation), and the 1 / 255 moves into
+// the operands the raw values meet: the stage-1 A operands (the folded L0 + L1 stride-2 weights) and the head's skip rows are
+// multiplied by fl(1 / 255) -- the first in registers, once per wave; the second at pack time (OFF_WSK8) -- and `+ base` becomes
+// fma(byte, fl(1 / 255), .).  nn_rgb - nn_base is an exact integer in [-255, 255].  fl(W / 255) . u instead of W . fl(u / 255):
+// the uint8 variant is no longer bit-identical to the float kernel on the assembled batch, it is <= 3e-7 rel-L2 from it
+// (tests/test_gpu_front4.py; reported per output there).
 __device__ __forceinline__ f32x4 u8x4_unit(unsigned v) {
-  return (f32x4){u8_unit(v & 255u), u8_unit((v >> 8) & 255u), u8_unit((v >> 16) & 255u), u8_unit(v >> 24)};
+  return (f32x4){(float)(v & 255u), (float)((v >> 8) & 255u), (float)((v >> 16) & 255u), (float)(v >> 24)};
 }
 
 __device__ __forceinline__ void wave_sync() {       // orders this wave's LDS traffic for the compiler; no instruction
@@ -251,6 +257,13 @@ __global__ __launch_bounds__(512, 1) void front4_kernel(
   for (int m = 0; m < 3; ++m) ao2[m] = blob[OFF_AO2 + m * 64 + lane];
 #pragma unroll
   for (int m = 0; m < 8; ++m) aq2[m] = blob[OFF_AQ2 + m * 64 + lane];
+  constexpr float INV255 = 1.0f / 255.0f;
+  if constexpr (U8) {                                                    // stage 1 multiplies byte values (see u8x4_unit)
+#pragma unroll
+    for (int m = 0; m < 3; ++m) ao2[m] *= INV255;
+#pragma unroll
+    for (int m = 0; m < 8; ++m) aq2[m] *= INV255;
+  }
   const float* const bl = lds_all + W_BIAS + 4 * kk;                     // biases: read where they are added
   auto bias4 = [&](int off) { return *reinterpret_cast<const f32x4*>(bl + off); };
   f32x4 ao1[4];
@@ -433,7 +446,7 @@ __global__ __launch_bounds__(512, 1) void front4_kernel(
     {
       float wsk[24];                                                       // wave-uniform: scalar loads
 #pragma unroll
-      for (int rr = 0; rr < 24; ++rr) wsk[rr] = blob[OFF_WSK + rr];
+      for (int rr = 0; rr < 24; ++rr) wsk[rr] = blob[(U8 ? OFF_WSK8 : OFF_WSK) + rr];
       const int jq = opaque(j);
       // stage 1 (8 MFMAs per column tile): raw = (base r g b, cvis, lvis, mean raw observation r g b)
 #pragma unroll
@@ -480,7 +493,10 @@ __global__ __launch_bounds__(512, 1) void front4_kernel(
               s1 = fmaf(raw[c][rr], wsk[rr * 3 + 1], s1);
               s2 = fmaf(raw[c][rr], wsk[rr * 3 + 2], s2);
             }
-            if (add_base) { s0 += raw[c][0]; s1 += raw[c][1]; s2 += raw[c][2]; }
+            if (add_base) {
+              if constexpr (U8) { s0 = fmaf(raw[c][0], INV255, s0); s1 = fmaf(raw[c][1], INV255, s1); s2 = fmaf(raw[c][2], INV255, s2); }
+              else { s0 += raw[c][0]; s1 += raw[c][1]; s2 += raw[c][2]; }
+            }
             const int t = (c0 + c) * 16 + jq;
             // (staging these rows through LDS for 16-byte stores was built and measured in r03: no change -- the stores are not
             // what the query path waits for)

@@ -21,7 +21,8 @@ constexpr int OFF_AO1 = 1728;              // [4][64][4]
 constexpr int OFF_BQ2 = 2752, OFF_BO2 = 2768, OFF_BQ1 = 2784, OFF_BO1 = 2800;   // [16] each
 constexpr int OFF_WSK = 2816;              // [8][3]  head share of the raw channels
 constexpr int OFF_BSK = 2840;              // [3]
-constexpr int BLOB = 2848;
+constexpr int OFF_WSK8 = 2848;             // [8][3]  the same rows times fl(1 / 255): the uint8-store front kernel feeds raw BYTE values (r05)
+constexpr int BLOB = 2880;
 
 __device__ __forceinline__ f32x4 lrelu4(f32x4 v, float alpha) {
   return (f32x4){v[0] > 0.f ? v[0] : alpha * v[0], v[1] > 0.f ? v[1] : alpha * v[1],

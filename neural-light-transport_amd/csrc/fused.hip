@@ -77,6 +77,12 @@ __global__ void front_pack_kernel(FrontW w, float* __restrict__ blob) {
       v = fmaf(w.bq0[c], w.wh[(4 + c) * 3 + o], v);
       v = fmaf(w.bo0[c], w.wh[(20 + c) * 3 + o], v);
     }
+  } else if (idx >= OFF_WSK8 && idx < OFF_WSK8 + 24) {          // WSKIP[r][o] / 255 (uint8-store front kernel)
+    const int r = (idx - OFF_WSK8) / 3, o = (idx - OFF_WSK8) % 3;
+    for (int c = 0; c < 16; ++c)
+      v = r < 5 ? fmaf(w.wq0[r * 16 + c], w.wh[(4 + c) * 3 + o], v)
+                : fmaf(w.wo0[(r - 5) * 16 + c], w.wh[(20 + c) * 3 + o], v);
+    v *= 1.0f / 255.0f;
   }
   blob[idx] = v;
 }

@@ -1,8 +1,8 @@
 """-m gpu: second-generation front kernel (csrc/front4.hip) -- float inputs against front_kernel<true> (same folded
 weights, same MFMA sequences; since r05 the biases are the accumulators' initial values instead of a separate add, so the
 two kernels differ by that re-association: <= 5e-7 rel-L2, r04 review item 5), uint8-store inputs against the float kernel
-on nlt_assemble_batch's output (bit-identical: the uint8 -> float32 conversion is exact), the train form against the
-inference form (bit-identical), and the whole Model.call with the plan switch on / off."""
+on nlt_assemble_batch's output (<= 5e-7: byte-valued staging since r05), the train form against the inference form
+(bit-identical), and the whole Model.call with the plan switch on / off."""
 import numpy as np
 import pytest
 import torch
@@ -68,7 +68,10 @@ def test_front4_float_matches_front2(n, k, h, w):
 
 
 @pytest.mark.parametrize('n,k,h,w', [(2, 1, 64, 96), (3, 4, 64, 64), (1, 2, 40, 72), (2, 4, 512, 512), (1, 7, 32, 64)])
-def test_front4_u8_store_is_bit_identical_to_float_on_assembled_batch(n, k, h, w):
+def test_front4_u8_store_matches_float_on_assembled_batch(n, k, h, w):
+    """r05: the uint8 variant feeds stage 1 the byte values and carries 1 / 255 in its weights (fl(W / 255) . u instead of
+    W . fl(u / 255)): <= 5e-7 rel-L2 from the float kernel on nlt_assemble_batch's output (measured 1-3e-7), no texel off by more
+    than a few ulps of the map's range; bit-identical until r04."""
     pm, blob, blob_l2 = _weights(seed=10 + k)
     g = torch.Generator(device='cuda').manual_seed(7 * n + k + h)
     F = 6
@@ -84,7 +87,8 @@ def test_front4_u8_store_is_bit_identical_to_float_on_assembled_batch(n, k, h, w
     torch.cuda.synchronize()
     for name, a, c in zip(('fm1', 'skip3', 'qtmp2', 'otmp2'), ref, got):
         assert not torch.isnan(c).any(), name
-        assert torch.equal(a, c), (name, float((a - c).abs().max()))
+        assert close(c, a), (name, float((a - c).abs().max()))
+        assert float((a - c).abs().max()) <= 3e-6 * float(a.abs().max()), name
 
 
 @pytest.mark.parametrize('n,k,h,w', [(2, 1, 64, 96), (1, 2, 40, 72), (1, 4, 64, 64), (1, 1, 1024, 1024), (1, 3, 36, 100)])
@@ -169,16 +173,17 @@ def test_model_call_on_a_store_resident_batch_equals_the_eager_float_batch():
     for mode in ('test', 'vali'):
         a, b = pm.call(eager, mode, want_indices=True), pm.call(res, mode, want_indices=True)
         torch.cuda.synchronize()
-        assert torch.equal(a[0], b[0]) and torch.equal(a[3]['pred'], b[3]['pred'])
+        assert close(b[0], a[0], 1e-6) and close(b[3]['pred'], a[3]['pred'], 1e-6)     # (r05: byte-valued staging, 1 / 255 in the weights)
         # base and the uv2cam map gathered straight from the uint8 / fp16 stores (nlt_warp_forward_store): same bits,
         # same integer UV indices
         assert torch.equal(a[3]['base_camspc'], b[3]['base_camspc']) and torch.equal(a[3]['uv_indices'], b[3]['uv_indices'])
         if mode == 'vali':
             assert torch.equal(a[1], b[1]) and torch.equal(a[3]['gt'], b[3]['gt'])
+    first = b[0].clone()
     for _ in range(3):                                          # recorded launch tape, then replays
         b = pm.call(res, 'test')
     torch.cuda.synchronize()
-    assert torch.equal(a[0], b[0])
+    assert torch.equal(first, b[0])
     grads = []
     for batch in (eager, res):
         pred, gt, kw, _ = pm(batch, mode='train')
