@@ -306,9 +306,10 @@ def cpu_baseline(args):
 
 
 def bench_train(args, device, world, rank, n_steps, loss):
-    """BASELINE config 4 per GPU: 4 frames, 1024^2 UV, k=1, Keras Adam-AMSGrad, ONE RCCL all-reduce(sum) of the flat
-    fp32 gradient bucket per step; batches rotate through `Dataset.load_batch`'s staging ring.  Reported beside the
-    headline, one line per loss (the released configs train with `barron`)."""
+    """BASELINE config 4 per GPU: 4 frames, 1024^2 UV, k=1, Keras Adam-AMSGrad, the RCCL all-reduce(sum) of the flat fp32
+    gradient bucket in three fixed ranges per step (two of them issued inside the backward); batches rotate through
+    `Dataset.load_batch`'s staging ring.  Beside the headline at N = 1, one line per loss (the released configs train with
+    `barron`); at N > 1 the first loss's line IS the top-level line (main)."""
     import torch
     import torch.distributed as dist
     from nlt_amd import trainvali
