@@ -562,6 +562,8 @@ class Model(BaseModel):
         the PSNR sums run on the device when the maps live there (`metric.PSNR`, float64)."""
         is_linear = self.config.getboolean('DEFAULT', 'linear_space')
         self._validate_mode(mode)
+        if data_dict.get('id') is None or data_dict.get('nn_id') is None:
+            raise ValueError("vis_batch needs the samples' ids (`id`, `nn_id` of the batch tuple): this batch carries none")
         ids = [V.to_str(x) for x in data_dict['id']]
         nn_ids = [V.to_str(x) for x in data_dict['nn_id']]
         keys = ('base_camspc', 'pred_camspc', 'nn_camspc') + (() if mode == 'test' else ('gt_camspc',))

@@ -123,6 +123,8 @@ def test_vis_batch_writes_the_reference_s_files(monkeypatch, tmp_path, mode, lin
     assert set(back) == set(to_vis) and np.array_equal(back['pred_camspc'], to_vis['pred_camspc'].numpy())
     with pytest.raises(ValueError):
         pm.vis_batch(to_vis, outdir, 'eval')
+    with pytest.raises(ValueError):                             # a synthetic batch without ids: said so, not a TypeError deep inside
+        pm.vis_batch(dict(to_vis, id=None), outdir, mode)
 
 
 def test_compile_batch_vis_webpage_and_frame_roll_up(monkeypatch, tmp_path):
