@@ -387,3 +387,31 @@ def test_clipnorm_train_step_on_the_gpu():
         assert float((pm.flat_params.grad - ref).norm() / ref.norm()) < 5e-4, step
     worst = max(float((po.detach() - c.kernel.cpu()).abs().max()) for po, c in zip(om.parameters()[::2], pm._conv_layers()))
     assert worst < 2e-4, worst
+
+
+@pytest.mark.parametrize('uv,k', [(256, 1), (256, 2)])
+def test_backward_plan_is_bit_reproducible_given_the_texel_gradient(uv, k):
+    """DESIGN section 3 / INTEGRATION: the only run-to-run variation of a train step comes from the float atomics of the resampler /
+    resize adjoints and the Barron loss.  Given the SAME gradient w.r.t. the rendered texels the whole backward plan -- fused ends,
+    backward-data launches, the LDS-tiled / row-walking / narrow weight gradients with their slice reductions, the weight-gradient
+    side stream -- fills the flat bucket bit for bit the same, eager or replayed from its launch tape.  (UV >= 256 at depth 256: a level
+    narrower than 4 texels -- depth 1024 at 256^2, toy sizes -- takes the first-generation weight-gradient kernel, whose partial
+    sums meet in float atomics: one bias gradient then varies in its last bit, measured 5.8e-11 at UV 128.)"""
+    _, pm = make_pair(depth=256, uv=uv, im=uv // 2, loss='l2', seed=31)
+    pm.build('cuda')
+    batch = to_device_batch(*O.synth_batch(2, uv, uv, uv // 2, uv // 2, uv // 2, uv // 2, k=k, seed=32))
+    base, cvis, lvis, nn_base, nn_rgb = batch[1], batch[2], batch[3], batch[8], batch[9]
+    g = torch.Generator(device='cuda').manual_seed(5)
+    dpred = (torch.rand((2, uv, uv, 3), device='cuda', generator=g) - 0.5).contiguous()
+    runs = []
+    for i in range(5):                                          # first sights eager (+ plan-time trials), then recorded, then replays
+        with torch.no_grad():
+            pm._render(base, cvis, lvis, batch[4], nn_rgb, nn_base, None, None, False, inference=False)
+            pm.flat_grads.zero_()
+            pm.plan.backward(dpred, base, cvis, lvis, nn_rgb, nn_base, None, generation=pm.plan.generation)
+        torch.cuda.synchronize()
+        runs.append(pm.flat_grads.clone())
+    assert float(runs[0].abs().max()) > 0
+    assert pm.plan.tape_replays >= 1
+    for r in runs[1:]:
+        assert torch.equal(r, runs[0])
