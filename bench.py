@@ -50,6 +50,49 @@ def pmc_traffic(label):
                 return int(rec['hbm_bytes']), os.path.basename(path)
     return None, None
 
+def live_pmc_traffic(label, args, tune_file):
+    """HBM bytes per launch of the dominant kernel MEASURED IN THIS RUN: two child passes of this script's timed forward under
+    `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` (separate passes, kernel trace only, as MI355X_MICROARCH.md prescribes;
+    tools/pmc_summary.py's reading: FETCH_SIZE doubled for this streaming kernel, WRITE_SIZE as reported), the children loading
+    the parent's tile choices so that no plan-time trial launch is in the trace.  (None, reason) when the profiler is not there
+    or a pass fails -- the committed figure then stays in the line."""
+    import shutil
+    import subprocess
+    import tempfile
+    rp = shutil.which('rocprofv3') or ('/opt/rocm/bin/rocprofv3' if os.path.exists('/opt/rocm/bin/rocprofv3') else None)
+    if rp is None:
+        return None, "rocprofv3 not found"
+    sys.path.insert(0, os.path.join(ROOT, 'tools'))
+    try:
+        import pmc_summary
+    except ImportError as e:
+        return None, "tools/pmc_summary.py: %s" % e
+    frags = KERNEL_OF_LABEL.get(label, ())
+    got = {}
+    with tempfile.TemporaryDirectory(dir='/tmp') as td:
+        for counter in ('FETCH_SIZE', 'WRITE_SIZE'):
+            out = os.path.join(td, counter)
+            cmd = [rp, '--pmc', counter, '--kernel-trace', '--output-format', 'csv', '-d', out, '--', sys.executable,
+                   os.path.join(ROOT, 'bench.py'), '--headline-only', '--steps', '4', '--warmup', '2', '--precision', args.precision,
+                   '--uv', str(args.uv), '--cam', str(args.cam), '--frames', str(args.frames), '--k', str(args.k),
+                   '--depth', str(args.depth), '--warp', args.warp, '--tune-cache', tune_file]
+            env = dict(os.environ, TMPDIR='/tmp')
+            for v in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE'):
+                env.pop(v, None)
+            try:
+                r = subprocess.run(cmd, cwd='/tmp', env=env, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, timeout=240)
+            except (subprocess.TimeoutExpired, OSError) as e:
+                return None, "%s pass: %s" % (counter, type(e).__name__)
+            if r.returncode != 0:
+                return None, "%s pass: rc %d: %s" % (counter, r.returncode, r.stderr.decode(errors='replace')[-160:])
+            vals = [sum(d.values()) / len(d) for (name, cname), d in pmc_summary.collect(out).items()
+                    if cname == counter and any(fr in name for fr in frags) and d]
+            if not vals:
+                return None, "%s pass: no %s launch in the counter file" % (counter, label)
+            got[counter] = max(vals) * 1024.0                            # KiB -> bytes (the variant that ran: one kernel name)
+    return int(2 * got['FETCH_SIZE'] + got['WRITE_SIZE']), None
+
+
 def pmc_cfg5_bytes(prec):
     """HBM bytes one forward step of BASELINE config 5 (2048^2, 2 frames, k = 1) moves at `prec`, from the newest committed
     tools/pmc_cfg5.sh summary (profiles/*_pmc_traffic_cfg5_<prec>.json)."""
@@ -144,6 +187,8 @@ def parse():
     ap.add_argument('--pipelined', action='store_true', help='with --headline-only: also the several-batches-in-flight sub-line')
     ap.add_argument('--no-released-shapes', action='store_true', help='skip the config 1 / config 2 sub-lines (released .ini shapes)')
     ap.add_argument('--per-op-train', action='store_true', help='per-launch timing table of one train step (stderr)')
+    ap.add_argument('--no-live-pmc', action='store_true', help='skip the two rocprofv3 --pmc child passes that measure the dominant '
+                    "launch's HBM traffic in this run (roofline.traffic then comes from the committed profiles/*_pmc_traffic.json)")
     return ap.parse_args()
 
 
@@ -920,6 +965,22 @@ def main():
         traffic, traffic_src = pmc_traffic(dominant)
         if traffic_src is not None:
             traffic_src = "profiles/%s (committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, not this run)" % traffic_src
+        traffic_committed, live_note = traffic, None
+        if world == 1 and not args.headline_only and not args.no_live_pmc and not args.graph:
+            import tempfile
+            with tempfile.NamedTemporaryFile(suffix='.json', dir='/tmp', delete=False) as tf_:
+                tune_tmp = tf_.name
+            try:
+                os.unlink(tune_tmp)
+                model.plan.save_tuning(tune_tmp)
+                live, live_note = live_pmc_traffic(dominant, args, tune_tmp)
+            finally:
+                if os.path.exists(tune_tmp):
+                    os.unlink(tune_tmp)
+            if live is not None:
+                traffic = live
+                traffic_src = ("measured in this run: two child passes of the timed forward under rocprofv3 --pmc FETCH_SIZE / "
+                               "--pmc WRITE_SIZE (FETCH_SIZE doubled per MI355X_MICROARCH.md, WRITE_SIZE as reported)")
         if dom_flops / max(dom_bytes, 1) > MFMA_F32_PEAK_TFLOPS * 1e12 / (HBM_PEAK_GBS * 1e9):   # above the fp32 ridge
             tf = dom_flops / (dom_ms * 1e-3) / 1e12
             roof = {"bound": "mfma", "kernel": dominant, "achieved": round(tf, 2), "peak": MFMA_F32_PEAK_TFLOPS,
@@ -930,6 +991,10 @@ def main():
             roof = {"bound": "hbm", "kernel": dominant, "achieved": round(ach, 1), "peak": HBM_PEAK_GBS,
                     "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
                     "launch_ms": round(dom_ms, 4), "algorithmic_bytes_per_launch": int(dom_bytes)}
+        if traffic is not traffic_committed or live_note:
+            roof["traffic_committed_profile"] = traffic_committed
+            if live_note:
+                roof["traffic_live_pass"] = "not taken: " + live_note
         if dom_layerwise != dom_bytes:                          # fused launch: also what it replaces, layer by layer
             roof["layerwise_bytes_replaced"] = int(dom_layerwise)
         # both roofs of the dominant launch, whichever binds: algorithmic (compulsory) bytes and measured (PMC) bytes over its
