@@ -62,6 +62,9 @@ def live_pmc_traffic(label, args, tune_file):
     rp = shutil.which('rocprofv3') or ('/opt/rocm/bin/rocprofv3' if os.path.exists('/opt/rocm/bin/rocprofv3') else None)
     if rp is None:
         return None, "rocprofv3 not found"
+    if (any(k.startswith(('ROCPROF', 'ROCP_', 'ROCPROFILER')) for k in os.environ)
+            or 'rocprofiler' in os.environ.get('LD_PRELOAD', '') or 'rocprofiler' in os.environ.get('HSA_TOOLS_LIB', '')):
+        return None, "this process already runs under a profiler (no nested rocprofv3)"
     sys.path.insert(0, os.path.join(ROOT, 'tools'))
     try:
         import pmc_summary
@@ -80,7 +83,7 @@ def live_pmc_traffic(label, args, tune_file):
             for v in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE'):
                 env.pop(v, None)
             try:
-                r = subprocess.run(cmd, cwd='/tmp', env=env, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, timeout=240)
+                r = subprocess.run(cmd, cwd='/tmp', env=env, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, timeout=150)
             except (subprocess.TimeoutExpired, OSError) as e:
                 return None, "%s pass: %s" % (counter, type(e).__name__)
             if r.returncode != 0:
