@@ -88,12 +88,15 @@ def live_pmc_traffic(label, args, tune_file):
                 return None, "%s pass: %s" % (counter, type(e).__name__)
             if r.returncode != 0:
                 return None, "%s pass: rc %d: %s" % (counter, r.returncode, r.stderr.decode(errors='replace')[-160:])
-            vals = [sum(d.values()) / len(d) for (name, cname), d in pmc_summary.collect(out).items()
-                    if cname == counter and any(fr in name for fr in frags) and d]
-            if not vals:
+            acc = {name: d for (name, cname), d in pmc_summary.collect(out).items() if cname == counter and d}
+            dom = [(len(d), sum(d.values()) / len(d)) for name, d in acc.items() if any(fr in name for fr in frags)]
+            if not dom:
                 return None, "%s pass: no %s launch in the counter file" % (counter, label)
-            got[counter] = max(vals) * 1024.0                            # KiB -> bytes (the variant that ran: one kernel name)
-    return int(2 * got['FETCH_SIZE'] + got['WRITE_SIZE']), None
+            calls, avg = max(dom)                                        # (the variant that ran: one kernel name)
+            got[counter] = avg * 1024.0                                  # KiB -> bytes
+            got[counter + '_step'] = sum(sum(d.values()) for d in acc.values()) * 1024.0 / calls   # every kernel, per forward step
+    return {'dominant': int(2 * got['FETCH_SIZE'] + got['WRITE_SIZE']),
+            'step': int(2 * got['FETCH_SIZE_step'] + got['WRITE_SIZE_step'])}, None
 
 
 def pmc_cfg5_bytes(prec):
@@ -131,13 +134,16 @@ def pmc_step_bytes():
     return None, None
 
 
-def whole_pass(args, timer, sec_per_step, layerwise_bpt):
+def whole_pass(args, timer, sec_per_step, layerwise_bpt, live_step_bytes=None):
     """Two utilisation figures for the whole forward (per GPU): useful FLOP/s against the fp32 MFMA peak, and the HBM
     bytes the step really moves (PMC) against the HBM peak.  SURVEY 8d's layer-wise bytes are what an unfused
     implementation would move -- kept as a reference figure, NOT as a utilisation."""
     flops = sum(timer.flops.get(l, 0) for l in timer.records)            # 2 x MACs of the plan's launches (L0 folded)
     tf = flops / sec_per_step / 1e12
     hbm, src = pmc_step_bytes()
+    if live_step_bytes:
+        hbm, src = int(live_step_bytes), ("measured in this run (rocprofv3 --pmc child passes; FETCH_SIZE doubled for every kernel: an upper "
+                                          "bound for the gather / half-line launches, DESIGN 9)")
     out = {"useful_flops_per_step": int(flops), "tflops": round(tf, 2), "frac_of_fp32_mfma_peak": round(tf / MFMA_F32_PEAK_TFLOPS, 4),
            "hbm_bytes_per_step_pmc": hbm, "pmc_source": src,
            "frac_of_hbm_peak": round(hbm / sec_per_step / 1e9 / HBM_PEAK_GBS, 4) if hbm else None,
@@ -968,7 +974,7 @@ def main():
         traffic, traffic_src = pmc_traffic(dominant)
         if traffic_src is not None:
             traffic_src = "profiles/%s (committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, not this run)" % traffic_src
-        traffic_committed, live_note = traffic, None
+        traffic_committed, live_note, live_step_bytes = traffic, None, None
         if world == 1 and not args.headline_only and not args.no_live_pmc and not args.graph:
             import tempfile
             with tempfile.NamedTemporaryFile(suffix='.json', dir='/tmp', delete=False) as tf_:
@@ -981,7 +987,8 @@ def main():
                 if os.path.exists(tune_tmp):
                     os.unlink(tune_tmp)
             if live is not None:
-                traffic = live
+                live_step_bytes = live['step']
+                traffic = live['dominant']
                 traffic_src = ("measured in this run: two child passes of the timed forward under rocprofv3 --pmc FETCH_SIZE / "
                                "--pmc WRITE_SIZE (FETCH_SIZE doubled per MI355X_MICROARCH.md, WRITE_SIZE as reported)")
         if dom_flops / max(dom_bytes, 1) > MFMA_F32_PEAK_TFLOPS * 1e12 / (HBM_PEAK_GBS * 1e9):   # above the fp32 ridge
@@ -1027,7 +1034,7 @@ def main():
                        "launch_tape_replays": fwd_replays, "parallelism": "dp%d (frames sharded, no forward collective)" % world,
                        "world": world, "dist_world_size": dist.get_world_size() if world > 1 else 1, "device": str(device)},
             "roofline": roof,
-            "whole_pass": whole_pass(args, timer, elapsed / args.steps, bpt),
+            "whole_pass": whole_pass(args, timer, elapsed / args.steps, bpt, live_step_bytes),
         }
         if with_loader:
             out["forward_including_loader"] = with_loader
