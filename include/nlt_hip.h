@@ -702,6 +702,36 @@ int nlt_conv_forward_splitk(int mode, int tile_hint, int ksplit, float* workspac
                             const float* mask_src, int ldm, int accumulate, void* stream);
 
 /*
+ * The reference's INFERENCE mode: Model.call(batch, 'test', obs_override=feat_agg) (nlt/nlt_test.py:78-94,
+ * nlt/models/nlt.py:154-155,172-174).  Every level's aggregated observation map is GIVEN -- one [1,h,w,C] map shared by all
+ * frames -- and concatenated behind the query features, so what it adds to the next conv's pre-activation,
+ * W[o rows] * ovr + b, is linear and frame-independent: the host evaluates it once per feat_agg (an "override map") and the
+ * per-frame convs read it where a bias would be added.
+ *
+ * nlt_conv_forward_map = nlt_conv_forward_splitk (MFMA path, optional split-K) with the per-output-texel bias map
+ * bias_map [map_frames, oh, ow, cout] (dense; map_frames = 1: shared by all n frames, or n) added next to `bias` before
+ * the activation:  out = act(conv(src0 | src1) + bias + bias_map).
+ */
+int nlt_conv_forward_map(int mode, int tile_hint, int ksplit, float* workspace,
+                         const float* src0, int ld0, int c0, const float* src1, int ld1, int c1,
+                         int n, int h, int w, const float* w_packed, const float* bias,
+                         int cout, float* out, int ldo, int act, float alpha,
+                         const float* bias_map, int map_frames, void* stream);
+
+/* Query-only fused front launch of that mode (csrc/front_ovr.hip): layers 0-1 of the query path and level 2's stride-2
+ * conv from the raw texel buffers base [n,h,w,3], cvis / lvis [n,h,w,1] (nlt/models/nlt.py:95) --
+ *   y1 = lrelu(fold(L0, L1.s2)[query rows] * raw5 + p1)          p1 [h/2,w/2,16]: L1.s2's observation rows * ovr0 + folded bias
+ *   q1 = lrelu(L1.s1 * y1 + b)                                   -> q1 [n,h/2,w/2,16], per-texel stride ldq
+ *   qtmp2 = lrelu(L2.s2[query rows] * q1 + p2)                   p2 [h/4,w/4,32]: L2.s2's observation rows * ovr1 + bias
+ *   skip3 = head[L0 query rows, folded] * raw5 + s0 (+ base)     s0 [h,w,4] (3 used): head's observation rows * ovr0 + folded bias
+ * `packed` = nlt_front_pack_weights with a ZERO observation L0 (its observation rows and bias terms then vanish),
+ * `packed_l2` = nlt_front_pack_l2_weights.  h, w multiples of 4; 0 <= alpha <= 1; 16-byte aligned arrays. */
+int nlt_front_ovr_forward(const float* base, const float* cvis, const float* lvis, int n, int h, int w,
+                          const float* packed, const float* packed_l2, const float* p1, const float* s0,
+                          const float* p2, int add_base, float alpha, float* q1, int ldq, float* skip3,
+                          float* qtmp2, void* stream);
+
+/*
  * Backward-data of one conv: the gradient w.r.t. the layer's input channels from the gradient w.r.t. its pre-activation
  * output dpre [n,h,w,cpre] (stride ldp), as the ADJOINT conv family on the same Keras array (CONV_K2Sx <-> DECONV_K2Sx;
  * w_packed = nlt_pack_conv_weights(adj_mode, slice of the forward kernel), zero_bias = cout zeros), MFMA path, optional

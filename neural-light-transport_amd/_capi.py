@@ -107,6 +107,10 @@ SIGNATURES = {
     'nlt_conv_forward_splitk': (_c_int, [_c_int, _c_int, _c_int, _vp, _vp, _c_int, _c_int, _vp, _c_int, _c_int,
                                          _c_int, _c_int, _c_int, _vp, _vp, _c_int, _vp, _c_int, _c_int, _c_float,
                                          _vp, _c_int, _c_int, _vp]),
+    'nlt_conv_forward_map': (_c_int, [_c_int, _c_int, _c_int, _vp, _vp, _c_int, _c_int, _vp, _c_int, _c_int,
+                                      _c_int, _c_int, _c_int, _vp, _vp, _c_int, _vp, _c_int, _c_int, _c_float,
+                                      _vp, _c_int, _vp]),
+    'nlt_front_ovr_forward': (_c_int, [_vp] * 3 + [_c_int] * 3 + [_vp] * 5 + [_c_int, _c_float, _vp, _c_int, _vp, _vp, _vp]),
     'nlt_conv_backward_data': (_c_int, [_c_int, _c_int, _c_int, _vp, _vp, _c_int, _c_int, _c_int, _c_int, _c_int, _vp, _vp, _c_int,
                                         _vp, _c_int, _vp, _c_int, _c_float, _c_int, _c_int, _vp, _vp, _c_float, _c_int, _vp]),
     'nlt_conv_tile_packed_floats': (_c_long, [_c_int] * 4),
@@ -858,6 +862,27 @@ def conv_forward_splitk(mode, ksplit, src0, c0, ld0, src1, c1, ld1, n, h, w, w_p
                                          _ptr(mask_src), ldm, 1 if accumulate else 0, _stream()), 'nlt_conv_forward_splitk')
 
 
+def conv_forward_map(mode, ksplit, src0, c0, ld0, src1, c1, ld1, n, h, w, w_packed, bias, cout, out, ldo, bias_map,
+                     act=True, alpha=0.3, tile_hint=0, w_keras=None):
+    """out = act(conv(src0 | src1) + bias + bias_map): the per-frame half of a conv over concat(q, given observation map)
+    (include/nlt_hip.h: nlt_conv_forward_map).  bias_map [1 or n, oh, ow, cout] dense.  (w_keras is not read here; the host
+    tests' CPU emulation of this adapter computes from it.)"""
+    ws = None
+    if ksplit > 1:
+        need = lib().nlt_conv_splitk_workspace_floats(mode, n, h, w, cout, ksplit)
+        if need <= 0:
+            raise NLTError("nlt_conv_splitk_workspace_floats failed")
+        key = (str(src0.device), _stream(), getattr(_tls, 'scope', 0))
+        ws = _splitk_ws.get(key)
+        if ws is None or ws.numel() < need:
+            ws = torch.empty(need, device=src0.device, dtype=torch.float32)
+            _splitk_ws[key] = ws
+            _alloc_epoch[0] += 1
+    _check(lib().nlt_conv_forward_map(mode, tile_hint, ksplit, _ptr(ws), _ptr(src0), ld0, c0, _ptr(src1), ld1, c1, n, h, w,
+                                      _ptr(w_packed), _ptr(bias), cout, _ptr(out), ldo, 1 if act else 0, float(alpha),
+                                      _ptr(_dense(bias_map, 'bias_map')), bias_map.shape[0], _stream()), 'nlt_conv_forward_map')
+
+
 def conv_backward_data(adj_mode, dpre, cpre, ldp, n, h, w, w_packed, zero_bias, cout, out, ldo, mask_src=None, ldm=0,
                        mask_alpha=0.3, accumulate=False, tile_hint=0, ksplit=1, split=None, w_keras=None):
     """Gradient w.r.t. a conv's input channels (include/nlt_hip.h: nlt_conv_backward_data).  split = (c, obs_y, dobs,
@@ -1157,6 +1182,15 @@ def front4_forward_train(base, cvis, lvis, nn_rgb, nn_base, n, k, h, w, packed, 
     _check(lib().nlt_front4_forward_train(_ptr(base), _ptr(cvis), _ptr(lvis), _ptr(nn_rgb), _ptr(nn_base), n, k, h, w, _ptr(packed),
                                           _ptr(packed_l2), 1 if add_base else 0, float(alpha), _ptr(fm1), _ptr(skip3), _ptr(qtmp2),
                                           _ptr(otmp2), _ptr(obs1), _ptr(qtmp1), _ptr(otmp1), _stream()), 'nlt_front4_forward_train')
+
+
+def front_ovr_forward(base, cvis, lvis, n, h, w, packed, packed_l2, p1, s0, p2, add_base, alpha, q1, ldq, skip3, qtmp2):
+    """The query-only front launch of the reference's inference mode (include/nlt_hip.h: nlt_front_ovr_forward)."""
+    for t, nm in ((base, 'base'), (cvis, 'cvis'), (lvis, 'lvis'), (p1, 'p1'), (s0, 's0'), (p2, 'p2')):
+        _dense(t, nm)
+    _check(lib().nlt_front_ovr_forward(_ptr(base), _ptr(cvis), _ptr(lvis), n, h, w, _ptr(packed), _ptr(packed_l2), _ptr(p1),
+                                       _ptr(s0), _ptr(p2), 1 if add_base else 0, float(alpha), _ptr(q1), ldq, _ptr(skip3),
+                                       _ptr(qtmp2), _stream()), 'nlt_front_ovr_forward')
 
 
 def dec_block_forward(x, cx, skip, cs, n, h, w, w_s2, b_s2, w_s1, b_s1, c, alpha, out):

@@ -63,6 +63,22 @@ extern "C" int nlt_conv_forward_splitk(int mode, int tile_hint, int ksplit, floa
   return nlt_conv_mfma_launch(mode, p, tile_hint, static_cast<hipStream_t>(stream), ksplit, workspace);
 }
 
+extern "C" int nlt_conv_forward_map(int mode, int tile_hint, int ksplit, float* workspace,
+                                    const float* src0, int ld0, int c0, const float* src1, int ld1, int c1,
+                                    int n, int h, int w, const float* w_packed, const float* bias,
+                                    int cout, float* out, int ldo, int act, float alpha,
+                                    const float* bias_map, int map_frames, void* stream) {
+  if (ksplit < 1 || (ksplit > 1 && (!workspace || !nlt_aligned16(workspace)))) return NLT_ERR_BAD_ARG;
+  if (!bias_map || !nlt_aligned16(bias_map) || (map_frames != 1 && map_frames != n)) return NLT_ERR_BAD_ARG;
+  ConvP p;
+  const int st = nlt_fill_conv_params(p, mode, src0, ld0, c0, src1, ld1, c1, n, h, w, w_packed, bias, cout, out, ldo,
+                                      act, alpha, nullptr, 0, 0);
+  if (st != NLT_OK) return st;
+  p.bmap = bias_map;
+  p.bmap_mod = map_frames == 1 ? p.oh * p.ow : 0;
+  return nlt_conv_mfma_launch(mode, p, tile_hint, static_cast<hipStream_t>(stream), ksplit, workspace);
+}
+
 extern "C" int nlt_conv_backward_data(int adj_mode, int tile_hint, int ksplit, float* workspace,
                                       const float* dpre, int ldp, int cpre, int n, int h, int w,
                                       const float* w_packed, const float* zero_bias, int cout, float* out, int ldo,

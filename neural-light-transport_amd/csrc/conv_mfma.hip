@@ -213,6 +213,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvP p, int mtiles, int
       int otex = rm[rt];
       if (MODE == NLT_DECONV_K2S2) otex = (rf[rt] * p.oh + 2 * ry[rt] + (ab >> 1)) * p.ow + 2 * rx[rt] + (ab & 1);
       f32x4 v = acc[rt][ct] + bv;
+      if (p.bmap) v += *reinterpret_cast<const f32x4*>(p.bmap + (size_t)(p.bmap_mod ? otex % p.bmap_mod : otex) * p.cout + oc);
       f32x4* o = reinterpret_cast<f32x4*>(p.out + (size_t)otex * p.ldo + oc);
       if (p.accumulate) v += *o;
       if (p.split_c && oc >= p.split_c) { split_store(p, otex, oc, v); continue; }
@@ -240,6 +241,7 @@ __device__ __forceinline__ void splitk_finish(const ConvP& p, int m, int ncol, f
     otex = (f * p.oh + 2 * y + (ab >> 1)) * p.ow + 2 * x + (ab & 1);
   }
   v += *reinterpret_cast<const f32x4*>(p.bias + oc);
+  if (p.bmap) v += *reinterpret_cast<const f32x4*>(p.bmap + (size_t)(p.bmap_mod ? otex % p.bmap_mod : otex) * p.cout + oc);
   f32x4* o = reinterpret_cast<f32x4*>(p.out + (size_t)otex * p.ldo + oc);
   if (p.accumulate) v += *o;
   if (p.split_c && oc >= p.split_c) { split_store(p, otex, oc, v); return; }

@@ -1,0 +1,373 @@
+// Fused front kernel of the reference's INFERENCE mode (nlt/nlt_test.py:78-94 -> Model.call(obs_override=feat_agg),
+// nlt/models/nlt.py:154-155,172-173): the observation path is not run; every level's aggregated observation feature
+// map is GIVEN, one [1,h,w,C] map shared by all frames of the batch (and by all batches of a video).
+//
+// What the given maps contribute to a conv's pre-activation is linear and frame-independent:
+//   conv(concat(q, ovr)) = Wq * q + (Wo * ovr + b)
+// so the plan evaluates the bracket ONCE per feat_agg ("override maps", engine.RenderPlan._prepare_override) and the
+// per-frame pass reads it where a bias would be added.  This kernel is the query half of front4_kernel (front4.hip) with
+// no observation items: layers 0-1 of the query path (L0 folded into L1's stride-2 conv) and level 2's stride-2 conv from
+// the raw texel buffers,
+//   stage 1  y1 = lrelu(Wfold * raw5 + P1[texel])            P1 [h/2,w/2,16] = W_L1s2[o rows] * ovr0 + folded bias
+//   stage 2  q1 = lrelu(W_L1s1 * y1 + b)                     -> fm1[..., 0:16]  (the [16:32) half is the given ovr1)
+//   stage 3  qtmp2 = lrelu(W_L2s2[q rows] * q1 + P2[texel])  P2 [h/4,w/4,32] = W_L2s2[o rows] * ovr1 + bias
+//   skip3 = Wskip * raw5 + S0[texel] (+ base)                S0 [h,w,4]     = W_head[o rows] * ovr0 + folded bias
+// with the maps as the INITIAL VALUES of the MFMA accumulator chains (no add).  Same organisation as front4: persistent
+// 8-wave workgroups, a wave owns a 4 x 16 strip of level-1 texels, raw rows staged through wave-private LDS by 16-byte
+// row-contiguous loads, the next strip's raw rows and map values in flight in registers under the current strip's MFMAs,
+// no workgroup barrier after the prologue.
+#include "front_common.h"
+
+namespace {
+
+constexpr int SH = 4, SW = 16;
+constexpr int AH = SH + 1, AW = SW + 1;
+constexpr int AT = AH * AW;
+constexpr int NC = (AT + 15) / 16;         // 6 column tiles
+constexpr int SLOTS = NC * 16;
+constexpr int XH = 2 * AH;                 // raw rows: 10
+constexpr int R3 = 104, R1 = 40;           // floats per staged 3- / 1-channel raw row (34 texels)
+constexpr int W_RQ = 0;
+constexpr int W_RC = W_RQ + XH * R3;
+constexpr int W_RL = W_RC + XH * R1;
+constexpr int W_OT = W_RL + XH * R1;       // stage-1 tile [4 channel quads][96 slots][4]; then the level-1 tile of stage 3
+constexpr int W_END = W_OT + 4 * SLOTS * 4;            // 3376 floats per wave
+constexpr int W_AQ3 = 0;                   // workgroup-shared: level 2's query-row fragments [rt 2][c4 4][lane 64][4]
+constexpr int W_AQ1 = W_AQ3 + 2 * 4 * 64 * 4;          // stride-1 fragments [tap 4][lane 64][4]
+constexpr int W_BQ1 = W_AQ1 + 4 * 64 * 4;              // stride-1 bias [16]
+constexpr int W_WAVES = W_BQ1 + 16;
+
+template <int NW> constexpr int lds_floats() { return W_WAVES + NW * W_END; }
+
+__device__ __forceinline__ void wave_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f32x4 lrelu4m(f32x4 v, f32x2 alpha2) {   // front4.hip: max(v, alpha v) for 0 <= alpha <= 1
+  const f32x2 plo = (f32x2){v[0], v[1]} * alpha2, phi = (f32x2){v[2], v[3]} * alpha2;
+  const float top = 3.4028234663852886e38f;
+  return (f32x4){__builtin_amdgcn_fmed3f(v[0], plo[0], top), __builtin_amdgcn_fmed3f(v[1], plo[1], top),
+                 __builtin_amdgcn_fmed3f(v[2], phi[0], top), __builtin_amdgcn_fmed3f(v[3], phi[1], top)};
+}
+
+struct OvrMaps { const float *p1, *s0, *p2; };
+
+template <int NW>
+__global__ __launch_bounds__(64 * NW, 1) void front_ovr_kernel(
+    const float* __restrict__ base, const float* __restrict__ cvis, const float* __restrict__ lvis, int h, int w,
+    int tiles_y, int tiles_x, int ntiles, const float* __restrict__ blob, const float* __restrict__ blob3, OvrMaps maps,
+    int add_base, float alpha, float* __restrict__ q1, int ldq, float* __restrict__ skip3, float* __restrict__ qtmp2) {
+  __shared__ __attribute__((aligned(16))) float lds_all[lds_floats<NW>()];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int kk = lane >> 4, j = lane & 15;
+  const int h2 = h >> 1, w2 = w >> 1;
+  const long hw = (long)h * w;
+  const f32x4 zero4 = (f32x4){0.f, 0.f, 0.f, 0.f};
+  const f32x2 alpha2 = (f32x2){alpha, alpha};
+
+  // ---- level 2's query-row fragments (slab 0 of OFF3_AQ), the stride-1 fragments and bias: once per workgroup
+  for (int u = tid; u < 2 * 4 * 64; u += 64 * NW) {
+    const int rt = u >> 8, r = u & 255;                                  // r = c4 * 64 + lane
+    *reinterpret_cast<f32x4*>(lds_all + W_AQ3 + u * 4) = *reinterpret_cast<const f32x4*>(blob3 + OFF3_AQ + ((rt * 8) * 64 + r) * 4);
+  }
+  for (int u = tid; u < 256; u += 64 * NW)
+    *reinterpret_cast<f32x4*>(lds_all + W_AQ1 + u * 4) = *reinterpret_cast<const f32x4*>(blob + OFF_AQ1 + u * 4);
+  if (tid < 16) lds_all[W_BQ1 + tid] = blob[OFF_BQ1 + tid];
+  __syncthreads();
+
+  // ---- this wave's strips (front4.hip: one contiguous run of tiles per XCD, its waves round-robin)
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int per_xcd = (ntiles + 7) >> 3;
+  const int t_lo = (blockIdx.x & 7) * per_xcd;
+  const int t_hi = min(t_lo + per_xcd, ntiles);
+  const int stride = (gridDim.x >> 3) * NW;
+  int tile = t_lo + wv * (int)(gridDim.x >> 3) + (int)(blockIdx.x >> 3);
+  if (tile >= t_hi) return;
+  float* const lds = lds_all + W_WAVES + wv * W_END;
+
+  // ---- staging of the raw rows (float inputs): item = pass * 64 + lane -> (raw row, 16-byte piece of the row)
+  constexpr int N3 = 26, P3 = 5, N1 = 9, P1 = 2;
+  unsigned g3[P3], g1[P1];                                               // byte offsets inside a frame
+  int lf = 0;
+  auto opaque = [](int v) { asm volatile("" : "+v"(v)); return v; };
+  auto load_geom = [&](int t) {
+    const int tx0 = (t % tiles_x) * SW; t /= tiles_x;
+    const int ty0 = (t % tiles_y) * SH;
+    lf = t / tiles_y;
+    const int ln = opaque(lane);
+#pragma unroll
+    for (int p = 0; p < P3; ++p) {
+      const int item = p * 64 + ln;
+      const int r = item / N3, i = item - r * N3;
+      const int gy = 2 * ty0 + r;
+      const bool ok = item < XH * N3 && gy < h && 3 * (2 * tx0) + 4 * i < 3 * w;
+      g3[p] = ok ? (unsigned)((gy * w + 2 * tx0) * 3 + 4 * i) * 4u : 0u;
+    }
+#pragma unroll
+    for (int p = 0; p < P1; ++p) {
+      const int item = p * 64 + ln;
+      const int r = item / N1, i = item - r * N1;
+      const int gy = 2 * ty0 + r;
+      const bool ok = item < XH * N1 && gy < h && 2 * tx0 + 4 * i < w;
+      g1[p] = ok ? (unsigned)(gy * w + 2 * tx0 + 4 * i) * 4u : 0u;
+    }
+  };
+  f32x4 st[P3 + 2 * P1];
+  auto load_query = [&]() {
+    const long fr = lf;
+#pragma unroll
+    for (int p = 0; p < P3; ++p)
+      st[p] = *reinterpret_cast<const f32x4*>(reinterpret_cast<const unsigned char*>(base) + fr * hw * 12 + g3[p]);
+#pragma unroll
+    for (int p = 0; p < P1; ++p) {
+      st[P3 + p] = *reinterpret_cast<const f32x4*>(reinterpret_cast<const unsigned char*>(cvis) + fr * hw * 4 + g1[p]);
+      st[P3 + P1 + p] = *reinterpret_cast<const f32x4*>(reinterpret_cast<const unsigned char*>(lvis) + fr * hw * 4 + g1[p]);
+    }
+  };
+  auto store_query = [&]() {
+#pragma unroll
+    for (int p = 0; p < P3; ++p) {
+      const int item = p * 64 + lane;
+      if ((p + 1) * 64 > XH * N3 && item >= XH * N3) continue;
+      *reinterpret_cast<f32x4*>(lds + W_RQ + item * 4) = st[p];
+    }
+    const int ln = opaque(lane);
+#pragma unroll
+    for (int p = 0; p < P1; ++p) {
+      const int item = p * 64 + ln;
+      if ((p + 1) * 64 > XH * N1 && item >= XH * N1) continue;
+      const int r = item / N1, i = item - r * N1;
+      *reinterpret_cast<f32x4*>(lds + W_RC + r * R1 + 4 * i) = st[P3 + p];
+      *reinterpret_cast<f32x4*>(lds + W_RL + r * R1 + 4 * i) = st[P3 + P1 + p];
+    }
+  };
+
+  // ---- weights held in registers: the folded stage-1 rows of the five query channels (the three observation rows of
+  // the blob are zero: it was packed with a zero observation L0)
+  float aq2[5];
+#pragma unroll
+  for (int m = 0; m < 5; ++m) aq2[m] = blob[OFF_AQ2 + m * 64 + lane];
+
+  // ---- this lane's six stage-1 positions: haloed level-1 texel t = c * 16 + j, tap kk
+  int rd3[NC];
+  unsigned live_m = 0, own_m = 0;
+#pragma unroll
+  for (int c = 0; c < NC; ++c) {
+    const int t = c * 16 + j;
+    const bool live = t < AT;
+    const int hy = live ? t / AW : 0, hx = live ? t % AW : 0;
+    rd3[c] = (2 * hy + (kk >> 1)) * R3 + (2 * hx + (kk & 1)) * 3;
+    live_m |= (unsigned)live << c;
+    own_m |= (unsigned)(live && hy < SH && hx < SW) << c;
+  }
+  float* const ot = lds + W_OT;
+  const int Y = j >> 3, X = j & 7;
+  const int h4 = h2 >> 1, w4 = w2 >> 1;
+  const int l1_rd = ((kk & 1) * 32 + ((((2 * Y + (kk >> 1)) * 8) + X) ^ ((kk & 1) * 8))) * 4;
+  auto l1_wr = [&](int row) { return (kk * 64 + (j & 1) * 32 + (((row * 8) + (j >> 1)) ^ ((j & 1) * 8))) * 4; };
+
+  // ---- the override maps of a strip: P1 at the lane's six haloed level-1 texels, S0 at its six raw texels, P2 at its
+  // level-2 texel.  Texels beyond the image read the map's first texel: their results are masked / never stored.
+  f32x4 mp1[NC], ms0[NC], mp2[2];
+  auto load_maps = [&](int t) {
+    const int tx0 = (t % tiles_x) * SW; t /= tiles_x;
+    const int ty0 = (t % tiles_y) * SH;
+    const int jo = opaque(j);
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+      const int tt = c * 16 + jo;
+      const bool live = (live_m >> c) & 1;
+      const int hy = live ? tt / AW : 0, hx = live ? tt % AW : 0;
+      const int y1 = ty0 + hy, x1 = tx0 + hx;
+      const bool in1 = live && y1 < h2 && x1 < w2;
+      const unsigned o1 = in1 ? (unsigned)((y1 * w2 + x1) * 16 + 4 * kk) : 0u;
+      mp1[c] = *reinterpret_cast<const f32x4*>(maps.p1 + o1);
+      const bool own = in1 && hy < SH && hx < SW;
+      const unsigned o0 = own ? (unsigned)(((2 * y1 + (kk >> 1)) * w + 2 * x1 + (kk & 1)) * 4) : 0u;
+      ms0[c] = *reinterpret_cast<const f32x4*>(maps.s0 + o0);
+    }
+    const int gy2 = (ty0 >> 1) + Y, gx2 = (tx0 >> 1) + X;
+    const unsigned o2 = (gy2 < h4 && gx2 < w4) ? (unsigned)((gy2 * w4 + gx2) * 32 + 4 * kk) : 0u;
+    mp2[0] = *reinterpret_cast<const f32x4*>(maps.p2 + o2);
+    mp2[1] = *reinterpret_cast<const f32x4*>(maps.p2 + o2 + 16);
+  };
+
+  auto stage2 = [&](f32x4 (&out)[SH]) {
+    const float* tilep = ot + kk * SLOTS * 4;
+    const f32x4 bias = *reinterpret_cast<const f32x4*>(lds_all + W_BQ1 + 4 * kk);
+    f32x4 acc[SH] = {bias, bias, bias, bias};
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const f32x4 a = *reinterpret_cast<const f32x4*>(lds_all + W_AQ1 + (t * 64 + lane) * 4);
+      f32x4 b[SH];
+#pragma unroll
+      for (int r = 0; r < SH; ++r) b[r] = *reinterpret_cast<const f32x4*>(tilep + ((r + (t >> 1)) * AW + j + (t & 1)) * 4);
+#pragma unroll
+      for (int s4 = 0; s4 < 4; ++s4)
+#pragma unroll
+        for (int r = 0; r < SH; ++r) acc[r] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s4], b[r][s4], acc[r], 0, 0, 0);
+    }
+#pragma unroll
+    for (int r = 0; r < SH; ++r) out[r] = lrelu4m(acc[r], alpha2);
+  };
+
+  // ---- prologue: the first strip's raw rows into LDS and its maps into registers, the second strip's raw rows in flight
+  load_geom(tile);
+  load_query();
+  load_maps(tile);
+  store_query();
+  if (tile + stride < t_hi) { load_geom(tile + stride); load_query(); }
+  wave_sync();
+
+  float wsk[15];                                                         // wave-uniform: scalar loads
+#pragma unroll
+  for (int rr = 0; rr < 15; ++rr) wsk[rr] = blob[OFF_WSK + rr];
+
+  for (;;) {
+    int tt = tile;
+    const int tx0 = (tt % tiles_x) * SW; tt /= tiles_x;
+    const int ty0 = (tt % tiles_y) * SH;
+    const int f = tt / tiles_y;
+    const int next = tile + stride;
+    const bool has_next = next < t_hi;
+    const bool interior = ty0 + AH <= h2 && tx0 + AW <= w2;
+    unsigned inside_m = live_m, owned_m = own_m;
+    if (!interior) {
+      inside_m = owned_m = 0;
+      const int jo = opaque(j);
+#pragma unroll
+      for (int c = 0; c < NC; ++c) {
+        const int t = c * 16 + jo;
+        const bool live = (live_m >> c) & 1;
+        const int hy = live ? t / AW : 0, hx = live ? t % AW : 0;
+        const bool inside = live && ty0 + hy < h2 && tx0 + hx < w2;
+        inside_m |= (unsigned)inside << c;
+        owned_m |= (unsigned)(inside && hy < SH && hx < SW) << c;
+      }
+    }
+    const int gy2 = (ty0 >> 1) + Y, gx2 = (tx0 >> 1) + X;
+    const bool in2 = gy2 < h4 && gx2 < w4;
+    const long tex2 = (long)gy2 * w4 + gx2;
+    const f32x4 p2a = mp2[0], p2b = mp2[1];                              // (mp2 is refilled for the next strip below)
+
+    // ---- stage 1 (5 MFMAs per column tile) + the head's share of the L0 features
+    const int jq = opaque(j);
+#pragma unroll
+    for (int c0 = 0; c0 < NC; c0 += 3) {
+      f32x4 acc[3] = {mp1[c0], mp1[c0 + 1], mp1[c0 + 2]};
+      float raw[3][5];
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        const float* s = lds + W_RQ + rd3[c0 + c];
+        raw[c][0] = s[0]; raw[c][1] = s[1]; raw[c][2] = s[2];
+        const int t = (c0 + c) * 16 + jq;
+        const bool live = (live_m >> (c0 + c)) & 1;
+        const int hy = live ? t / AW : 0, hx = live ? t % AW : 0;
+        const int o1c = (2 * hy + (kk >> 1)) * R1 + 2 * hx + (kk & 1);
+        raw[c][3] = lds[W_RC + o1c]; raw[c][4] = lds[W_RL + o1c];
+      }
+#pragma unroll
+      for (int m = 0; m < 5; ++m)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) acc[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(aq2[m], raw[c][m], acc[c], 0, 0, 0);
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        f32x4 v = lrelu4m(acc[c], alpha2);
+        if (!interior) {
+          asm volatile("" ::: "memory");
+          if (!((inside_m >> (c0 + c)) & 1)) v = zero4;
+        }
+        *reinterpret_cast<f32x4*>(ot + (kk * SLOTS + (c0 + c) * 16 + j) * 4) = v;
+        if ((owned_m >> (c0 + c)) & 1) {
+          float s0 = ms0[c0 + c][0], s1 = ms0[c0 + c][1], s2 = ms0[c0 + c][2];
+#pragma unroll
+          for (int rr = 0; rr < 5; ++rr) {
+            s0 = fmaf(raw[c][rr], wsk[rr * 3], s0);
+            s1 = fmaf(raw[c][rr], wsk[rr * 3 + 1], s1);
+            s2 = fmaf(raw[c][rr], wsk[rr * 3 + 2], s2);
+          }
+          if (add_base) { s0 += raw[c][0]; s1 += raw[c][1]; s2 += raw[c][2]; }
+          const int t = (c0 + c) * 16 + jq;
+          float* sk = skip3 + ((long)f * hw + (long)(2 * (ty0 + t / AW) + (kk >> 1)) * w + 2 * (tx0 + t % AW) + (kk & 1)) * 3;
+          sk[0] = s0; sk[1] = s1; sk[2] = s2;
+        }
+      }
+    }
+    wave_sync();                                                         // every lane has its raw values: the raw tile is free
+    if (has_next) {                                                      // next strip: raw rows to LDS, maps requested;
+      store_query();                                                     // the strip after it: raw rows requested
+      load_maps(next);
+      if (next + stride < t_hi) { load_geom(next + stride); load_query(); }
+    }
+    // ---- stage 2: L1 stride-1 conv
+    f32x4 qv[SH];
+    stage2(qv);
+    {
+      const long hw2 = (long)h2 * w2;
+      const int gx = tx0 + j;
+#pragma unroll
+      for (int r = 0; r < SH; ++r)
+        if (ty0 + r < h2 && gx < w2)
+          *reinterpret_cast<f32x4*>(q1 + ((long)f * hw2 + (long)(ty0 + r) * w2 + gx) * ldq + 4 * kk) = qv[r];
+    }
+    wave_sync();                                                         // stage-2 reads of `ot` are done: it becomes the level-1 tile
+    // ---- stage 3: level 2's stride-2 conv, query rows only
+#pragma unroll
+    for (int r = 0; r < SH; ++r) *reinterpret_cast<f32x4*>(ot + l1_wr(r)) = qv[r];
+    wave_sync();
+    {
+      f32x4 a3[2] = {p2a, p2b};
+#pragma unroll
+      for (int c4 = 0; c4 < 4; ++c4) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(ot + c4 * 256 + l1_rd);
+        const f32x4 w0 = *reinterpret_cast<const f32x4*>(lds_all + W_AQ3 + ((0 * 4 + c4) * 64 + lane) * 4);
+        const f32x4 w1 = *reinterpret_cast<const f32x4*>(lds_all + W_AQ3 + ((1 * 4 + c4) * 64 + lane) * 4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          a3[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(w0[e], v[e], a3[0], 0, 0, 0);
+          a3[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(w1[e], v[e], a3[1], 0, 0, 0);
+        }
+      }
+      if (in2) {
+        float* o = qtmp2 + ((long)f * h4 * w4 + tex2) * 32 + 4 * kk;
+        *reinterpret_cast<f32x4*>(o) = lrelu4m(a3[0], alpha2);
+        *reinterpret_cast<f32x4*>(o + 16) = lrelu4m(a3[1], alpha2);
+      }
+    }
+    wave_sync();                                                         // the level-1 tile is consumed: `ot` is free again
+    if (!has_next) break;
+    tile = next;
+  }
+}
+
+}  // namespace
+
+extern "C" int nlt_front_ovr_forward(const float* base, const float* cvis, const float* lvis, int n, int h, int w,
+                                     const float* packed, const float* packed_l2, const float* p1, const float* s0,
+                                     const float* p2, int add_base, float alpha, float* q1, int ldq, float* skip3,
+                                     float* qtmp2, void* stream) {
+  if (!base || !cvis || !lvis || !packed || !packed_l2 || !p1 || !s0 || !p2 || !q1 || !skip3 || !qtmp2) return NLT_ERR_BAD_ARG;
+  if (n <= 0 || h <= 0 || w <= 0 || ldq < 16 || (ldq & 3)) return NLT_ERR_BAD_ARG;
+  if ((h | w) & 3) return NLT_ERR_UNSUPPORTED;
+  if (!(alpha >= 0.f && alpha <= 1.f)) return NLT_ERR_UNSUPPORTED;
+  if (!nlt_aligned16(packed) || !nlt_aligned16(packed_l2) || !nlt_aligned16(q1) || !nlt_aligned16(qtmp2) || !nlt_aligned16(p1) ||
+      !nlt_aligned16(s0) || !nlt_aligned16(p2))
+    return NLT_ERR_BAD_ARG;
+  if (!nlt_aligned16(base) || !nlt_aligned16(cvis) || !nlt_aligned16(lvis)) return NLT_ERR_UNSUPPORTED;
+  if ((long long)n * h * w * 3 >= (1ll << 31) || (long long)h * w * 16 >= (1ll << 31)) return NLT_ERR_UNSUPPORTED;
+  const int ty = (h / 2 + SH - 1) / SH, tx = (w / 2 + SW - 1) / SW;
+  const long tiles = (long)n * ty * tx;
+  if (tiles >= (1l << 31)) return NLT_ERR_UNSUPPORTED;
+  constexpr int NW = 8;
+  const long per_xcd = (tiles + 7) / 8;
+  long groups = per_xcd;
+  if (groups > 32) groups = 32;
+  OvrMaps maps = {p1, s0, p2};
+  hipLaunchKernelGGL(front_ovr_kernel<NW>, dim3((unsigned)(8 * groups)), dim3(64 * NW), 0, static_cast<hipStream_t>(stream),
+                     base, cvis, lvis, h, w, ty, tx, (int)tiles, packed, packed_l2, maps, add_base, alpha, q1, ldq, skip3, qtmp2);
+  NLT_CHECK_LAUNCH();
+  return NLT_OK;
+}

@@ -52,6 +52,11 @@ struct ConvP {
   float split_alpha;
   const float* split_y;
   float* split_d;
+  // nlt_conv_forward_map only: a per-OUTPUT-texel bias map [bmap_frames, oh, ow, cout] added to the pre-activation next to
+  // `bias` (the frame-independent half of a conv over concat(q, given map): nlt/models/nlt.py:172-174 with obs_override);
+  // bmap_mod = oh * ow when one map serves every frame (output texel index modulo it), 0 when there is one per frame.
+  const float* bmap;
+  int bmap_mod;
 };
 
 template <int MODE> struct ConvTraits;
@@ -90,6 +95,7 @@ static inline int nlt_fill_conv_params(ConvP& p, int mode, const float* src0, in
   p.n = n; p.h = h; p.w = w; p.c0 = c0; p.c1 = c1; p.ld0 = ld0; p.ld1 = ld1;
   p.cout = cout; p.ldo = ldo; p.ldm = ldm; p.act = act; p.accumulate = accumulate; p.alpha = alpha;
   p.split_c = 0; p.split_partial = 0; p.split_alpha = 0.f; p.split_y = nullptr; p.split_d = nullptr;
+  p.bmap = nullptr; p.bmap_mod = 0;
   p.gh = h; p.gw = w; p.oh = h; p.ow = w; p.N = cout;
   if (mode == NLT_CONV_K2S2) { p.gh = p.oh = h / 2; p.gw = p.ow = w / 2; }
   if (mode == NLT_DECONV_K2S2) { p.oh = 2 * h; p.ow = 2 * w; p.N = 4 * cout; }

@@ -19,6 +19,7 @@ import os
 import torch
 
 from . import _capi as C
+from .engine_infer import OverrideMixin
 
 
 class OpTimer:
@@ -47,7 +48,7 @@ class OpTimer:
         return self.records
 
 
-class RenderPlan:
+class RenderPlan(OverrideMixin):
     def __init__(self, net_query, net_obs, use_obs=True):
         self.timer = None               # set to an OpTimer (or a set of labels via timer.only) to time launches
         self.q, self.o, self.use_obs = net_query, net_obs, use_obs
@@ -56,6 +57,10 @@ class RenderPlan:
         self.autotune = os.environ.get('NLT_AUTOTUNE', '1') != '0'
         self.fuse_ends = os.environ.get('NLT_FUSED', '1') != '0'   # inference: csrc/fused.hip for layers 0-1 and the last block + head
         self._front_blob = None
+        # inference with obs_override = one map per level shared by all frames (nlt_test.infer): the fused query-only plan of
+        # engine_infer.py (0: the general layer-by-layer plan, which also serves per-frame override maps)
+        self.fuse_override = os.environ.get('NLT_FUSED_OVERRIDE', '1') != '0'
+        self._ovr = None                # override maps + derived convs of the feat_agg seen last (engine_infer.py)
         self.front_l2 = os.environ.get('NLT_FRONT_L2', '1') != '0'      # front kernel also runs level 2's stride-2 convs (k <= 4)
         # inference: expanding blocks with 8 / 16 output channels as ONE launch each (csrc/dec_block.hip: intermediate map in LDS)
         self.fuse_dec = os.environ.get('NLT_FUSED_DEC', '1') != '0'
@@ -172,6 +177,10 @@ class RenderPlan:
         self._bufs = {key: b}           # keep one shape resident
         return b
 
+    def _level_channels(self):
+        q = self.q
+        return [q.layers[0].n_ch_out] + [q.layers[l].convs()[0][0].n_ch_out for l in range(1, self.n_down + 1)]
+
     def _launch(self, label, nbytes, fn, *args, flops=0, moved=None, **kw):
         t = self.timer
         if t is not None:
@@ -183,7 +192,8 @@ class RenderPlan:
         else:
             fn(*args, **kw)
 
-    def _conv(self, label, layer, act, src0, c0, ld0, src1, c1, ld1, n, h, w, out, ldo, algo=C.ALGO_AUTO):
+    def _conv(self, label, layer, act, src0, c0, ld0, src1, c1, ld1, n, h, w, out, ldo, algo=C.ALGO_AUTO, bmap=None):
+        """bmap: per-output-texel bias map [1 | n, oh, ow, cout] added before the activation (engine_infer.py; MFMA path only)."""
         layer.build(c0 + c1, src0.device)
         assert layer.cin == c0 + c1, (layer.cin, c0, c1)
         small = (c0 + c1) * layer.n_ch_out <= 1024
@@ -209,6 +219,15 @@ class RenderPlan:
             waves = -(-rows // (16 * rt)) * (-(-ncols // 16) // ct)
             npad = -(-ncols // 16) * 16
             ks = self._trial_splitk if (waves < 4096 and rows * npad * self._trial_splitk <= (1 << 24)) else 1
+        if bmap is not None:
+            if not ok:
+                raise C.NLTError("a bias-map conv needs channel counts that are multiples of 4 (%s)" % label)
+            if ks > 1:
+                self._ran_splitk.add(label)
+            self._launch(label, nbytes, C.conv_forward_map, layer.mode, max(ks, 1), src0, c0, ld0, src1, c1, ld1, n, h, w,
+                         layer.packed(c0, c1), layer.bias.detach(), layer.n_ch_out, out, ldo, bmap, act=act is not None,
+                         alpha=act.alpha if act is not None else 0.0, tile_hint=tile_hint, w_keras=layer.kernel.detach(), flops=flops)
+            return
         if ks > 1 and ok:
             self._ran_splitk.add(label)
             self._launch(label, nbytes, C.conv_forward_splitk, layer.mode, ks, src0, c0, ld0, src1, c1, ld1, n, h, w,
@@ -513,7 +532,10 @@ class RenderPlan:
         n, h, w, _ = base.shape
         k = nn_rgb.shape[1]
         dev = base.device
-        b = self._buffers(n, k, h, w, dev)
+        # the reference's inference mode (one given map per level for every frame): the fused query-only plan, no observation buffers
+        use_ovr = (obs_override is not None and inference and obs_weights is None
+                   and self.can_fuse_override(self._level_channels(), obs_override, h, w, (base, cvis, lvis)))
+        b = self._buffers(n, 0 if use_ovr else k, h, w, dev)
         if not self._tuning:
             self.generation += 1
         reg = getattr(self.q.layers[0], '_registry', None)
@@ -521,24 +543,26 @@ class RenderPlan:
             if not self._tuning:
                 reg.tick()
             reg.refresh_if_stale()          # all packed fragments, one launch, before any stream is forked
-        fused = (inference or self.fuse_train) and self.can_fuse(b, obs_weights, obs_override)
+        ovr = self._prepare_override(b, obs_override, dev) if use_ovr else None
+        fused = not use_ovr and (inference or self.fuse_train) and self.can_fuse(b, obs_weights, obs_override)
         if fused and not inference and w % 8:                           # the training ends: w/2 in groups of 4 texels
             fused = False
         b['train_fused'] = fused and not inference
-        tuned_key = ('tuned_fused' if inference else 'tuned_train') if fused else 'tuned'
+        tuned_key = 'tuned_ovr' if use_ovr else (('tuned_fused' if inference else 'tuned_train') if fused else 'tuned')
         if self.autotune and not b.get(tuned_key) and base.is_cuda:
             b[tuned_key] = True
             self._autotune(lambda: self.forward(base, cvis, lvis, nn_rgb, nn_base, obs_weights, obs_override,
                                                 skip_connect_base, algo, inference, pred_out=pred_out))
         # launch tape (second sight of the same inputs records, later sights replay)
-        if fused:
+        if fused or use_ovr:
             self._front_weights(dev, l2=inference or self.front4_train)   # folded front-kernel weights, refreshed in place OUTSIDE any tape
         tkey = None
         if (self.use_tape and base.is_cuda and self.timer is None and not self._tuning and reg is not None
-                and obs_weights is None and obs_override is None
+                and obs_weights is None and (obs_override is None or use_ovr)
                 and all(t.is_contiguous() for t in (base, cvis, lvis, nn_rgb, nn_base))):    # (a replay skips the adapters' layout checks)
             tkey = ('fwd', base.data_ptr(), cvis.data_ptr(), lvis.data_ptr(), nn_rgb.data_ptr(), nn_base.data_ptr(),
-                    bool(skip_connect_base), algo, inference, fused, C._stream(), pred_out is not None, self.decoder_hook is not None)
+                    bool(skip_connect_base), algo, inference, fused, C._stream(), pred_out is not None, self.decoder_hook is not None,
+                    ovr['serial'] if use_ovr else 0)
             tapes = b.setdefault('tapes', {})
             if len(tapes) > 16:                     # ever-changing input addresses (a loader that allocates per step): forget
                 tapes.clear()
@@ -554,14 +578,14 @@ class RenderPlan:
                 C.tape_begin()
                 try:
                     out = self._forward_body(b, base, cvis, lvis, nn_rgb, nn_base, obs_weights, obs_override, skip_connect_base,
-                                             algo, fused, inference)
+                                             algo, fused, inference, ovr)
                 except BaseException:
                     C.tape_abort()
                     raise
                 tapes[tkey] = C.tape_end(reg.version) or 1  # (None: a workspace grew while recording -> record again)
                 return out
         return self._forward_body(b, base, cvis, lvis, nn_rgb, nn_base, obs_weights, obs_override, skip_connect_base, algo,
-                                  fused, inference)
+                                  fused, inference, ovr)
 
     def _forward_resident(self, res, skip_connect_base, algo):
         """Inference forward whose inputs are still in the resident uint8 store: same plan, the front launch is
@@ -610,7 +634,9 @@ class RenderPlan:
         return self._forward_fused(b, None, None, None, None, None, skip_connect_base, algo, resident=res)
 
     def _forward_body(self, b, base, cvis, lvis, nn_rgb, nn_base, obs_weights, obs_override, skip_connect_base, algo, fused,
-                      inference):
+                      inference, ovr=None):
+        if ovr is not None:
+            return self._forward_ovr(b, base, cvis, lvis, ovr, skip_connect_base, algo)
         n, h, w, _ = base.shape
         k = nn_rgb.shape[1]
         dev = base.device

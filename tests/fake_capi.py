@@ -613,7 +613,33 @@ def front4_forward_u8(diffuse_store, rgb_store, cvis_store, lvis_store, ids, nn_
                    qtmp2, otmp2)
 
 
-_FUSED = _FUSED + ('front_pack_l2_weights', 'front2_forward', 'front4_supported', 'front4_forward', 'front4_forward_u8', 'front4_forward_train', 'dec_block_forward', 'act_forward', 'act_backward',
+def conv_forward_map(mode, ksplit, src0, c0, ld0, src1, c1, ld1, n, h, w, w_packed, bias, cout, out, ldo, bias_map,
+                     act=True, alpha=0.3, tile_hint=0, w_keras=None):
+    x = _view(src0, n, h, w, c0, ld0)
+    if c1:
+        x = torch.cat((x, _view(src1, n, h, w, c1, ld1)), -1)
+    s, tr = _MODES[mode]
+    y = (T.conv2d_transpose_same if tr else T.conv2d_same)(x, w_keras, bias[:cout], s) + bias_map
+    if act:
+        y = T.leaky_relu(y, alpha)
+    _view(out, n, y.shape[1], y.shape[2], cout, ldo).copy_(y)
+
+
+def front_ovr_forward(base, cvis, lvis, n, h, w, P, P2, p1, s0, p2, add_base, alpha, q1, ldq, skip3, qtmp2):
+    """Layer-by-layer evaluation of csrc/front_ovr.hip: the query rows of L0 -> L1 -> L2's stride-2 conv, the given maps'
+    share (and every bias upstream of an activation) arriving through p1 / s0 / p2."""
+    lr = lambda x: T.leaky_relu(x, alpha)
+    z = lambda c: torch.zeros(c)
+    q0 = torch.cat((base, cvis, lvis), -1) @ P['wq0'][0, 0]                  # (L0's bias lives in the maps)
+    y1 = lr(T.conv2d_same(q0, P['wqa'][:, :, :16, :].contiguous(), z(16), 2) + p1)
+    v = lr(T.conv2d_same(y1, P['wqb'], P['bqb'], 1))
+    _view(q1, n, h // 2, w // 2, 16, ldq).copy_(v)
+    qtmp2.copy_(lr(T.conv2d_same(v, P2['wq'][:, :, :16, :].contiguous(), z(32), 2) + p2))
+    sk = q0 @ P['wh'][0, 0, 4:20, :] + s0[..., :3]
+    skip3.copy_(sk + base if add_base else sk)
+
+
+_FUSED = _FUSED + ('conv_forward_map', 'front_ovr_forward', 'front_pack_l2_weights', 'front2_forward', 'front4_supported', 'front4_forward', 'front4_forward_u8', 'front4_forward_train', 'dec_block_forward', 'act_forward', 'act_backward',
                   'pixelnorm_forward', 'pixelnorm_backward', 'norm_forward', 'norm_backward', 'pool2x2_forward', 'pool2x2_backward', 'sub_forward', 'finish_pred')
 
 

@@ -276,6 +276,60 @@ def test_nlt_test_orchestration_extract_feat_and_infer(monkeypatch):
         nlt_test.extract_feat(pm, [])
 
 
+@pytest.mark.parametrize('depth,uv,n', [(256, 64, 2), (1024, 256, 1), (64, 32, 3)])
+def test_fused_override_plan_matches_oracle_and_the_general_plan(monkeypatch, depth, uv, n):
+    """engine_infer.py: Model.call(obs_override = one map per level) on the fused query-only plan -- override maps, derived
+    query-row convs, bottleneck self-concat folded into one kernel -- against the oracle's `_call(obs_override=...)` and against
+    the layer-by-layer plan; a per-frame override (a real [N, ...] tensor) must keep taking the general plan."""
+    fake_capi.install(monkeypatch)
+    from nlt_amd.engine import OpTimer
+
+    class Rec(OpTimer):
+        def launch(self, label, nbytes, fn, *a, **kw):
+            self.records[label] = [1, 0.0, nbytes]
+            fn(*a, **kw)
+    om, pm = make(depth, uv, 32)
+    batch, nn = O.synth_batch(n, uv, uv, 32, 32, 32, 32, k=1, seed=60)
+    x = torch.cat((batch[1], batch[2], batch[3]), 3)
+    with torch.no_grad():
+        _, feats = om._call(x, [r - b for b, r in nn], return_feats=True)
+        agg = [f.mean(0, keepdim=True) * 1.7 + 0.05 for f in feats]
+        ref = om.call(batch, 'test', obs_override=[f.expand(n, -1, -1, -1) for f in agg], nn_list=nn)
+    pm.plan.timer = Rec()
+    got = pm.call(cpu_batch(batch, nn), 'test', obs_override=agg)
+    recs = set(pm.plan.timer.records)
+    assert 'F.front' in recs and 'F.back' in recs and 'V3.q.s2' in recs and not any('.o.' in l or l == 'L0.stem' for l in recs)
+    assert rel_l2(got[3]['pred'], ref[3]['pred']) < 1e-5 and rel_l2(got[0], ref[0]) < 1e-5
+    # an expand()ed view is the same thing; a materialised per-frame override is not
+    pm.plan.timer = Rec()
+    got2 = pm.call(cpu_batch(batch, nn), 'test', obs_override=[f.expand(n, -1, -1, -1) for f in agg])
+    assert torch.equal(got2[3]['pred'], got[3]['pred']) or n == 1
+    pm.plan.timer = Rec()
+    per_frame = [f.repeat(n, 1, 1, 1) * torch.linspace(1.0, 1.5, n).view(n, 1, 1, 1) for f in agg]
+    with torch.no_grad():
+        ref3 = om.call(batch, 'test', obs_override=per_frame, nn_list=nn)
+    got3 = pm.call(cpu_batch(batch, nn), 'test', obs_override=per_frame)
+    assert 'F.front' not in pm.plan.timer.records or n == 1
+    assert rel_l2(got3[3]['pred'], ref3[3]['pred']) < 1e-5
+    # the general plan on the shared maps (NLT_FUSED_OVERRIDE=0) agrees with the fused one
+    pm.plan.fuse_override = False
+    pm.plan.timer = Rec()
+    gen = pm.call(cpu_batch(batch, nn), 'test', obs_override=agg)
+    assert 'F.front' not in pm.plan.timer.records
+    assert rel_l2(gen[3]['pred'], got[3]['pred']) < 1e-5
+    # new weights -> new maps
+    pm.plan.fuse_override = True
+    pm.plan.timer = None
+    serial = pm.plan._ovr['serial']
+    head = pm.net['query'].layers[-1]
+    head.kernel = head.kernel * 1.25
+    got4 = pm.call(cpu_batch(batch, nn), 'test', obs_override=agg)
+    assert pm.plan._ovr['serial'] != serial
+    pm.plan.fuse_override = False
+    gen4 = pm.call(cpu_batch(batch, nn), 'test', obs_override=agg)
+    assert rel_l2(got4[3]['pred'], gen4[3]['pred']) < 1e-5 and rel_l2(got4[3]['pred'], got[3]['pred']) > 1e-3
+
+
 def test_render_pipeline_lane_bookkeeping_on_the_host(monkeypatch):
     """pipeline.RenderPipeline without a GPU (lanes are a launch-scheduling matter; on CPU tensors every lane just calls):
     batches go round-robin to lanes, a lane is the model's render state only (own plan, shared nets / weights), the
