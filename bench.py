@@ -710,6 +710,99 @@ def bench_released_shapes(args, device, world, rank):
     return out
 
 
+def bench_infer_mode(args, device):
+    """Sub-line `nlt_test_infer`: the reference's own way of rendering a test set (nlt/nlt_test.py:78-127) -- `extract_feat`
+    averages every level's observation features over the training frames once, `infer` then calls
+    `Model.call(batch, 'test', obs_override=feat_agg)` per batch -- on the fused query-only plan (engine_infer.py,
+    csrc/front_ovr.hip), at BASELINE config 3's UV size and config 2's, 4 frames per batch like the released configs,
+    feat_agg from 8 training frames.  One step = one Model.call (network + UV -> camera warp) over one of three rotating
+    batches resident in HBM; fp32 (every product on v_mfma_f32).  Beside it the general layer-by-layer plan on the same
+    inputs (what rounds 1-5 ran for this mode) and two batches in flight."""
+    import torch
+    import nlt_amd
+    from nlt_amd import nlt_test
+    from nlt_amd.engine import OpTimer
+    from nlt_amd.models import get_model_class
+    out = {"what": "nlt_test.extract_feat + nlt_test.infer: Model.call(batch, 'test', obs_override=feat_agg), 4 frames per batch, "
+                   "feat_agg from 8 training frames, fp32"}
+    for name, uv, cam in (("uv1024_cam512", 1024, 512), ("uv512_identity_warp", 512, 512)):
+        cfg = nlt_amd.make_config(depth=args.depth, uvh=uv, uvw=uv, imh=cam, imw=cam, bs=4)
+        model = get_model_class('nlt')(cfg).build(device)
+        g = torch.Generator(device=device).manual_seed(1234)
+        for v in model.register_trainable() or model.trainable_variables:
+            if v.dim() == 1:
+                v.data.uniform_(-0.1, 0.1, generator=g)
+        train = [synth_device_batch(4, uv, cam, 1, device, seed=700 + i) for i in range(2)]
+        batches = identity_batches(4, uv, cam, 1, device)
+        agg = nlt_test.extract_feat(model, train)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(3):
+            agg = nlt_test.extract_feat(model, train)
+        torch.cuda.synchronize()
+        t_feat = (time.perf_counter() - t0) / 3
+        del train
+
+        def run(steps, **kw):
+            for i in range(3 * len(batches)):
+                model.call(batches[i % len(batches)], 'test', obs_override=agg)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for i in range(steps):
+                model.call(batches[i % len(batches)], 'test', obs_override=agg)
+            torch.cuda.synchronize()
+            return (time.perf_counter() - t1) / steps
+        t_first0 = time.perf_counter()
+        model.call(batches[0], 'test', obs_override=agg)
+        torch.cuda.synchronize()
+        t_first = time.perf_counter() - t_first0
+        dt = run(max(20, args.steps))
+        replays = int(model.plan.tape_replays)
+        timer = OpTimer()
+        model.plan.timer = timer
+        for i in range(3):
+            model.call(batches[i % len(batches)], 'test', obs_override=agg)
+        rec_ = timer.collect()
+        model.plan.timer = None
+        flops = sum(timer.flops.get(l, 0) for l in rec_)
+        moved = sum(timer.moved.get(l, r[2]) for l, r in rec_.items())
+        table = sorted(((r[1] / r[0], l) for l, r in rec_.items()), reverse=True)
+        dom_ms, dom = table[0]
+        texels = 4 * uv * uv
+        rec = {"ms_per_step": round(1e3 * dt, 4), "Mtexels_per_s": round(texels / dt / 1e6, 1), "launch_tape_replays": replays,
+               "plan_launches": len(rec_), "useful_flops_per_step": int(flops), "flop_per_texel": round(flops / texels, 1),
+               "frac_of_fp32_mfma_peak": round(flops / dt / 1e12 / MFMA_F32_PEAK_TFLOPS, 4),
+               "plan_algorithmic_bytes_per_step": int(moved), "frac_of_hbm_peak_algorithmic": round(moved / dt / 1e9 / HBM_PEAK_GBS, 4),
+               "dominant_launch": {"label": dom, "ms": round(dom_ms, 4), "TFLOPs": round(timer.flops.get(dom, 0) / dom_ms / 1e9, 2),
+                                   "GBps_of_its_own_traffic": round(timer.moved.get(dom, rec_[dom][2]) / dom_ms / 1e6, 1)},
+               "extract_feat_8_frames_ms": round(1e3 * t_feat, 3),
+               "extract_feat_Mtexels_per_s": round(8 * uv * uv / t_feat / 1e6, 1),
+               "first_call_ms_override_maps_and_plan_time_trials": round(1e3 * t_first, 1)}
+        if name == "uv1024_cam512":
+            try:
+                from nlt_amd.pipeline import RenderPipeline
+                with RenderPipeline(model, 2) as pipe:
+                    seq = [batches[i % len(batches)] for i in range(max(20, args.steps))]
+                    pipe.render(seq[:12], 'test', obs_override=agg)
+                    torch.cuda.synchronize()
+                    t1 = time.perf_counter()
+                    pipe.render(seq, 'test', obs_override=agg)
+                    torch.cuda.synchronize()
+                    d2 = (time.perf_counter() - t1) / len(seq)
+                rec["two_batches_in_flight"] = {"ms_per_step": round(1e3 * d2, 4), "Mtexels_per_s": round(texels / d2 / 1e6, 1)}
+            except Exception as e:
+                rec["two_batches_in_flight"] = {"error": "%s: %s" % (type(e).__name__, str(e)[:200])}
+            model.plan.fuse_override = False
+            dg = run(10)
+            model.plan.fuse_override = True
+            rec["general_layer_by_layer_plan"] = {"ms_per_step": round(1e3 * dg, 4), "Mtexels_per_s": round(texels / dg / 1e6, 1),
+                                                  "note": "NLT_FUSED_OVERRIDE=0: the plan rounds 1-5 ran this mode on (also serves per-frame override maps)"}
+        out[name] = rec
+        del model, batches, agg
+        torch.cuda.empty_cache()
+    return out
+
+
 def bench_released_pipelined(args, device):
     """The released shapes at the render loop's own batch size (4 frames) with several batches in flight
     (nlt_amd.pipeline.RenderPipeline).  At these shapes one batch is a 28-deep chain of 10-30 us launches that leaves most of
@@ -1048,6 +1141,11 @@ def main():
                 out["config3_f32_split"] = others
         if released:
             out["released_shapes"] = released
+        if world == 1 and not args.headline_only and args.uv == 1024 and not args.no_fused:
+            try:
+                out["nlt_test_infer"] = bench_infer_mode(args, device)
+            except Exception as e:                                    # a sub-line: never take the line with it
+                out["nlt_test_infer"] = {"error": "%s: %s" % (type(e).__name__, str(e)[:300])}
         if world > 1 and train:
             # N > 1: what shards with a collective is BASELINE config 4's train step (frames data-parallel, RCCL gradient
             # all-reduce) -- that is the line the scaling curve is drawn on.  The collective-free forward (replicas: scales
@@ -1094,6 +1192,8 @@ def main():
             "native_fp32_ms_per_step": out.get("native_fp32", {}).get("ms_per_step"),
             "dominant_kernel": dominant, "dominant_ms": round(dom_ms, 4), "dominant_frac_of_fp32_mfma_peak": roof.get("mfma", {}).get("frac"),
             "dominant_frac_of_hbm_peak_algorithmic": roof["hbm"]["frac"], "dominant_frac_of_hbm_peak_pmc_traffic": roof["hbm"]["traffic_frac"],
+            "nlt_test_infer_1024_ms_per_step": out.get("nlt_test_infer", {}).get("uv1024_cam512", {}).get("ms_per_step"),
+            "nlt_test_infer_1024_Mtexels_per_s": out.get("nlt_test_infer", {}).get("uv1024_cam512", {}).get("Mtexels_per_s"),
             "train_step_l2_ms": ts.get("l2", {}).get("ms_per_step"), "train_step_barron_ms": ts.get("barron", {}).get("ms_per_step"),
             "train_step_l2_host_enqueue_ms": ts.get("l2", {}).get("host_enqueue_ms_per_step"),
             "cpu_baseline_Mtexels_per_s": out.get("cpu_baseline", {}).get("value"), "cpu_cores": out.get("cpu_baseline", {}).get("cores")}

@@ -88,15 +88,41 @@ __global__ __launch_bounds__(64 * NW, 1) void front_ovr_kernel(
   if (tile >= t_hi) return;
   float* const lds = lds_all + W_WAVES + wv * W_END;
 
-  // ---- staging of the raw rows (float inputs): item = pass * 64 + lane -> (raw row, 16-byte piece of the row)
+  // ---- staging of the raw rows (float inputs): item = pass * 64 + lane -> (raw row, 16-byte piece of the row).
+  // This kernel has registers to spare (front4 has none): everything that depends on the lane only is computed ONCE --
+  // byte offsets of the lane's pieces inside a strip, LDS offsets, map offsets -- and a strip whose haloed tile lies inside
+  // the image (all but the last row / column of strips) adds wave-uniform bases to them; border strips re-derive with clamps.
   constexpr int N3 = 26, P3 = 5, N1 = 9, P1 = 2;
-  unsigned g3[P3], g1[P1];                                               // byte offsets inside a frame
+  unsigned g3[P3], g1[P1];                                               // byte offsets inside a frame, strip being loaded
+  unsigned c3[P3], c1[P1];                                               // their lane-constant parts (interior strips)
+  int l1o[P1];                                                           // LDS offset of the lane's 1-channel pieces
+#pragma unroll
+  for (int p = 0; p < P3; ++p) {
+    const int item = p * 64 + lane;
+    const int r = item / N3, i = item - r * N3;
+    c3[p] = item < XH * N3 ? (unsigned)((r * w) * 3 + 4 * i) * 4u : 0u;
+  }
+#pragma unroll
+  for (int p = 0; p < P1; ++p) {
+    const int item = p * 64 + lane;
+    const int r = item / N1, i = item - r * N1;
+    c1[p] = item < XH * N1 ? (unsigned)(r * w + 4 * i) * 4u : 0u;
+    l1o[p] = r * R1 + 4 * i;
+  }
   int lf = 0;
   auto opaque = [](int v) { asm volatile("" : "+v"(v)); return v; };
   auto load_geom = [&](int t) {
     const int tx0 = (t % tiles_x) * SW; t /= tiles_x;
     const int ty0 = (t % tiles_y) * SH;
     lf = t / tiles_y;
+    if (ty0 + AH <= h2 && tx0 + AW <= w2) {                              // interior (wave-uniform)
+      const unsigned b3 = (unsigned)((2 * ty0 * w + 2 * tx0) * 3) * 4u, b1 = (unsigned)(2 * ty0 * w + 2 * tx0) * 4u;
+#pragma unroll
+      for (int p = 0; p < P3; ++p) g3[p] = (p + 1) * 64 > XH * N3 && p * 64 + lane >= XH * N3 ? 0u : b3 + c3[p];
+#pragma unroll
+      for (int p = 0; p < P1; ++p) g1[p] = (p + 1) * 64 > XH * N1 && p * 64 + lane >= XH * N1 ? 0u : b1 + c1[p];
+      return;
+    }
     const int ln = opaque(lane);
 #pragma unroll
     for (int p = 0; p < P3; ++p) {
@@ -134,14 +160,11 @@ __global__ __launch_bounds__(64 * NW, 1) void front_ovr_kernel(
       if ((p + 1) * 64 > XH * N3 && item >= XH * N3) continue;
       *reinterpret_cast<f32x4*>(lds + W_RQ + item * 4) = st[p];
     }
-    const int ln = opaque(lane);
 #pragma unroll
     for (int p = 0; p < P1; ++p) {
-      const int item = p * 64 + ln;
-      if ((p + 1) * 64 > XH * N1 && item >= XH * N1) continue;
-      const int r = item / N1, i = item - r * N1;
-      *reinterpret_cast<f32x4*>(lds + W_RC + r * R1 + 4 * i) = st[P3 + p];
-      *reinterpret_cast<f32x4*>(lds + W_RL + r * R1 + 4 * i) = st[P3 + P1 + p];
+      if ((p + 1) * 64 > XH * N1 && p * 64 + lane >= XH * N1) continue;
+      *reinterpret_cast<f32x4*>(lds + W_RC + l1o[p]) = st[P3 + p];
+      *reinterpret_cast<f32x4*>(lds + W_RL + l1o[p]) = st[P3 + P1 + p];
     }
   };
 
@@ -152,7 +175,8 @@ __global__ __launch_bounds__(64 * NW, 1) void front_ovr_kernel(
   for (int m = 0; m < 5; ++m) aq2[m] = blob[OFF_AQ2 + m * 64 + lane];
 
   // ---- this lane's six stage-1 positions: haloed level-1 texel t = c * 16 + j, tap kk
-  int rd3[NC];
+  int rd3[NC], rd1[NC];                                                  // LDS offsets of the lane's raw texel (3- / 1-channel tiles)
+  unsigned mo1[NC], tex0[NC];                                            // interior strips: P1 offset (floats), raw texel index, minus the strip's base
   unsigned live_m = 0, own_m = 0;
 #pragma unroll
   for (int c = 0; c < NC; ++c) {
@@ -160,8 +184,12 @@ __global__ __launch_bounds__(64 * NW, 1) void front_ovr_kernel(
     const bool live = t < AT;
     const int hy = live ? t / AW : 0, hx = live ? t % AW : 0;
     rd3[c] = (2 * hy + (kk >> 1)) * R3 + (2 * hx + (kk & 1)) * 3;
+    rd1[c] = (2 * hy + (kk >> 1)) * R1 + 2 * hx + (kk & 1);
+    mo1[c] = (unsigned)((hy * w2 + hx) * 16 + 4 * kk);
+    const bool own = live && hy < SH && hx < SW;
+    tex0[c] = own ? (unsigned)((2 * hy + (kk >> 1)) * w + 2 * hx + (kk & 1)) : 0u;
     live_m |= (unsigned)live << c;
-    own_m |= (unsigned)(live && hy < SH && hx < SW) << c;
+    own_m |= (unsigned)own << c;
   }
   float* const ot = lds + W_OT;
   const int Y = j >> 3, X = j & 7;
@@ -172,9 +200,23 @@ __global__ __launch_bounds__(64 * NW, 1) void front_ovr_kernel(
   // ---- the override maps of a strip: P1 at the lane's six haloed level-1 texels, S0 at its six raw texels, P2 at its
   // level-2 texel.  Texels beyond the image read the map's first texel: their results are masked / never stored.
   f32x4 mp1[NC], ms0[NC], mp2[2];
+  const unsigned mo2 = (unsigned)((Y * w4 + X) * 32 + 4 * kk);
   auto load_maps = [&](int t) {
     const int tx0 = (t % tiles_x) * SW; t /= tiles_x;
     const int ty0 = (t % tiles_y) * SH;
+    if (ty0 + AH <= h2 && tx0 + AW <= w2) {                              // interior (wave-uniform): bases + lane constants
+      const float* b1 = maps.p1 + (size_t)(ty0 * w2 + tx0) * 16;
+      const float* b0 = maps.s0 + (size_t)(2 * ty0 * w + 2 * tx0) * 4;
+      const float* b2 = maps.p2 + (size_t)((ty0 >> 1) * w4 + (tx0 >> 1)) * 32;
+#pragma unroll
+      for (int c = 0; c < NC; ++c) {
+        mp1[c] = *reinterpret_cast<const f32x4*>(b1 + (((live_m >> c) & 1) ? mo1[c] : 0u));
+        ms0[c] = *reinterpret_cast<const f32x4*>(b0 + tex0[c] * 4u);
+      }
+      mp2[0] = *reinterpret_cast<const f32x4*>(b2 + mo2);
+      mp2[1] = *reinterpret_cast<const f32x4*>(b2 + mo2 + 16);
+      return;
+    }
     const int jo = opaque(j);
 #pragma unroll
     for (int c = 0; c < NC; ++c) {
@@ -254,7 +296,7 @@ __global__ __launch_bounds__(64 * NW, 1) void front_ovr_kernel(
     const f32x4 p2a = mp2[0], p2b = mp2[1];                              // (mp2 is refilled for the next strip below)
 
     // ---- stage 1 (5 MFMAs per column tile) + the head's share of the L0 features
-    const int jq = opaque(j);
+    float* const skbase = skip3 + ((long)f * hw + (long)(2 * ty0) * w + 2 * tx0) * 3;   // (owned texels are inside the image)
 #pragma unroll
     for (int c0 = 0; c0 < NC; c0 += 3) {
       f32x4 acc[3] = {mp1[c0], mp1[c0 + 1], mp1[c0 + 2]};
@@ -263,11 +305,7 @@ __global__ __launch_bounds__(64 * NW, 1) void front_ovr_kernel(
       for (int c = 0; c < 3; ++c) {
         const float* s = lds + W_RQ + rd3[c0 + c];
         raw[c][0] = s[0]; raw[c][1] = s[1]; raw[c][2] = s[2];
-        const int t = (c0 + c) * 16 + jq;
-        const bool live = (live_m >> (c0 + c)) & 1;
-        const int hy = live ? t / AW : 0, hx = live ? t % AW : 0;
-        const int o1c = (2 * hy + (kk >> 1)) * R1 + 2 * hx + (kk & 1);
-        raw[c][3] = lds[W_RC + o1c]; raw[c][4] = lds[W_RL + o1c];
+        raw[c][3] = lds[W_RC + rd1[c0 + c]]; raw[c][4] = lds[W_RL + rd1[c0 + c]];
       }
 #pragma unroll
       for (int m = 0; m < 5; ++m)
@@ -290,8 +328,9 @@ __global__ __launch_bounds__(64 * NW, 1) void front_ovr_kernel(
             s2 = fmaf(raw[c][rr], wsk[rr * 3 + 2], s2);
           }
           if (add_base) { s0 += raw[c][0]; s1 += raw[c][1]; s2 += raw[c][2]; }
-          const int t = (c0 + c) * 16 + jq;
-          float* sk = skip3 + ((long)f * hw + (long)(2 * (ty0 + t / AW) + (kk >> 1)) * w + 2 * (tx0 + t % AW) + (kk & 1)) * 3;
+          // (one 12-byte store per lane.  Collecting the strip's rows in LDS for 16-byte stores was built and measured in r06:
+          // 0.0956 ms either way -- the texture addresser's 65 % busy is not these stores)
+          float* sk = skbase + tex0[c0 + c] * 3u;
           sk[0] = s0; sk[1] = s1; sk[2] = s2;
         }
       }
