@@ -232,12 +232,13 @@ def tape_begin():
     _tls.epoch = _alloc_epoch[0]
 
 
-def tape_end(tag=None):
-    """Closes the tape and returns [launch list, allocation epoch it is valid for, caller's validity tag, native form]."""
+def tape_end(tag=None, extra=None):
+    """Closes the tape and returns [launch list, allocation epoch it is valid for, caller's validity tag, native form, extra]
+    (`extra`: whatever the recorder wants back at replay time -- engine.py keeps the packed-buffer keys the tape reads)."""
     t, _tls.tape = _tls.tape, None
     if _tls.epoch != _alloc_epoch[0]:
         return None                                     # a cached buffer was re-allocated while recording: pointers are stale
-    return (t, _alloc_epoch[0], tag, [None])
+    return (t, _alloc_epoch[0], tag, [None], extra)
 
 
 def tape_abort():

@@ -24,7 +24,9 @@
 //   * the raw inputs of a strip are a sequence of staged items -- observation 0 .. k - 1, then the query inputs -- that
 //     continues into the next strip: while item t is computed, item t + 1 is converted into LDS and item t + 2 is in flight
 //     in registers, so no strip starts with a wait.
-// The arithmetic of a strip is unchanged (tests/test_gpu_front4.py: still bit-identical to front_kernel<true>).
+// The arithmetic of a strip was unchanged by r04's persistence (bit-identical to front_kernel<true> then).  r05: the biases became
+// the initial values of the MFMA chains and the uint8 variant feeds raw bytes -- a re-association: <= 3.3e-7 max-abs from
+// front_kernel<true>, float / uint8 forms <= 3e-7 rel-L2 apart (tests/test_gpu_front4.py: 5e-7 bars); float = train form bit for bit.
 //
 // U8 = true reads the resident uint8 capture store (nlt/datasets/nlt.py:131-136,173-181) and feeds the byte values themselves:
 // see u8x4_unit.

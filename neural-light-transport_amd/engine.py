@@ -569,6 +569,7 @@ class RenderPlan(OverrideMixin):
             ent = tapes.get(tkey, 0)
             if isinstance(ent, tuple):
                 if self._replayable(b, ent, reg):
+                    reg.touch_keys(ent[4])              # (a replay reads its fragment buffers without asking: tell a running census)
                     C.replay(ent)
                     self.tape_replays += 1
                     return self._finish_pred(b), b
@@ -576,13 +577,15 @@ class RenderPlan(OverrideMixin):
             tapes[tkey] = 1
             if ent == 1:
                 C.tape_begin()
+                reg.begin_record()
                 try:
                     out = self._forward_body(b, base, cvis, lvis, nn_rgb, nn_base, obs_weights, obs_override, skip_connect_base,
                                              algo, fused, inference, ovr)
                 except BaseException:
                     C.tape_abort()
+                    reg.end_record()
                     raise
-                tapes[tkey] = C.tape_end(reg.version) or 1  # (None: a workspace grew while recording -> record again)
+                tapes[tkey] = C.tape_end(reg.version, reg.end_record()) or 1  # (None: a workspace grew while recording -> record again)
                 return out
         return self._forward_body(b, base, cvis, lvis, nn_rgb, nn_base, obs_weights, obs_override, skip_connect_base, algo,
                                   fused, inference, ovr)
@@ -617,6 +620,7 @@ class RenderPlan(OverrideMixin):
             ent = tapes.get(tkey, 0)
             if isinstance(ent, tuple):
                 if self._replayable(b, ent, reg):
+                    reg.touch_keys(ent[4])
                     C.replay(ent)
                     self.tape_replays += 1
                     return self._finish_pred(b), b
@@ -624,12 +628,14 @@ class RenderPlan(OverrideMixin):
             tapes[tkey] = 1
             if ent == 1:
                 C.tape_begin()
+                reg.begin_record()
                 try:
                     out = self._forward_fused(b, None, None, None, None, None, skip_connect_base, algo, resident=res)
                 except BaseException:
                     C.tape_abort()
+                    reg.end_record()
                     raise
-                tapes[tkey] = C.tape_end(reg.version) or 1
+                tapes[tkey] = C.tape_end(reg.version, reg.end_record()) or 1
                 return out
         return self._forward_fused(b, None, None, None, None, None, skip_connect_base, algo, resident=res)
 
@@ -1108,6 +1114,7 @@ class RenderPlan(OverrideMixin):
             ent = tapes.get(tkey, 0)
             if isinstance(ent, tuple):
                 if C.tape_valid(ent, reg.version):
+                    reg.touch_keys(ent[4])
                     C.replay(ent)
                     self.tape_replays += 1
                     return
@@ -1115,14 +1122,16 @@ class RenderPlan(OverrideMixin):
             tapes[tkey] = 1
             if ent == 1:
                 C.tape_begin()
+                reg.begin_record()
         try:
             self._backward_streams(dpred, base, cvis, lvis, nn_rgb, nn_base, obs_weights, b, g, n, h, w, k)
         except BaseException:
             if tkey is not None and ent == 1:
                 C.tape_abort()
+                reg.end_record()
             raise
         if tkey is not None and ent == 1:
-            b['tapes'][tkey] = C.tape_end(reg.version) or 1
+            b['tapes'][tkey] = C.tape_end(reg.version, reg.end_record()) or 1
 
     def _backward_streams(self, dpred, base, cvis, lvis, nn_rgb, nn_base, obs_weights, b, g, n, h, w, k):
         concurrent = self.bwd_streams and dpred.is_cuda and self.timer is None

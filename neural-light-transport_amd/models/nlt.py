@@ -207,6 +207,7 @@ class Model(BaseModel):
                 flat[o:o + n].copy_(getattr(c, name).detach().reshape(-1))
         self.flat_params = flat.requires_grad_(True)
         self.flat_grads = torch.zeros_like(flat)
+        self._slots = slots                 # (offset, count, shape) of every variable, in CANONICAL order: `_conv_layers()` x (kernel, bias)
         self.n_params = sum(n for _, n, _ in slots)
         self._epoch = [0]
         from ..networks.elements import PackRegistry
@@ -254,21 +255,47 @@ class Model(BaseModel):
                                   for c in _convs_of(layer)])
         return out
 
+    # -- the flat bucket's slot ORDER is a tuning choice (`_flatten`: backward-completion order, NLT_GRAD_RANGES): anything that
+    # leaves the process -- checkpoints, optimizer slots -- is exchanged per VARIABLE in canonical order and never as a raw bucket
+    def bucket_to_variables(self, flat):
+        """A bucket-shaped vector (parameters, Adam m / v / vhat) -> list of tensors, one per variable, canonical order."""
+        flat = flat.detach().reshape(-1)
+        assert flat.numel() == self.flat_params.numel()
+        return [flat[o:o + n].reshape(shp).clone() for o, n, shp in self._slots]
+
+    def variables_to_bucket(self, variables, out):
+        """The inverse, into the bucket-shaped tensor `out` (padding floats between slots stay as they are)."""
+        if len(variables) != len(self._slots):
+            raise ValueError("checkpoint was written by a different architecture (%d variables, this one has %d)" % (len(variables), len(self._slots)))
+        for (o, n, shp), v in zip(self._slots, variables):
+            if tuple(v.shape) != tuple(shp):
+                raise ValueError("checkpoint was written by a different architecture (variable of shape %s where %s is expected)"
+                                 % (tuple(v.shape), tuple(shp)))
+        with torch.no_grad():
+            flat = out.detach().reshape(-1)
+            for (o, n, shp), v in zip(self._slots, variables):
+                flat[o:o + n].copy_(v.reshape(-1))
+        return out
+
     def state_dict(self):
-        """Everything `tf.train.Checkpoint(net=...)` tracks for this model (nlt/trainvali.py:134-141): the flat parameter
-        bucket and the slot table that maps it onto the layers (so a mismatching architecture is refused on load)."""
+        """Everything `tf.train.Checkpoint(net=...)` tracks for this model (nlt/trainvali.py:134-141): every kernel / bias as
+        its own tensor, in canonical order (query layers, then obs layers; kernel then bias) -- independent of how this
+        process happens to lay its flat bucket out."""
         assert getattr(self, 'flat_params', None) is not None, "build() the model first"
-        slots = [(tuple(c.kernel.shape), tuple(c.bias.shape)) for c in self._conv_layers()]
-        return {'flat_params': self.flat_params.detach().clone(), 'slots': slots}
+        return {'variables': self.bucket_to_variables(self.flat_params)}
 
     def load_state_dict(self, sd):
-        slots = [(tuple(c.kernel.shape), tuple(c.bias.shape)) for c in self._conv_layers()]
-        if [tuple(map(tuple, x)) for x in sd['slots']] != slots or sd['flat_params'].numel() != self.flat_params.numel():
-            raise ValueError("checkpoint was written by a different architecture (layer shapes differ)")
-        with torch.no_grad():
-            self.flat_params.copy_(sd['flat_params'])
+        if 'variables' not in sd:
+            raise ValueError("not a per-variable state dict (format nlt_amd-ckpt-2)")
+        self.variables_to_bucket(list(sd['variables']), self.flat_params)
         self.mark_weights_updated()
         return self
+
+    def legacy_bucket_layout(self):
+        """How rounds 1-5 (format nlt_amd-ckpt-1) laid the RAW flat bucket out in a checkpoint: the slot table of the
+        CURRENT process.  A ckpt-1 file does not say which layout wrote it; `trainvali.restore_checkpoint` refuses it unless
+        the caller vouches for the layout (`legacy_layout=True`: same NLT_GRAD_RANGES, same code generation)."""
+        return list(self._slots)
 
     # ---------------------------------------------------------------- forward
     def _render(self, base, cvis, lvis, warp, nn_rgb, nn_base, obs_weights, obs_override, want_indices, inference=True,
@@ -612,7 +639,9 @@ class Model(BaseModel):
             self._compile_into_webpage(batch_vis_dirs, outpath, title="NLT (%s)" % mode)
         else:
             outpath = outpref + '.mp4'
-            self._compile_into_video(batch_vis_dirs, outpath, fps=fps)
+            written = self._compile_into_video(batch_vis_dirs, outpath, fps=fps)
+            if outpath not in written:          # no matplotlib / ffmpeg here (advisor r05): link the file that exists
+                outpath = outpref + '.apng'
         return file_explorer + outpath
 
     @staticmethod
@@ -647,3 +676,4 @@ class Model(BaseModel):
         written = V.write_frames([frames[k] for k in order], out_mp4, fps=fps)
         stem = out_mp4[:-len('.mp4')]
         V.write_json({'fps': fps, 'ids': order, 'frames': [paths[k] for k in order], 'written': written}, stem + '.frames.json')
+        return written

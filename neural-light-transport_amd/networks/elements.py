@@ -103,11 +103,27 @@ class Conv2D(Layer):
         reg = self._registry
         if reg is not None:
             reg.touch(self, key)
+            if ent is not None and reg.is_inactive(self, key):
+                # A buffer the census had retired is asked for again (advisor r05): it is stale or about to be -- the one-launch
+                # refresh skips inactive buffers -- whatever its version stamp says.  Back into the refresh set, and THIS buffer
+                # alone re-packed now, in place (recorded tapes and graphs keep its address), with any open launch tape paused:
+                # the pack launch belongs to no step.
+                paused = C.tape_pause()
+                try:
+                    reg.activate(self, key)
+                    ent[1].copy_(make())
+                finally:
+                    C.tape_resume(paused)
+                self._packed[key] = (ver, ent[1])
+                return ent[1]
         if ent is not None and ent[0] == ver:
             return ent[1]
         if ent is not None and reg is not None and reg.owns(self, key):
-            reg.activate(self, key)          # (a buffer the census had retired: back into the one-launch refresh)
-            reg.refresh()
+            paused = C.tape_pause()                  # (a stale ACTIVE buffer outside the top-of-pass refresh: same rule)
+            try:
+                reg.refresh()
+            finally:
+                C.tape_resume(paused)
             return self._packed[key][1]
         buf = make()
         self._packed[key] = (ver, buf)
@@ -225,13 +241,37 @@ class PackRegistry:
         self.inactive = set()
         self.used = None             # keys asked for since the census began (None: no census running)
         self.ticks_left = 0
+        import threading
+        self._rec = threading.local()    # keys touched while THIS host thread records a launch tape
 
     def owns(self, layer, key):
         return (id(layer), key) in self.entries
 
+    def is_inactive(self, layer, key):
+        return (id(layer), key) in self.inactive
+
     def touch(self, layer, key):
+        k = (id(layer), key)
         if self.used is not None:
-            self.used.add((id(layer), key))
+            self.used.add(k)
+        rec = getattr(self._rec, 'keys', None)
+        if rec is not None:
+            rec.add(k)
+
+    # A recorded launch tape reads its fragment buffers WITHOUT asking for them (`_cached_pack` is not on the replay path), so
+    # a census that only sees asks would retire buffers that live tapes -- of this plan or of another plan over the same nets
+    # (pipeline lanes) -- still use (advisor r05).  A plan brackets its recording with begin_record / end_record, keeps the
+    # keys with the tape and re-touches them on every replay.
+    def begin_record(self):
+        self._rec.keys = set()
+
+    def end_record(self):
+        keys, self._rec.keys = getattr(self._rec, 'keys', None), None
+        return frozenset(keys or ())
+
+    def touch_keys(self, keys):
+        if self.used is not None and keys:
+            self.used.update(keys)
 
     def begin_census(self, passes=4):
         """Called when a plan's choices have just been made: the next `passes` plan passes (forward / backward, whichever

@@ -35,13 +35,19 @@ class AdamAMSGrad:
         self.model.mark_weights_updated()
 
     def state_dict(self):
-        return {'t': self.t, 'm': self.m, 'v': self.v, 'vhat': self.vhat}
+        """Per VARIABLE in canonical order (Model.bucket_to_variables), like the net's own state: the flat bucket's slot order is
+        a tuning choice of this process and must not leak into files."""
+        m = self.model
+        return {'t': self.t, 'm': m.bucket_to_variables(self.m), 'v': m.bucket_to_variables(self.v),
+                'vhat': m.bucket_to_variables(self.vhat)}
 
     def load_state_dict(self, sd):
+        m = self.model
         for k in ('m', 'v', 'vhat'):
-            if not torch.is_tensor(sd.get(k)) or sd[k].numel() != getattr(self, k).numel():
-                raise ValueError("optimizer state '%s' has %s elements, this model's flat bucket has %d"
-                                 % (k, sd[k].numel() if torch.is_tensor(sd.get(k)) else None, getattr(self, k).numel()))
+            if not isinstance(sd.get(k), (list, tuple)):
+                raise ValueError("optimizer state '%s' is not a per-variable list (format nlt_amd-ckpt-2)" % k)
+            if len(sd[k]) != len(m._slots) or any(tuple(t.shape) != tuple(shp) for t, (_, _, shp) in zip(sd[k], m._slots)):
+                raise ValueError("optimizer state '%s' does not match this model's variables" % k)
         self.t = int(sd['t'])
         for k in ('m', 'v', 'vhat'):
-            getattr(self, k).copy_(sd[k].reshape(getattr(self, k).shape))
+            m.variables_to_bucket(list(sd[k]), getattr(self, k))

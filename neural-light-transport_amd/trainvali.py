@@ -31,21 +31,51 @@ def make_optimizer(model, config):
     return optim.AdamAMSGrad(model, lr, clipnorm=mgm if (mgm > 0 and apply_clip) else None)
 
 
+CKPT_FORMAT = 'nlt_amd-ckpt-2'
+
+
 def save_checkpoint(path, model, optimizer, step):
     """`tf.train.Checkpoint(step=, optimizer=, net=)` + `CheckpointManager.save` of the reference train loop
     (nlt/trainvali.py:134-141,197): weights, Adam-AMSGrad slots (m, v, vhat) and iteration count, global step -- enough to
-    resume training bit for bit, and what `nlt_test`-style inference restores.  One torch.save file (tensors on CPU)."""
-    cpu = lambda d: {k: (v.detach().cpu() if torch.is_tensor(v) else v) for k, v in d.items()}
-    torch.save({'format': 'nlt_amd-ckpt-1', 'step': int(step), 'net': cpu(model.state_dict()),
-                'optimizer': cpu(optimizer.state_dict()) if optimizer is not None else None}, path)
+    resume training bit for bit, and what `nlt_test`-style inference restores.  One torch.save file (tensors on CPU).
+    Format 2 (r06): every kernel / bias and every optimizer slot is stored PER VARIABLE in canonical order; format 1 stored
+    the raw flat bucket, whose slot order depends on the writer's `_flatten` (advisor r05: a file written under another
+    NLT_GRAD_RANGES loaded without error and with permuted weights)."""
+    cpu = lambda x: ([t.detach().cpu() for t in x] if isinstance(x, (list, tuple)) else (x.detach().cpu() if torch.is_tensor(x) else x))
+    cpud = lambda d: {k: cpu(v) for k, v in d.items()}
+    torch.save({'format': CKPT_FORMAT, 'step': int(step), 'net': cpud(model.state_dict()),
+                'optimizer': cpud(optimizer.state_dict()) if optimizer is not None else None}, path)
     return path
 
 
-def restore_checkpoint(path, model, optimizer=None):
+def _convert_ckpt1(ck, model):
+    """A format-1 file (raw flat buckets) -> format-2 dicts, cutting the buckets by THIS process's slot table."""
+    net = ck['net']
+    shapes = [(tuple(c.kernel.shape), tuple(c.bias.shape)) for c in model._conv_layers()]
+    if [tuple(map(tuple, x)) for x in net['slots']] != shapes or net['flat_params'].numel() != model.flat_params.numel():
+        raise ValueError("checkpoint was written by a different architecture (layer shapes differ)")
+    cut = lambda flat: [flat.reshape(-1)[o:o + n].reshape(shp).clone() for o, n, shp in model.legacy_bucket_layout()]
+    out = {'net': {'variables': cut(net['flat_params'])}, 'optimizer': None}
+    if ck.get('optimizer') is not None:
+        o = ck['optimizer']
+        out['optimizer'] = {'t': o['t'], 'm': cut(o['m']), 'v': cut(o['v']), 'vhat': cut(o['vhat'])}
+    return out
+
+
+def restore_checkpoint(path, model, optimizer=None, legacy_layout=False):
     """Loads what `save_checkpoint` wrote into a built model (and optimizer); returns the global step.  The optimizer may be
-    omitted (inference: nlt/nlt_test.py:92-97 restores the net alone)."""
-    ck = torch.load(path, map_location='cpu', weights_only=True)     # tensors, ints, strings, tuples only: no pickle code runs
-    if ck.get('format') != 'nlt_amd-ckpt-1':
+    omitted (inference: nlt/nlt_test.py:92-97 restores the net alone).  A format-1 file (rounds 1-5: raw flat buckets) is
+    refused unless `legacy_layout=True` states that it was written with the bucket layout this process uses (same code
+    generation, same NLT_GRAD_RANGES) -- the file itself cannot tell."""
+    ck = torch.load(path, map_location='cpu', weights_only=True)     # tensors, ints, strings, lists only: no pickle code runs
+    fmt = ck.get('format')
+    if fmt == 'nlt_amd-ckpt-1':
+        if not legacy_layout:
+            raise ValueError("%s is a format-1 checkpoint (raw flat parameter bucket): its slot order depends on the writer's "
+                             "bucket layout and is not recorded in the file.  Pass legacy_layout=True if it was written by the "
+                             "same code generation with the same NLT_GRAD_RANGES, then save it again (format 2)." % path)
+        ck = dict(ck, **_convert_ckpt1(ck, model))
+    elif fmt != CKPT_FORMAT:
         raise ValueError("%s is not an nlt_amd checkpoint" % path)
     model.load_state_dict(ck['net'])
     if optimizer is not None:
@@ -150,6 +180,7 @@ class GraphedTrainStep:
         self.model, self.optimizer, self.global_bs, self.group = model, optimizer, global_bs, group
         self.warmup, self.seen = warmup, 0
         self.graph, self.static, self.out, self.failed = None, None, None, None
+        self._table = self._reg_version = None       # the registry's descriptor table the graph embeds, and the buffer-set version it was captured at
 
     def static_batch(self):
         """The graph's own input tensors (None before the capture): a loader that fills THESE and passes them back
@@ -174,6 +205,11 @@ class GraphedTrainStep:
         if self.failed is not None or not dev_ok or self.seen < self.warmup:
             self.seen += 1
             return distributed_train_step(self.model, batch, self.optimizer, self.global_bs, self.group)
+        reg = getattr(self.model, 'pack_registry', None)
+        if self.graph is not None and reg is not None and reg.version != self._reg_version:
+            # the SET of packed buffers changed after the capture (a census retired some, a plan re-tuned: advisor r05): the
+            # captured repack launch would walk a descriptor table the registry no longer maintains -- capture again
+            self.graph = self.out = None
         if self.graph is None:
             try:
                 self.static = list(batch)
@@ -191,6 +227,8 @@ class GraphedTrainStep:
                 with torch.cuda.graph(graph):
                     self.out = self._body(tuple(self.static))
                 self.graph = graph
+                if reg is not None:
+                    self._table, self._reg_version = reg.table, reg.version   # (keeps the captured table's tensors alive)
             except Exception as e:                       # capture is an optimisation, never a requirement
                 self.failed = repr(e)
                 self.graph = None

@@ -206,6 +206,7 @@ def write_frames(frames, out_mp4, fps=12):
                 writer.grab_frame()
         plt.close(fig)
         written.append(out_mp4)
-    except Exception:                                            # noqa: BLE001 -- no encoder here: the .apng is the roll-up
-        pass
+    except Exception as e:                                       # noqa: BLE001 -- no encoder here: the .apng is the roll-up
+        import warnings
+        warnings.warn("no .mp4 written (%s: %s); the roll-up is %s" % (type(e).__name__, e, written[0]))
     return written

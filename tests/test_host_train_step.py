@@ -155,9 +155,35 @@ def test_checkpoint_save_restore_resumes_training_bit_for_bit(monkeypatch, tmp_p
         trainvali.restore_checkpoint(path, deep)
     # optimizer slots of another size are refused before anything is overwritten; a resident batch trains like its float twin
     sd = opt.state_dict()
-    sd['v'] = sd['v'][:100]
+    sd['v'] = sd['v'][:10]
     with pytest.raises(ValueError, match="optimizer state 'v'"):
         opt2.load_state_dict(sd)
+    # advisor r05 (high): the checkpoint must not depend on the flat bucket's slot ORDER.  A model built with the other
+    # gradient-range layout (NLT_GRAD_RANGES=2: r01-r04's order) restores the same file to the same per-layer weights and the
+    # same optimizer slots, and continues to the same weights.
+    monkeypatch.setenv('NLT_GRAD_RANGES', '2')
+    pm5, opt5 = fresh(5)
+    monkeypatch.delenv('NLT_GRAD_RANGES')
+    assert pm5.bucket_ranges != pm2.bucket_ranges and [s_[0] for s_ in pm5._slots] != [s_[0] for s_ in pm2._slots]
+    assert trainvali.restore_checkpoint(path, pm5, opt5) == 2
+    for _ in range(2):
+        trainvali.distributed_train_step(pm5, b, opt5, 2)
+    for a_, b_ in zip(pm5.bucket_to_variables(pm5.flat_params), pm2.bucket_to_variables(pm2.flat_params)):
+        assert torch.equal(a_, b_)
+    for k_ in ('m', 'v', 'vhat'):
+        for a_, b_ in zip(opt5.state_dict()[k_], opt2.state_dict()[k_]):
+            assert torch.equal(a_, b_)
+    # a format-1 file (raw flat bucket) is refused unless the caller vouches for its layout; vouched for, it converts
+    raw = lambda o_: {'t': o_.t, 'm': o_.m.clone(), 'v': o_.v.clone(), 'vhat': o_.vhat.clone()}
+    old = str(tmp_path / 'old.pt')
+    torch.save({'format': 'nlt_amd-ckpt-1', 'step': 7, 'optimizer': raw(opt2),
+                'net': {'flat_params': pm2.flat_params.detach().clone(),
+                        'slots': [(tuple(c.kernel.shape), tuple(c.bias.shape)) for c in pm2._conv_layers()]}}, old)
+    pm6, opt6 = fresh(6)
+    with pytest.raises(ValueError, match='format-1'):
+        trainvali.restore_checkpoint(old, pm6, opt6)
+    assert trainvali.restore_checkpoint(old, pm6, opt6, legacy_layout=True) == 7
+    assert torch.equal(pm6.flat_params.detach(), pm2.flat_params.detach()) and torch.equal(opt6.vhat, opt2.vhat)
     # the file is loaded with weights_only=True: a pickle that would run code is refused
     import pickle
 

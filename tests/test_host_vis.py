@@ -7,6 +7,8 @@ import os
 import pickle
 from os.path import exists, join
 
+import warnings
+
 import numpy as np
 import pytest
 import torch
@@ -152,8 +154,11 @@ def test_compile_batch_vis_webpage_and_frame_roll_up(monkeypatch, tmp_path):
         for i in range(2):
             assert join(d, '%d_base-vs-pred.apng' % i) in html and join(d, '%d_gt-vs-pred.apng' % i) in html and join(d, '%d_nn.png' % i) in html
     assert 'pred_psnr' in html and 'Nearest Neighbor' in html
-    link = pm.compile_batch_vis(dirs['test'], str(tmp_path / 'test_all'), 'test', fps=5)
-    assert link == str(tmp_path / 'test_all') + '.mp4'
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        link = pm.compile_batch_vis(dirs['test'], str(tmp_path / 'test_all'), 'test', fps=5)
+    # the link names a file that EXISTS: the .mp4 where matplotlib + ffmpeg encoded one, the .apng otherwise (advisor r05)
+    assert link in (str(tmp_path / 'test_all') + '.mp4', str(tmp_path / 'test_all') + '.apng') and os.path.exists(link)
     roll = json.load(open(str(tmp_path / 'test_all.frames.json')))
     want = sorted(k for k in ids if k.startswith('test'))
     assert roll['ids'] == want and roll['frames'] == [ids[k] for k in want] and roll['fps'] == 5
