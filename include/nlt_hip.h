@@ -505,25 +505,6 @@ int nlt_front4_forward_u8(const unsigned char* diffuse_store, const unsigned cha
                           const float* packed, const float* packed_l2, int add_base, float alpha,
                           float* fm1, float* skip3, float* qtmp2, float* otmp2, int waves_per_simd, void* stream);
 
-/* Fourth generation of the fused front launch (csrc/front5.hip), for `precision = f32x3_9 / f32x3`: inputs, outputs, packed
- * blobs and conditions of nlt_front4_forward, with the 16-channel stages (L1's stride-1 convs, level 2's stride-2 convs) on the
- * bf16 matrix cores through the exact three-term split of nlt_conv_tile3_forward (fp32 accumulate; `products` = 9: every
- * term product, 6: the three of relative order 2^-24 dropped; 0 = 9), biases as the accumulators' initial values.  One
- * persistent 512-thread workgroup per CU (all 160 KB of its LDS: level 2's weight terms once per CU, 15.4 KB per wave); each
- * wave walks its own strips and prefetches the next strip's inputs under the current one.  Results agree with
- * nlt_front4_forward to the split's re-association (~1e-8 relative), not bit for bit.
- *   replaces: what nlt_front2_forward replaces (nlt/models/nlt.py:95-96,153-180).
- * nlt_front5_forward_u8 reads the RESIDENT uint8 capture store like nlt_front4_forward_u8 (nlt/datasets/nlt.py:131-136,173-181). */
-int nlt_front5_forward(const float* base, const float* cvis, const float* lvis, const float* nn_rgb,
-                       const float* nn_base, int n, int k, int h, int w, const float* packed,
-                       const float* packed_l2, int add_base, float alpha, float* fm1, float* skip3,
-                       float* qtmp2, float* otmp2, int products, void* stream);
-int nlt_front5_forward_u8(const unsigned char* diffuse_store, const unsigned char* rgb_store,
-                          const unsigned char* cvis_store, const unsigned char* lvis_store,
-                          const int* ids, const int* nn_ids, int n, int k, int h, int w,
-                          const float* packed, const float* packed_l2, int add_base, float alpha,
-                          float* fm1, float* skip3, float* qtmp2, float* otmp2, int products, void* stream);
-
 /* TRAINING form of nlt_front4_forward: the same launch, which additionally keeps the maps the backward pass reads -- exactly what
  * nlt_front_forward_train keeps (obs1 [n,k,h/2,w/2,16], qtmp1 [n,h/2,w/2,16], otmp1 [n,k,h/2,w/2,16]) -- while STILL running level
  * 2's stride-2 convs (qtmp2 / otmp2, which the backward needs as stored activations anyway): the train forward then launches neither
@@ -679,15 +660,6 @@ int nlt_back_backward(const float* x, const float* fm1, const float* u, const fl
                       int n, int h2, int w2, const float* w_s2, const float* w_s1, const float* w_head,
                       float alpha, float* dx, float* dfm1, float* dw_s2, float* db_s2, float* dw_s1,
                       float* db_s1, float* dw_head, float* db_head, float* workspace, void* stream);
-/* The same pass in two launches (r05): parts = 1 -> dx and dfm1 only (the backward-data chain, nlt/trainvali.py:279, continues
- * behind it; the weight-gradient pointers and the workspace may be NULL), parts = 2 -> the weight / bias gradient sums only (dx /
- * dfm1 may be NULL; meant for the weight-gradient stream), parts = 3 -> nlt_back_backward.  Both halves recompute the two
- * intermediate gradients from (v, dpred, u); the results are those of the one-launch form up to fp32 re-association (<= 1e-6).
- * Measured slower inside the train step than the one-launch form (the second launch competes with the chain): opt-in. */
-int nlt_back_backward_parts(const float* x, const float* fm1, const float* u, const float* v, const float* dpred,
-                            int n, int h2, int w2, const float* w_s2, const float* w_s1, const float* w_head,
-                            float alpha, float* dx, float* dfm1, float* dw_s2, float* db_s2, float* dw_s1,
-                            float* db_s1, float* dw_head, float* db_head, float* workspace, int parts, void* stream);
 
 /* nlt_conv_forward on the MFMA path with the K loop split into `ksplit` slices run by different waves (for
  * the deep levels: a few hundred texels x thousands of input channels would otherwise occupy a fraction of the

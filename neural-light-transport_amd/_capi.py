@@ -91,8 +91,6 @@ SIGNATURES = {
     'nlt_front2_forward': (_c_int, [_vp] * 5 + [_c_int] * 4 + [_vp, _vp, _c_int, _c_float, _vp, _vp, _vp, _vp, _vp]),
     'nlt_front4_forward': (_c_int, [_vp] * 5 + [_c_int] * 4 + [_vp, _vp, _c_int, _c_float, _vp, _vp, _vp, _vp, _c_int, _vp]),
     'nlt_front4_forward_u8': (_c_int, [_vp] * 6 + [_c_int] * 4 + [_vp, _vp, _c_int, _c_float, _vp, _vp, _vp, _vp, _c_int, _vp]),
-    'nlt_front5_forward': (_c_int, [_vp] * 5 + [_c_int] * 4 + [_vp, _vp, _c_int, _c_float, _vp, _vp, _vp, _vp, _c_int, _vp]),
-    'nlt_front5_forward_u8': (_c_int, [_vp] * 6 + [_c_int] * 4 + [_vp, _vp, _c_int, _c_float, _vp, _vp, _vp, _vp, _c_int, _vp]),
     'nlt_front4_forward_train': (_c_int, [_vp] * 5 + [_c_int] * 4 + [_vp, _vp, _c_int, _c_float] + [_vp] * 7 + [_vp]),
     'nlt_dec_block_forward': (_c_int, [_vp, _c_int, _vp, _c_int, _c_int, _c_int, _c_int, _vp, _vp, _vp, _vp, _c_int, _c_float, _vp, _vp]),
     'nlt_back_forward': (_c_int, [_vp] * 3 + [_c_int] * 3 + [_vp] * 5 + [_c_float, _vp, _vp]),
@@ -102,7 +100,6 @@ SIGNATURES = {
     'nlt_front_backward': (_c_int, [_vp] * 5 + [_c_int] * 4 + [_vp] * 21),
     'nlt_back_backward_workspace_floats': (_c_long, [_c_int] * 3),
     'nlt_back_backward': (_c_int, [_vp] * 5 + [_c_int] * 3 + [_vp] * 3 + [_c_float] + [_vp] * 10),
-    'nlt_back_backward_parts': (_c_int, [_vp] * 5 + [_c_int] * 3 + [_vp] * 3 + [_c_float] + [_vp] * 9 + [_c_int, _vp]),
     'nlt_conv_splitk_workspace_floats': (_c_long, [_c_int] * 6),
     'nlt_conv_forward_splitk': (_c_int, [_c_int, _c_int, _c_int, _vp, _vp, _c_int, _c_int, _vp, _c_int, _c_int,
                                          _c_int, _c_int, _c_int, _vp, _vp, _c_int, _vp, _c_int, _c_int, _c_float,
@@ -373,12 +370,30 @@ class LightEvent:
             pass
 
 
-LIGHT_EVENTS = os.environ.get('NLT_LIGHT_EVENTS', '1') != '0'
+LIGHT_EVENTS = None         # None: decide per event (below); True / False: forced (tests, the bench's A/B leg)
+
+
+def light_events_enabled():
+    """Events WITHOUT a system-scope fence at the record (csrc/tape.hip) order the plan's device-to-device hand-overs; the
+    kernels' own agent-scope release / acquire orders the data.  In a multi-rank process group one of those hand-overs feeds the
+    side-stream RCCL all-reduce of a gradient range, whose peers read the bucket over xGMI: until that has been A/B-tested
+    on real multi-GPU hardware (bench.py's `light_events_ab` leg does it, bitwise) the default at world > 1 is the FENCED event
+    (advisor r04 / review r05).  NLT_LIGHT_EVENTS=0 / 1 forces either."""
+    if LIGHT_EVENTS is not None:
+        return bool(LIGHT_EVENTS)
+    e = os.environ.get('NLT_LIGHT_EVENTS')
+    if e is not None:
+        return e != '0'
+    try:
+        import torch.distributed as dist
+        return not (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1)
+    except Exception:
+        return True
 
 
 def new_event():
-    """Event for the plan's cross-stream hand-overs (NLT_LIGHT_EVENTS=0: an ordinary torch.cuda.Event)."""
-    return LightEvent() if LIGHT_EVENTS else torch.cuda.Event()
+    """Event for the plan's cross-stream hand-overs (`light_events_enabled`; otherwise an ordinary torch.cuda.Event)."""
+    return LightEvent() if light_events_enabled() else torch.cuda.Event()
 
 
 def record_event(ev, stream):
@@ -1156,27 +1171,6 @@ def front4_forward_u8(diffuse_store, rgb_store, cvis_store, lvis_store, ids, nn_
            'nlt_front4_forward_u8')
 
 
-def front5_forward(base, cvis, lvis, nn_rgb, nn_base, n, k, h, w, packed, packed_l2, add_base, alpha, fm1, skip3, qtmp2, otmp2,
-                   products=9):
-    """front4_forward with the 16-channel stages on the bf16 matrix cores (three-term split, `products` = 9 or 6)."""
-    for t, nm in ((base, 'base'), (cvis, 'cvis'), (lvis, 'lvis'), (nn_rgb, 'nn_rgb'), (nn_base, 'nn_base')):
-        _dense(t, nm)
-    _check(lib().nlt_front5_forward(_ptr(base), _ptr(cvis), _ptr(lvis), _ptr(nn_rgb), _ptr(nn_base), n, k, h, w,
-                                    _ptr(packed), _ptr(packed_l2), 1 if add_base else 0, float(alpha), _ptr(fm1), _ptr(skip3),
-                                    _ptr(qtmp2), _ptr(otmp2), int(products), _stream()), 'nlt_front5_forward')
-
-
-def front5_forward_u8(diffuse_store, rgb_store, cvis_store, lvis_store, ids, nn_ids, n, k, h, w, packed, packed_l2, add_base,
-                      alpha, fm1, skip3, qtmp2, otmp2, products=9):
-    u8 = torch.uint8
-    _check(lib().nlt_front5_forward_u8(_tptr(diffuse_store, u8, 'diffuse_store'), _tptr(rgb_store, u8, 'rgb_store'),
-                                       _tptr(cvis_store, u8, 'cvis_store'), _tptr(lvis_store, u8, 'lvis_store'),
-                                       _tptr(ids, torch.int32, 'ids'), _tptr(nn_ids, torch.int32, 'nn_ids'), n, k, h, w,
-                                       _ptr(packed), _ptr(packed_l2), 1 if add_base else 0, float(alpha), _ptr(fm1),
-                                       _ptr(skip3), _ptr(qtmp2), _ptr(otmp2), int(products), _stream()),
-           'nlt_front5_forward_u8')
-
-
 def front4_forward_train(base, cvis, lvis, nn_rgb, nn_base, n, k, h, w, packed, packed_l2, add_base, alpha, fm1, skip3, qtmp2, otmp2,
                          obs1, qtmp1, otmp1):
     """front4_forward that also keeps the level-1 maps the backward pass reads (train mode)."""
@@ -1247,23 +1241,6 @@ def back_backward(x, fm1, u, v, dpred, n, h2, w2, w_s2, w_s1, w_head, alpha, dx,
     wts = [_ptr(_dense(t, 'weight')) for t in (w_s2, w_s1, w_head)]
     outs = [_ptr(_dense(t, 'grad')) for t in (dx, dfm1, dw_s2, db_s2, dw_s1, db_s1, dw_head, db_head)]
     _check(lib().nlt_back_backward(*ins, n, h2, w2, *wts, float(alpha), *outs, _ptr(ws), _stream()), 'nlt_back_backward')
-
-
-def back_backward_parts(parts, x, fm1, u, v, dpred, n, h2, w2, w_s2, w_s1, w_head, alpha, dx, dfm1, dw_s2, db_s2, dw_s1, db_s1,
-                        dw_head, db_head):
-    """`back_backward` as two launches: parts = 1 writes dx / dfm1 (the chain continues behind it), parts = 2 accumulates the
-    weight / bias gradients (for the weight-gradient stream: its workspace is per stream)."""
-    ws = None
-    if parts & 2:
-        need = lib().nlt_back_backward_workspace_floats(n, h2, w2)
-        if need <= 0:
-            raise NLTError("nlt_back_backward_workspace_floats(%d,%d,%d) failed" % (n, h2, w2))
-        ws = _workspace('back_bwd.%d' % _stream(), x.device, need)
-    ins = [_ptr(_dense(t, nm)) for t, nm in ((x, 'x'), (fm1, 'fm1'), (u, 'u'), (v, 'v'), (dpred, 'dpred'))]
-    wts = [_ptr(_dense(t, 'weight')) for t in (w_s2, w_s1, w_head)]
-    outs = [_ptr(_dense(t, 'grad')) if t is not None else None for t in (dx, dfm1, dw_s2, db_s2, dw_s1, db_s1, dw_head, db_head)]
-    _check(lib().nlt_back_backward_parts(*ins, n, h2, w2, *wts, float(alpha), *outs, _ptr(ws), int(parts), _stream()),
-           'nlt_back_backward_parts')
 
 
 # ---------------------------------------------------------------- texel-buffer assembly

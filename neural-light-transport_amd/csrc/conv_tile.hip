@@ -64,15 +64,15 @@ __global__ void pack_tile_kernel(const float* __restrict__ wk, int cin, int cout
 // Register budget: the forward modes keep the allocation they were tuned with (<= 225 VGPR + AGPR, 2 workgroups per CU; the
 // mean-free instantiation and a forced 2-waves-per-SIMD allocation were measured on the whole forward pass: 3 workgroups per
 // CU of the query-path launches slow the observation-path launch running beside them, +2 % per step).  The transposed
-// (backward-data) modes and the 128-channel k2s2 tile are compiled for 2 waves per SIMD (the transposed k2s1 tile at 64
+// (backward-data) modes are compiled for 2 waves per SIMD (the transposed k2s1 tile at 64
 // channels otherwise allocates past 256 registers = one workgroup per CU).
 #ifndef NLT_TILE_MEANFREE
 #define NLT_TILE_MEANFREE 0
 #endif
 template <int MODE, int TNT, bool MEAN>
-__global__ __launch_bounds__(256, (MODE == NLT_DECONV_K2S1 || MODE == NLT_DECONV_K2S2 || TNT == 8) ? 2 : 1) void conv_tile_kernel(TileP p) {
+__global__ __launch_bounds__(256, (MODE == NLT_DECONV_K2S1 || MODE == NLT_DECONV_K2S2) ? 2 : 1) void conv_tile_kernel(TileP p) {
   using TT = TileTraits<MODE>;
-  constexpr int WN = TNT >= 4 ? 2 : 1, WM = 4 / WN, RT = TH / WM, CT = TNT / WN;   // TNT = 8 (k2s2 only): 4 x 4 tiles per wave
+  constexpr int WN = TNT >= 4 ? 2 : 1, WM = 4 / WN, RT = TH / WM, CT = TNT / WN;
   constexpr int A_FLOATS = TT::STAGE_TAPS * TNT * 256;
   constexpr int A_UNITS = A_FLOATS / 4, NA = A_UNITS / 256, NB = (TT::B_UNITS + 255) / 256;
   constexpr int STAGE = A_FLOATS + TT::B_FLOATS;
@@ -266,7 +266,7 @@ int launch(const TileP& p, hipStream_t s) {
   const int ncols = MODE == NLT_DECONV_K2S2 ? 4 * p.cout : p.cout;
   const dim3 grid((unsigned)tiles, (unsigned)(ncols / (16 * TNT)));
   constexpr bool FWD = MODE == NLT_CONV_K2S1 || MODE == NLT_CONV_K2S2;       // (the transposed modes are backward-data only: never a mean)
-  if (FWD && (p.kobs > 1 || p.mean_out || !(NLT_TILE_MEANFREE || TNT == 8))) hipLaunchKernelGGL((conv_tile_kernel<MODE, TNT, FWD>), grid, dim3(256), 0, s, p);
+  if (FWD && (p.kobs > 1 || p.mean_out || !NLT_TILE_MEANFREE)) hipLaunchKernelGGL((conv_tile_kernel<MODE, TNT, FWD>), grid, dim3(256), 0, s, p);
   else hipLaunchKernelGGL((conv_tile_kernel<MODE, TNT, false>), grid, dim3(256), 0, s, p);
   NLT_CHECK_LAUNCH();
   return NLT_OK;
@@ -280,7 +280,7 @@ extern "C" long nlt_conv_tile_packed_floats(int mode, int cin, int cout, int tn)
     return (long)4 * cin * cout;
   }
   if ((mode != NLT_CONV_K2S1 && mode != NLT_CONV_K2S2 && mode != NLT_DECONV_K2S1) || cin <= 0 || cout <= 0) return -1;
-  if ((cin & 15) || (tn != 32 && tn != 64 && !(tn == 128 && mode == NLT_CONV_K2S2)) || cout % tn) return -1;
+  if ((cin & 15) || (tn != 32 && tn != 64) || cout % tn) return -1;
   return (long)4 * cin * cout;
 }
 
@@ -308,7 +308,6 @@ static int tile_run(int mode, TileP& p, int tn, hipStream_t s) {
   if (mode == NLT_CONV_K2S1) return tn == 64 ? launch<NLT_CONV_K2S1, 4>(p, s) : launch<NLT_CONV_K2S1, 2>(p, s);
   if (mode == NLT_DECONV_K2S1) return tn == 64 ? launch<NLT_DECONV_K2S1, 4>(p, s) : launch<NLT_DECONV_K2S1, 2>(p, s);
   if (mode == NLT_DECONV_K2S2) return tn == 64 ? launch<NLT_DECONV_K2S2, 4>(p, s) : launch<NLT_DECONV_K2S2, 2>(p, s);
-  if (tn == 128) return launch<NLT_CONV_K2S2, 8>(p, s);
   return tn == 64 ? launch<NLT_CONV_K2S2, 4>(p, s) : launch<NLT_CONV_K2S2, 2>(p, s);
 }
 

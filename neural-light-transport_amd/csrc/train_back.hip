@@ -27,11 +27,9 @@ __device__ __forceinline__ float wave_sum(float v) {
   return v;
 }
 
-// PARTS (r05): 3 = everything (one launch, the r01-r04 form); 1 = backward-DATA only (dx, dfm1: what the backward chain waits
-// for); 2 = the weight / bias gradient sums only.  Split, the chain's launch drops the 24 x | fm1 operand loads, every
-// accumulator and the workspace hand-off (fewer registers: three workgroups per CU instead of two), and the sums run beside
-// the next backward-data launches on the weight-gradient stream; both halves recompute dv and du from (v, dpred, u), the
-// cheap part.
+// PARTS: 3 = everything, the only form launched.  (r05 also launched 1 = backward-data only on the chain + 2 = the weight / bias
+// sums on the weight-gradient stream: 3.16 vs 3.06 ms per l2 step -- the second launch re-reads (v, dpred, u) beside the chain's
+// full-resolution launches -- so the split entry point was removed in r06; profiles/README.md r05.)
 template <int PARTS>
 __global__ __launch_bounds__(256) void back_bwd_kernel(
     const float* __restrict__ x, const float* __restrict__ fm1, const float* __restrict__ u, const float* __restrict__ v,
@@ -317,8 +315,8 @@ namespace {
 int back_backward_launch(const float* x, const float* fm1, const float* u, const float* v, const float* dpred,
                          int n, int h2, int w2, const float* w_s2, const float* w_s1, const float* w_head,
                          float alpha, float* dx, float* dfm1, float* dw_s2, float* db_s2, float* dw_s1,
-                         float* db_s1, float* dw_head, float* db_head, float* workspace, int parts, void* stream) {
-  if (parts < 1 || parts > 3) return NLT_ERR_BAD_ARG;
+                         float* db_s1, float* dw_head, float* db_head, float* workspace, void* stream) {
+  constexpr int parts = 3;
   if (!x || !fm1 || !u || !v || !dpred || !w_s2 || !w_s1 || !w_head) return NLT_ERR_BAD_ARG;
   if ((parts & 1) && (!dx || !dfm1)) return NLT_ERR_BAD_ARG;
   if ((parts & 2) && (!dw_s2 || !db_s2 || !dw_s1 || !db_s1 || !dw_head || !db_head || !workspace)) return NLT_ERR_BAD_ARG;
@@ -331,7 +329,7 @@ int back_backward_launch(const float* x, const float* fm1, const float* u, const
   const int blocks = (int)back_bwd_blocks(n, h2, w2);
 #define NLT_BB(P_) hipLaunchKernelGGL(back_bwd_kernel<P_>, dim3(blocks), dim3(256), 0, s, x, fm1, u, v, dpred, h2, w2, ty, tx, tiles, \
                                       w_s2, w_s1, w_head, alpha, dx, dfm1, workspace)
-  if (parts == 3) NLT_BB(3); else if (parts == 1) NLT_BB(1); else NLT_BB(2);
+  NLT_BB(3);
 #undef NLT_BB
   NLT_CHECK_LAUNCH();
   if (parts & 2) {
@@ -348,13 +346,5 @@ extern "C" int nlt_back_backward(const float* x, const float* fm1, const float* 
                                  float alpha, float* dx, float* dfm1, float* dw_s2, float* db_s2, float* dw_s1,
                                  float* db_s1, float* dw_head, float* db_head, float* workspace, void* stream) {
   return back_backward_launch(x, fm1, u, v, dpred, n, h2, w2, w_s2, w_s1, w_head, alpha, dx, dfm1, dw_s2, db_s2, dw_s1, db_s1, dw_head,
-                              db_head, workspace, 3, stream);
-}
-
-extern "C" int nlt_back_backward_parts(const float* x, const float* fm1, const float* u, const float* v, const float* dpred,
-                                       int n, int h2, int w2, const float* w_s2, const float* w_s1, const float* w_head,
-                                       float alpha, float* dx, float* dfm1, float* dw_s2, float* db_s2, float* dw_s1,
-                                       float* db_s1, float* dw_head, float* db_head, float* workspace, int parts, void* stream) {
-  return back_backward_launch(x, fm1, u, v, dpred, n, h2, w2, w_s2, w_s1, w_head, alpha, dx, dfm1, dw_s2, db_s2, dw_s1, db_s1, dw_head,
-                              db_head, workspace, parts, stream);
+                              db_head, workspace, stream);
 }

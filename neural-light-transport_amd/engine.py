@@ -73,7 +73,6 @@ class RenderPlan(OverrideMixin):
         # it: 3.213 / 3.195 -> 3.173 / 3.173 ms l2 (two pairs, one box), so it is the default; 0 = front_kernel<false>
         self.front4_train = os.environ.get('NLT_FRONT4_TRAIN', '1') != '0'
         self.two_streams = os.environ.get('NLT_STREAMS', '2') != '1'   # inference: query-path encoder convs on a side stream
-        self.lazy_fork = os.environ.get('NLT_LAZY_FORK', '0') != '0'   # ... forked behind level 2's observation conv (see _forward_fused)
         self._side = None               # (side stream, [events]) created on first use
         self._bside = None              # backward: (side stream for the weight gradients, [events], cursor)
         self.wgrad_tiled = os.environ.get('NLT_WGRAD', 'tiled') != 'atomic'   # csrc/wgrad_tile.hip vs first-generation csrc/wgrad.hip
@@ -81,11 +80,6 @@ class RenderPlan(OverrideMixin):
         # weight gradients on a side stream, off the backward-data chain (config 4: 5.17 -> 4.63 ms / step)
         self.bwd_streams = int(os.environ.get('NLT_BWD_STREAMS', '1'))   # 0: one stream; 1: weight gradients on a side stream; 2: on two, alternately
         # launch tape: replay a step's C calls with their resolved arguments instead of re-deriving them (see _capi.py)
-        # ... handed over in batches of this many behind one event (1 = an event per launch, the default: batches of 3 / 6 measured
-        # SLOWER in r04 -- 3.22-3.24 -> 3.28 / 3.33 ms l2: the later start of the weight gradients costs more than the ~5 us
-        # marker gaps on the backward-data chain, which mostly sit under the side stream's work anyway)
-        self.wgrad_batch = int(os.environ.get('NLT_WGRAD_BATCH', '1'))
-        self._pending_wgrad = []
         self.use_tape = os.environ.get('NLT_TAPE', '1') != '0'
         # backward, one observation per frame: the per-level LeakyReLU' / observation-mean adjoint pass folded into the
         # epilogue of the backward-data launch that completes dfm[l] (0: the separate nlt_level_split_backward launches)
@@ -100,13 +94,6 @@ class RenderPlan(OverrideMixin):
         self.precision = os.environ.get('NLT_PRECISION', 'fp32')
         self._pred_out = None           # this forward's caller-owned output tensor (see `forward`)
         self._pred_slot = 'back_infer'
-        # callable fired (also on tape replays) when the fused inference pass reaches its expanding blocks: the chip is mostly idle
-        # under that chain of small launches, so Model.call queues the network-independent part of the resampler there
-        self.decoder_hook = None
-        # F.back.bwd as a backward-data launch on the chain + a weight-gradient launch on the side stream: built and measured in r05
-        # -- 3.16 vs 3.06 ms per l2 step, two A/B pairs on one box: the second launch re-reads (v, dpred, u) beside the chain's
-        # full-resolution launches and costs more than the 0.05 ms the lighter first launch saves.  Opt-in.
-        self.split_back_bwd = os.environ.get('NLT_SPLIT_BACK_BWD', '0') == '1'
         self.prune_packs = os.environ.get('NLT_PRUNE_PACKS', '1') != '0'   # retire fragment buffers only plan-time trials read
         self.grad_hook = None           # grad_hook(i): fired by backward() once range i of the gradient bucket has its weight gradients queued
         self.grad_mid_level = 0         # encoder level that closes range 1 (0: no such range); set by Model._flatten
@@ -116,11 +103,9 @@ class RenderPlan(OverrideMixin):
         self._ran_direct = set()
         self._trial_lds = 0             # autotune: try the LDS-tiled kernel with this many output channels per workgroup
         self._ran_lds = set()
-        self.lds_tn128 = os.environ.get('NLT_LDS_TN128', '0') != '0'   # opt-in trials: k2s2 launches with 128 channels per workgroup (faster alone, slower beside the other stream's launch)
         self.lds_hints = {}             # label -> tn (32 / 64) [+256: observations unfolded]: launches that go to csrc/conv_tile.hip
         # Winograd F(2x2, 2x2) kernel for the stride-1 k2 convs (csrc/conv_wino.hip: 9/16 of the matrix-pipe work); 0 = never
         self.use_wino = os.environ.get('NLT_WINO', '1') != '0'
-        self.wino_v1 = os.environ.get('NLT_WINO_V1', '0') == '1'       # A/B: the register-staged first generation
         self._trial_wino = 0            # autotune: try it with this many output channels per workgroup
         self._ran_wino = set()
         self.wino_hints = {}            # label -> tn (32 / 64) [+256: observations unfolded]: launches that go to csrc/conv_wino.hip
@@ -241,10 +226,9 @@ class RenderPlan(OverrideMixin):
 
     def _wino(self, label, layer, act, src, cin, ld, frames, kobs, h, w, out, ldo, mean_out, ldm, flops, obs_weights=None):
         """The launch on the Winograd kernel if the plan (or the running trial) gave it to it; False otherwise.
-        The observation mean stays in the kernel's registers; +256 runs the observations as frames and the mean in its own
-        launch (always so at 64 channels on the first-generation kernel, NLT_WINO_V1=1)."""
+        The observation mean stays in the kernel's registers; +256 runs the observations as frames and the mean in its own launch."""
         hint = self._trial_wino or self.wino_hints.get(label, 0)
-        tn, unfold = hint & 255, bool(hint >> 8) or ((hint & 255) == 64 and self.wino_v1)
+        tn, unfold = hint & 255, bool(hint >> 8)
         if not (tn and self.use_wino and obs_weights is None and layer.mode in (C.CONV_K2S1, C.DECONV_K2S1) and layer.cin == cin
                 and cin % 8 == 0 and layer.n_ch_out % tn == 0 and ld % 4 == 0 and ldo % 4 == 0):
             return False
@@ -311,8 +295,6 @@ class RenderPlan(OverrideMixin):
         tn, unfold = hint & 255, bool(hint >> 8)       # +256: observations as separate frames, mean in its own launch
         ok = (tn and obs_weights is None and algo == C.ALGO_AUTO and layer.mode in (C.CONV_K2S2, C.CONV_K2S1)
               and layer.cin == cin and cin % 16 == 0 and layer.n_ch_out % tn == 0)
-        if tn == 128:                                   # 128 output channels per workgroup: stride-2 convs of the native kernel only
-            ok = ok and layer.mode == C.CONV_K2S2 and self.precision not in ('f32x3', 'f32x3_9')
         if ok and unfold and kobs == 1:
             ok = self._trial_lds == 0                   # nothing to unfold here: leave this launch to the other trials
             unfold = False
@@ -362,8 +344,6 @@ class RenderPlan(OverrideMixin):
             trials.append(('direct', 0))    # only the 4/8-channel full-resolution layers ever preferred it
         if not backward:
             trials += [('lds', 32), ('lds', 64), ('lds', 256 + 32), ('lds', 256 + 64)]
-            if self.lds_tn128:
-                trials += [('lds', 128), ('lds', 256 + 128)]
         elif self.tile_dgrad:
             trials += [('lds', 32), ('lds', 64)]                  # backward-data launches on the LDS-tiled kernel
         if self.use_c32 and not backward:
@@ -561,7 +541,7 @@ class RenderPlan(OverrideMixin):
                 and obs_weights is None and (obs_override is None or use_ovr)
                 and all(t.is_contiguous() for t in (base, cvis, lvis, nn_rgb, nn_base))):    # (a replay skips the adapters' layout checks)
             tkey = ('fwd', base.data_ptr(), cvis.data_ptr(), lvis.data_ptr(), nn_rgb.data_ptr(), nn_base.data_ptr(),
-                    bool(skip_connect_base), algo, inference, fused, C._stream(), pred_out is not None, self.decoder_hook is not None,
+                    bool(skip_connect_base), algo, inference, fused, C._stream(), pred_out is not None,
                     ovr['serial'] if use_ovr else 0)
             tapes = b.setdefault('tapes', {})
             if len(tapes) > 16:                     # ever-changing input addresses (a loader that allocates per step): forget
@@ -612,8 +592,7 @@ class RenderPlan(OverrideMixin):
         self._front_weights(dev)
         tkey = None
         if self.use_tape and self.timer is None and not self._tuning and reg is not None:
-            tkey = ('fwd_u8',) + res.key() + (bool(skip_connect_base), algo, C._stream(), self._pred_out is not None,
-                                              self.decoder_hook is not None)
+            tkey = ('fwd_u8',) + res.key() + (bool(skip_connect_base), algo, C._stream(), self._pred_out is not None)
             tapes = b.setdefault('tapes', {})
             if len(tapes) > 16:
                 tapes.clear()
@@ -779,15 +758,11 @@ class RenderPlan(OverrideMixin):
                 self._side = (torch.cuda.Stream(device=dev), [C.new_event() for _ in range(D + 3)])
             side, ev = self._side
             main = torch.cuda.current_stream()
-            # An event record is a marker packet on the recording stream: the next launch behind it starts 4-12 us late (r04
-            # trace: 54 us of such gaps on the observation chain per pass, 46 with events that carry no system-scope fence).
-            # So the query stream is not forked right behind the front kernel (12.6 us before the largest launch of the chain)
-            # but behind level 2's observation conv -- its first wait is ev[2] --, and the record nobody waits for (level D) is
-            # gone.  OPT-IN (NLT_LAZY_FORK=1): measured r04 1.268 / 1.278 vs 1.275 / 1.268 ms -- the gap goes, the query path starts 125 us later, nothing is won.
-            lazy = self.lazy_fork
-            if not lazy:
-                C.record_event(ev[0], main)                         # front kernel done: fm[1], obs[1]
-                C.wait_event(side, ev[0])
+            # (An event record is a marker packet on the recording stream: the launch behind it starts 4-12 us late -- 46 us of
+            # such gaps per pass.  Forking the query stream later, behind level 2's observation conv, removed one gap and
+            # delayed the query path by as much: measured r04, no gain, removed in r06; profiles/README.md.)
+            C.record_event(ev[0], main)                             # front kernel done: fm[1], obs[1]
+            C.wait_event(side, ev[0])
         hh, ww = h // 2, w // 2
         bf = self.precision == 'bf16' and not train
         for l in range(2, D + 1):
@@ -822,13 +797,10 @@ class RenderPlan(OverrideMixin):
 
             obs_path()
             if concurrent:
-                if l < D or not lazy or l == 2:
-                    C.record_event(ev[l], main)                     # fm[l]'s observation half is complete
+                C.record_event(ev[l], main)                         # fm[l]'s observation half is complete
                 with torch.cuda.stream(side):
                     if l > 2:
                         C.wait_event(side, ev[l - 1])
-                    elif lazy:
-                        C.wait_event(side, ev[2])                   # (also orders the side stream behind the front kernel)
                     query_path()
             else:
                 query_path()
@@ -836,8 +808,6 @@ class RenderPlan(OverrideMixin):
         if concurrent:
             C.record_event(ev[D + 1], side)
             C.wait_event(main, ev[D + 1])                              # the decoder needs both halves of every fm[l]
-        if self.decoder_hook is not None and not train and not self._tuning:
-            C.tape_call(self._fire_decoder_hook)
         x, cx = b['fm'][D], 2 * cl[D]
         for j in range(U - 1):
             (da, dact_a), (db, dact_b) = q.layers[D + 1 + j].convs()
@@ -895,12 +865,6 @@ class RenderPlan(OverrideMixin):
             C.tape_resume(paused)
         return out, b
 
-    def _fire_decoder_hook(self):
-        """Runs the CURRENT call's `decoder_hook` (a replayed tape re-invokes this, not the closure it was recorded with)."""
-        hook = self.decoder_hook
-        if hook is not None and not self._tuning:
-            hook()
-
     def _finish_pred(self, b):
         """After a tape replay: the launch that was kept out of the tape (see `forward`, pred_out)."""
         if self._pred_out is None:
@@ -931,15 +895,9 @@ class RenderPlan(OverrideMixin):
         chain -- the critical path -- carries on; `backward` joins the streams at the end."""
         bs = self._bside
         if bs is not None and bs[2] is not None:
-            if self.wgrad_batch > 1 and (len(bs) <= 3 or bs[3] is None):
-                # every event record is a marker packet on the backward-data chain: the launch behind it starts ~5 us late (r04
-                # trace of the train step: 39 such gaps, 216 us of 3.2 ms).  The weight gradients are off the critical path and
-                # their operands are final when they are queued, so they are handed to the side stream a few at a time behind
-                # ONE event.
-                self._pending_wgrad.append((label, layer, src0, c0, ld0, src1, c1, ld1, n, h, w, dpre, ldp))
-                if len(self._pending_wgrad) >= self.wgrad_batch:
-                    self._flush_wgrads()
-                return
+            # (An event per launch.  Handing the weight gradients over in batches of 3 / 6 behind one event was measured SLOWER in
+            # r04 -- 3.22-3.24 -> 3.28 / 3.33 ms l2: their later start costs more than the ~5 us marker gaps on the chain --
+            # and removed in r06.)
             side, events, cur = bs[:3]
             if cur[0] == len(events):
                 events.append(C.new_event())
@@ -954,31 +912,9 @@ class RenderPlan(OverrideMixin):
             return
         self._wgrad_now(label, layer, src0, c0, ld0, src1, c1, ld1, n, h, w, dpre, ldp)
 
-    def _flush_wgrads(self):
-        """Queues the weight-gradient launches collected by `_wgrad` on the side stream, behind one event on the current stream."""
-        pend, self._pending_wgrad = self._pending_wgrad, []
-        bs = self._bside
-        if not pend:
-            return
-        if bs is None or bs[2] is None:
-            for a in pend:
-                self._wgrad_now(*a)
-            return
-        side, events, cur = bs[:3]
-        if cur[0] == len(events):
-            events.append(C.new_event())
-        ev = events[cur[0]]
-        cur[0] += 1
-        C.record_event(ev, torch.cuda.current_stream())
-        with torch.cuda.stream(side):
-            C.wait_event(side, ev)
-            for a in pend:
-                self._wgrad_now(*a)
-
     def _grad_range_done(self, i):
         """Range i of the flat gradient bucket (models/nlt.py:_flatten: 0 = expanding blocks, 1 = encoder levels D .. grad_mid_level)
         has all its weight-gradient launches queued: fire the hook on their stream."""
-        self._flush_wgrads()
         bs = self._bside
         if bs is not None and bs[2] is not None and bs[3] is not None:
             side, events, cur, side2 = bs                            # (two weight-gradient streams: the hook's stream waits for the other)
@@ -1140,12 +1076,9 @@ class RenderPlan(OverrideMixin):
                 self._bside = [torch.cuda.Stream(device=dpred.device), [], None,
                                torch.cuda.Stream(device=dpred.device) if self.bwd_streams > 1 else None]
             self._bside[2] = [0]                                     # event cursor: weight gradients go to the side stream
-        self._pending_wgrad = []
         try:
             self._backward_plan(dpred, base, cvis, lvis, nn_rgb, nn_base, obs_weights, b, g, n, h, w, k)
-            self._flush_wgrads()
         finally:
-            self._pending_wgrad = []
             if concurrent:
                 side, events, cur, side2 = self._bside
                 self._bside[2] = None
@@ -1175,24 +1108,9 @@ class RenderPlan(OverrideMixin):
             bb_in = (b['dec'][U - 2], b['fm'][1], b['dtmp'][U - 1], b['dec'][U - 1], dpred, n, h // 2, w // 2, da.kernel.detach(),
                      db.kernel.detach(), head.kernel.detach(), act_a.alpha)
             bb_w = (da.dkernel, da.dbias, db.dkernel, db.dbias, head.dkernel, head.dbias)
-            bs = self._bside
-            if self.split_back_bwd and bs is not None and bs[2] is not None and not self._tuning:
-                # r05: the chain waits for dx / dfm1 only -- a launch without the x | fm1 operand loads and the accumulators
-                # (112 registers: four workgroups per CU); the weight / bias sums go to the weight-gradient stream like every
-                # other weight gradient (they recompute dv / du from the same three maps)
-                self._launch('F.back.bwd', 4 * n * h * w * (4 + 4 + 3 + 10), C.back_backward_parts, 1, *bb_in, g['dec'][U - 2], g['fm'][1],
-                             None, None, None, None, None, None)
-                side, events, cur = bs[:3]
-                if cur[0] == len(events):
-                    events.append(C.new_event())
-                ev = events[cur[0]]
-                cur[0] += 1
-                C.record_event(ev, torch.cuda.current_stream())
-                with torch.cuda.stream(side):
-                    C.wait_event(side, ev)
-                    self._launch('F.back.wgrad', 4 * n * h * w * (4 + 4 + 3 + 10), C.back_backward_parts, 2, *bb_in, None, None, *bb_w)
-            else:
-                self._launch('F.back.bwd', 4 * n * h * w * (4 + 4 + 3 + 20), C.back_backward, *bb_in, g['dec'][U - 2], g['fm'][1], *bb_w)
+            # (F.back.bwd as a backward-data launch on the chain + a weight-gradient launch on the side stream was built and measured
+            # in r05 -- 3.16 vs 3.06 ms per l2 step -- and removed in r06.)
+            self._launch('F.back.bwd', 4 * n * h * w * (4 + 4 + 3 + 20), C.back_backward, *bb_in, g['dec'][U - 2], g['fm'][1], *bb_w)
         else:
             self._launch('bwd.head', 4 * n * h * w * (2 * (cx + cs) + 3), C.head_backward, x_last, cx, cx, b['fm'][0], cs, cs,
                          head.kernel.detach(), dpred, n, h, w, g['dec'][U - 1], cx, g['fm'][0], cs, head.dkernel, head.dbias)

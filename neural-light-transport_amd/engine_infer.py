@@ -186,8 +186,6 @@ class OverrideMixin:
                            b['qtmp'][l], c, algo, bmap=pmap)
             hh, ww = hh // 2, ww // 2
             self._conv_enc('L%d.q.s1' % l, qb, qact_b, b['qtmp'][l], c, c, n, 1, hh, ww, b['fm'][l], 2 * c, algo)
-        if self.decoder_hook is not None and not self._tuning:
-            C.tape_call(self._fire_decoder_hook)
         x, cx = b['fm'][D], 2 * cl[D]
         for j in range(U - 1):
             (da, dact_a), (db, dact_b) = q.layers[D + 1 + j].convs()

@@ -322,45 +322,13 @@ class Model(BaseModel):
                 C.warp_forward_store(pred_, resident.diffuse, resident.uv2cam, resident.ids, n, self.uvh, self.uvw, hc, wc, pc, bc, fc, ix)
             else:
                 C.warp_forward(pred_, base, warp, n, self.uvh, self.uvw, hc, wc, pc, bc, fc, ix)
-        # The base / foreground gathers (two thirds of the resampler's traffic, nlt/models/nlt.py:113-114) and the UV indices do
-        # not depend on the network.  Inference queues them on a side stream when the pass reaches its expanding blocks -- a chain
-        # of small launches under which the chip is mostly idle -- and only the gather of `pred` stays behind the last launch.
-        # OPT-IN (NLT_WARP_SPLIT=1): measured r04 at the bench shape it gains nothing -- 1.294 vs 1.285 ms with / without, inside the
-        # run-to-run spread; issued at the START of the pass, beside the front kernel, it costs 0.03 ms (that kernel is sensitive
-        # to other memory traffic: 0.264 -> 0.286 ms).
-        early = (inference and dev.type == 'cuda' and not timing_all and not self.use_graphs
-                 and os.environ.get('NLT_WARP_SPLIT', '0') != '0')
-        fired = []
-        if early:
-            ws = getattr(self, '_warp_side', None)
-            if ws is None or ws[0].device != dev:
-                ws = self._warp_side = (torch.cuda.Stream(device=dev), torch.cuda.Event(), torch.cuda.Event())
-            side, ev0, ev1 = ws
-
-            def hook():
-                paused = C.tape_pause()                          # (output addresses of THIS call: never part of a launch tape)
-                try:
-                    ev0.record(torch.cuda.current_stream(dev))   # behind the loader and whatever used the recycled blocks
-                    side.wait_event(ev0)
-                    with torch.cuda.stream(side):
-                        resample(None, None, base_camspc, fg_camspc, idx)
-                        ev1.record(side)
-                    fired.append(True)
-                finally:
-                    C.tape_resume(paused)
-            self.plan.decoder_hook = hook
-        try:
-            pred, _ = self.plan.forward(base, cvis, lvis, nn_rgb, nn_base, obs_weights=obs_weights,
-                                        obs_override=obs_override, skip_connect_base=self.skip_connect_base,
-                                        algo=self.conv_algo, inference=inference, resident=resident, pred_out=fresh)
-        finally:
-            self.plan.decoder_hook = None
+        # (The base / foreground gathers do not depend on the network; queueing them on a side stream under the expanding blocks
+        # was built and measured in r04 -- 1.294 vs 1.285 ms, nothing -- and removed in r06.)
+        pred, _ = self.plan.forward(base, cvis, lvis, nn_rgb, nn_base, obs_weights=obs_weights,
+                                    obs_override=obs_override, skip_connect_base=self.skip_connect_base,
+                                    algo=self.conv_algo, inference=inference, resident=resident, pred_out=fresh)
         self._pred_fresh = fresh is not None and pred is fresh
-        if fired:
-            resample(pred, pred_camspc, None, None, None)
-            torch.cuda.current_stream(dev).wait_event(ev1)
-        else:
-            resample(pred, pred_camspc, base_camspc, fg_camspc, idx)
+        resample(pred, pred_camspc, base_camspc, fg_camspc, idx)
         if (hc, wc) != (self.imh, self.imw):
             fg_camspc = C.resize_bilinear_forward(fg_camspc, self.imh, self.imw)
             base_camspc = C.resize_bilinear_forward(base_camspc, self.imh, self.imw)

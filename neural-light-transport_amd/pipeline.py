@@ -43,7 +43,7 @@ import torch
 from . import _capi as C
 from .engine import RenderPlan
 
-_PLAN_SWITCHES = ('precision', 'fuse_ends', 'front_l2', 'fuse_dec', 'front_v4', 'two_streams', 'use_tape', 'lds_tn128', 'use_wino', 'use_c32', 'lazy_fork', 'fuse_override')
+_PLAN_SWITCHES = ('precision', 'fuse_ends', 'front_l2', 'fuse_dec', 'front_v4', 'two_streams', 'use_tape', 'use_wino', 'use_c32', 'fuse_override')
 
 
 def _copy_tuning(dst, src):
@@ -146,7 +146,6 @@ class RenderPipeline:
             lane = copy.copy(m)                             # same nets, flat bucket, pack registry
             lane.plan = RenderPlan(m.net['query'], m.net['obs'], m.use_obs)
             lane._graph, lane._graphs = None, {}
-            lane._warp_side = None                          # (NLT_WARP_SPLIT: side stream + events are per lane, never shared)
             lane.use_graphs = self._graphs
             self._lanes[i] = lane
         lane.conv_algo, lane.skip_connect_base = m.conv_algo, m.skip_connect_base

@@ -16,8 +16,7 @@ pytestmark = pytest.mark.gpu
     (C.CONV_K2S1, 16, 32, 32, 10, 20, 2, 2), (C.CONV_K2S1, 32, 64, 64, 8, 16, 1, 1), (C.CONV_K2S1, 64, 64, 32, 33, 47, 1, 3),
     (C.CONV_K2S1, 256, 256, 64, 16, 16, 2, 2), (C.CONV_K2S1, 128, 128, 64, 64, 64, 1, 4),
     (C.CONV_K2S2, 16, 32, 32, 20, 36, 2, 2), (C.CONV_K2S2, 32, 128, 64, 16, 32, 1, 1), (C.CONV_K2S2, 64, 64, 64, 66, 94, 1, 2),
-    (C.CONV_K2S2, 512, 256, 64, 32, 32, 1, 1), (C.CONV_K2S2, 32, 32, 32, 256, 256, 2, 1),
-    (C.CONV_K2S2, 64, 128, 128, 20, 36, 2, 2), (C.CONV_K2S2, 256, 256, 128, 32, 32, 1, 1), (C.CONV_K2S2, 32, 128, 128, 66, 94, 1, 3)])
+    (C.CONV_K2S2, 512, 256, 64, 32, 32, 1, 1), (C.CONV_K2S2, 32, 32, 32, 256, 256, 2, 1)])
 def test_conv_tile_vs_oracle(mode, cin, cout, tn, h, w, frames, kobs):
     rng = np.random.default_rng(cin + cout + h + kobs)
     ld = cin + 8
@@ -170,21 +169,6 @@ def test_conv_tile_rejects_what_it_cannot_do():
     with pytest.raises(C.NLTError):                      # odd input size for the stride-2 conv
         C.conv_tile_forward(C.CONV_K2S2, torch.zeros(1, 7, 8, 16, device='cuda'), 16, 16, 1, 1, 7, 8, packed,
                             torch.zeros(32, device='cuda'), 32, 32, torch.zeros(1, 3, 4, 32, device='cuda'), 32, None, 0)
-
-
-def test_model_with_128_channel_workgroups_on_the_stride2_convs():
-    om, pm = make_pair(depth=256, uv=128, im=64, seed=77)
-    batch, nn = O.synth_batch(1, 128, 128, 64, 64, 64, 64, k=3, seed=31)
-    with torch.no_grad():
-        o_vis = om.call(batch, 'test', nn_list=nn)[3]
-    pm.plan.autotune = False
-    nlev = sum(pm.net['query'].is_contracting) - 1
-    pm.plan.lds_hints = {'L%d.%s.s2' % (l, p): 128 for l in range(1, nlev + 1) for p in 'qo'}
-    p_vis = pm.call(to_device_batch(batch, nn), 'test')[3]
-    torch.cuda.synchronize()
-    ran = pm.plan._ran_lds
-    assert 'L%d.q.s2' % nlev in ran and 'L%d.o.s2' % nlev in ran and 'L4.o.s2' in ran and 'L3.o.s2' not in ran   # (64 channels at level 3)
-    assert rel_l2(p_vis['pred'].cpu(), o_vis['pred']) <= 1e-4
 
 
 @pytest.mark.parametrize('depth,uv,k,tn,mode', [(256, 64, 2, 32, 'test'), (256, 128, 3, 64, 'test'), (1024, 256, 1, 64, 'test'),

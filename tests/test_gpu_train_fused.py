@@ -155,17 +155,3 @@ def test_back_backward_matches_autograd_through_the_last_block(n, h2, w2):
     run(again)
     torch.cuda.synchronize()
     assert all(torch.equal(again[k_], grads[k_]) for k_ in ref)
-    # r05: the same pass as two launches (backward-data on the chain, the sums on the weight-gradient stream)
-    dx2 = torch.full_like(dx, float('nan')); dfm2 = torch.full_like(dfm1, float('nan'))
-    two = {k_: dev(init[k_]) for k_ in ref}
-    ins = (dev(x), dev(fm1), dev(u), dev(v), dev(dpred), n, h2, w2, dev(P['w_s2']), dev(P['w_s1']), dev(P['wh']), 0.3)
-    C.back_backward_parts(1, *ins, dx2, dfm2, None, None, None, None, None, None)
-    torch.cuda.synchronize()
-    assert all(torch.equal(two[k_].cpu(), init[k_]) for k_ in ref)          # part 1 touches no weight gradient
-    C.back_backward_parts(2, *ins, None, None, two['w_s2'], two['b_s2'], two['w_s1'], two['b_s1'], two['wh'], two['bh'])
-    torch.cuda.synchronize()
-    # (three instantiations of one template: the compiler contracts / orders the VALU chains of dv and du differently in each)
-    assert rel_l2(dx2.cpu(), dx.cpu()) <= 1e-6 and rel_l2(dfm2.cpu(), dfm1.cpu()) <= 1e-6
-    assert all(rel_l2(two[k_].cpu() - init[k_], grads[k_].cpu() - init[k_]) <= 1e-5 for k_ in ref)
-    with pytest.raises(C.NLTError):
-        C.back_backward_parts(2, *ins, None, None, None, None, None, None, None, None)

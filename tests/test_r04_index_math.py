@@ -1,13 +1,10 @@
 """CPU: lane- and wave-level NumPy emulation of the index math that is NEW in round 4's kernels (the arithmetic on the values is
 the MFMA's; what can go wrong is WHICH value meets which):
 
-  * the persistent tile schedules of front4 / front5 (8-wave workgroups) and conv_c32 (256-thread workgroups): every tile is taken
+  * the persistent tile schedules of front4 / front_ovr (8-wave workgroups) and conv_c32 (256-thread workgroups): every tile is taken
     by exactly one wave / workgroup, XCD x = blockIdx & 7 owns a contiguous run, ragged tile counts and small grids included;
   * the staged-item sequence of a persistent front wave (observation 0 .. k - 1, query inputs, next strip's observation 0 ...):
     every item is stored exactly once, after it was loaded, before the stage that reads it, and never over data still to be read;
-  * front5's register hand-offs: lane (kk, j = (Y, X)) of stage-1 tile (u, v) / stage-2 tile (a, b) holds exactly the texel the
-    next stage's tap needs -- checked by running the whole three-conv chain of one strip through the kernel's dataflow in float64
-    and comparing it with the three convs applied to the image;
   * dec_block10's work units: (column tile, row half) pairs cover the haloed tile's 10 column tiles x MT row tiles once, and the
     chunk -> (x | skip) channel mapping walks the virtual concat in order.
 """
@@ -20,7 +17,7 @@ KK, J = LANE >> 4, LANE & 15
 
 # ------------------------------------------------------------------------------------------------ persistent schedules
 def front_schedule(ntiles, grid, nwaves=8):
-    """(block, wave) -> list of tiles, as csrc/front4.hip / front5.hip compute it."""
+    """(block, wave) -> list of tiles, as csrc/front4.hip / front_ovr.hip compute it."""
     per = (ntiles + 7) >> 3
     stride = (grid >> 3) * nwaves
     out = {}
@@ -107,9 +104,8 @@ def test_conv_c32_schedule_takes_every_tile_once(tiles):
 @pytest.mark.parametrize('k', [1, 2, 3, 4, 7])
 @pytest.mark.parametrize('nstrips', [1, 2, 5])
 def test_staged_item_sequence_of_a_persistent_front_wave(k, nstrips):
-    """Event-level replay of the loop in front4_kernel / front5_kernel: `st` = the item in flight in registers, `lds_o` = what the raw
-    observation tile holds, `lds_q` = the query tiles (front4 keeps them apart; for front5, where they share the observation's tile,
-    the same replay with one buffer is run below)."""
+    """Event-level replay of the loop in front4_kernel: `st` = the item in flight in registers, `lds_o` = what the raw
+    observation tile holds, `lds_q` = the query tiles (front4 keeps them apart; the same replay with ONE shared buffer is run below as well)."""
     for shared in (False, True):
         st, lds_o, lds_q = None, None, None
         log = []
@@ -152,107 +148,6 @@ def test_staged_item_sequence_of_a_persistent_front_wave(k, nstrips):
                 load((s + 1, 1) if k > 1 else (s + 1, 'Q'))
         assert st is None
         assert log == [(s, x) for s in range(nstrips) for x in list(range(k)) + ['Q']]
-
-
-# ------------------------------------------------------------------------------------------------ front5 register hand-offs
-def lrelu(v, a=0.3):
-    return np.where(v > 0, v, a * v)
-
-
-def conv_same(x, w, stride):
-    """TF Conv2D 'same' for k = 2: pads bottom / right.  x [H, W, Cin], w [2, 2, Cin, Cout]."""
-    H, W, _ = x.shape
-    xp = np.pad(x, ((0, 1), (0, 1), (0, 0)))
-    oh, ow = (H + stride - 1) // stride, (W + stride - 1) // stride
-    out = np.zeros((oh, ow, w.shape[3]))
-    for a in range(2):
-        for b in range(2):
-            out += np.einsum('hwc,co->hwo', xp[a:a + H:stride, b:b + W:stride][:oh, :ow], w[a, b])
-    return out
-
-
-@pytest.mark.parametrize('h,w', [(16, 64), (8, 32), (12, 40), (4, 4), (20, 36)])
-def test_front5_tile_dataflow_is_the_three_conv_chain(h, w):
-    """raw [h, w, 3] -> stride-2 conv (3 -> 16, stands for the folded L0 + L1.s2) + lrelu -> stride-1 conv (16 -> 16) + lrelu ->
-    stride-2 conv (16 -> 32) + lrelu, evaluated (a) directly and (b) strip by strip with csrc/front5.hip's tiles: stage 1 produces
-    T[u][v] at level-1 texel (2Y + u, 2X + v) from raw texel (4Y + 2u + tap / 2, 4X + 2v + tap % 2), zeroed outside the image;
-    stage 2 produces O[a][b] = sum over taps (a', b') of W1[a', b'] . T[a + a'][b + b']; stage 3 sums W3[a, b] . O[a][b]."""
-    rng = np.random.default_rng(h * 100 + w)
-    raw = rng.standard_normal((h, w, 3))
-    w_s2, w_s1, w_l2 = rng.standard_normal((2, 2, 3, 16)), rng.standard_normal((2, 2, 16, 16)), rng.standard_normal((2, 2, 16, 32))
-    t1 = lrelu(conv_same(raw, w_s2, 2))
-    o1 = lrelu(conv_same(t1, w_s1, 1))
-    ref = lrelu(conv_same(o1, w_l2, 2))
-    h2, w2, h4, w4 = h // 2, w // 2, h // 4, w // 4
-    got = np.full((h4, w4, 32), np.nan)
-    got_o1 = np.full((h2, w2, 16), np.nan)
-    SH, SW = 4, 16
-    for ty0 in range(0, h2, SH):
-        for tx0 in range(0, w2, SW):
-            for j in range(16):                                              # one lane column = one level-2 texel (Y, X)
-                Y, X = j >> 3, j & 7
-                lim_r, lim_c = h2 - ty0 - 2 * Y, w2 - tx0 - 2 * X
-                T = np.zeros((3, 3, 16))
-                for u in range(3):
-                    for v in range(3):
-                        acc = np.zeros(16)
-                        for tap in range(4):                                 # lane group kk = tap of the stride-2 conv
-                            ry, rx = 2 * ty0 + 4 * Y + 2 * u + (tap >> 1), 2 * tx0 + 4 * X + 2 * v + (tap & 1)
-                            if u < lim_r and v < lim_c:                      # (outside: whatever the staged tile holds; masked below)
-                                assert ry < h and rx < w
-                                acc += raw[ry, rx] @ w_s2[tap >> 1, tap & 1]
-                        T[u, v] = lrelu(acc) if (u < lim_r and v < lim_c) else 0.0
-                O = np.zeros((2, 2, 16))
-                for a in range(2):
-                    for b in range(2):
-                        for a1 in range(2):                                  # K block = tap row a1: tiles (a + a1, b) | (a + a1, b + 1)
-                            for b1 in range(2):
-                                O[a, b] += T[a + a1, b + b1] @ w_s1[a1, b1]
-                O = lrelu(O)
-                for a in range(2):
-                    for b in range(2):
-                        if a < lim_r and b < lim_c:
-                            assert np.isnan(got_o1[ty0 + 2 * Y + a, tx0 + 2 * X + b]).all(), "two owners of a level-1 texel"
-                            got_o1[ty0 + 2 * Y + a, tx0 + 2 * X + b] = O[a, b]
-                gy2, gx2 = (ty0 >> 1) + Y, (tx0 >> 1) + X
-                if gy2 < h4 and gx2 < w4:
-                    acc3 = np.zeros(32)
-                    for a in range(2):                                       # K block = tap row a: tiles (a, 0) | (a, 1)
-                        for b in range(2):
-                            acc3 += O[a, b] @ w_l2[a, b]
-                    assert np.isnan(got[gy2, gx2]).all()
-                    got[gy2, gx2] = lrelu(acc3)
-    assert not np.isnan(got).any() and not np.isnan(got_o1).any()
-    np.testing.assert_allclose(got_o1, o1, rtol=1e-12, atol=1e-12)
-    np.testing.assert_allclose(got, ref, rtol=1e-12, atol=1e-12)
-
-
-def test_front5_k_block_slots_pair_the_tiles_with_the_weight_fragments():
-    """A bf16 K block of 32: lane group kk, slot e < 4 = channel 4 kk + e of the FIRST tap's tile, e >= 4 = channel 4 kk + e - 4 of the
-    second's.  The weight fragment (a1_load: tap = 2 a' + eh, channels 4 kk ..) must use the same (tap, channel) per slot."""
-    for a1 in range(2):
-        for kk in range(4):
-            for e in range(8):
-                tile_tap = (a1, e >> 2)                                      # pair8(T[.][b], T[.][b + 1])
-                tile_ch = 4 * kk + (e & 3)
-                frag_tap = 2 * a1 + (e >> 2)                                 # a1_load: r[2 a + eh], eh = e >> 2
-                frag_ch = 4 * kk + (e & 3)                                   # blob [tap][lane' = kk * 16 + o][s4]
-                assert (frag_tap >> 1, frag_tap & 1) == tile_tap and frag_ch == tile_ch
-    # the raw staging offsets of tile (u, v): immediates on one lane base, inside the 10 x 34 staged tile
-    R3, R1 = 104, 40
-    Y, X = J >> 3, J & 7
-    rd3 = (4 * Y + (KK >> 1)) * R3 + (4 * X + (KK & 1)) * 3
-    rd1 = (4 * Y + (KK >> 1)) * R1 + 4 * X + (KK & 1)
-    for u in range(3):
-        for v in range(3):
-            o3 = rd3 + u * 2 * R3 + v * 6
-            row, col = o3 // R3, (o3 % R3) // 3
-            np.testing.assert_array_equal(row, 4 * Y + 2 * u + (KK >> 1))
-            np.testing.assert_array_equal(col, 4 * X + 2 * v + (KK & 1))
-            assert row.max() <= 9 and col.max() <= 33
-            o1 = rd1 + u * 2 * R1 + v * 2
-            np.testing.assert_array_equal(o1 // R1, row)
-            np.testing.assert_array_equal(o1 % R1, col)
 
 
 # ------------------------------------------------------------------------------------------------ dec_block10

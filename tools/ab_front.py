@@ -30,7 +30,7 @@ def time_it(fn, reps=5, inner=20):
 
 def main():
     print("lib:", C.LIB_PATH)
-    res, res5 = {}, {}
+    res = {}
     for (n, h, w, ks) in ((4, 1024, 1024, (1, 2, 4)), (2, 2048, 2048, (1,))):
         pm = get_model_class('nlt')(nlt_amd.make_config(depth=256, uvh=h, uvw=w, imh=512, imw=512)).build('cuda')
         blob, blob_l2 = pm.plan._front_weights(torch.device('cuda'))
@@ -49,24 +49,10 @@ def main():
             cs = [float(o.double().sum()) for o in outs]
             t8 = time_it(lambda: C.front4_forward_u8(diffuse, rgb, cvis, lvis, ids, nn_ids, n, k, h, w, blob, blob_l2, True, 0.3, *outs, 2))
             print("n %d  %4d^2  k %d:  f32 %.4f ms   u8 %.4f ms   checksums %s" % (n, h, k, t32, t8, ' '.join('%.6e' % c for c in cs)))
-            if hasattr(C, 'front5_forward') and hasattr(C.lib(), 'nlt_front5_forward'):
-                ref = [o.clone() for o in outs]
-                C.front4_forward(*fl, n, k, h, w, blob, blob_l2, True, 0.3, *ref, 2)
-                line = "     front5 (bf16 three-term split):"
-                for prod in (9, 6):
-                    t5 = time_it(lambda: C.front5_forward(*fl, n, k, h, w, blob, blob_l2, True, 0.3, *outs, prod))
-                    rel = max(float((a.double() - b.double()).norm() / a.double().norm()) for a, b in zip(ref, outs))
-                    t58 = time_it(lambda: C.front5_forward_u8(diffuse, rgb, cvis, lvis, ids, nn_ids, n, k, h, w, blob, blob_l2, True, 0.3, *outs, prod))
-                    line += "   x3-%d f32 %.4f ms  u8 %.4f ms  (rel-L2 vs front4 %.1e)" % (prod, t5, t58, rel)
-                    res5[(h, k, prod)] = t5
-                print(line)
             res[(h, k)] = t32
     if (1024, 1) in res and (1024, 4) in res:
         per = (res[(1024, 4)] - res[(1024, 1)]) / 3
         print("1024^2: per observation %.4f ms, everything else %.4f ms" % (per, res[(1024, 1)] - per))
-    if (1024, 1, 9) in res5 and (1024, 4, 9) in res5:
-        per = (res5[(1024, 4, 9)] - res5[(1024, 1, 9)]) / 3
-        print("1024^2, front5 x3-9: per observation %.4f ms, everything else %.4f ms" % (per, res5[(1024, 1, 9)] - per))
 
 
 if __name__ == '__main__':

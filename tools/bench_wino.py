@@ -49,12 +49,8 @@ for name, c, res, frames, kobs in cases:
     tw64 = tm = float('nan')
     if c % 64 == 0:
         pw6 = C.pack_conv_wino_weights(C.CONV_K2S1, wk, c, c, 64)
-        try:                                                        # second generation: the observation mean folded at 64 channels too
-            tw64 = timeit(lambda: C.conv_wino_forward(C.CONV_K2S1, src, c, c, frames, kobs, res, res, pw6, bias, c, 64, out, c, mean, c))
-            tm = tw64
-        except C.NLTError:                                          # NLT_WINO_V1=1: observations as frames + the mean in its own launch
-            tw64 = timeit(lambda: C.conv_wino_forward(C.CONV_K2S1, src, c, c, frames * kobs, 1, res, res, pw6, bias, c, 64, out, c, None, 0))
-            tm = tw64 + (timeit(lambda: C.obs_mean_forward(out, None, frames, kobs, res * res, c, mean, c)) if kobs > 1 else 0.0)
+        tw64 = timeit(lambda: C.conv_wino_forward(C.CONV_K2S1, src, c, c, frames, kobs, res, res, pw6, bias, c, 64, out, c, mean, c))
+        tm = tw64
     if C.conv_c32_supported(C.CONV_K2S1, c, c):
         pc = C.pack_conv_tile_weights(C.CONV_K2S1, wk, c, c, 32)
         tc = timeit(lambda: C.conv_c32_forward(C.CONV_K2S1, src, c, c, frames, kobs, res, res, pc, bias, c, out, c, mean, c))
