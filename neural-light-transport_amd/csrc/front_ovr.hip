@@ -16,6 +16,7 @@
 // 8-wave workgroups, a wave owns a 4 x 16 strip of level-1 texels, raw rows staged through wave-private LDS by 16-byte
 // row-contiguous loads, the next strip's raw rows and map values in flight in registers under the current strip's MFMAs,
 // no workgroup barrier after the prologue.
+#include <type_traits>
 #include "front_common.h"
 
 namespace {
@@ -201,22 +202,26 @@ __global__ __launch_bounds__(64 * NW, 1) void front_ovr_kernel(
   // level-2 texel.  Texels beyond the image read the map's first texel: their results are masked / never stored.
   f32x4 mp1[NC], ms0[NC], mp2[2];
   const unsigned mo2 = (unsigned)((Y * w4 + X) * 32 + 4 * kk);
-  auto load_maps = [&](int t) {
+#pragma unroll
+  for (int c = 0; c < NC; ++c)
+    if (!((live_m >> c) & 1)) mo1[c] = 0u;                               // (dead slots read the strip's first texel: no select per strip)
+  auto maps_fast = [&](int t) {                                          // interior strips: wave-uniform bases + lane constants
     const int tx0 = (t % tiles_x) * SW; t /= tiles_x;
     const int ty0 = (t % tiles_y) * SH;
-    if (ty0 + AH <= h2 && tx0 + AW <= w2) {                              // interior (wave-uniform): bases + lane constants
-      const float* b1 = maps.p1 + (size_t)(ty0 * w2 + tx0) * 16;
-      const float* b0 = maps.s0 + (size_t)(2 * ty0 * w + 2 * tx0) * 4;
-      const float* b2 = maps.p2 + (size_t)((ty0 >> 1) * w4 + (tx0 >> 1)) * 32;
+    const float* b1 = maps.p1 + (size_t)(ty0 * w2 + tx0) * 16;
+    const float* b0 = maps.s0 + (size_t)(2 * ty0 * w + 2 * tx0) * 4;
+    const float* b2 = maps.p2 + (size_t)((ty0 >> 1) * w4 + (tx0 >> 1)) * 32;
 #pragma unroll
-      for (int c = 0; c < NC; ++c) {
-        mp1[c] = *reinterpret_cast<const f32x4*>(b1 + (((live_m >> c) & 1) ? mo1[c] : 0u));
-        ms0[c] = *reinterpret_cast<const f32x4*>(b0 + tex0[c] * 4u);
-      }
-      mp2[0] = *reinterpret_cast<const f32x4*>(b2 + mo2);
-      mp2[1] = *reinterpret_cast<const f32x4*>(b2 + mo2 + 16);
-      return;
+    for (int c = 0; c < NC; ++c) {
+      mp1[c] = *reinterpret_cast<const f32x4*>(b1 + mo1[c]);
+      ms0[c] = *reinterpret_cast<const f32x4*>(b0 + tex0[c] * 4u);
     }
+    mp2[0] = *reinterpret_cast<const f32x4*>(b2 + mo2);
+    mp2[1] = *reinterpret_cast<const f32x4*>(b2 + mo2 + 16);
+  };
+  auto maps_slow = [&](int t) {
+    const int tx0 = (t % tiles_x) * SW; t /= tiles_x;
+    const int ty0 = (t % tiles_y) * SH;
     const int jo = opaque(j);
 #pragma unroll
     for (int c = 0; c < NC; ++c) {
@@ -237,65 +242,37 @@ __global__ __launch_bounds__(64 * NW, 1) void front_ovr_kernel(
     mp2[1] = *reinterpret_cast<const f32x4*>(maps.p2 + o2 + 16);
   };
 
-  auto stage2 = [&](f32x4 (&out)[SH]) {
-    const float* tilep = ot + kk * SLOTS * 4;
-    const f32x4 bias = *reinterpret_cast<const f32x4*>(lds_all + W_BQ1 + 4 * kk);
-    f32x4 acc[SH] = {bias, bias, bias, bias};
-#pragma unroll
-    for (int t = 0; t < 4; ++t) {
-      const f32x4 a = *reinterpret_cast<const f32x4*>(lds_all + W_AQ1 + (t * 64 + lane) * 4);
-      f32x4 b[SH];
-#pragma unroll
-      for (int r = 0; r < SH; ++r) b[r] = *reinterpret_cast<const f32x4*>(tilep + ((r + (t >> 1)) * AW + j + (t & 1)) * 4);
-#pragma unroll
-      for (int s4 = 0; s4 < 4; ++s4)
-#pragma unroll
-        for (int r = 0; r < SH; ++r) acc[r] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s4], b[r][s4], acc[r], 0, 0, 0);
-    }
-#pragma unroll
-    for (int r = 0; r < SH; ++r) out[r] = lrelu4m(acc[r], alpha2);
-  };
-
-  // ---- prologue: the first strip's raw rows into LDS and its maps into registers, the second strip's raw rows in flight
-  load_geom(tile);
-  load_query();
-  load_maps(tile);
-  store_query();
-  if (tile + stride < t_hi) { load_geom(tile + stride); load_query(); }
-  wave_sync();
-
   float wsk[15];                                                         // wave-uniform: scalar loads
 #pragma unroll
   for (int rr = 0; rr < 15; ++rr) wsk[rr] = blob[OFF_WSK + rr];
 
-  for (;;) {
-    int tt = tile;
-    const int tx0 = (tt % tiles_x) * SW; tt /= tiles_x;
-    const int ty0 = (tt % tiles_y) * SH;
-    const int f = tt / tiles_y;
-    const int next = tile + stride;
-    const bool has_next = next < t_hi;
-    const bool interior = ty0 + AH <= h2 && tx0 + AW <= w2;
+  // ---- one strip: stage 1 -> [`between`: the staging of later strips] -> stage 2 -> stage 3.  FAST = the strip's haloed tile
+  // lies inside the image: no masks, and NO CONDITION AROUND A GLOBAL STORE OR LOAD (see the loop below for why that matters).
+  auto strip = [&](auto fast_tag, int t, auto&& between) {
+    constexpr bool FAST = decltype(fast_tag)::value;
+    const int tx0 = (t % tiles_x) * SW; t /= tiles_x;
+    const int ty0 = (t % tiles_y) * SH;
+    const int f = t / tiles_y;
     unsigned inside_m = live_m, owned_m = own_m;
-    if (!interior) {
+    if constexpr (!FAST) {
       inside_m = owned_m = 0;
       const int jo = opaque(j);
 #pragma unroll
       for (int c = 0; c < NC; ++c) {
-        const int t = c * 16 + jo;
+        const int tt = c * 16 + jo;
         const bool live = (live_m >> c) & 1;
-        const int hy = live ? t / AW : 0, hx = live ? t % AW : 0;
+        const int hy = live ? tt / AW : 0, hx = live ? tt % AW : 0;
         const bool inside = live && ty0 + hy < h2 && tx0 + hx < w2;
         inside_m |= (unsigned)inside << c;
         owned_m |= (unsigned)(inside && hy < SH && hx < SW) << c;
       }
     }
     const int gy2 = (ty0 >> 1) + Y, gx2 = (tx0 >> 1) + X;
-    const bool in2 = gy2 < h4 && gx2 < w4;
+    const bool in2 = FAST || (gy2 < h4 && gx2 < w4);
     const long tex2 = (long)gy2 * w4 + gx2;
-    const f32x4 p2a = mp2[0], p2b = mp2[1];                              // (mp2 is refilled for the next strip below)
+    const f32x4 p2a = mp2[0], p2b = mp2[1];                              // (mp2 is refilled for a later strip in `between`)
 
-    // ---- stage 1 (5 MFMAs per column tile) + the head's share of the L0 features
+    // stage 1 (5 MFMAs per column tile) + the head's share of the L0 features
     float* const skbase = skip3 + ((long)f * hw + (long)(2 * ty0) * w + 2 * tx0) * 3;   // (owned texels are inside the image)
 #pragma unroll
     for (int c0 = 0; c0 < NC; c0 += 3) {
@@ -303,8 +280,8 @@ __global__ __launch_bounds__(64 * NW, 1) void front_ovr_kernel(
       float raw[3][5];
 #pragma unroll
       for (int c = 0; c < 3; ++c) {
-        const float* s = lds + W_RQ + rd3[c0 + c];
-        raw[c][0] = s[0]; raw[c][1] = s[1]; raw[c][2] = s[2];
+        const float* sp = lds + W_RQ + rd3[c0 + c];
+        raw[c][0] = sp[0]; raw[c][1] = sp[1]; raw[c][2] = sp[2];
         raw[c][3] = lds[W_RC + rd1[c0 + c]]; raw[c][4] = lds[W_RL + rd1[c0 + c]];
       }
 #pragma unroll
@@ -314,46 +291,63 @@ __global__ __launch_bounds__(64 * NW, 1) void front_ovr_kernel(
 #pragma unroll
       for (int c = 0; c < 3; ++c) {
         f32x4 v = lrelu4m(acc[c], alpha2);
-        if (!interior) {
-          asm volatile("" ::: "memory");
+        if constexpr (!FAST) {
           if (!((inside_m >> (c0 + c)) & 1)) v = zero4;
         }
         *reinterpret_cast<f32x4*>(ot + (kk * SLOTS + (c0 + c) * 16 + j) * 4) = v;
-        if ((owned_m >> (c0 + c)) & 1) {
-          float s0 = ms0[c0 + c][0], s1 = ms0[c0 + c][1], s2 = ms0[c0 + c][2];
+        // every lane forms its three sums (a lane that owns no texel wastes nothing: SIMD); only the 12-byte store is predicated
+        float s0 = ms0[c0 + c][0], s1 = ms0[c0 + c][1], s2 = ms0[c0 + c][2];
 #pragma unroll
-          for (int rr = 0; rr < 5; ++rr) {
-            s0 = fmaf(raw[c][rr], wsk[rr * 3], s0);
-            s1 = fmaf(raw[c][rr], wsk[rr * 3 + 1], s1);
-            s2 = fmaf(raw[c][rr], wsk[rr * 3 + 2], s2);
+        for (int rr = 0; rr < 5; ++rr) {
+          s0 = fmaf(raw[c][rr], wsk[rr * 3], s0);
+          s1 = fmaf(raw[c][rr], wsk[rr * 3 + 1], s1);
+          s2 = fmaf(raw[c][rr], wsk[rr * 3 + 2], s2);
+        }
+        if (add_base) { s0 += raw[c][0]; s1 += raw[c][1]; s2 += raw[c][2]; }
+        if ((owned_m >> (c0 + c)) & 1) {
+          unsigned at;
+          if constexpr (FAST) at = tex0[c0 + c];
+          else {
+            const int tt = (c0 + c) * 16 + opaque(j);
+            at = (unsigned)((2 * (tt / AW) + (kk >> 1)) * w + 2 * (tt % AW) + (kk & 1));
           }
-          if (add_base) { s0 += raw[c][0]; s1 += raw[c][1]; s2 += raw[c][2]; }
-          // (one 12-byte store per lane.  Collecting the strip's rows in LDS for 16-byte stores was built and measured in r06:
-          // 0.0956 ms either way -- the texture addresser's 65 % busy is not these stores)
-          float* sk = skbase + tex0[c0 + c] * 3u;
+          float* sk = skbase + at * 3u;
           sk[0] = s0; sk[1] = s1; sk[2] = s2;
         }
       }
     }
     wave_sync();                                                         // every lane has its raw values: the raw tile is free
-    if (has_next) {                                                      // next strip: raw rows to LDS, maps requested;
-      store_query();                                                     // the strip after it: raw rows requested
-      load_maps(next);
-      if (next + stride < t_hi) { load_geom(next + stride); load_query(); }
-    }
-    // ---- stage 2: L1 stride-1 conv
+    between();
+    // stage 2: L1 stride-1 conv
     f32x4 qv[SH];
-    stage2(qv);
+    {
+      const float* tilep = ot + kk * SLOTS * 4;
+      const f32x4 bias = *reinterpret_cast<const f32x4*>(lds_all + W_BQ1 + 4 * kk);
+      f32x4 acc[SH] = {bias, bias, bias, bias};
+#pragma unroll
+      for (int tp = 0; tp < 4; ++tp) {
+        const f32x4 a = *reinterpret_cast<const f32x4*>(lds_all + W_AQ1 + (tp * 64 + lane) * 4);
+        f32x4 bb[SH];
+#pragma unroll
+        for (int r = 0; r < SH; ++r) bb[r] = *reinterpret_cast<const f32x4*>(tilep + ((r + (tp >> 1)) * AW + j + (tp & 1)) * 4);
+#pragma unroll
+        for (int s4 = 0; s4 < 4; ++s4)
+#pragma unroll
+          for (int r = 0; r < SH; ++r) acc[r] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s4], bb[r][s4], acc[r], 0, 0, 0);
+      }
+#pragma unroll
+      for (int r = 0; r < SH; ++r) qv[r] = lrelu4m(acc[r], alpha2);
+    }
     {
       const long hw2 = (long)h2 * w2;
       const int gx = tx0 + j;
 #pragma unroll
       for (int r = 0; r < SH; ++r)
-        if (ty0 + r < h2 && gx < w2)
+        if (FAST || (ty0 + r < h2 && gx < w2))
           *reinterpret_cast<f32x4*>(q1 + ((long)f * hw2 + (long)(ty0 + r) * w2 + gx) * ldq + 4 * kk) = qv[r];
     }
     wave_sync();                                                         // stage-2 reads of `ot` are done: it becomes the level-1 tile
-    // ---- stage 3: level 2's stride-2 conv, query rows only
+    // stage 3: level 2's stride-2 conv, query rows only
 #pragma unroll
     for (int r = 0; r < SH; ++r) *reinterpret_cast<f32x4*>(ot + l1_wr(r)) = qv[r];
     wave_sync();
@@ -377,8 +371,75 @@ __global__ __launch_bounds__(64 * NW, 1) void front_ovr_kernel(
       }
     }
     wave_sync();                                                         // the level-1 tile is consumed: `ot` is free again
-    if (!has_next) break;
-    tile = next;
+  };
+
+  // ---- INTERIOR strips (all but the last row / column of strips): a software pipeline across strips -- while strip s is
+  // computed, strip s + 1's raw rows go registers -> LDS and its maps are requested, strip s + 2's raw rows are requested.
+  //
+  // r06 (PMC + ISA of the first version): the pipeline existed but the compiler's wait-count insertion defeated it -- at the top
+  // of every strip and before the LDS staging it emitted `s_waitcnt vmcnt(0)`, draining EVERY outstanding memory operation, the
+  // stores issued a moment earlier included (matrix pipe 0.37 busy, waves waiting 0.34 of their cycles).  Two causes, both
+  // structural: (1) a global store / load behind a condition (`if (has_next)`, per-lane store predicates inside larger blocks)
+  // makes the pass merge paths with different operation counts, and it keeps the smaller count; (2) the loop header merges the
+  // back edge with the PROLOGUE's state, where nothing has been issued behind the first loads, so their allowed-outstanding
+  // count is 0 for every iteration.  Hence: every memory operation of this loop body is unconditional (prefetches past the last
+  // strip are clamped to a valid strip and simply unused; border strips run in the second loop), and the first iteration is
+  // PEELED so that both predecessors of the loop header have issued the same sequence.
+  auto is_interior = [&](int t) {
+    const int tx0 = (t % tiles_x) * SW; t /= tiles_x;
+    const int ty0 = (t % tiles_y) * SH;
+    return ty0 + AH <= h2 && tx0 + AW <= w2;
+  };
+  auto next_interior = [&](int t) {
+    do { t += stride; } while (t < t_hi && !is_interior(t));
+    return t;
+  };
+  auto geom_fast = [&](int t) {
+    const int tx0 = (t % tiles_x) * SW; t /= tiles_x;
+    const int ty0 = (t % tiles_y) * SH;
+    lf = t / tiles_y;
+    const unsigned b3 = (unsigned)((2 * ty0 * w + 2 * tx0) * 3) * 4u, b1 = (unsigned)(2 * ty0 * w + 2 * tx0) * 4u;
+#pragma unroll
+    for (int p = 0; p < P3; ++p) g3[p] = b3 + c3[p];                     // (lanes without a piece: c3 = 0, the strip's first bytes)
+#pragma unroll
+    for (int p = 0; p < P1; ++p) g1[p] = b1 + c1[p];
+  };
+  int cur = is_interior(tile) ? tile : next_interior(tile);
+  if (cur < t_hi) {
+    geom_fast(cur);
+    load_query();
+    maps_fast(cur);
+    store_query();
+    int nx = next_interior(cur);
+    geom_fast(nx < t_hi ? nx : cur);
+    load_query();
+    wave_sync();
+    auto iteration = [&](int c_, int n_) {
+      strip(std::true_type{}, c_, [&]() {
+        store_query();                                                   // raw rows of the next strip: registers -> LDS
+        const int pf = n_ < t_hi ? n_ : c_;
+        maps_fast(pf);                                                   // its maps
+        const int n2 = next_interior(pf);
+        geom_fast(n2 < t_hi ? n2 : pf);                                  // the raw rows of the strip after it
+        load_query();
+      });
+    };
+    iteration(cur, nx);                                                  // peeled (see above)
+    while (nx < t_hi) {
+      cur = nx;
+      nx = next_interior(cur);
+      iteration(cur, nx);
+    }
+  }
+  // ---- border strips (halo beyond the image): one at a time, masks and clamps, no pipelining across strips
+  for (int t = tile; t < t_hi; t += stride) {
+    if (is_interior(t)) continue;
+    load_geom(t);
+    load_query();
+    maps_slow(t);
+    store_query();
+    wave_sync();
+    strip(std::false_type{}, t, []() {});
   }
 }
 
