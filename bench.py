@@ -927,6 +927,25 @@ def bench_infer_mode(args, device):
                 rec["two_batches_in_flight"] = {"ms_per_step": round(1e3 * d2, 4), "Mtexels_per_s": round(texels / d2 / 1e6, 1)}
             except Exception as e:
                 rec["two_batches_in_flight"] = {"error": "%s: %s" % (type(e).__name__, str(e)[:200])}
+            # frames per call (nlt_test.py --batch_size_override): the mid-network launches of a 4-frame batch are latency-bound
+            try:
+                b16 = identity_batches(16, uv, cam, 1, device)
+                for i in range(6):
+                    model.call(b16[i % 3], 'test', obs_override=agg)
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                n16 = 20
+                for i in range(n16):
+                    model.call(b16[i % 3], 'test', obs_override=agg)
+                torch.cuda.synchronize()
+                d16 = (time.perf_counter() - t1) / n16
+                rec["16_frames_per_call"] = {"ms_per_step": round(1e3 * d16, 4), "Mtexels_per_s": round(16 * uv * uv / d16 / 1e6, 1)}
+                del b16
+                torch.cuda.empty_cache()
+                for i in range(3):                                    # (back on the 4-frame buffers / tapes)
+                    model.call(batches[i], 'test', obs_override=agg)
+            except Exception as e:
+                rec["16_frames_per_call"] = {"error": "%s: %s" % (type(e).__name__, str(e)[:200])}
             model.plan.fuse_override = False
             dg = run(10)
             model.plan.fuse_override = True

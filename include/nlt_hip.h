@@ -690,6 +690,19 @@ int nlt_conv_forward_map(int mode, int tile_hint, int ksplit, float* workspace,
                          int cout, float* out, int ldo, int act, float alpha,
                          const float* bias_map, int map_frames, void* stream);
 
+/* The two fused tail launches of that mode, reading the QUERY half of the interleaved encoder map only:
+ *   nlt_dec_block_forward_map = nlt_dec_block_forward for the U-Net's widths (x [n,h,w,2c], skip = [query 4c | given 4c] with
+ *     per-texel stride lds), w_s2q = the Keras (2,2,c,6c) slice of the first conv over [x | query]; bias_map [1,2h,2w,c] = its
+ *     given-half rows * the given map + its bias.  c = 8 or 16.
+ *   nlt_back_forward_map = nlt_back_forward with q1 = the 16 query channels of the level-1 map (stride ldq), w_s2q = the Keras
+ *     (2,2,4,24) slice over [x 8 | query 16], bias_map [1,2 h2,2 w2,4].  The head's share of L0 arrives through skip3 as before. */
+int nlt_dec_block_forward_map(const float* x, const float* skip, int lds, int n, int h, int w,
+                              const float* w_s2q, const float* w_s1, const float* b_s1, int c, float alpha,
+                              const float* bias_map, float* out, void* stream);
+int nlt_back_forward_map(const float* x, const float* q1, int ldq, const float* skip3, int n, int h2, int w2,
+                         const float* w_s2q, const float* w_s1, const float* b_s1, const float* w_head, float alpha,
+                         const float* bias_map, float* pred, void* stream);
+
 /* Query-only fused front launch of that mode (csrc/front_ovr.hip): layers 0-1 of the query path and level 2's stride-2
  * conv from the raw texel buffers base [n,h,w,3], cvis / lvis [n,h,w,1] (nlt/models/nlt.py:95) --
  *   y1 = lrelu(fold(L0, L1.s2)[query rows] * raw5 + p1)          p1 [h/2,w/2,16]: L1.s2's observation rows * ovr0 + folded bias

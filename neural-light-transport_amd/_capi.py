@@ -107,6 +107,8 @@ SIGNATURES = {
     'nlt_conv_forward_map': (_c_int, [_c_int, _c_int, _c_int, _vp, _vp, _c_int, _c_int, _vp, _c_int, _c_int,
                                       _c_int, _c_int, _c_int, _vp, _vp, _c_int, _vp, _c_int, _c_int, _c_float,
                                       _vp, _c_int, _vp]),
+    'nlt_dec_block_forward_map': (_c_int, [_vp, _vp, _c_int, _c_int, _c_int, _c_int, _vp, _vp, _vp, _c_int, _c_float, _vp, _vp, _vp]),
+    'nlt_back_forward_map': (_c_int, [_vp, _vp, _c_int, _vp, _c_int, _c_int, _c_int, _vp, _vp, _vp, _vp, _c_float, _vp, _vp, _vp]),
     'nlt_front_ovr_forward': (_c_int, [_vp] * 3 + [_c_int] * 3 + [_vp] * 5 + [_c_int, _c_float, _vp, _c_int, _vp, _vp, _vp]),
     'nlt_conv_backward_data': (_c_int, [_c_int, _c_int, _c_int, _vp, _vp, _c_int, _c_int, _c_int, _c_int, _c_int, _vp, _vp, _c_int,
                                         _vp, _c_int, _vp, _c_int, _c_float, _c_int, _c_int, _vp, _vp, _c_float, _c_int, _vp]),
@@ -1186,6 +1188,21 @@ def front_ovr_forward(base, cvis, lvis, n, h, w, packed, packed_l2, p1, s0, p2, 
     _check(lib().nlt_front_ovr_forward(_ptr(base), _ptr(cvis), _ptr(lvis), n, h, w, _ptr(packed), _ptr(packed_l2), _ptr(p1),
                                        _ptr(s0), _ptr(p2), 1 if add_base else 0, float(alpha), _ptr(q1), ldq, _ptr(skip3),
                                        _ptr(qtmp2), _stream()), 'nlt_front_ovr_forward')
+
+
+def dec_block_forward_map(x, skip, lds, n, h, w, w_s2q, w_s1, b_s1, c, alpha, bias_map, out):
+    """One expanding block of the inference mode: [x 2c | query half 4c of `skip`] + bias map (include/nlt_hip.h)."""
+    _check(lib().nlt_dec_block_forward_map(_ptr(_dense(x, 'x')), _ptr(skip), lds, n, h, w, _ptr(_dense(w_s2q, 'w_s2q')),
+                                           _ptr(_dense(w_s1, 'w_s1')), _ptr(b_s1), c, float(alpha), _ptr(_dense(bias_map, 'bias_map')),
+                                           _ptr(_dense(out, 'out')), _stream()), 'nlt_dec_block_forward_map')
+
+
+def back_forward_map(x, q1, ldq, skip3, n, h2, w2, w_s2q, w_s1, b_s1, w_head, alpha, bias_map, pred):
+    """Last expanding block + head of the inference mode: [x 8 | 16 query channels of the level-1 map] + bias map."""
+    _check(lib().nlt_back_forward_map(_ptr(_dense(x, 'x')), _ptr(q1), ldq, _ptr(_dense(skip3, 'skip3')), n, h2, w2,
+                                      _ptr(_dense(w_s2q, 'w_s2q')), _ptr(_dense(w_s1, 'w_s1')), _ptr(b_s1), _ptr(_dense(w_head, 'w_head')),
+                                      float(alpha), _ptr(_dense(bias_map, 'bias_map')), _ptr(_dense(pred, 'pred')), _stream()),
+           'nlt_back_forward_map')
 
 
 def dec_block_forward(x, cx, skip, cs, n, h, w, w_s2, b_s2, w_s1, b_s1, c, alpha, out):

@@ -39,6 +39,11 @@ struct DecP {
   float* out;                       // [n,2h,2w,C]
   int h, w, cx, cs, tiles_y, tiles_x;
   float alpha;
+  // nlt_dec_block_forward_map (the reference's inference mode, engine_infer.py): `skip` is the interleaved encoder map
+  // [query 4C | given 4C] with per-texel stride lds, of which only the QUERY half is read; what the given half adds to the first
+  // conv's pre-activation (+ its bias) arrives as bmap [1,2h,2w,C], shared by all frames
+  int lds;
+  const float* bmap;
 };
 
 template <int C>
@@ -167,10 +172,11 @@ __global__ __launch_bounds__(256) void dec_block_kernel(DecP p) {
 //   * the texel loads run NPF column tiles ahead of the MFMAs (requested before the weights; one exposed round trip per wave);
 //   * biases and the second conv's fragments are fetched in the prologue, before the barrier.
 // The accumulation order of every output is the one of dec_block_kernel: results are bit-identical.
-template <int C>
+template <int C, bool OVR = false>
 __global__ __launch_bounds__(256, C == 8 ? 4 : 2) void dec_block10_kernel(DecP p) {
   constexpr int MT = C / 4, MH = MT / 2;          // stage 1: row tiles of the 4C columns (a, b, o); per wave
-  constexpr int K = 10 * C, NCH = K / 16;         // 16-channel chunks of the virtual concat [x 2C | skip 8C]
+  constexpr int K = (OVR ? 6 : 10) * C, NCH = K / 16;   // 16-channel chunks of the virtual concat [x 2C | skip 8C] (OVR: [x 2C | query 4C])
+  constexpr int LDS_ = OVR ? 0 : 8 * C;           // (OVR: the skip map's per-texel stride is an argument)
   constexpr int NQ = C / 4;                       // channel quads of the intermediate map
   constexpr int NS = 4 * C / 16;                  // stage 2: 16-wide K slabs
   constexpr int NI = NT / 2;                      // column tiles per wave
@@ -195,16 +201,34 @@ __global__ __launch_bounds__(256, C == 8 ? 4 : 2) void dec_block10_kernel(DecP p
     const bool inside = live && gy >= 0 && gx >= 0 && gy < p.h && gx < p.w;
     const long tex = (long)f * hw + (inside ? (long)gy * p.w + gx : 0);
     const float* xp = p.x + tex * (2 * C);
-    const float* sp = p.skip + tex * (8 * C) - 2 * C;                     // indexed by the concat channel
+    const float* sp = p.skip + tex * (OVR ? p.lds : LDS_) - 2 * C;        // indexed by the concat channel
 #pragma unroll
     for (int ch = 0; ch < NCH; ++ch) {
       const int c0 = 16 * ch + 4 * kk;                                    // (C = 8: chunk 0 is x for every lane, 2C = 16)
       dst[ch] = *reinterpret_cast<const f32x4*>(c0 < 2 * C ? xp + c0 : sp + c0);
     }
   };
-  f32x4 bq[NPF][NCH];
+  // OVR: the map values of the lane's columns (ab, o0 .. o0 + 3) at column tile i's texel: the accumulators' initial values
+  const int o0_ = (4 * kk) % C;
+  auto load_m = [&](int i, f32x4 (&dst)[MH]) {
+    if constexpr (OVR) {
+      const int t = (cg + 2 * i) * 16 + j;
+      const bool live = t < HT;
+      const int hy = live ? t / HW : 0, hx = live ? t % HW : 0;
+      const int gy = ty0 - 1 + hy, gx = tx0 - 1 + hx;
+      const bool inside = live && gy >= 0 && gx >= 0 && gy < p.h && gx < p.w;
 #pragma unroll
-  for (int i = 0; i < NPF; ++i) load_b(i, bq[i]);
+      for (int m = 0; m < MH; ++m) {
+        const int ab = (16 * (mh * MH + m) + 4 * kk) / C;
+        const long at = inside ? ((long)(2 * gy + (ab >> 1)) * (2 * p.w) + 2 * gx + (ab & 1)) * C + o0_ : 0;
+        dst[m] = *reinterpret_cast<const f32x4*>(p.bmap + at);
+      }
+    }
+  };
+  f32x4 bq[NPF][NCH];
+  f32x4 mq[NPF][MH];
+#pragma unroll
+  for (int i = 0; i < NPF; ++i) { load_b(i, bq[i]); load_m(i, mq[i]); }
   f32x4 a[MH][NCH];
 #pragma unroll
   for (int m = 0; m < MH; ++m)
@@ -228,14 +252,14 @@ __global__ __launch_bounds__(256, C == 8 ? 4 : 2) void dec_block10_kernel(DecP p
   for (int i = 0; i < NI; ++i) {
     f32x4 acc[MH];
 #pragma unroll
-    for (int m = 0; m < MH; ++m) acc[m] = z4;
+    for (int m = 0; m < MH; ++m) acc[m] = OVR ? mq[i % NPF][m] : z4;
 #pragma unroll
     for (int ch = 0; ch < NCH; ++ch)
 #pragma unroll
       for (int s4 = 0; s4 < 4; ++s4)
 #pragma unroll
         for (int m = 0; m < MH; ++m) acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[m][ch][s4], bq[i % NPF][ch][s4], acc[m], 0, 0, 0);
-    if (i + NPF < NI) load_b(i + NPF, bq[i % NPF]);
+    if (i + NPF < NI) { load_b(i + NPF, bq[i % NPF]); load_m(i + NPF, mq[i % NPF]); }
     const int t = (cg + 2 * i) * 16 + j;
     const bool live = t < HT;
     const int hy = live ? t / HW : 0, hx = live ? t % HW : 0;
@@ -245,7 +269,7 @@ __global__ __launch_bounds__(256, C == 8 ? 4 : 2) void dec_block10_kernel(DecP p
     for (int m = 0; m < MH; ++m) {
       const int col = 16 * (mh * MH + m) + 4 * kk;
       const int ab = col / C;
-      f32x4 v = lrelu4(acc[m] + bias2, p.alpha);
+      f32x4 v = lrelu4(OVR ? acc[m] : acc[m] + bias2, p.alpha);           // (OVR: the bias is part of the map)
       if (!inside) v = z4;                                               // zero padding above / left of the image
       const int ly = 2 * hy + (ab >> 1) - 1, lx = 2 * hx + (ab & 1) - 1;
       if (live && ly >= 0 && lx >= 0) *reinterpret_cast<f32x4*>(tile + ((o0 >> 2) * FP + ly * FW + lx) * 4) = v;
@@ -302,7 +326,7 @@ extern "C" int nlt_dec_block_forward(const float* x, int cx, const float* skip, 
   if ((long long)n * h * w * 4 * (long long)(c > cs ? c : cs) >= (1ll << 31)) return NLT_ERR_UNSUPPORTED;
   DecP p;
   p.x = x; p.skip = skip; p.w2 = w_s2; p.b2 = b_s2; p.w1 = w_s1; p.b1 = b_s1; p.out = out;
-  p.h = h; p.w = w; p.cx = cx; p.cs = cs; p.alpha = alpha;
+  p.h = h; p.w = w; p.cx = cx; p.cs = cs; p.alpha = alpha; p.lds = cs; p.bmap = nullptr;
   p.tiles_y = (h + TH - 1) / TH; p.tiles_x = (w + TW - 1) / TW;
   const long blocks = (long)n * p.tiles_y * p.tiles_x;
   hipStream_t s = static_cast<hipStream_t>(stream);
@@ -315,6 +339,29 @@ extern "C" int nlt_dec_block_forward(const float* x, int cx, const float* skip, 
     if (ten) hipLaunchKernelGGL(dec_block10_kernel<16>, dim3((unsigned)blocks), dim3(256), 0, s, p);
     else hipLaunchKernelGGL(dec_block_kernel<16>, dim3((unsigned)blocks), dim3(256), 0, s, p);
   }
+  NLT_CHECK_LAUNCH();
+  return NLT_OK;
+}
+
+extern "C" int nlt_dec_block_forward_map(const float* x, const float* skip, int lds, int n, int h, int w,
+                                         const float* w_s2q, const float* w_s1, const float* b_s1, int c, float alpha,
+                                         const float* bias_map, float* out, void* stream) {
+  if (!x || !skip || !w_s2q || !w_s1 || !b_s1 || !bias_map || !out) return NLT_ERR_BAD_ARG;
+  if (n <= 0 || h <= 0 || w <= 0) return NLT_ERR_BAD_ARG;
+  if (c != 8 && c != 16) return NLT_ERR_UNSUPPORTED;
+  if (lds < 4 * c || (lds & 3)) return NLT_ERR_BAD_ARG;
+  if (!nlt_aligned16(x) || !nlt_aligned16(skip) || !nlt_aligned16(w_s2q) || !nlt_aligned16(w_s1) || !nlt_aligned16(b_s1) ||
+      !nlt_aligned16(bias_map) || !nlt_aligned16(out))
+    return NLT_ERR_BAD_ARG;
+  if ((long long)n * h * w * 4 * (long long)(c > lds ? c : lds) >= (1ll << 31)) return NLT_ERR_UNSUPPORTED;
+  DecP p;
+  p.x = x; p.skip = skip; p.w2 = w_s2q; p.b2 = b_s1; p.w1 = w_s1; p.b1 = b_s1; p.out = out;     // (b2 unused: the map carries it)
+  p.h = h; p.w = w; p.cx = 2 * c; p.cs = 4 * c; p.alpha = alpha; p.lds = lds; p.bmap = bias_map;
+  p.tiles_y = (h + TH - 1) / TH; p.tiles_x = (w + TW - 1) / TW;
+  const long blocks = (long)n * p.tiles_y * p.tiles_x;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  if (c == 8) hipLaunchKernelGGL((dec_block10_kernel<8, true>), dim3((unsigned)blocks), dim3(256), 0, s, p);
+  else hipLaunchKernelGGL((dec_block10_kernel<16, true>), dim3((unsigned)blocks), dim3(256), 0, s, p);
   NLT_CHECK_LAUNCH();
   return NLT_OK;
 }

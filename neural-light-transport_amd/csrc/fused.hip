@@ -356,12 +356,17 @@ __global__ __launch_bounds__(256) void front_kernel(
 // ---------------------------------------------------------------------------------------
 constexpr int FH = 2 * TH + 1, FW = 2 * TW + 1;        // 17 x 33 full-resolution texels incl. top/left halo
 
+// OVR (nlt_back_forward_map: the reference's inference mode, engine_infer.py): `fm1` is the interleaved level-1 map of which
+// only the 16 QUERY channels are read (per-texel stride ld1), w_s2 is the Keras (2,2,4,24) slice over [x 8 | query 16], and what
+// the given half adds to the first conv's pre-activation (+ its bias) arrives as bmap [1,2 h2,2 w2,4], shared by all frames.
+template <bool OVR = false>
 __global__ __launch_bounds__(256) void back_kernel(
     const float* __restrict__ x, const float* __restrict__ fm1, const float* __restrict__ skip3,
     int h2, int w2, int tiles_y, int tiles_x,
     const float* __restrict__ w_s2, const float* __restrict__ b_s2, const float* __restrict__ w_s1,
     const float* __restrict__ b_s1, const float* __restrict__ w_head, float alpha, float* __restrict__ pred,
-    float* __restrict__ usave, float* __restrict__ vsave) {
+    float* __restrict__ usave, float* __restrict__ vsave, int ld1 = 32, const float* __restrict__ bmap = nullptr) {
+  constexpr int KC = OVR ? 24 : 40, NCK = OVR ? 2 : 3;                 // channels / 16-channel chunks of the virtual concat
   __shared__ __attribute__((aligned(16))) float tile_lds[FH * FW * 4];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int kk = lane >> 4, j = lane & 15;
@@ -372,19 +377,20 @@ __global__ __launch_bounds__(256) void back_kernel(
   const long hw2 = (long)h2 * w2;
 
   // A operands: column i = (ab = i >> 2, o = i & 3) of the Keras (2,2,Cout=4,Cin=40) kernel = row i of [16][40]
-  f32x4 a2[3];
+  f32x4 a2[NCK];
 #pragma unroll
-  for (int c = 0; c < 3; ++c) {
+  for (int c = 0; c < NCK; ++c) {
     const int c0 = 16 * c + 4 * kk;
-    a2[c] = c0 < 40 ? *reinterpret_cast<const f32x4*>(w_s2 + j * 40 + c0) : (f32x4){0.f, 0.f, 0.f, 0.f};
+    a2[c] = c0 < KC ? *reinterpret_cast<const f32x4*>(w_s2 + j * KC + c0) : (f32x4){0.f, 0.f, 0.f, 0.f};
   }
-  const f32x4 bs2 = *reinterpret_cast<const f32x4*>(b_s2);
+  const f32x4 bs2 = OVR ? (f32x4){0.f, 0.f, 0.f, 0.f} : *reinterpret_cast<const f32x4*>(b_s2);   // (OVR: the bias is part of the map)
 
   // r04: every HBM request of the workgroup is issued before the first MFMA -- the texels of the wave's (up to) three column
   // tiles AND the skip3 rows stage 2 will add -- instead of one exposed round trip per column tile and one more after the barrier
   // (the kernel ran at 0.50 of the HBM peak with 8 workgroups per CU to cover for that).
   constexpr int NIT = (NT + 3) / 4;
-  f32x4 bq[NIT][3];
+  f32x4 bq[NIT][NCK];
+  f32x4 mq[NIT];                                                       // OVR: the map at the lane's output sub-texel (a, b) = kk
 #pragma unroll
   for (int it = 0; it < NIT; ++it) {
     const int mt = wave + 4 * it;
@@ -395,14 +401,19 @@ __global__ __launch_bounds__(256) void back_kernel(
     const bool inside = live && gy >= 0 && gx >= 0 && gy < h2 && gx < w2;
     const long tex = (long)f * hw2 + (inside ? (long)gy * w2 + gx : 0);
 #pragma unroll
-    for (int c = 0; c < 3; ++c) {
-      const int c0 = 16 * c + 4 * kk;                                  // channel of the virtual concat [x 8 | fm1 32]
+    for (int c = 0; c < NCK; ++c) {
+      const int c0 = 16 * c + 4 * kk;                                  // channel of the virtual concat [x 8 | fm1 32 (OVR: its query 16)]
       f32x4 b = (f32x4){0.f, 0.f, 0.f, 0.f};
       if (mt < NT) {                                                   // wave-uniform
         if (c0 < 8) b = *reinterpret_cast<const f32x4*>(x + tex * 8 + c0);
-        else if (c0 < 40) b = *reinterpret_cast<const f32x4*>(fm1 + tex * 32 + (c0 - 8));
+        else if (c0 < KC) b = *reinterpret_cast<const f32x4*>(fm1 + tex * (OVR ? ld1 : 32) + (c0 - 8));
       }
       bq[it][c] = b;
+    }
+    if constexpr (OVR) {
+      mq[it] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      if (mt < NT)
+        mq[it] = *reinterpret_cast<const f32x4*>(bmap + (inside ? ((long)(2 * gy + (kk >> 1)) * (2 * w2) + 2 * gx + (kk & 1)) * 4 : 0));
     }
   }
   const int h = 2 * h2, w = 2 * w2;
@@ -423,9 +434,9 @@ __global__ __launch_bounds__(256) void back_kernel(
     const int hy = live ? t / HW : 0, hx = live ? t % HW : 0;
     const int gy = ty0 - 1 + hy, gx = tx0 - 1 + hx;
     const bool inside = live && gy >= 0 && gx >= 0 && gy < h2 && gx < w2;
-    f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+    f32x4 acc = OVR ? mq[it] : (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int c = 0; c < 3; ++c) {
+    for (int c = 0; c < NCK; ++c) {
 #pragma unroll
       for (int s4 = 0; s4 < 4; ++s4) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a2[c][s4], bq[it][c][s4], acc, 0, 0, 0);
     }
@@ -564,8 +575,23 @@ static int back_launch(const float* x, const float* fm1, const float* skip3, int
   if ((long long)n * h2 * w2 * 4 * 8 >= (1ll << 31)) return NLT_ERR_UNSUPPORTED;
   const int ty = (h2 + TH - 1) / TH, tx = (w2 + TW - 1) / TW;
   const long blocks = (long)n * ty * tx;
-  hipLaunchKernelGGL(back_kernel, dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(stream),
-                     x, fm1, skip3, h2, w2, ty, tx, w_s2, b_s2, w_s1, b_s1, w_head, alpha, pred, u, v);
+  hipLaunchKernelGGL(back_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(stream),
+                     x, fm1, skip3, h2, w2, ty, tx, w_s2, b_s2, w_s1, b_s1, w_head, alpha, pred, u, v, 32, nullptr);
+  NLT_CHECK_LAUNCH();
+  return NLT_OK;
+}
+
+extern "C" int nlt_back_forward_map(const float* x, const float* q1, int ldq, const float* skip3, int n, int h2, int w2,
+                                    const float* w_s2q, const float* w_s1, const float* b_s1, const float* w_head, float alpha,
+                                    const float* bias_map, float* pred, void* stream) {
+  if (!x || !q1 || !skip3 || !w_s2q || !w_s1 || !b_s1 || !w_head || !bias_map || !pred) return NLT_ERR_BAD_ARG;
+  if (n <= 0 || h2 <= 0 || w2 <= 0 || ldq < 16 || (ldq & 3)) return NLT_ERR_BAD_ARG;
+  if (!nlt_aligned16(x) || !nlt_aligned16(q1) || !nlt_aligned16(w_s2q) || !nlt_aligned16(bias_map)) return NLT_ERR_BAD_ARG;
+  if ((long long)n * h2 * w2 * 4 * 8 >= (1ll << 31)) return NLT_ERR_UNSUPPORTED;
+  const int ty = (h2 + TH - 1) / TH, tx = (w2 + TW - 1) / TW;
+  const long blocks = (long)n * ty * tx;
+  hipLaunchKernelGGL(back_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(stream),
+                     x, q1, skip3, h2, w2, ty, tx, w_s2q, b_s1, w_s1, b_s1, w_head, alpha, pred, nullptr, nullptr, ldq, bias_map);
   NLT_CHECK_LAUNCH();
   return NLT_OK;
 }

@@ -14,8 +14,8 @@ them ONCE per (feat_agg, weights) with the ordinary conv kernels -- "override ma
 output resolution -- and the per-frame pass reads them where a bias would be added (csrc/front_ovr.hip for the full- / half-
 resolution levels, nlt_conv_forward_map for the rest): no per-frame copy of the maps into the interleaved feature buffers, half
 the K of every stride-2 encoder conv, a quarter (bottleneck) to two thirds of the K of the expanding blocks' first convs.
-The two fused expanding blocks (csrc/dec_block.hip) and the back kernel (csrc/fused.hip) still read `fm[l]` interleaved; their
-observation halves are written once per feat_agg, not once per batch.
+The two fused expanding blocks (csrc/dec_block.hip) and the back kernel (csrc/fused.hip) have map variants as well
+(nlt_dec_block_forward_map, nlt_back_forward_map): the given half of no interleaved feature buffer is ever written or read.
 
 Same re-association as the folded front kernel (sum over [q | ovr] channels split into two sums): <= 1e-6 rel-L2 from the
 layer-by-layer plan, <= 1e-4 from the oracle (tests/test_gpu_infer.py).
@@ -97,8 +97,6 @@ class OverrideMixin:
         if self._ovr is not st:
             self._ovr = st
             self._drop_tapes()
-        if b.get('ovr_serial') != st['serial']:
-            b['ovr_serial'], b['ovr_levels'] = st['serial'], set()      # levels of THESE buffers whose given half holds this feat_agg
         return st
 
     def _build_override(self, obs_override, dev, stamp):
@@ -136,7 +134,7 @@ class OverrideMixin:
                 zero = torch.zeros_like(sa.bias)
                 st['enc'][l] = (_Derived(sa, [[(0, c)]], zero).conv, run_map(_Derived(sa, [[(c, 2 * c)]], sa.bias), ovr[l - 1]))
             cx = 2 * cl[D]
-            for j in range(U - 1):
+            for j in range(U):
                 (da, _), (db, _) = q.layers[D + 1 + j].convs()
                 c = cl[D - j]
                 da.build(cx + 2 * c, dev)
@@ -163,12 +161,6 @@ class OverrideMixin:
             b['skip3'] = torch.empty((n, h, w, 3), device=dev, dtype=torch.float32)
         blob, blob_l2 = self._front_weights(dev, l2=True)
 
-        def given_half(l):
-            # dec_block / back kernels read fm[l] interleaved [query | given map]: the given half is written once per
-            # (feat_agg, buffer set) -- by the first pass that needs it, never by a replayed tape -- not once per batch
-            if l not in b['ovr_levels']:
-                b['fm'][l][..., cl[l]:].copy_(st['ovr'][l].expand(n, -1, -1, -1))
-                b['ovr_levels'].add(l)
         h2, w2, h4, w4 = h // 2, w // 2, h // 4, w // 4
         # SURVEY 8d accounting of what this launch replaces (query path of L0, L1 and L2's stride-2 conv)
         nbytes = 4 * n * h * w * (5 + 16) + 4 * n * h2 * w2 * (32 + 16 + 16 + 16) + 4 * n * (h2 * w2 * 32 + h4 * w4 * 32)
@@ -192,14 +184,16 @@ class OverrideMixin:
             skip, cs = b['fm'][D - j], 2 * cl[D - j]
             lab = 'L%d.q' % (D + 1 + j)
             nl = da.n_ch_out
-            if (self.fuse_dec and nl in (8, 16) and db.n_ch_out == nl and cx % 4 == 0 and algo == C.ALGO_AUTO
+            if (self.fuse_dec and nl in (8, 16) and db.n_ch_out == nl and cx == 2 * nl and cs == 8 * nl and algo == C.ALGO_AUTO
                     and dact_a is not None and dact_b is not None and dact_a.alpha == dact_b.alpha and j > 0):
-                given_half(D - j)
-                nbytes = 4 * n * hh * ww * ((cx + cs) + 4 * nl) + 4 * n * 4 * hh * ww * 2 * nl
-                self._launch(lab, nbytes, C.dec_block_forward, x, cx, skip, cs, n, hh, ww, da.kernel.detach(), da.bias.detach(),
-                             db.kernel.detach(), db.bias.detach(), nl, dact_a.alpha, b['dec'][j],
-                             flops=2 * n * hh * ww * (cx + cs) * 4 * nl + 2 * n * 4 * hh * ww * 4 * nl * nl,
-                             moved=4 * n * hh * ww * ((cx + cs) + 4 * nl))
+                # csrc/dec_block.hip on [x | QUERY half of fm[D - j]] + the block's override map: the given half is never read
+                dq, dmap = st['dec'][j]
+                db.build(nl, dev)
+                nbytes = 4 * n * hh * ww * ((cx + cs // 2) + 4 * nl) + 4 * n * 4 * hh * ww * 2 * nl
+                self._launch(lab, nbytes, C.dec_block_forward_map, x, skip, cs, n, hh, ww, dq.kernel.detach(), db.kernel.detach(),
+                             db.bias.detach(), nl, dact_a.alpha, dmap, b['dec'][j],
+                             flops=2 * n * hh * ww * (cx + cs // 2) * 4 * nl + 2 * n * 4 * hh * ww * 4 * nl * nl,
+                             moved=4 * n * hh * ww * ((cx + cs // 2) + 4 * nl) + 4 * 4 * hh * ww * nl)
                 hh, ww = hh * 2, ww * 2
                 x, cx = b['dec'][j], nl
                 continue
@@ -214,16 +208,16 @@ class OverrideMixin:
             x, cx = b['dec'][j], db.n_ch_out
         (da, _), (db, _) = q.layers[D + U].convs()
         head = q.layers[-1]
-        da.build(cx + 2 * cl[1], dev); db.build(4, dev)
-        assert (hh, ww) == (h2, w2) and cx == 8 and da.cin == 40
-        given_half(1)
-        nbytes = 4 * n * h * w * ((10 + 4) + (4 + 4) + (36 + 3))
-        back_args = (x, b['fm'][1], b['skip3'], n, hh, ww, da.kernel.detach(), da.bias.detach(), db.kernel.detach(), db.bias.detach(),
-                     head.kernel.detach(), alpha)
-        back_kw = dict(flops=2 * n * hh * ww * 40 * 16 + 2 * n * h * w * (64 + 12), moved=4 * n * h * w * (10 + 3 + 3))
+        db.build(4, dev)
+        dq, dmap = st['dec'][U - 1]
+        assert (hh, ww) == (h2, w2) and cx == 8 and dq.cin == 24
+        nbytes = 4 * n * h * w * ((6 + 4) + (4 + 4) + (36 + 3))
+        back_args = (x, b['fm'][1], 2 * cl[1], b['skip3'], n, hh, ww, dq.kernel.detach(), db.kernel.detach(), db.bias.detach(),
+                     head.kernel.detach(), alpha, dmap)
+        back_kw = dict(flops=2 * n * hh * ww * 24 * 16 + 2 * n * h * w * (64 + 12), moved=4 * n * h * w * (6 + 3 + 3) + 4 * h * w * 4)
 
         def back(pred):
-            self._launch('F.back', nbytes, C.back_forward, *back_args, pred, **back_kw)
+            self._launch('F.back', nbytes, C.back_forward_map, *back_args, pred, **back_kw)
         out = self._pred_out if not self._tuning else None
         if out is None:
             back(b['pred'])

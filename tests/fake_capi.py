@@ -639,7 +639,23 @@ def front_ovr_forward(base, cvis, lvis, n, h, w, P, P2, p1, s0, p2, add_base, al
     skip3.copy_(sk + base if add_base else sk)
 
 
-_FUSED = _FUSED + ('conv_forward_map', 'front_ovr_forward', 'front_pack_l2_weights', 'front2_forward', 'front4_supported', 'front4_forward', 'front4_forward_u8', 'front4_forward_train', 'dec_block_forward', 'act_forward', 'act_backward',
+def dec_block_forward_map(x, skip, lds, n, h, w, w_s2q, w_s1, b_s1, c, alpha, bias_map, out):
+    lr = lambda v: T.leaky_relu(v, alpha)
+    xin = torch.cat((x, _view(skip, n, h, w, 4 * c, lds)), 3)
+    u = lr(T.conv2d_transpose_same(xin, w_s2q, torch.zeros(c), 2) + bias_map)
+    out.copy_(lr(T.conv2d_transpose_same(u, w_s1, b_s1, 1)))
+
+
+def back_forward_map(x, q1, ldq, skip3, n, h2, w2, w_s2q, w_s1, b_s1, w_head, alpha, bias_map, pred):
+    lr = lambda t: T.leaky_relu(t, alpha)
+    xin = torch.cat((x, _view(q1, n, h2, w2, 16, ldq)), 3)
+    d = lr(T.conv2d_transpose_same(lr(T.conv2d_transpose_same(xin, w_s2q, torch.zeros(4), 2) + bias_map), w_s1, b_s1, 1))
+    y = d @ w_head.reshape(-1, 3)[:4] + skip3
+    y[:, 0, 0, :] = 0
+    pred.copy_(y)
+
+
+_FUSED = _FUSED + ('conv_forward_map', 'front_ovr_forward', 'dec_block_forward_map', 'back_forward_map', 'front_pack_l2_weights', 'front2_forward', 'front4_supported', 'front4_forward', 'front4_forward_u8', 'front4_forward_train', 'dec_block_forward', 'act_forward', 'act_backward',
                   'pixelnorm_forward', 'pixelnorm_backward', 'norm_forward', 'norm_backward', 'pool2x2_forward', 'pool2x2_backward', 'sub_forward', 'finish_pred')
 
 

@@ -96,6 +96,46 @@ def test_conv_forward_map_equals_conv_plus_map(mode, c0, c1, cout, hw, frames):
         assert rel_l2(out.cpu(), want.cpu()) <= 1e-6, (ks, hint)
 
 
+@pytest.mark.parametrize('c,hw,n', [(8, (16, 32), 2), (8, (20, 24), 1), (16, (8, 16), 2), (16, (12, 40), 3)])
+def test_dec_block_forward_map_equals_the_interleaved_block(c, hw, n):
+    """nlt_dec_block_forward_map([x | query half], map) == nlt_dec_block_forward([x | query | given]) when the map is what the given
+    half contributes: conv over the given rows of the first kernel + its bias (both on the GPU; <= 2e-6: a re-association)."""
+    h, w = hw
+    g = torch.Generator().manual_seed(c * 100 + h)
+    R = lambda *s, sc=0.5: ((torch.rand(s, generator=g) - 0.5) * 2 * sc).cuda()
+    x, fm = R(n, h, w, 2 * c), R(n, h, w, 8 * c)
+    given = R(1, h, w, 4 * c)
+    fm[..., 4 * c:] = given                                 # the interleaved map's given half: the same for every frame
+    w2, b2, w1, b1 = R(2, 2, c, 10 * c, sc=0.2), R(c, sc=0.1), R(2, 2, c, c, sc=0.3), R(c, sc=0.1)
+    ref = torch.empty((n, 2 * h, 2 * w, c), device='cuda')
+    C.dec_block_forward(x, 2 * c, fm, 8 * c, n, h, w, w2, b2, w1, b1, c, 0.3, ref)
+    wq = w2[..., :6 * c].contiguous()
+    bmap = T.conv2d_transpose_same(given.cpu().double(), w2[..., 6 * c:].cpu().double(), b2.cpu().double(), 2).float().cuda().contiguous()
+    out = torch.full_like(ref, float('nan'))
+    C.dec_block_forward_map(x, fm, 8 * c, n, h, w, wq, w1, b1, c, 0.3, bmap, out)
+    torch.cuda.synchronize()
+    assert rel_l2(out.cpu(), ref.cpu()) <= 2e-6
+
+
+@pytest.mark.parametrize('hw,n', [((16, 32), 2), ((20, 24), 1), ((64, 48), 3)])
+def test_back_forward_map_equals_the_interleaved_kernel(hw, n):
+    h2, w2 = hw
+    g = torch.Generator().manual_seed(h2 * 7 + w2)
+    R = lambda *s, sc=0.5: ((torch.rand(s, generator=g) - 0.5) * 2 * sc).cuda()
+    x, fm1, skip3 = R(n, h2, w2, 8), R(n, h2, w2, 32), R(n, 2 * h2, 2 * w2, 3)
+    given = R(1, h2, w2, 16)
+    fm1[..., 16:] = given
+    ws2, bs2, ws1, bs1, wh = R(2, 2, 4, 40, sc=0.2), R(4, sc=0.1), R(2, 2, 4, 4, sc=0.3), R(4, sc=0.1), R(1, 1, 36, 3, sc=0.3)
+    ref = torch.empty((n, 2 * h2, 2 * w2, 3), device='cuda')
+    C.back_forward(x, fm1, skip3, n, h2, w2, ws2, bs2, ws1, bs1, wh, 0.3, ref)
+    wq = ws2[..., :24].contiguous()
+    bmap = T.conv2d_transpose_same(given.cpu().double(), ws2[..., 24:].cpu().double(), bs2.cpu().double(), 2).float().cuda().contiguous()
+    out = torch.full_like(ref, float('nan'))
+    C.back_forward_map(x, fm1, 32, skip3, n, h2, w2, wq, ws1, bs1, wh, 0.3, bmap, out)
+    torch.cuda.synchronize()
+    assert rel_l2(out.cpu(), ref.cpu()) <= 2e-6
+
+
 def _infer_vs_oracle(depth, uv, cam, n, identity_warp, seed, train_frames=2):
     torch.set_num_threads(min(os.cpu_count() or 1, 64))
     om, pm = make_pair(depth=depth, uv=uv, im=cam, seed=seed)
