@@ -946,6 +946,32 @@ def bench_infer_mode(args, device):
                     model.call(batches[i], 'test', obs_override=agg)
             except Exception as e:
                 rec["16_frames_per_call"] = {"error": "%s: %s" % (type(e).__name__, str(e)[:200])}
+            # the headline's precision (three-term split, 9 exact products, on the LDS-tiled stride-1 encoder convs) on the same weights
+            try:
+                ref_pred = model.call(batches[0], 'test', obs_override=agg)[3]['pred'].double()
+                cfg9 = nlt_amd.make_config(depth=args.depth, uvh=uv, uvw=uv, imh=cam, imw=cam, bs=4, precision='f32x3_9')
+                m9 = get_model_class('nlt')(cfg9).build(device)
+                m9.register_trainable()
+                with torch.no_grad():
+                    m9.flat_params.copy_(model.flat_params)
+                m9.mark_weights_updated()
+                for i in range(3 * len(batches)):
+                    m9.call(batches[i % len(batches)], 'test', obs_override=agg)
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                n9 = max(20, args.steps)
+                for i in range(n9):
+                    m9.call(batches[i % len(batches)], 'test', obs_override=agg)
+                torch.cuda.synchronize()
+                d9 = (time.perf_counter() - t1) / n9
+                p9 = m9.call(batches[0], 'test', obs_override=agg)[3]['pred'].double()
+                rec["f32x3_9"] = {"ms_per_step": round(1e3 * d9, 4), "Mtexels_per_s": round(texels / d9 / 1e6, 1),
+                                  "rel_l2_pred_vs_fp32": float((p9 - ref_pred).norm() / ref_pred.norm()),
+                                  "launches_on_the_three_term_kernel": sorted(l for l in m9.plan.lds_hints if l.endswith('.q.s1'))}
+                del m9
+                torch.cuda.empty_cache()
+            except Exception as e:
+                rec["f32x3_9"] = {"error": "%s: %s" % (type(e).__name__, str(e)[:200])}
             model.plan.fuse_override = False
             dg = run(10)
             model.plan.fuse_override = True

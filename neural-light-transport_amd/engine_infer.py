@@ -67,7 +67,7 @@ class OverrideMixin:
         hh, ww = h, w
         for l, t in enumerate(obs_override):                # one map per level, shared by every frame
             if not (torch.is_tensor(t) and t.dim() == 4 and t.dtype == torch.float32 and tuple(t.shape[1:]) == (hh, ww, cl[l])
-                    and (t.shape[0] == 1 or t.stride(0) == 0)):
+                    and (t.shape[0] == 1 or t.stride(0) == 0) and (not arrays or t.device == arrays[0].device)):
                 return False
             hh, ww = hh // 2, ww // 2
         last = q.layers[D + U].convs()
