@@ -503,7 +503,8 @@ def bench_train(args, device, world, rank, n_steps, loss):
         # the scaling figure of THIS run: N ranks finish N x the frames of one rank in (overlapped) instead of (no collective)
         comm["speedup_vs_one_rank"] = round(world * el_local / el, 3)
         comm["scaling_efficiency"] = round(el_local / el, 4)
-        comm["light_events_ab"] = light_events_ab(args, device, world, rank, cfg, batches[0])
+        if loss == args.train_loss.split(',')[0]:                   # (once per run: the leg does not depend on the loss)
+            comm["light_events_ab"] = light_events_ab(args, device, world, rank, cfg, batches[0])
         comm["events"] = ("fenced (torch.cuda.Event) -- the default at world > 1 until `light_events_ab` has passed on real xGMI"
                           if not capi_light() else "light (no system-scope fence; NLT_LIGHT_EVENTS=1)")
     # per-rank host side of the step (what 8 single-threaded Python ranks on one host have to sustain): this rank's enqueue
