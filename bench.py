@@ -399,6 +399,13 @@ def cpu_baseline(args):
     four = run(1, args.frames, 90)
     out["one_process_4_frames"] = ({k: four[0][k] for k in ("value", "unit", "cores", "seconds_per_pass", "sample")} if four else
                                    {"value": None, "sample": "did not finish within 90 s"})
+    if four and four[0]["value"] > out["value"]:
+        # the concurrent leg collapsed on this host (seen on some boxes: 35 s per pass instead of 5 with 8 x 32 threads): the
+        # better CPU figure is the baseline -- one process, 32 threads, the bench's own 4-frame batch
+        out["all_cores_concurrent"] = {k: out[k] for k in ("value", "cores", "processes", "threads_per_process", "seconds_per_pass")}
+        out.update({"value": four[0]["value"], "cores": four[0]["cores"], "seconds_per_pass": four[0]["seconds_per_pass"],
+                    "sample": four[0]["sample"] + "; (the %d-process all-cores leg gave LESS on this host: %.3f Mtexels/s summed)"
+                              % (len(recs), out["all_cores_concurrent"]["value"])})
     return out
 
 
