@@ -566,6 +566,7 @@ def light_events_ab(args, device, world, rank, cfg, batch, steps=6):
     g = torch.Generator(device=device).manual_seed(77)
     dpred = (torch.rand(tuple(base.shape), device=device, generator=g) - 0.5).contiguous()
     results, times, tuning = {}, {}, None
+    model_ranges, weights = [], []
     saved = capi.LIGHT_EVENTS
 
     def one_leg(light, n_steps):
@@ -576,6 +577,11 @@ def light_events_ab(args, device, world, rank, cfg, batch, steps=6):
         with torch.no_grad():
             for c in model._conv_layers():
                 c.bias.uniform_(-0.1, 0.1, generator=gw)
+            if weights:                                      # the SAME weights in every leg (kernels are drawn per model instance)
+                model.flat_params.copy_(weights[0])
+            else:
+                weights.append(model.flat_params.detach().clone())
+        model.mark_weights_updated()
         if tuning is not None:
             model.plan.import_tuning(tuning)                 # the SAME plan-time choices in both legs: same kernels, same summation orders
         grad, r = model.flat_grads, model.bucket_ranges
@@ -606,6 +612,7 @@ def light_events_ab(args, device, world, rank, cfg, batch, steps=6):
         torch.cuda.synchronize()
         dt = (time.perf_counter() - t0) / n_steps
         tune = model.plan.export_tuning()
+        model_ranges[:] = list(model.bucket_ranges)
         del model
         torch.cuda.empty_cache()
         return outs, dt, tune
@@ -622,10 +629,15 @@ def light_events_ab(args, device, world, rank, cfg, batch, steps=6):
         capi.LIGHT_EVENTS = saved
     same = all(torch.equal(a, b) for a, b in zip(results["light"], results["fenced"]))
     stable = all(torch.equal(a, results["fenced"][0]) for a in results["fenced"][1:])
-    flag = torch.tensor([int(same), int(stable)], device=device)
+    lstable = all(torch.equal(a, results["light"][0]) for a in results["light"][1:])
+    flag = torch.tensor([int(same), int(stable), int(lstable)], device=device)
     dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+    rg = [int(x) for x in model_ranges]
+    diff = [[float((a[rg[i]:rg[i + 1]] - b[rg[i]:rg[i + 1]]).abs().max()) if rg[i + 1] > rg[i] else 0.0 for i in range(len(rg) - 1)]
+            for a, b in zip(results["light"], results["fenced"])]
     return {"steps_per_leg": steps, "bit_identical_light_vs_fenced_on_every_rank": bool(flag[0].item()),
-            "fenced_leg_bit_reproducible_step_to_step": bool(flag[1].item()), "ms_per_step": times,
+            "fenced_leg_bit_reproducible_step_to_step": bool(flag[1].item()), "light_leg_bit_reproducible_step_to_step": bool(flag[2].item()),
+            "max_abs_difference_per_step_and_range_on_rank_0": diff, "ms_per_step": times,
             "gradient_abs_max": float(results["fenced"][0].abs().max()),
             "what": "forward(train) + backward on a FIXED texel gradient with the 3-range RCCL all-reduce; flat buckets compared bitwise"}
 
