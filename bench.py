@@ -897,7 +897,9 @@ def bench_infer_mode(args, device):
             a2 = copy.copy(args)
             a2.uv, a2.cam, a2.frames, a2.k, a2.batches, a2.store_frames = uv, cam, frames, 1, nb, nb * frames
             _, ds_, ids_ = make_loader(a2, device, 1, 'train', seed=seed)
+            loaders[frames] = (ds_, ids_[:nb])
             return [ds_.load_batch(i_) for i_ in ids_[:nb]]
+        loaders = {}
         train = loader_batches(4, 700)[:2]
         batches = loader_batches(4, 900)
         for _ in range(3):                                            # (allocator + first-launch warm-up)
@@ -925,6 +927,37 @@ def bench_infer_mode(args, device):
         t_first = time.perf_counter() - t_first0
         dt = run(max(20, args.steps))
         replays = int(model.plan.tape_replays)
+        with_loader = None
+        if 4 in loaders:                                              # the render loop as nlt_test.infer runs it: the loader inside
+            ds_, ids_ = loaders[4]
+            for i in range(2 * len(ids_)):
+                model.call(ds_.load_batch(ids_[i % len(ids_)]), 'test', obs_override=agg)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            nl = max(20, min(args.steps, 50))
+            for i in range(nl):
+                model.call(ds_.load_batch(ids_[i % len(ids_)]), 'test', obs_override=agg)
+            torch.cuda.synchronize()
+            dl = (time.perf_counter() - t1) / nl
+            with_loader = {"ms_per_step": round(1e3 * dl, 4), "Mtexels_per_s": round(4 * uv * uv / dl / 1e6, 1),
+                           "what": "Dataset.load_batch (uint8 store -> float32 11-tuple, staging ring) inside the timed loop"}
+            try:                                                      # ... and with the texel buffers left in the uint8 store
+                for i in range(2 * len(ids_)):
+                    model.call(ds_.load_batch(ids_[i % len(ids_)], resident=True), 'test', obs_override=agg)
+                torch.cuda.synchronize()
+                r_before = int(model.plan.tape_replays)
+                t1 = time.perf_counter()
+                for i in range(nl):
+                    model.call(ds_.load_batch(ids_[i % len(ids_)], resident=True), 'test', obs_override=agg)
+                torch.cuda.synchronize()
+                dr = (time.perf_counter() - t1) / nl
+                with_loader_resident = {
+                    "ms_per_step": round(1e3 * dr, 4), "Mtexels_per_s": round(4 * uv * uv / dr / 1e6, 1),
+                    "launch_tape_replays_in_the_timed_loop": int(model.plan.tape_replays) - r_before,
+                    "what": "Dataset.load_batch(resident=True) inside the timed loop: frame ids only; nlt_front_ovr_forward_u8 and "
+                            "nlt_warp_forward_store read the uint8 / fp16 capture store in place (no float batch is assembled)"}
+            except Exception as e:
+                with_loader_resident = {"error": "%s: %s" % (type(e).__name__, str(e)[:200])}
         timer = OpTimer()
         model.plan.timer = timer
         for i in range(3):
@@ -945,6 +978,9 @@ def bench_infer_mode(args, device):
                "extract_feat_8_frames_ms": round(1e3 * t_feat, 3),
                "extract_feat_Mtexels_per_s": round(8 * uv * uv / t_feat / 1e6, 1),
                "first_call_ms_override_maps_and_plan_time_trials": round(1e3 * t_first, 1)}
+        if with_loader:
+            rec["including_loader_float32_batch_assembled_per_step"] = with_loader
+            rec["including_loader_uint8_store_resident"] = with_loader_resident
         if name == "uv1024_cam512":
             try:
                 from nlt_amd.pipeline import RenderPipeline

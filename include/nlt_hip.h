@@ -715,6 +715,15 @@ int nlt_front_ovr_forward(const float* base, const float* cvis, const float* lvi
                           const float* packed, const float* packed_l2, const float* p1, const float* s0,
                           const float* p2, int add_base, float alpha, float* q1, int ldq, float* skip3,
                           float* qtmp2, void* stream);
+/* The same launch on a STORE-RESIDENT batch (nlt/datasets/nlt.py:131-136,173-181 keep the capture as uint8 images; this run's
+ * Dataset keeps them in HBM): frame ids[i] of the uint8 stores diffuse [F,h,w,3], cvis / lvis [F,h,w] instead of float
+ * buffers -- `_load_data`'s `/ 255` happens in registers, as in nlt_front4_forward_u8.  w a multiple of 8.  <= 3e-7 relative
+ * from nlt_front_ovr_forward on the assembled batch (fl(W / 255) . u against W . fl(u / 255)). */
+int nlt_front_ovr_forward_u8(const unsigned char* diffuse_store, const unsigned char* cvis_store,
+                             const unsigned char* lvis_store, const int* ids, int n, int h, int w,
+                             const float* packed, const float* packed_l2, const float* p1, const float* s0,
+                             const float* p2, int add_base, float alpha, float* q1, int ldq, float* skip3,
+                             float* qtmp2, void* stream);
 
 /*
  * Backward-data of one conv: the gradient w.r.t. the layer's input channels from the gradient w.r.t. its pre-activation

@@ -110,6 +110,7 @@ SIGNATURES = {
     'nlt_dec_block_forward_map': (_c_int, [_vp, _vp, _c_int, _c_int, _c_int, _c_int, _vp, _vp, _vp, _c_int, _c_float, _vp, _vp, _vp]),
     'nlt_back_forward_map': (_c_int, [_vp, _vp, _c_int, _vp, _c_int, _c_int, _c_int, _vp, _vp, _vp, _vp, _c_float, _vp, _vp, _vp]),
     'nlt_front_ovr_forward': (_c_int, [_vp] * 3 + [_c_int] * 3 + [_vp] * 5 + [_c_int, _c_float, _vp, _c_int, _vp, _vp, _vp]),
+    'nlt_front_ovr_forward_u8': (_c_int, [_vp] * 4 + [_c_int] * 3 + [_vp] * 5 + [_c_int, _c_float, _vp, _c_int, _vp, _vp, _vp]),
     'nlt_conv_backward_data': (_c_int, [_c_int, _c_int, _c_int, _vp, _vp, _c_int, _c_int, _c_int, _c_int, _c_int, _vp, _vp, _c_int,
                                         _vp, _c_int, _vp, _c_int, _c_float, _c_int, _c_int, _vp, _vp, _c_float, _c_int, _vp]),
     'nlt_conv_tile_packed_floats': (_c_long, [_c_int] * 4),
@@ -1188,6 +1189,19 @@ def front_ovr_forward(base, cvis, lvis, n, h, w, packed, packed_l2, p1, s0, p2, 
     _check(lib().nlt_front_ovr_forward(_ptr(base), _ptr(cvis), _ptr(lvis), n, h, w, _ptr(packed), _ptr(packed_l2), _ptr(p1),
                                        _ptr(s0), _ptr(p2), 1 if add_base else 0, float(alpha), _ptr(q1), ldq, _ptr(skip3),
                                        _ptr(qtmp2), _stream()), 'nlt_front_ovr_forward')
+
+
+def front_ovr_forward_u8(diffuse_store, cvis_store, lvis_store, ids, n, h, w, packed, packed_l2, p1, s0, p2, add_base, alpha, q1, ldq,
+                         skip3, qtmp2):
+    """front_ovr_forward on a store-resident batch: frame ids of the uint8 capture store (nlt_front_ovr_forward_u8)."""
+    u8 = torch.uint8
+    for t, nm in ((p1, 'p1'), (s0, 's0'), (p2, 'p2')):
+        _dense(t, nm)
+    _check(lib().nlt_front_ovr_forward_u8(_tptr(diffuse_store, u8, 'diffuse_store'), _tptr(cvis_store, u8, 'cvis_store'),
+                                          _tptr(lvis_store, u8, 'lvis_store'), _tptr(ids, torch.int32, 'ids'), n, h, w,
+                                          _ptr(packed), _ptr(packed_l2), _ptr(p1), _ptr(s0), _ptr(p2), 1 if add_base else 0,
+                                          float(alpha), _ptr(q1), ldq, _ptr(skip3), _ptr(qtmp2), _stream()),
+           'nlt_front_ovr_forward_u8')
 
 
 def dec_block_forward_map(x, skip, lds, n, h, w, w_s2q, w_s1, b_s1, c, alpha, bias_map, out):

@@ -56,9 +56,12 @@ __device__ __forceinline__ f32x4 lrelu4m(f32x4 v, f32x2 alpha2) {   // front4.hi
 
 struct OvrMaps { const float *p1, *s0, *p2; };
 
-template <int NW>
+// U8 = true reads the resident uint8 capture store (nlt/datasets/nlt.py:131-136,173-181: diffuse / cvis / lvis stores, frame id per
+// sample) and stages the raw BYTE values, like front4_kernel<true>: the 1 / 255 lives in the stage-1 A operands, in the head's skip
+// rows (OFF_WSK8) and in `+ base`; <= 3e-7 rel-L2 from the float variant on the assembled batch (fl(W / 255) . u vs W . fl(u / 255)).
+template <int NW, bool U8>
 __global__ __launch_bounds__(64 * NW, 1) void front_ovr_kernel(
-    const float* __restrict__ base, const float* __restrict__ cvis, const float* __restrict__ lvis, int h, int w,
+    const void* __restrict__ base, const void* __restrict__ cvis, const void* __restrict__ lvis, const int* __restrict__ ids, int h, int w,
     int tiles_y, int tiles_x, int ntiles, const float* __restrict__ blob, const float* __restrict__ blob3, OvrMaps maps,
     int add_base, float alpha, float* __restrict__ q1, int ldq, float* __restrict__ skip3, float* __restrict__ qtmp2) {
   __shared__ __attribute__((aligned(16))) float lds_all[lds_floats<NW>()];
@@ -93,7 +96,9 @@ __global__ __launch_bounds__(64 * NW, 1) void front_ovr_kernel(
   // This kernel has registers to spare (front4 has none): everything that depends on the lane only is computed ONCE --
   // byte offsets of the lane's pieces inside a strip, LDS offsets, map offsets -- and a strip whose haloed tile lies inside
   // the image (all but the last row / column of strips) adds wave-uniform bases to them; border strips re-derive with clamps.
-  constexpr int N3 = 26, P3 = 5, N1 = 9, P1 = 2;
+  constexpr int N3 = U8 ? 13 : 26, P3 = U8 ? 3 : 5, E3 = U8 ? 8 : 4;    // pieces per 3-channel row, passes, texel-floats per piece
+  constexpr int N1 = U8 ? 5 : 9, P1 = U8 ? 1 : 2, E1 = U8 ? 8 : 4;
+  constexpr unsigned BPE = U8 ? 1u : 4u;                                  // bytes per stored element
   unsigned g3[P3], g1[P1];                                               // byte offsets inside a frame, strip being loaded
   unsigned c3[P3], c1[P1];                                               // their lane-constant parts (interior strips)
   int l1o[P1];                                                           // LDS offset of the lane's 1-channel pieces
@@ -101,14 +106,14 @@ __global__ __launch_bounds__(64 * NW, 1) void front_ovr_kernel(
   for (int p = 0; p < P3; ++p) {
     const int item = p * 64 + lane;
     const int r = item / N3, i = item - r * N3;
-    c3[p] = item < XH * N3 ? (unsigned)((r * w) * 3 + 4 * i) * 4u : 0u;
+    c3[p] = item < XH * N3 ? (unsigned)((r * w) * 3 + E3 * i) * BPE : 0u;
   }
 #pragma unroll
   for (int p = 0; p < P1; ++p) {
     const int item = p * 64 + lane;
     const int r = item / N1, i = item - r * N1;
-    c1[p] = item < XH * N1 ? (unsigned)(r * w + 4 * i) * 4u : 0u;
-    l1o[p] = r * R1 + 4 * i;
+    c1[p] = item < XH * N1 ? (unsigned)(r * w + E1 * i) * BPE : 0u;
+    l1o[p] = r * R1 + E1 * i;
   }
   int lf = 0;
   auto opaque = [](int v) { asm volatile("" : "+v"(v)); return v; };
@@ -117,7 +122,7 @@ __global__ __launch_bounds__(64 * NW, 1) void front_ovr_kernel(
     const int ty0 = (t % tiles_y) * SH;
     lf = t / tiles_y;
     if (ty0 + AH <= h2 && tx0 + AW <= w2) {                              // interior (wave-uniform)
-      const unsigned b3 = (unsigned)((2 * ty0 * w + 2 * tx0) * 3) * 4u, b1 = (unsigned)(2 * ty0 * w + 2 * tx0) * 4u;
+      const unsigned b3 = (unsigned)((2 * ty0 * w + 2 * tx0) * 3) * BPE, b1 = (unsigned)(2 * ty0 * w + 2 * tx0) * BPE;
 #pragma unroll
       for (int p = 0; p < P3; ++p) g3[p] = (p + 1) * 64 > XH * N3 && p * 64 + lane >= XH * N3 ? 0u : b3 + c3[p];
 #pragma unroll
@@ -130,28 +135,41 @@ __global__ __launch_bounds__(64 * NW, 1) void front_ovr_kernel(
       const int item = p * 64 + ln;
       const int r = item / N3, i = item - r * N3;
       const int gy = 2 * ty0 + r;
-      const bool ok = item < XH * N3 && gy < h && 3 * (2 * tx0) + 4 * i < 3 * w;
-      g3[p] = ok ? (unsigned)((gy * w + 2 * tx0) * 3 + 4 * i) * 4u : 0u;
+      const bool ok = item < XH * N3 && gy < h && 3 * (2 * tx0) + E3 * i < 3 * w;
+      g3[p] = ok ? (unsigned)((gy * w + 2 * tx0) * 3 + E3 * i) * BPE : 0u;
     }
 #pragma unroll
     for (int p = 0; p < P1; ++p) {
       const int item = p * 64 + ln;
       const int r = item / N1, i = item - r * N1;
       const int gy = 2 * ty0 + r;
-      const bool ok = item < XH * N1 && gy < h && 2 * tx0 + 4 * i < w;
-      g1[p] = ok ? (unsigned)(gy * w + 2 * tx0 + 4 * i) * 4u : 0u;
+      const bool ok = item < XH * N1 && gy < h && 2 * tx0 + E1 * i < w;
+      g1[p] = ok ? (unsigned)(gy * w + 2 * tx0 + E1 * i) * BPE : 0u;
     }
   };
-  f32x4 st[P3 + 2 * P1];
+  using Piece = typename std::conditional<U8, uint2, f32x4>::type;
+  Piece st[P3 + 2 * P1];     // the staged item: 16-byte (float) / 8-byte (uint8) pieces
   auto load_query = [&]() {
-    const long fr = lf;
+    long fr = lf;
+    if constexpr (U8) fr = ids[lf];
+    const unsigned char* pb = static_cast<const unsigned char*>(base) + fr * hw * (3 * BPE);
+    const unsigned char* pc = static_cast<const unsigned char*>(cvis) + fr * hw * BPE;
+    const unsigned char* pl = static_cast<const unsigned char*>(lvis) + fr * hw * BPE;
 #pragma unroll
-    for (int p = 0; p < P3; ++p)
-      st[p] = *reinterpret_cast<const f32x4*>(reinterpret_cast<const unsigned char*>(base) + fr * hw * 12 + g3[p]);
+    for (int p = 0; p < P3; ++p) st[p] = *reinterpret_cast<const Piece*>(pb + g3[p]);
 #pragma unroll
     for (int p = 0; p < P1; ++p) {
-      st[P3 + p] = *reinterpret_cast<const f32x4*>(reinterpret_cast<const unsigned char*>(cvis) + fr * hw * 4 + g1[p]);
-      st[P3 + P1 + p] = *reinterpret_cast<const f32x4*>(reinterpret_cast<const unsigned char*>(lvis) + fr * hw * 4 + g1[p]);
+      st[P3 + p] = *reinterpret_cast<const Piece*>(pc + g1[p]);
+      st[P3 + P1 + p] = *reinterpret_cast<const Piece*>(pl + g1[p]);
+    }
+  };
+  auto put = [&](float* dst, int at) {                                   // one staged piece -> E floats in LDS (bytes stay byte VALUES)
+    if constexpr (U8) {
+      const unsigned lo = st[at].x, hi = st[at].y;
+      *reinterpret_cast<f32x4*>(dst) = (f32x4){(float)(lo & 255u), (float)((lo >> 8) & 255u), (float)((lo >> 16) & 255u), (float)(lo >> 24)};
+      *reinterpret_cast<f32x4*>(dst + 4) = (f32x4){(float)(hi & 255u), (float)((hi >> 8) & 255u), (float)((hi >> 16) & 255u), (float)(hi >> 24)};
+    } else {
+      *reinterpret_cast<f32x4*>(dst) = st[at];
     }
   };
   auto store_query = [&]() {
@@ -159,21 +177,22 @@ __global__ __launch_bounds__(64 * NW, 1) void front_ovr_kernel(
     for (int p = 0; p < P3; ++p) {
       const int item = p * 64 + lane;
       if ((p + 1) * 64 > XH * N3 && item >= XH * N3) continue;
-      *reinterpret_cast<f32x4*>(lds + W_RQ + item * 4) = st[p];
+      put(lds + W_RQ + item * E3, p);
     }
 #pragma unroll
     for (int p = 0; p < P1; ++p) {
       if ((p + 1) * 64 > XH * N1 && p * 64 + lane >= XH * N1) continue;
-      *reinterpret_cast<f32x4*>(lds + W_RC + l1o[p]) = st[P3 + p];
-      *reinterpret_cast<f32x4*>(lds + W_RL + l1o[p]) = st[P3 + P1 + p];
+      put(lds + W_RC + l1o[p], P3 + p);
+      put(lds + W_RL + l1o[p], P3 + P1 + p);
     }
   };
 
   // ---- weights held in registers: the folded stage-1 rows of the five query channels (the three observation rows of
   // the blob are zero: it was packed with a zero observation L0)
+  constexpr float INV255 = 1.0f / 255.0f;
   float aq2[5];
 #pragma unroll
-  for (int m = 0; m < 5; ++m) aq2[m] = blob[OFF_AQ2 + m * 64 + lane];
+  for (int m = 0; m < 5; ++m) aq2[m] = blob[OFF_AQ2 + m * 64 + lane] * (U8 ? INV255 : 1.0f);
 
   // ---- this lane's six stage-1 positions: haloed level-1 texel t = c * 16 + j, tap kk
   int rd3[NC], rd1[NC];                                                  // LDS offsets of the lane's raw texel (3- / 1-channel tiles)
@@ -244,7 +263,7 @@ __global__ __launch_bounds__(64 * NW, 1) void front_ovr_kernel(
 
   float wsk[15];                                                         // wave-uniform: scalar loads
 #pragma unroll
-  for (int rr = 0; rr < 15; ++rr) wsk[rr] = blob[OFF_WSK + rr];
+  for (int rr = 0; rr < 15; ++rr) wsk[rr] = blob[(U8 ? OFF_WSK8 : OFF_WSK) + rr];
 
   // ---- one strip: stage 1 -> [`between`: the staging of later strips] -> stage 2 -> stage 3.  FAST = the strip's haloed tile
   // lies inside the image: no masks, and NO CONDITION AROUND A GLOBAL STORE OR LOAD (see the loop below for why that matters).
@@ -303,7 +322,10 @@ __global__ __launch_bounds__(64 * NW, 1) void front_ovr_kernel(
           s1 = fmaf(raw[c][rr], wsk[rr * 3 + 1], s1);
           s2 = fmaf(raw[c][rr], wsk[rr * 3 + 2], s2);
         }
-        if (add_base) { s0 += raw[c][0]; s1 += raw[c][1]; s2 += raw[c][2]; }
+        if (add_base) {
+          if constexpr (U8) { s0 = fmaf(raw[c][0], INV255, s0); s1 = fmaf(raw[c][1], INV255, s1); s2 = fmaf(raw[c][2], INV255, s2); }
+          else { s0 += raw[c][0]; s1 += raw[c][1]; s2 += raw[c][2]; }
+        }
         if ((owned_m >> (c0 + c)) & 1) {
           unsigned at;
           if constexpr (FAST) at = tex0[c0 + c];
@@ -398,7 +420,7 @@ __global__ __launch_bounds__(64 * NW, 1) void front_ovr_kernel(
     const int tx0 = (t % tiles_x) * SW; t /= tiles_x;
     const int ty0 = (t % tiles_y) * SH;
     lf = t / tiles_y;
-    const unsigned b3 = (unsigned)((2 * ty0 * w + 2 * tx0) * 3) * 4u, b1 = (unsigned)(2 * ty0 * w + 2 * tx0) * 4u;
+    const unsigned b3 = (unsigned)((2 * ty0 * w + 2 * tx0) * 3) * BPE, b1 = (unsigned)(2 * ty0 * w + 2 * tx0) * BPE;
 #pragma unroll
     for (int p = 0; p < P3; ++p) g3[p] = b3 + c3[p];                     // (lanes without a piece: c3 = 0, the strip's first bytes)
 #pragma unroll
@@ -445,13 +467,14 @@ __global__ __launch_bounds__(64 * NW, 1) void front_ovr_kernel(
 
 }  // namespace
 
-extern "C" int nlt_front_ovr_forward(const float* base, const float* cvis, const float* lvis, int n, int h, int w,
-                                     const float* packed, const float* packed_l2, const float* p1, const float* s0,
-                                     const float* p2, int add_base, float alpha, float* q1, int ldq, float* skip3,
-                                     float* qtmp2, void* stream) {
+static int front_ovr_launch(bool u8, const void* base, const void* cvis, const void* lvis, const int* ids, int n, int h, int w,
+                            const float* packed, const float* packed_l2, const float* p1, const float* s0, const float* p2,
+                            int add_base, float alpha, float* q1, int ldq, float* skip3, float* qtmp2, void* stream) {
   if (!base || !cvis || !lvis || !packed || !packed_l2 || !p1 || !s0 || !p2 || !q1 || !skip3 || !qtmp2) return NLT_ERR_BAD_ARG;
+  if (u8 && !ids) return NLT_ERR_BAD_ARG;
   if (n <= 0 || h <= 0 || w <= 0 || ldq < 16 || (ldq & 3)) return NLT_ERR_BAD_ARG;
   if ((h | w) & 3) return NLT_ERR_UNSUPPORTED;
+  if (u8 && (w & 7)) return NLT_ERR_UNSUPPORTED;                        // 8-byte pieces of a uint8 row
   if (!(alpha >= 0.f && alpha <= 1.f)) return NLT_ERR_UNSUPPORTED;
   if (!nlt_aligned16(packed) || !nlt_aligned16(packed_l2) || !nlt_aligned16(q1) || !nlt_aligned16(qtmp2) || !nlt_aligned16(p1) ||
       !nlt_aligned16(s0) || !nlt_aligned16(p2))
@@ -466,8 +489,31 @@ extern "C" int nlt_front_ovr_forward(const float* base, const float* cvis, const
   long groups = per_xcd;
   if (groups > 32) groups = 32;
   OvrMaps maps = {p1, s0, p2};
-  hipLaunchKernelGGL(front_ovr_kernel<NW>, dim3((unsigned)(8 * groups)), dim3(64 * NW), 0, static_cast<hipStream_t>(stream),
-                     base, cvis, lvis, h, w, ty, tx, (int)tiles, packed, packed_l2, maps, add_base, alpha, q1, ldq, skip3, qtmp2);
+  const dim3 grid((unsigned)(8 * groups)), block(64 * NW);
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  if (u8)
+    hipLaunchKernelGGL((front_ovr_kernel<NW, true>), grid, block, 0, s, base, cvis, lvis, ids, h, w, ty, tx, (int)tiles, packed, packed_l2,
+                       maps, add_base, alpha, q1, ldq, skip3, qtmp2);
+  else
+    hipLaunchKernelGGL((front_ovr_kernel<NW, false>), grid, block, 0, s, base, cvis, lvis, ids, h, w, ty, tx, (int)tiles, packed, packed_l2,
+                       maps, add_base, alpha, q1, ldq, skip3, qtmp2);
   NLT_CHECK_LAUNCH();
   return NLT_OK;
+}
+
+extern "C" int nlt_front_ovr_forward(const float* base, const float* cvis, const float* lvis, int n, int h, int w,
+                                     const float* packed, const float* packed_l2, const float* p1, const float* s0,
+                                     const float* p2, int add_base, float alpha, float* q1, int ldq, float* skip3,
+                                     float* qtmp2, void* stream) {
+  return front_ovr_launch(false, base, cvis, lvis, nullptr, n, h, w, packed, packed_l2, p1, s0, p2, add_base, alpha, q1, ldq, skip3,
+                          qtmp2, stream);
+}
+
+extern "C" int nlt_front_ovr_forward_u8(const unsigned char* diffuse_store, const unsigned char* cvis_store,
+                                        const unsigned char* lvis_store, const int* ids, int n, int h, int w,
+                                        const float* packed, const float* packed_l2, const float* p1, const float* s0,
+                                        const float* p2, int add_base, float alpha, float* q1, int ldq, float* skip3,
+                                        float* qtmp2, void* stream) {
+  return front_ovr_launch(true, diffuse_store, cvis_store, lvis_store, ids, n, h, w, packed, packed_l2, p1, s0, p2, add_base, alpha, q1,
+                          ldq, skip3, qtmp2, stream);
 }

@@ -499,7 +499,7 @@ class RenderPlan(OverrideMixin):
         inference=True lets the plan use the fused ends (csrc/fused.hip), which do not keep the
         activations a backward pass would need (fm0, obs0, the L1 / last-block intermediates).
         resident = ResidentTexels (datasets/nlt.py): the five float buffers are None and the front kernel reads the
-        uint8 capture store itself (inference only; `resident_ok` says when).
+        uint8 capture store itself (inference only; `resident_ok` says when -- `resident_override_ok` with an obs_override).
         pred_out [N,H,W,3] (inference, fused ends): the last launch writes the rendered texels THERE instead of the plan's
         reusable buffer, so the caller can hand them out without a copy (50 MB and 19 us per step at 4 x 1024^2).  That one
         launch stays out of the launch tape -- its output address changes every step -- and is re-issued after a replay.
@@ -508,6 +508,8 @@ class RenderPlan(OverrideMixin):
         self._pred_out = pred_out
         self._pred_slot = 'back_infer' if inference else 'back_train'
         if resident is not None:
+            if obs_override is not None:
+                return self._forward_resident_ovr(resident, obs_override, skip_connect_base, algo)
             return self._forward_resident(resident, skip_connect_base, algo)
         n, h, w, _ = base.shape
         k = nn_rgb.shape[1]

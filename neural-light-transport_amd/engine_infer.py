@@ -151,10 +151,70 @@ class OverrideMixin:
             C.tape_resume(paused)
         return st
 
-    def _forward_ovr(self, b, base, cvis, lvis, st, skip_connect_base, algo):
+    def resident_override_ok(self, res, obs_override, alpha):
+        """Can the fused override forward read this store-resident batch in place (csrc/front_ovr.hip, uint8 variant)?"""
+        return (res.w % 8 == 0 and all(torch.is_tensor(t) and t.device == res.cvis.device for t in obs_override)
+                and 0.0 <= alpha <= 1.0 and all(t.data_ptr() % 16 == 0 for t in (res.diffuse, res.cvis, res.lvis))
+                and (res.h * res.w) % 16 == 0
+                and self.can_fuse_override(self._level_channels(), obs_override, res.h, res.w))
+
+    def _forward_resident_ovr(self, res, obs_override, skip_connect_base, algo):
+        """`forward(inference=True, obs_override=...)` on a store-resident batch (nlt_test.infer over Dataset.load_batch(resident=True)):
+        the same plan as `_forward_ovr`, its front launch reading frame ids of the uint8 capture store -- no float batch is assembled."""
+        n, h, w = res.n, res.h, res.w
+        dev = res.cvis.device
+        if not self.resident_override_ok(res, obs_override, self.q.layers[1].convs()[0][1].alpha):
+            raise C.NLTError("this network / plan / obs_override cannot take store-resident inputs: materialise the batch")
+        b = self._buffers(n, 0, h, w, dev)
+        if not self._tuning:
+            self.generation += 1
+        reg = getattr(self.q.layers[0], '_registry', None)
+        if reg is not None:
+            if not self._tuning:
+                reg.tick()
+            reg.refresh_if_stale()
+        ovr = self._prepare_override(b, obs_override, dev)
+        b['train_fused'] = False
+        if self.autotune and not b.get('tuned_ovr') and dev.type == 'cuda':
+            b['tuned_ovr'] = True
+            self._autotune(lambda: self._forward_resident_ovr(res, obs_override, skip_connect_base, algo))
+        self._front_weights(dev, l2=True)
+        body = lambda: self._forward_ovr(b, None, None, None, ovr, skip_connect_base, algo, resident=res)
+        if self.use_tape and dev.type == 'cuda' and self.timer is None and not self._tuning and reg is not None:
+            tkey = ('ovr_u8', res.diffuse.data_ptr(), res.cvis.data_ptr(), res.lvis.data_ptr(), res.ids.data_ptr(), n,
+                    bool(skip_connect_base), algo, C._stream(), self._pred_out is not None, ovr['serial'])
+            tapes = b.setdefault('tapes', {})
+            if len(tapes) > 16:
+                tapes.clear()
+            ent = tapes.get(tkey, 0)
+            if isinstance(ent, tuple):
+                if self._replayable(b, ent, reg):
+                    reg.touch_keys(ent[4])
+                    C.replay(ent)
+                    self.tape_replays += 1
+                    return self._finish_pred(b), b
+                ent = 1
+            tapes[tkey] = 1
+            if ent == 1:
+                C.tape_begin()
+                reg.begin_record()
+                try:
+                    out = body()
+                except BaseException:
+                    C.tape_abort()
+                    reg.end_record()
+                    raise
+                tapes[tkey] = C.tape_end(reg.version, reg.end_record()) or 1
+                return out
+        return body()
+
+    def _forward_ovr(self, b, base, cvis, lvis, st, skip_connect_base, algo, resident=None):
         """front_ovr -> levels 2..D (query path only) -> expanding blocks -> back kernel; one stream."""
-        n, h, w, _ = base.shape
-        dev = base.device
+        if resident is not None:
+            n, h, w, dev = resident.n, resident.h, resident.w, resident.cvis.device
+        else:
+            n, h, w, _ = base.shape
+            dev = base.device
         q, D, U, cl = self.q, self.n_down, self.n_up, b['C']
         alpha = q.layers[1].convs()[0][1].alpha
         if b['skip3'] is None:
@@ -166,8 +226,14 @@ class OverrideMixin:
         nbytes = 4 * n * h * w * (5 + 16) + 4 * n * h2 * w2 * (32 + 16 + 16 + 16) + 4 * n * (h2 * w2 * 32 + h4 * w4 * 32)
         flops = 2 * n * h2 * w2 * (20 + 64) * 16 + 2 * n * h * w * 15 + 2 * n * h4 * w4 * 64 * 32
         moved = 4 * n * h * w * (5 + 3) + 4 * n * h2 * w2 * 16 + 4 * n * h4 * w4 * 32 + 4 * (h2 * w2 * 16 + h * w * 4 + h4 * w4 * 32)
-        self._launch('F.front', nbytes, C.front_ovr_forward, base, cvis, lvis, n, h, w, blob, blob_l2, st['p1'], st['s0'], st['p2'],
-                     skip_connect_base, alpha, b['fm'][1], 2 * cl[1], b['skip3'], b['qtmp'][2], flops=flops, moved=moved)
+        if resident is not None:         # uint8 store in, 5 bytes a texel instead of 20
+            moved -= 15 * n * h * w
+            self._launch('F.front', nbytes, C.front_ovr_forward_u8, resident.diffuse, resident.cvis, resident.lvis, resident.ids, n, h, w,
+                         blob, blob_l2, st['p1'], st['s0'], st['p2'], skip_connect_base, alpha, b['fm'][1], 2 * cl[1], b['skip3'],
+                         b['qtmp'][2], flops=flops, moved=moved)
+        else:
+            self._launch('F.front', nbytes, C.front_ovr_forward, base, cvis, lvis, n, h, w, blob, blob_l2, st['p1'], st['s0'], st['p2'],
+                         skip_connect_base, alpha, b['fm'][1], 2 * cl[1], b['skip3'], b['qtmp'][2], flops=flops, moved=moved)
         hh, ww = h2, w2
         for l in range(2, D + 1):
             (qa, qact_a), (qb, qact_b) = q.layers[l].convs()

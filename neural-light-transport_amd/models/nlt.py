@@ -464,9 +464,10 @@ class Model(BaseModel):
             # texel buffers still in the uint8 store (Dataset.load_batch(resident=True)): the fused front kernel reads
             # them there when this call is an inference forward it can take; anything else gets the float tensors
             act0 = self.net['query'].layers[1].convs()[0][1] if (not self.generic and len(self.net['query'].layers) > 2) else None
-            if (not self.generic and not differentiable and obs_override is None and obs_weights is None and act0 is not None
+            if (not self.generic and not differentiable and obs_weights is None and act0 is not None
                     and getattr(self, 'flat_params', None) is not None
-                    and self.plan.resident_ok(base.n, base.k, base.h, base.w, act0.alpha)):
+                    and (self.plan.resident_ok(base.n, base.k, base.h, base.w, act0.alpha) if obs_override is None
+                         else self.plan.resident_override_ok(base, obs_override, act0.alpha))):
                 resident = base
                 base = cvis = lvis = nn_rgb = nn_base = None
             else:
@@ -488,7 +489,7 @@ class Model(BaseModel):
                 pred_copy = pred
             differentiable = False                                   # (`pred` is a fresh tensor on this path: no clone below)
         elif resident is not None:
-            pred, pred_camspc, base_camspc, fg_camspc, idx = self._render(None, None, None, warp, None, None, None, None,
+            pred, pred_camspc, base_camspc, fg_camspc, idx = self._render(None, None, None, warp, None, None, None, obs_override,
                                                                           want_indices, resident=resident)
             pred_copy = pred if getattr(self, '_pred_fresh', False) else pred.clone()
             if mode != 'test' and rgb is None:

@@ -639,6 +639,13 @@ def front_ovr_forward(base, cvis, lvis, n, h, w, P, P2, p1, s0, p2, add_base, al
     skip3.copy_(sk + base if add_base else sk)
 
 
+def front_ovr_forward_u8(diffuse_store, cvis_store, lvis_store, ids, n, h, w, P, P2, p1, s0, p2, add_base, alpha, q1, ldq, skip3, qtmp2):
+    idx = ids.long()
+    f = lambda st: st[idx].double().div(255.0).float()                                # datasets/nlt.py `_load_data`: uint8 image / 255
+    front_ovr_forward(f(diffuse_store), f(cvis_store).unsqueeze(-1), f(lvis_store).unsqueeze(-1), n, h, w, P, P2, p1, s0, p2,
+                      add_base, alpha, q1, ldq, skip3, qtmp2)
+
+
 def dec_block_forward_map(x, skip, lds, n, h, w, w_s2q, w_s1, b_s1, c, alpha, bias_map, out):
     lr = lambda v: T.leaky_relu(v, alpha)
     xin = torch.cat((x, _view(skip, n, h, w, 4 * c, lds)), 3)
@@ -655,7 +662,7 @@ def back_forward_map(x, q1, ldq, skip3, n, h2, w2, w_s2q, w_s1, b_s1, w_head, al
     pred.copy_(y)
 
 
-_FUSED = _FUSED + ('conv_forward_map', 'front_ovr_forward', 'dec_block_forward_map', 'back_forward_map', 'front_pack_l2_weights', 'front2_forward', 'front4_supported', 'front4_forward', 'front4_forward_u8', 'front4_forward_train', 'dec_block_forward', 'act_forward', 'act_backward',
+_FUSED = _FUSED + ('conv_forward_map', 'front_ovr_forward', 'front_ovr_forward_u8', 'dec_block_forward_map', 'back_forward_map', 'front_pack_l2_weights', 'front2_forward', 'front4_supported', 'front4_forward', 'front4_forward_u8', 'front4_forward_train', 'dec_block_forward', 'act_forward', 'act_backward',
                   'pixelnorm_forward', 'pixelnorm_backward', 'norm_forward', 'norm_backward', 'pool2x2_forward', 'pool2x2_backward', 'sub_forward', 'finish_pred')
 
 

@@ -225,3 +225,84 @@ def test_nlt_test_infer_end_to_end_with_lanes_and_new_feat_agg():
     pm.plan.fuse_override = False
     gen3 = nlt_test.infer(pm, dbs[:1], agg2)
     assert rel_l2(out3[0]['pred'].cpu(), gen3[0]['pred'].cpu()) <= 1e-5
+
+
+@pytest.mark.parametrize('hw,n', [((64, 64), 3), ((72, 40), 2), ((36, 136), 2), ((256, 256), 2)])
+def test_front_ovr_u8_reads_the_capture_store_like_the_float_kernel_reads_the_assembled_batch(hw, n):
+    """nlt_front_ovr_forward_u8 (frame ids of the uint8 stores, 1 / 255 in registers) against nlt_front_ovr_forward on the float
+    buffers `_load_data` would assemble (nlt/datasets/nlt.py:131-136): <= 1e-6 rel-L2 (fl(W / 255) . u vs W . fl(u / 255))."""
+    h, w = hw
+    g = torch.Generator().manual_seed(h * 31 + w)
+    R = lambda *s, lo=-0.5, hi=0.5: (torch.rand(s, generator=g) * (hi - lo) + lo).cuda()
+    F = 5
+    U = lambda *s: torch.randint(0, 256, s, generator=g, dtype=torch.uint8).cuda()
+    diffuse, cvis, lvis = U(F, h, w, 3), U(F, h, w), U(F, h, w)
+    ids = torch.tensor([4, 0, 3][:n], dtype=torch.int32, device='cuda')
+    z = lambda *s: torch.zeros(s, device='cuda')
+    blob = C.front_pack_weights(R(1, 1, 5, 16), R(16, lo=-0.1, hi=0.1), z(1, 1, 3, 16), z(16), R(2, 2, 32, 16, lo=-0.2, hi=0.2),
+                                R(16, lo=-0.1, hi=0.1), R(2, 2, 16, 16, lo=-0.2, hi=0.2), R(16, lo=-0.1, hi=0.1), z(2, 2, 16, 16), z(16),
+                                z(2, 2, 16, 16), z(16), R(1, 1, 36, 3), R(3, lo=-0.1, hi=0.1))
+    blob2 = C.front_pack_l2_weights(R(2, 2, 32, 32, lo=-0.2, hi=0.2), R(32, lo=-0.1, hi=0.1), z(2, 2, 16, 32), z(32))
+    p1, s0, p2 = R(1, h // 2, w // 2, 16), R(1, h, w, 4), R(1, h // 4, w // 4, 32)
+    outs = []
+    for u8 in (False, True):
+        fm1 = torch.full((n, h // 2, w // 2, 32), -7.0, device='cuda')
+        skip3, qtmp2 = torch.empty((n, h, w, 3), device='cuda'), torch.empty((n, h // 4, w // 4, 32), device='cuda')
+        if u8:
+            C.front_ovr_forward_u8(diffuse, cvis, lvis, ids, n, h, w, blob, blob2, p1, s0, p2, True, 0.3, fm1, 32, skip3, qtmp2)
+        else:
+            f = lambda st: (st[ids.long()].double() / 255.0).float().contiguous()
+            C.front_ovr_forward(f(diffuse), f(cvis).unsqueeze(-1), f(lvis).unsqueeze(-1), n, h, w, blob, blob2, p1, s0, p2, True, 0.3,
+                                fm1, 32, skip3, qtmp2)
+        torch.cuda.synchronize()
+        outs.append((fm1, skip3, qtmp2))
+    for a, b in zip(*outs):
+        assert rel_l2(b.cpu(), a.cpu()) <= 1e-6
+    assert torch.all(outs[1][0][..., 16:] == -7.0)
+    with pytest.raises(C.NLTError):                       # 8-byte row pieces: w must be a multiple of 8
+        C.front_ovr_forward_u8(diffuse[:, :, :w - 4].contiguous(), cvis[:, :, :w - 4].contiguous(), lvis[:, :, :w - 4].contiguous(), ids, n, h,
+                               w - 4, blob, blob2, p1, s0, p2, True, 0.3, outs[1][0], 32, outs[1][1], outs[1][2])
+
+
+def test_infer_on_store_resident_batches_equals_infer_on_the_assembled_float_batches():
+    """nlt_test.infer over Dataset.load_batch(resident=True): the override plan's front launch reads the uint8 store by frame id
+    (no float batch assembled), base / uv2cam are gathered from the stores -- against the eager float batches: rendered texels
+    <= 1e-6 rel-L2, base_camspc and the UV gather indices bit-exact; tape replays and 2 lanes bit-identical to the first pass."""
+    import nlt_amd
+    from nlt_amd import nlt_test
+    from nlt_amd.datasets import get_dataset_class
+    from nlt_amd.datasets.synth import synthetic_store
+    from nlt_amd.models import get_model_class
+    uv, cam = 256, 128
+    store = synthetic_store(9, uv, cam, seed=5, k=1)
+    cfg = nlt_amd.make_config(depth=256, uvh=uv, uvw=uv, imh=cam, imw=cam, bs=2)
+    pm = get_model_class('nlt')(cfg).build('cuda')
+    pm.register_trainable()
+    ds = tr = get_dataset_class('nlt')(cfg, 'train', store, k=1, ring=0)
+    agg = nlt_test.extract_feat(pm, [tr.load_batch(store['ids'][i:i + 2]) for i in (0, 2)])
+    id_lists = [store['ids'][i:i + 2] for i in (4, 6, 7)]
+    eager = [ds.load_batch(i) for i in id_lists]
+    res = [ds.load_batch(i, resident=True) for i in id_lists]
+    assert res[0][2] is None
+    a = [pm.call(b, 'test', obs_override=agg, want_indices=True) for b in eager]
+    r0 = pm.plan.tape_replays
+    b = [pm.call(b, 'test', obs_override=agg, want_indices=True) for b in res]
+    torch.cuda.synchronize()
+    assert pm.plan._ovr is not None
+    for x, y in zip(a, b):
+        assert rel_l2(y[3]['pred'].cpu(), x[3]['pred'].cpu()) <= 1e-6 and rel_l2(y[0].cpu(), x[0].cpu()) <= 1e-6
+        assert torch.equal(x[3]['base_camspc'], y[3]['base_camspc']) and torch.equal(x[3]['uv_indices'], y[3]['uv_indices'])
+    first = [y[3]['pred'].clone() for y in b]
+    for _ in range(3):
+        again = [pm.call(x, 'test', obs_override=agg) for x in res]
+    torch.cuda.synchronize()
+    assert pm.plan.tape_replays > r0
+    for x, y in zip(first, again):
+        assert torch.equal(x, y[3]['pred'])
+    two = nlt_test.infer(pm, res, agg, lanes=2)
+    for x, y in zip(first, two):
+        assert torch.equal(x, y['pred'])
+    # what the plan cannot take in place is materialised (general plan), same answer to 1e-5
+    pm.plan.fuse_override = False
+    gen = pm.call(res[0], 'test', obs_override=agg)
+    assert rel_l2(gen[3]['pred'].cpu(), first[0].cpu()) <= 1e-5

@@ -357,3 +357,40 @@ def test_render_pipeline_lane_bookkeeping_on_the_host(monkeypatch):
     assert len(out) == 3 and torch.equal(out[2]['pred'], ref[2])
     with pytest.raises(ValueError):
         RenderPipeline(pm, 0)
+
+
+def test_fused_override_plan_on_a_store_resident_batch(monkeypatch):
+    """RenderPlan.forward(resident=ResidentTexels, obs_override=maps): the override plan with its front launch reading the uint8
+    capture store by frame id -- same texels as the plan on the float batch `_load_data` assembles (nlt/datasets/nlt.py:131-136)."""
+    fake_capi.install(monkeypatch)
+    from nlt_amd import _capi as C
+    from nlt_amd.datasets.nlt import ResidentTexels
+    uv, n = 64, 2
+    om, pm = make(256, uv, 32)
+    g = torch.Generator().manual_seed(3)
+    U = lambda *s: torch.randint(0, 256, s, generator=g, dtype=torch.uint8)
+    store = {'diffuse': U(5, uv, uv, 3), 'rgb': U(5, uv, uv, 3), 'cvis': U(5, uv, uv), 'lvis': U(5, uv, uv),
+             'uv2cam': torch.rand(5, 32, 32, 2, generator=g).half()}
+    ids, nn_ids = torch.tensor([3, 1], dtype=torch.int32), torch.tensor([[0], [2]], dtype=torch.int32)
+    res = ResidentTexels(store, ids, nn_ids, test_mode=True)
+    fl = res.materialize()
+    batch, nn = O.synth_batch(n, uv, uv, 32, 32, 32, 32, k=1, seed=61)
+    with torch.no_grad():
+        _, feats = om._call(torch.cat((batch[1], batch[2], batch[3]), 3), [r - b for b, r in nn], return_feats=True)
+    agg = [f.mean(0, keepdim=True) for f in feats]
+    plan = pm.plan
+    assert plan.resident_override_ok(res, agg, 0.3)
+    a, _ = plan.forward(fl['base'], fl['cvis'], fl['lvis'], fl['nn_rgb'], fl['nn_base'], obs_override=agg, inference=True)
+    a = a.clone()
+    b, _ = plan.forward(None, None, None, None, None, obs_override=agg, inference=True, resident=res)
+    assert plan._ovr is not None and rel_l2(b, a) < 1e-6
+    with torch.no_grad():
+        ref = om._call(torch.cat((fl['base'], fl['cvis'], fl['lvis']), 3), [fl['nn_rgb'][:, 0] - fl['nn_base'][:, 0]],
+                       obs_override=[f.expand(n, -1, -1, -1) for f in agg])
+    want = ref + fl['base']
+    want[:, 0, 0, :] = 0
+    assert rel_l2(b, want) < 1e-5
+    # a per-frame override cannot take the store-resident path
+    assert not plan.resident_override_ok(res, [f.repeat(n, 1, 1, 1) for f in agg], 0.3)
+    with pytest.raises(C.NLTError):
+        plan.forward(None, None, None, None, None, obs_override=[f.repeat(n, 1, 1, 1) for f in agg], inference=True, resident=res)
