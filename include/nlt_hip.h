@@ -663,9 +663,11 @@ int nlt_back_backward(const float* x, const float* fm1, const float* u, const fl
 
 /* nlt_conv_forward on the MFMA path with the K loop split into `ksplit` slices run by different waves (for
  * the deep levels: a few hundred texels x thousands of input channels would otherwise occupy a fraction of the
- * chip).  Slices write raw partial sums to `workspace` (nlt_conv_splitk_workspace_floats() floats); a second
- * launch adds them in slice order -- deterministic -- and applies the usual epilogue.  ksplit = 1 is
- * nlt_conv_forward(algo = MFMA). */
+ * chip).  ONE launch (r06): a workgroup adds four slices in LDS; with more than four slices the groups' partial tiles go to
+ * `workspace` and the workgroup that arrives last at a tile adds them in group order and applies the usual epilogue -- the
+ * order of additions depends on the launch shape only (bit-reproducible).  `workspace` = nlt_conv_splitk_workspace_floats()
+ * floats, ZEROED ONCE by the caller when it is allocated (its first 16384 words are the tiles' ticket counters; every launch
+ * leaves them zero) and used by one stream at a time.  ksplit = 1 is nlt_conv_forward(algo = MFMA). */
 long nlt_conv_splitk_workspace_floats(int mode, int n, int h, int w, int cout, int ksplit);
 int nlt_conv_forward_splitk(int mode, int tile_hint, int ksplit, float* workspace,
                             const float* src0, int ld0, int c0, const float* src1, int ld1, int c1,

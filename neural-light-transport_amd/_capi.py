@@ -863,6 +863,18 @@ def adam_amsgrad_step(param, grad, m, v, vhat, lr_t, beta1, beta2, eps):
 _splitk_ws = {}
 
 
+def _splitk_workspace(need, device):
+    """The split-K scratch of the current (device, stream, plan): cached, grown on demand, ZEROED when allocated -- its first words are
+    the tiles' ticket counters, which every launch leaves at zero (include/nlt_hip.h: nlt_conv_splitk_workspace_floats)."""
+    key = (str(device), _stream(), getattr(_tls, 'scope', 0))   # per stream (the query and observation paths run concurrently) and per plan (see set_workspace_scope)
+    ws = _splitk_ws.get(key)
+    if ws is None or ws.numel() < need:
+        ws = torch.zeros(need, device=device, dtype=torch.float32)
+        _splitk_ws[key] = ws
+        _alloc_epoch[0] += 1
+    return ws
+
+
 def conv_forward_splitk(mode, ksplit, src0, c0, ld0, src1, c1, ld1, n, h, w, w_packed, bias, cout, out, ldo,
                         act=True, alpha=0.3, tile_hint=0, mask_src=None, ldm=0, accumulate=False):
     """nlt_conv_forward (MFMA path) with the K loop split over `ksplit` wave slices; the partial-sum
@@ -870,12 +882,7 @@ def conv_forward_splitk(mode, ksplit, src0, c0, ld0, src1, c1, ld1, n, h, w, w_p
     need = lib().nlt_conv_splitk_workspace_floats(mode, n, h, w, cout, ksplit)
     if need <= 0:
         raise NLTError("nlt_conv_splitk_workspace_floats failed")
-    key = (str(src0.device), _stream(), getattr(_tls, 'scope', 0))   # per stream (the query and observation paths run concurrently) and per plan (see set_workspace_scope)
-    ws = _splitk_ws.get(key)
-    if ws is None or ws.numel() < need:
-        ws = torch.empty(need, device=src0.device, dtype=torch.float32)
-        _splitk_ws[key] = ws
-        _alloc_epoch[0] += 1
+    ws = _splitk_workspace(need, src0.device)
     _check(lib().nlt_conv_forward_splitk(mode, tile_hint, ksplit, _ptr(ws), _ptr(src0), ld0, c0, _ptr(src1), ld1, c1, n, h, w,
                                          _ptr(w_packed), _ptr(bias), cout, _ptr(out), ldo, 1 if act else 0, float(alpha),
                                          _ptr(mask_src), ldm, 1 if accumulate else 0, _stream()), 'nlt_conv_forward_splitk')
@@ -891,12 +898,7 @@ def conv_forward_map(mode, ksplit, src0, c0, ld0, src1, c1, ld1, n, h, w, w_pack
         need = lib().nlt_conv_splitk_workspace_floats(mode, n, h, w, cout, ksplit)
         if need <= 0:
             raise NLTError("nlt_conv_splitk_workspace_floats failed")
-        key = (str(src0.device), _stream(), getattr(_tls, 'scope', 0))
-        ws = _splitk_ws.get(key)
-        if ws is None or ws.numel() < need:
-            ws = torch.empty(need, device=src0.device, dtype=torch.float32)
-            _splitk_ws[key] = ws
-            _alloc_epoch[0] += 1
+        ws = _splitk_workspace(need, src0.device)
     _check(lib().nlt_conv_forward_map(mode, tile_hint, ksplit, _ptr(ws), _ptr(src0), ld0, c0, _ptr(src1), ld1, c1, n, h, w,
                                       _ptr(w_packed), _ptr(bias), cout, _ptr(out), ldo, 1 if act else 0, float(alpha),
                                       _ptr(_dense(bias_map, 'bias_map')), bias_map.shape[0], _stream()), 'nlt_conv_forward_map')
@@ -913,12 +915,7 @@ def conv_backward_data(adj_mode, dpre, cpre, ldp, n, h, w, w_packed, zero_bias, 
         need = lib().nlt_conv_splitk_workspace_floats(adj_mode, n, h, w, cout, ksplit)
         if need <= 0:
             raise NLTError("nlt_conv_splitk_workspace_floats failed")
-        key = (str(dpre.device), _stream(), getattr(_tls, 'scope', 0))
-        ws = _splitk_ws.get(key)
-        if ws is None or ws.numel() < need:
-            ws = torch.empty(need, device=dpre.device, dtype=torch.float32)
-            _splitk_ws[key] = ws
-            _alloc_epoch[0] += 1
+        ws = _splitk_workspace(need, dpre.device)
     sc, sy, sd, sa, sp = split if split is not None else (0, None, None, 0.0, False)
     _check(lib().nlt_conv_backward_data(adj_mode, tile_hint, ksplit, _ptr(ws), _ptr(dpre), ldp, cpre, n, h, w, _ptr(w_packed),
                                         _ptr(zero_bias), cout, _ptr(out), ldo, _ptr(mask_src), ldm, float(mask_alpha),

@@ -47,7 +47,8 @@ extern "C" long nlt_conv_splitk_workspace_floats(int mode, int n, int h, int w, 
   long rows = (long)n * h * w;
   if (mode == NLT_CONV_K2S2) rows /= 4;
   const long ncols = mode == NLT_DECONV_K2S2 ? 4l * cout : cout;
-  return ksplit * rows * ((ncols + 15) / 16 * 16);
+  const long groups = (ksplit + 3) / 4;                            // a workgroup adds 4 (or 16) slices in LDS; only groups meet in memory
+  return NLT_SPLITK_COUNTERS + (groups > 1 ? groups * rows * ((ncols + 15) / 16 * 16) : 0);
 }
 
 extern "C" int nlt_conv_forward_splitk(int mode, int tile_hint, int ksplit, float* workspace,

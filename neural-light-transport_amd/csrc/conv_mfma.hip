@@ -9,10 +9,25 @@
 // (texels straight from the NHWC tensor, weights from the pre-packed fragment array) and feed
 // four consecutive MFMA k-steps.  No LDS, no barriers: every texel element is used by exactly
 // one wave (register-level reuse across its CT column tiles) and the weights are L2-resident.
+//
+// Split-K (few GEMM rows, long K: the deep levels and the small released shapes) -- ONE launch since r06.  A workgroup is one
+// output tile x one group of NW K slices (NW = 4 waves, or 16 for >= 16 slices of a narrow tile): its waves each walk a slice,
+// meet in LDS (slice order), and
+//   * ksplit <= NW: wave 0 finishes the tile (bias / map / activation) -- no workspace, no second pass;
+//   * ksplit  > NW: wave 0 writes the group's partial tile to the workspace, releases it (agent scope) and draws a ticket from the
+//     tile's counter; the workgroup that draws the last ticket acquires, its waves add the groups' slabs in group order
+//     (wave w: groups w, w + NW, ...; then the NW sums in wave order: the same order whoever arrives last), finishes the tile and
+//     puts the counter back to zero.  The order of additions is a function of the launch shape only: bit-reproducible.
+// Rounds 2-5 ran a second launch (`splitk_epilogue*_kernel`) for this: 20 of the 62 launches of a depth-1024 / 256^2 forward.
+// Cross-workgroup visibility follows cdna_hip_programming.md section 6 G16 (per-XCD L2s are not coherent): plain slab stores ->
+// s_waitcnt vmcnt(0) -> barrier -> one lane: release fence (agent) -> restated wait -> relaxed agent fetch_add; last arriver: one
+// lane acquire fence (agent) -> barrier -> plain loads.
 #include "nlt_common.h"
 #include "pack_common.h"
 
 namespace {
+
+typedef __attribute__((address_space(1))) unsigned gu32;
 
 __host__ __device__ inline int chunks16(int c) { return (c + 15) >> 4; }
 
@@ -49,15 +64,26 @@ __device__ __forceinline__ void split_store(const ConvP& p, int otex, int oc, f3
   *d = v;
 }
 
-template <int MODE, int RT, int CT, int PF>
-__global__ __launch_bounds__(256) void conv_mfma_kernel(ConvP p, int mtiles, int ngroups, int ntiles, int ksplit,
+template <int MODE, int RT, int CT, int PF, int NW>           // NW = 0: no split, 4 independent waves; NW = 4 | 16: split-K workgroup
+__global__ __launch_bounds__(NW ? 64 * NW : 256) void conv_mfma_kernel(ConvP p, int mtiles, int ngroups, int ntiles, int ksplit,
                                                         float* ws) {
-  const int lane = threadIdx.x & 63;
-  int wave = blockIdx.x * 4 + (threadIdx.x >> 6);
-  const int ng = wave % ngroups; wave /= ngroups;
-  const int mt = wave % mtiles;
-  const int ks = wave / mtiles;                 // K slice (split-K: few GEMM rows, long K -> more waves)
-  if (ks >= ksplit) return;
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  int ng, mt, ks, kg = 0, tile = 0;
+  constexpr bool SPLIT = NW > 0;
+  if constexpr (SPLIT) {                         // workgroup = (tile, group of NW K slices); wave = slice in the group
+    const int kgroups = (ksplit + NW - 1) / NW;
+    tile = blockIdx.x / kgroups;
+    kg = blockIdx.x - tile * kgroups;
+    ng = tile % ngroups;
+    mt = tile / ngroups;
+    ks = kg * NW + wv;                            // (ks >= ksplit: an empty slice, zeros -- the wave still meets the barriers)
+  } else {
+    int wave = blockIdx.x * 4 + wv;
+    ng = wave % ngroups; wave /= ngroups;
+    mt = wave % mtiles;
+    ks = 0;
+    if (wave >= mtiles) return;
+  }
   const int px = lane & 15, kk = lane >> 4;
 
   int rf[RT], ry[RT], rx[RT], rm[RT];
@@ -85,7 +111,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvP p, int mtiles, int
   const int cps = ch0 + ch1;                    // K-chunks per tap: source 0 then source 1
   const int total = live_taps<MODE>(p) * cps;
   const int per = (total + ksplit - 1) / ksplit;
-  const int kbeg = ks * per;
+  const int kbeg = ks * per < total ? ks * per : total;
   const int kend = kbeg + per < total ? kbeg + per : total;
 
   // Fragment loads are UNCONDITIONAL (clamped addresses, value selected afterwards): a predicated
@@ -186,17 +212,73 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvP p, int mtiles, int
     }
 
   }
-  if (ksplit > 1) {                             // raw partial sums -> workspace [ks][M][ntiles*16]; the epilogue pass finishes
-    float* part = ws;
-    const int npad = ntiles * 16;
+  if constexpr (SPLIT) {
+    __shared__ f32x4 red[(NW - 1) * RT * CT * 64 + 1];          // waves 1..NW-1's tiles; the last slot carries "this workgroup finishes"
+    const int kgroups = (ksplit + NW - 1) / NW;
+    auto meet = [&]() {                                         // acc of wave 0 = sum over the waves, wave order
+      if (wv) {
 #pragma unroll
-    for (int ct = 0; ct < CT; ++ct) {
-      const int ncol = (ng * CT + ct) * 16 + kk * 4;
+        for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+          for (int ct = 0; ct < CT; ++ct) red[((wv - 1) * RT * CT + rt * CT + ct) * 64 + lane] = acc[rt][ct];
+      }
+      __syncthreads();
+      if (!wv) {
+#pragma unroll
+        for (int j = 0; j < NW - 1; ++j)
+#pragma unroll
+          for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+            for (int ct = 0; ct < CT; ++ct) acc[rt][ct] += red[(j * RT * CT + rt * CT + ct) * 64 + lane];
+      }
+    };
+    meet();
+    if (kgroups > 1) {
+      gu32* cnt = (gu32*)ws;                                     // (agent-scope words: global address space, never flat)
+      float* slabs = ws + NLT_SPLITK_COUNTERS;
+      const int npad = ntiles * 16;
+      const size_t slab = (size_t)p.M * npad;
+      if (!wv) {
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct) {
+          const int ncol = (ng * CT + ct) * 16 + kk * 4;
+#pragma unroll
+          for (int rt = 0; rt < RT; ++rt)
+            if (rv[rt]) *reinterpret_cast<f32x4*>(slabs + (size_t)kg * slab + (size_t)rm[rt] * npad + ncol) = acc[rt][ct];
+        }
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();                                          // (also: every wave is done reading `red`)
+      int* flag = reinterpret_cast<int*>(&red[(NW - 1) * RT * CT * 64]);
+      if (threadIdx.x == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // (restated: ROCm 7.2 may drop the wait behind buffer_wbl2)
+        const unsigned t = __hip_atomic_fetch_add(cnt + tile, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const int last = t == (unsigned)(kgroups - 1);
+        if (last) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        *flag = last;
+      }
+      __syncthreads();
+      if (!*flag) return;
+      // the last workgroup of this tile: wave w adds groups w, w + NW, ... (group order), then the waves meet in wave order
 #pragma unroll
       for (int rt = 0; rt < RT; ++rt)
-        if (rv[rt]) *reinterpret_cast<f32x4*>(part + ((size_t)ks * p.M + rm[rt]) * npad + ncol) = acc[rt][ct];
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct) acc[rt][ct] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll(NW == 4 ? 4 : 1)
+      for (int g = wv; g < kgroups; g += NW) {
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct) {
+          const int ncol = (ng * CT + ct) * 16 + kk * 4;
+#pragma unroll
+          for (int rt = 0; rt < RT; ++rt)                       // (clamped rows re-read a valid row; never stored)
+            acc[rt][ct] += *reinterpret_cast<const f32x4*>(slabs + (size_t)g * slab + (size_t)rm[rt] * npad + ncol);
+        }
+      }
+      meet();
+      if (threadIdx.x == 0) __hip_atomic_store(cnt + tile, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // for the next launch
     }
-    return;                                     // the epilogue launch adds the slices in order
+    if (wv) return;
   }
 
   // Epilogue: lane holds outputs [ncol, ncol+4) of texel px for every (rt, ct).
@@ -230,80 +312,6 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvP p, int mtiles, int
   }
 }
 
-// bias / accumulate / mask / LeakyReLU and the mode's output addressing of one output quad, exactly as the single-pass epilogue
-template <int MODE>
-__device__ __forceinline__ void splitk_finish(const ConvP& p, int m, int ncol, f32x4 v) {
-  int oc = ncol, ab = 0;
-  if (MODE == NLT_DECONV_K2S2) { ab = ncol / p.cout; oc = ncol - ab * p.cout; }
-  int otex = m;
-  if (MODE == NLT_DECONV_K2S2) {
-    const int x = m % p.gw, y = (m / p.gw) % p.gh, f = m / (p.gw * p.gh);
-    otex = (f * p.oh + 2 * y + (ab >> 1)) * p.ow + 2 * x + (ab & 1);
-  }
-  v += *reinterpret_cast<const f32x4*>(p.bias + oc);
-  if (p.bmap) v += *reinterpret_cast<const f32x4*>(p.bmap + (size_t)(p.bmap_mod ? otex % p.bmap_mod : otex) * p.cout + oc);
-  f32x4* o = reinterpret_cast<f32x4*>(p.out + (size_t)otex * p.ldo + oc);
-  if (p.accumulate) v += *o;
-  if (p.split_c && oc >= p.split_c) { split_store(p, otex, oc, v); return; }
-  if (p.mask_src) {
-    const f32x4 mk = *reinterpret_cast<const f32x4*>(p.mask_src + (size_t)otex * p.ldm + oc);
-#pragma unroll
-    for (int j = 0; j < 4; ++j) v[j] *= (mk[j] > 0.f) ? 1.f : p.alpha;
-  } else if (p.act) {
-#pragma unroll
-    for (int j = 0; j < 4; ++j) v[j] = v[j] > 0.f ? v[j] : p.alpha * v[j];
-  }
-  *o = v;
-}
-
-// Second pass of a split-K launch: sums the K slices in slice order (deterministic), then the usual epilogue.  Few slices
-// (the mid-network shapes: thousands of rows, 4-8 slices): one thread per output quad walks them.
-template <int MODE>
-__global__ __launch_bounds__(256) void splitk_epilogue_kernel(ConvP p, int ntiles, int ksplit, const float* __restrict__ ws) {
-  const int quads = p.N >> 2;
-  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx >= (long)p.M * quads) return;
-  const int m = idx / quads;
-  const int ncol = (idx - (long)m * quads) * 4;
-  const int npad = ntiles * 16;
-  f32x4 v = *reinterpret_cast<const f32x4*>(ws + (size_t)m * npad + ncol);
-  for (int ks = 1; ks < ksplit; ++ks) v += *reinterpret_cast<const f32x4*>(ws + ((size_t)ks * p.M + m) * npad + ncol);
-  splitk_finish<MODE>(p, m, ncol, v);
-}
-
-// Many slices (the deep levels: a handful of rows, 16-128 slices):
-template <int MODE>
-__global__ __launch_bounds__(256) void splitk_epilogue_wide_kernel(ConvP p, int ntiles, int ksplit, const float* __restrict__ ws) {
-  // 32 output quads per workgroup x 8 slice lanes: lane group j adds slices j, j + 8, ... (four independent running
-  // sums: a serial walk over 64-128 slices is pure load latency), the 8 partial sums meet in LDS in a fixed order.
-  __shared__ f32x4 part[8][32];
-  const int quads = p.N >> 2;
-  const int il = threadIdx.x & 31, ksl = threadIdx.x >> 5;
-  const long idx = (long)blockIdx.x * 32 + il;
-  const bool live = idx < (long)p.M * quads;
-  const int m = live ? idx / quads : 0;
-  const int ncol = live ? (idx - (long)m * quads) * 4 : 0;
-  const int npad = ntiles * 16;
-  const size_t slice = (size_t)p.M * npad;
-  const float* src = ws + (size_t)m * npad + ncol;
-  f32x4 s0 = (f32x4){0.f, 0.f, 0.f, 0.f}, s1 = s0, s2 = s0, s3 = s0;
-  int ks = ksl;
-  for (; ks + 24 < ksplit; ks += 32) {
-    s0 += *reinterpret_cast<const f32x4*>(src + (size_t)ks * slice);
-    s1 += *reinterpret_cast<const f32x4*>(src + (size_t)(ks + 8) * slice);
-    s2 += *reinterpret_cast<const f32x4*>(src + (size_t)(ks + 16) * slice);
-    s3 += *reinterpret_cast<const f32x4*>(src + (size_t)(ks + 24) * slice);
-  }
-  for (; ks < ksplit; ks += 8) s0 += *reinterpret_cast<const f32x4*>(src + (size_t)ks * slice);
-  part[ksl][il] = (s0 + s1) + (s2 + s3);
-  __syncthreads();
-  if (ksl || !live) return;
-  f32x4 v = part[0][il];
-#pragma unroll
-  for (int j = 1; j < 8; ++j) v += part[j][il];
-  splitk_finish<MODE>(p, m, ncol, v);
-}
-
 int taps_of(int mode) { return (mode == NLT_CONV1X1 || mode == NLT_DECONV_K2S2) ? 1 : 4; }
 
 template <int MODE, int RT, int CT>
@@ -314,21 +322,36 @@ int launch_tile(const ConvP& p, int ksplit, float* ws, hipStream_t s) {
   const int total = live_taps<MODE>(p) * (chunks16(p.c0) + chunks16(p.c1));
   if (ksplit > total) ksplit = total;
   if (ksplit < 1 || !ws) ksplit = 1;
-  const long waves = (long)mtiles * ngroups * ksplit;
-  const unsigned blocks = (unsigned)((waves + 3) / 4);
+  const long tiles = (long)mtiles * ngroups;
+  if (ksplit > 4 && tiles > NLT_SPLITK_COUNTERS) ksplit = 4;     // (one ticket counter per tile; such a launch has waves enough)
   // long K loops (>= 24 sixteen-channel chunks per wave): three register sets, loads two chunks ahead; short ones keep the
   // two-set loop (a deeper pipeline costs them its prologue and up to two zero-operand rounds: measured slower below ~16 chunks)
   const int per_wave = (total + ksplit - 1) / ksplit;
-  if (per_wave >= 24)
-    hipLaunchKernelGGL((conv_mfma_kernel<MODE, RT, CT, 3>), dim3(blocks), dim3(256), 0, s, p, mtiles, ngroups, ntiles, ksplit, ws);
-  else
-    hipLaunchKernelGGL((conv_mfma_kernel<MODE, RT, CT, 2>), dim3(blocks), dim3(256), 0, s, p, mtiles, ngroups, ntiles, ksplit, ws);
   if (ksplit > 1) {
-    const long items = (long)p.M * (p.N >> 2);
-    if (ksplit > 8)
-      hipLaunchKernelGGL(splitk_epilogue_wide_kernel<MODE>, dim3((unsigned)((items + 31) / 32)), dim3(256), 0, s, p, ntiles, ksplit, ws);
+    // 16 slices and more on a wave tile of up to four fragments: sixteen-wave workgroups (the whole reduction stays in LDS up to 16 slices, and a
+    // deep level's 64-128 slices meet in memory as 4-8 partial tiles instead of 16-32)
+    if constexpr (RT * CT <= 4) {
+      if (ksplit >= 16) {
+        const unsigned blocks = (unsigned)(tiles * ((ksplit + 15) >> 4));
+        if (per_wave >= 24 && RT * CT <= 2)
+          hipLaunchKernelGGL((conv_mfma_kernel<MODE, RT, CT, (RT * CT <= 2 ? 3 : 2), 16>), dim3(blocks), dim3(1024), 0, s, p, mtiles, ngroups, ntiles, ksplit, ws);
+        else
+          hipLaunchKernelGGL((conv_mfma_kernel<MODE, RT, CT, 2, 16>), dim3(blocks), dim3(1024), 0, s, p, mtiles, ngroups, ntiles, ksplit, ws);
+        NLT_CHECK_LAUNCH();
+        return NLT_OK;
+      }
+    }
+    const unsigned blocks = (unsigned)(tiles * ((ksplit + 3) >> 2));
+    if (per_wave >= 24)
+      hipLaunchKernelGGL((conv_mfma_kernel<MODE, RT, CT, 3, 4>), dim3(blocks), dim3(256), 0, s, p, mtiles, ngroups, ntiles, ksplit, ws);
     else
-      hipLaunchKernelGGL(splitk_epilogue_kernel<MODE>, dim3((unsigned)((items + 255) / 256)), dim3(256), 0, s, p, ntiles, ksplit, ws);
+      hipLaunchKernelGGL((conv_mfma_kernel<MODE, RT, CT, 2, 4>), dim3(blocks), dim3(256), 0, s, p, mtiles, ngroups, ntiles, ksplit, ws);
+  } else {
+    const unsigned blocks = (unsigned)((tiles + 3) / 4);
+    if (per_wave >= 24)
+      hipLaunchKernelGGL((conv_mfma_kernel<MODE, RT, CT, 3, 0>), dim3(blocks), dim3(256), 0, s, p, mtiles, ngroups, ntiles, 1, ws);
+    else
+      hipLaunchKernelGGL((conv_mfma_kernel<MODE, RT, CT, 2, 0>), dim3(blocks), dim3(256), 0, s, p, mtiles, ngroups, ntiles, 1, ws);
   }
   NLT_CHECK_LAUNCH();
   return NLT_OK;

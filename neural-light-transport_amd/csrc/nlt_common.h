@@ -29,6 +29,10 @@ __device__ __forceinline__ float u8_unit(unsigned u) {
 //             modes, INPUT texels for DECONV_K2S2 (each owns a 2x2 output block);
 //   K       = taps x (source0 channels | source1 channels), tap-major;
 //   columns = output channels (DECONV_K2S2: (a,b,o), 4*cout columns).
+// Split-K launches (conv_mfma.hip): the first NLT_SPLITK_COUNTERS words of the workspace are the tiles' ticket counters (zero between
+// launches), the partial tiles follow.
+constexpr int NLT_SPLITK_COUNTERS = 16384;
+
 struct ConvP {
   const float* src0; const float* src1;
   const float* wgt;      // Keras layout (direct) or packed fragments (mfma)

@@ -115,6 +115,43 @@ def test_conv_split_k_deep_levels():
     run_case(C.DECONV_K2S1, 4, 16, 16, 128, 0, 128, C.ALGO_MFMA, tile_hint=0x11, seed=23, ksplit=4)     # L7.q.s1 shape
 
 
+@pytest.mark.parametrize('mode,n,h,w,cin,cout,tile,ksplit', [
+    (C.CONV_K2S1, 4, 1, 1, 1024, 1024, 0x12, 64),       # depth-1024 bottleneck: 4 GEMM rows, one live tap
+    (C.CONV_K2S2, 4, 2, 2, 2048, 1024, 0x14, 128),      # 4 rows, K = 8192
+    (C.DECONV_K2S2, 4, 2, 2, 1024, 512, 0x12, 16),
+    (C.DECONV_K2S1, 4, 4, 4, 512, 512, 0x22, 32),
+    (C.CONV_K2S2, 4, 32, 32, 128, 256, 0x22, 8),        # mid-network: 1024 rows, two groups of four slices
+    (C.CONV_K2S1, 2, 16, 16, 256, 256, 0x44, 6),        # the widest wave tile (48 KB of LDS for the meeting)
+])
+def test_conv_split_k_in_launch_reduction_is_reproducible_and_fresh(mode, n, h, w, cin, cout, tile, ksplit):
+    """The in-launch split-K reduction (csrc/conv_mfma.hip: groups of four slices meet in LDS, groups meet through the workspace,
+    last-arriving workgroup finishes the tile): the SAME workspace serves launch after launch with new inputs while another stream
+    keeps the memory system busy -- a reducer that read stale partial tiles (per-XCD L2s, per-CU L1) or a counter left non-zero
+    would show here.  Each result against the single-slice launch (<= 2e-5 of the output scale); a repeated launch bit-identical."""
+    g = torch.Generator(device='cuda').manual_seed(ksplit * 7 + cin)
+    k, s, tr = MODES[mode]
+    wk = torch.randn((k, k, cout, cin) if tr else (k, k, cin, cout), device='cuda', generator=g) / (k * k * cin) ** 0.5
+    packed = C.pack_conv_weights(mode, wk, cin, 0, cout)
+    bias = torch.randn(cout, device='cuda', generator=g)
+    oh, ow = (h // 2, w // 2) if mode == C.CONV_K2S2 else ((2 * h, 2 * w) if mode == C.DECONV_K2S2 else (h, w))
+    out, ref, again = (torch.empty(n, oh, ow, cout, device='cuda') for _ in range(3))
+    side = torch.cuda.Stream()
+    big = torch.empty(64 << 20, device='cuda')
+    for it in range(12):
+        x = torch.randn(n, h, w, cin, device='cuda', generator=g) * (1.0 + it)
+        torch.cuda.synchronize()
+        with torch.cuda.stream(side):                     # streaming traffic on every XCD while the split launches run
+            for _ in range(4):
+                big.add_(1.0)
+        C.conv_forward_splitk(mode, ksplit, x, cin, cin, None, 0, 0, n, h, w, packed, bias, cout, out, cout, tile_hint=tile)
+        C.conv_forward_splitk(mode, ksplit, x, cin, cin, None, 0, 0, n, h, w, packed, bias, cout, again, cout, tile_hint=tile)
+        C.conv_forward(mode, x, cin, cin, None, 0, 0, n, h, w, wk, packed, bias, cout, ref, cout, algo=C.ALGO_MFMA, tile_hint=tile)
+        torch.cuda.synchronize()
+        scale = max(float(ref.abs().max()), 1.0)
+        assert float((out - ref).abs().max()) <= 2e-5 * scale, (it, float((out - ref).abs().max()), scale)
+        assert torch.equal(out, again), it
+
+
 @pytest.mark.parametrize('algo', [C.ALGO_DIRECT, C.ALGO_MFMA])
 def test_conv_backward_data_epilogue(algo):
     """mask_src / accumulate: out = (old + conv(x)) * lrelu'(mask)."""
