@@ -667,7 +667,10 @@ int nlt_back_backward(const float* x, const float* fm1, const float* u, const fl
  * `workspace` and the workgroup that arrives last at a tile adds them in group order and applies the usual epilogue -- the
  * order of additions depends on the launch shape only (bit-reproducible).  `workspace` = nlt_conv_splitk_workspace_floats()
  * floats, ZEROED ONCE by the caller when it is allocated (its first 16384 words are the tiles' ticket counters; every launch
- * leaves them zero) and used by one stream at a time.  ksplit = 1 is nlt_conv_forward(algo = MFMA). */
+ * leaves them zero) and used by one stream at a time.  ksplit = 1 is nlt_conv_forward(algo = MFMA).
+ * ksplit < 0: |ksplit| slices in the TWO-launch form of rounds 2-5 (every slice a wave of its own, a second launch adds the
+ * slices in slice order and applies the epilogue; same workspace contract, nlt_conv_splitk_workspace_floats(.., ksplit) floats):
+ * the faster form where a handful of GEMM rows meet 32-128 slices; callers choose by timing.  ksplit = 0 is an error. */
 long nlt_conv_splitk_workspace_floats(int mode, int n, int h, int w, int cout, int ksplit);
 int nlt_conv_forward_splitk(int mode, int tile_hint, int ksplit, float* workspace,
                             const float* src0, int ld0, int c0, const float* src1, int ld1, int c1,

@@ -877,7 +877,8 @@ def _splitk_workspace(need, device):
 
 def conv_forward_splitk(mode, ksplit, src0, c0, ld0, src1, c1, ld1, n, h, w, w_packed, bias, cout, out, ldo,
                         act=True, alpha=0.3, tile_hint=0, mask_src=None, ldm=0, accumulate=False):
-    """nlt_conv_forward (MFMA path) with the K loop split over `ksplit` wave slices; the partial-sum
+    """nlt_conv_forward (MFMA path) with the K loop split over |ksplit| wave slices (ksplit > 0: one launch, the last workgroup
+    to arrive at a tile adds the groups' partial tiles; ksplit < 0: the two-launch form of rounds 2-5); the partial-sum
     workspace is cached per device and grown on demand."""
     need = lib().nlt_conv_splitk_workspace_floats(mode, n, h, w, cout, ksplit)
     if need <= 0:
@@ -894,7 +895,7 @@ def conv_forward_map(mode, ksplit, src0, c0, ld0, src1, c1, ld1, n, h, w, w_pack
     (include/nlt_hip.h: nlt_conv_forward_map).  bias_map [1 or n, oh, ow, cout] dense.  (w_keras is not read here; the host
     tests' CPU emulation of this adapter computes from it.)"""
     ws = None
-    if ksplit > 1:
+    if abs(ksplit) > 1:
         need = lib().nlt_conv_splitk_workspace_floats(mode, n, h, w, cout, ksplit)
         if need <= 0:
             raise NLTError("nlt_conv_splitk_workspace_floats failed")
@@ -911,7 +912,7 @@ def conv_backward_data(adj_mode, dpre, cpre, ldp, n, h, w, w_packed, zero_bias, 
     (w_keras -- the Keras-layout slice the fragments were packed from -- is not read here; the host tests' CPU emulation of
     this adapter computes from it.)"""
     ws = None
-    if ksplit > 1:
+    if abs(ksplit) > 1:
         need = lib().nlt_conv_splitk_workspace_floats(adj_mode, n, h, w, cout, ksplit)
         if need <= 0:
             raise NLTError("nlt_conv_splitk_workspace_floats failed")

@@ -43,10 +43,11 @@ extern "C" int nlt_conv_forward(int mode, int algo, int tile_hint,
 }
 
 extern "C" long nlt_conv_splitk_workspace_floats(int mode, int n, int h, int w, int cout, int ksplit) {
-  if (n <= 0 || h <= 0 || w <= 0 || cout <= 0 || ksplit < 1) return -1;
+  if (n <= 0 || h <= 0 || w <= 0 || cout <= 0 || ksplit == 0) return -1;
   long rows = (long)n * h * w;
   if (mode == NLT_CONV_K2S2) rows /= 4;
   const long ncols = mode == NLT_DECONV_K2S2 ? 4l * cout : cout;
+  if (ksplit < 0) return NLT_SPLITK_COUNTERS + (ksplit < -1 ? -ksplit * rows * ((ncols + 15) / 16 * 16) : 0);   // two launches: a slab per slice
   const long groups = (ksplit + 3) / 4;                            // a workgroup adds 4 (or 16) slices in LDS; only groups meet in memory
   return NLT_SPLITK_COUNTERS + (groups > 1 ? groups * rows * ((ncols + 15) / 16 * 16) : 0);
 }
@@ -56,7 +57,7 @@ extern "C" int nlt_conv_forward_splitk(int mode, int tile_hint, int ksplit, floa
                                        int n, int h, int w, const float* w_packed, const float* bias,
                                        int cout, float* out, int ldo, int act, float alpha,
                                        const float* mask_src, int ldm, int accumulate, void* stream) {
-  if (ksplit < 1 || (ksplit > 1 && (!workspace || !nlt_aligned16(workspace)))) return NLT_ERR_BAD_ARG;
+  if (ksplit == 0 || ((ksplit > 1 || ksplit < -1) && (!workspace || !nlt_aligned16(workspace)))) return NLT_ERR_BAD_ARG;
   ConvP p;
   const int st = nlt_fill_conv_params(p, mode, src0, ld0, c0, src1, ld1, c1, n, h, w, w_packed, bias, cout, out, ldo,
                                       act, alpha, mask_src, ldm, accumulate);
@@ -69,7 +70,7 @@ extern "C" int nlt_conv_forward_map(int mode, int tile_hint, int ksplit, float* 
                                     int n, int h, int w, const float* w_packed, const float* bias,
                                     int cout, float* out, int ldo, int act, float alpha,
                                     const float* bias_map, int map_frames, void* stream) {
-  if (ksplit < 1 || (ksplit > 1 && (!workspace || !nlt_aligned16(workspace)))) return NLT_ERR_BAD_ARG;
+  if (ksplit == 0 || ((ksplit > 1 || ksplit < -1) && (!workspace || !nlt_aligned16(workspace)))) return NLT_ERR_BAD_ARG;
   if (!bias_map || !nlt_aligned16(bias_map) || (map_frames != 1 && map_frames != n)) return NLT_ERR_BAD_ARG;
   ConvP p;
   const int st = nlt_fill_conv_params(p, mode, src0, ld0, c0, src1, ld1, c1, n, h, w, w_packed, bias, cout, out, ldo,
@@ -86,7 +87,7 @@ extern "C" int nlt_conv_backward_data(int adj_mode, int tile_hint, int ksplit, f
                                       const float* mask_src, int ldm, float mask_alpha, int accumulate,
                                       int split_c, const float* split_y, float* split_d, float split_alpha, int split_partial,
                                       void* stream) {
-  if (ksplit < 1 || (ksplit > 1 && (!workspace || !nlt_aligned16(workspace)))) return NLT_ERR_BAD_ARG;
+  if (ksplit == 0 || ((ksplit > 1 || ksplit < -1) && (!workspace || !nlt_aligned16(workspace)))) return NLT_ERR_BAD_ARG;
   ConvP p;
   const int st = nlt_fill_conv_params(p, adj_mode, dpre, ldp, cpre, nullptr, 0, 0, n, h, w, w_packed, zero_bias, cout, out, ldo,
                                       0, mask_alpha, mask_src, ldm, accumulate);

@@ -81,8 +81,8 @@ __global__ __launch_bounds__(NW ? 64 * NW : 256) void conv_mfma_kernel(ConvP p, 
     int wave = blockIdx.x * 4 + wv;
     ng = wave % ngroups; wave /= ngroups;
     mt = wave % mtiles;
-    ks = 0;
-    if (wave >= mtiles) return;
+    ks = wave / mtiles;                          // (two-launch split-K: every K slice a wave of its own)
+    if (ks >= ksplit) return;
   }
   const int px = lane & 15, kk = lane >> 4;
 
@@ -281,6 +281,21 @@ __global__ __launch_bounds__(NW ? 64 * NW : 256) void conv_mfma_kernel(ConvP p, 
     if (wv) return;
   }
 
+  if constexpr (!SPLIT) {
+    if (ksplit > 1) {                           // raw partial sums -> workspace [ks][M][ntiles*16]; the second launch finishes
+      float* part = ws + NLT_SPLITK_COUNTERS;
+      const int npad = ntiles * 16;
+#pragma unroll
+      for (int ct = 0; ct < CT; ++ct) {
+        const int ncol = (ng * CT + ct) * 16 + kk * 4;
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt)
+          if (rv[rt]) *reinterpret_cast<f32x4*>(part + ((size_t)ks * p.M + rm[rt]) * npad + ncol) = acc[rt][ct];
+      }
+      return;
+    }
+  }
+
   // Epilogue: lane holds outputs [ncol, ncol+4) of texel px for every (rt, ct).
 #pragma unroll
   for (int ct = 0; ct < CT; ++ct) {
@@ -312,6 +327,85 @@ __global__ __launch_bounds__(NW ? 64 * NW : 256) void conv_mfma_kernel(ConvP p, 
   }
 }
 
+// bias / accumulate / mask / LeakyReLU and the mode's output addressing of one output quad, exactly as the single-pass epilogue
+template <int MODE>
+__device__ __forceinline__ void splitk_finish(const ConvP& p, int m, int ncol, f32x4 v) {
+  int oc = ncol, ab = 0;
+  if (MODE == NLT_DECONV_K2S2) { ab = ncol / p.cout; oc = ncol - ab * p.cout; }
+  int otex = m;
+  if (MODE == NLT_DECONV_K2S2) {
+    const int x = m % p.gw, y = (m / p.gw) % p.gh, f = m / (p.gw * p.gh);
+    otex = (f * p.oh + 2 * y + (ab >> 1)) * p.ow + 2 * x + (ab & 1);
+  }
+  v += *reinterpret_cast<const f32x4*>(p.bias + oc);
+  if (p.bmap) v += *reinterpret_cast<const f32x4*>(p.bmap + (size_t)(p.bmap_mod ? otex % p.bmap_mod : otex) * p.cout + oc);
+  f32x4* o = reinterpret_cast<f32x4*>(p.out + (size_t)otex * p.ldo + oc);
+  if (p.accumulate) v += *o;
+  if (p.split_c && oc >= p.split_c) { split_store(p, otex, oc, v); return; }
+  if (p.mask_src) {
+    const f32x4 mk = *reinterpret_cast<const f32x4*>(p.mask_src + (size_t)otex * p.ldm + oc);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) v[j] *= (mk[j] > 0.f) ? 1.f : p.alpha;
+  } else if (p.act) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) v[j] = v[j] > 0.f ? v[j] : p.alpha * v[j];
+  }
+  *o = v;
+}
+
+// TWO-LAUNCH split-K (ksplit < 0; rounds 2-5's only form): independent waves write their slices' raw partial sums, this second
+// launch sums them in slice order (deterministic), then the usual epilogue.  Kept beside the one-launch form because it is the
+// faster one where a handful of GEMM rows meet 64-128 slices (depth 1024 below 4 x 4 texels: every slice a wave of its own on any
+// CU, the sum spread over thousands of threads; tools/bench_deep.py) -- the plan-time trials choose per launch.  Few slices
+// (the mid-network shapes: thousands of rows, 4-8 slices): one thread per output quad walks them.
+template <int MODE>
+__global__ __launch_bounds__(256) void splitk_epilogue_kernel(ConvP p, int ntiles, int ksplit, const float* __restrict__ ws0) {
+  const float* __restrict__ ws = ws0 + NLT_SPLITK_COUNTERS;
+  const int quads = p.N >> 2;
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (long)p.M * quads) return;
+  const int m = idx / quads;
+  const int ncol = (idx - (long)m * quads) * 4;
+  const int npad = ntiles * 16;
+  f32x4 v = *reinterpret_cast<const f32x4*>(ws + (size_t)m * npad + ncol);
+  for (int ks = 1; ks < ksplit; ++ks) v += *reinterpret_cast<const f32x4*>(ws + ((size_t)ks * p.M + m) * npad + ncol);
+  splitk_finish<MODE>(p, m, ncol, v);
+}
+
+// Many slices (the deep levels: a handful of rows, 16-128 slices):
+template <int MODE>
+__global__ __launch_bounds__(256) void splitk_epilogue_wide_kernel(ConvP p, int ntiles, int ksplit, const float* __restrict__ ws0) {
+  const float* __restrict__ ws = ws0 + NLT_SPLITK_COUNTERS;
+  // 32 output quads per workgroup x 8 slice lanes: lane group j adds slices j, j + 8, ... (four independent running
+  // sums: a serial walk over 64-128 slices is pure load latency), the 8 partial sums meet in LDS in a fixed order.
+  __shared__ f32x4 part[8][32];
+  const int quads = p.N >> 2;
+  const int il = threadIdx.x & 31, ksl = threadIdx.x >> 5;
+  const long idx = (long)blockIdx.x * 32 + il;
+  const bool live = idx < (long)p.M * quads;
+  const int m = live ? idx / quads : 0;
+  const int ncol = live ? (idx - (long)m * quads) * 4 : 0;
+  const int npad = ntiles * 16;
+  const size_t slice = (size_t)p.M * npad;
+  const float* src = ws + (size_t)m * npad + ncol;
+  f32x4 s0 = (f32x4){0.f, 0.f, 0.f, 0.f}, s1 = s0, s2 = s0, s3 = s0;
+  int ks = ksl;
+  for (; ks + 24 < ksplit; ks += 32) {
+    s0 += *reinterpret_cast<const f32x4*>(src + (size_t)ks * slice);
+    s1 += *reinterpret_cast<const f32x4*>(src + (size_t)(ks + 8) * slice);
+    s2 += *reinterpret_cast<const f32x4*>(src + (size_t)(ks + 16) * slice);
+    s3 += *reinterpret_cast<const f32x4*>(src + (size_t)(ks + 24) * slice);
+  }
+  for (; ks < ksplit; ks += 8) s0 += *reinterpret_cast<const f32x4*>(src + (size_t)ks * slice);
+  part[ksl][il] = (s0 + s1) + (s2 + s3);
+  __syncthreads();
+  if (ksl || !live) return;
+  f32x4 v = part[0][il];
+#pragma unroll
+  for (int j = 1; j < 8; ++j) v += part[j][il];
+  splitk_finish<MODE>(p, m, ncol, v);
+}
+
 int taps_of(int mode) { return (mode == NLT_CONV1X1 || mode == NLT_DECONV_K2S2) ? 1 : 4; }
 
 template <int MODE, int RT, int CT>
@@ -320,9 +414,25 @@ int launch_tile(const ConvP& p, int ksplit, float* ws, hipStream_t s) {
   const int ngroups = ntiles / CT;
   const int mtiles = (p.M + 16 * RT - 1) / (16 * RT);
   const int total = live_taps<MODE>(p) * (chunks16(p.c0) + chunks16(p.c1));
+  const bool two_launches = ksplit < 0;                           // (negative: the two-launch form)
+  if (two_launches) ksplit = -ksplit;
   if (ksplit > total) ksplit = total;
   if (ksplit < 1 || !ws) ksplit = 1;
   const long tiles = (long)mtiles * ngroups;
+  if (two_launches && ksplit > 1) {
+    const unsigned blocks = (unsigned)((tiles * ksplit + 3) / 4);
+    if ((total + ksplit - 1) / ksplit >= 24)
+      hipLaunchKernelGGL((conv_mfma_kernel<MODE, RT, CT, 3, 0>), dim3(blocks), dim3(256), 0, s, p, mtiles, ngroups, ntiles, ksplit, ws);
+    else
+      hipLaunchKernelGGL((conv_mfma_kernel<MODE, RT, CT, 2, 0>), dim3(blocks), dim3(256), 0, s, p, mtiles, ngroups, ntiles, ksplit, ws);
+    const long items = (long)p.M * (p.N >> 2);
+    if (ksplit > 8)
+      hipLaunchKernelGGL(splitk_epilogue_wide_kernel<MODE>, dim3((unsigned)((items + 31) / 32)), dim3(256), 0, s, p, ntiles, ksplit, ws);
+    else
+      hipLaunchKernelGGL(splitk_epilogue_kernel<MODE>, dim3((unsigned)((items + 255) / 256)), dim3(256), 0, s, p, ntiles, ksplit, ws);
+    NLT_CHECK_LAUNCH();
+    return NLT_OK;
+  }
   if (ksplit > 4 && tiles > NLT_SPLITK_COUNTERS) ksplit = 4;     // (one ticket counter per tile; such a launch has waves enough)
   // long K loops (>= 24 sixteen-channel chunks per wave): three register sets, loads two chunks ahead; short ones keep the
   // two-set loop (a deeper pipeline costs them its prologue and up to two zero-operand rounds: measured slower below ~16 chunks)

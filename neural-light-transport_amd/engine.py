@@ -116,7 +116,7 @@ class RenderPlan(OverrideMixin):
         self.c32_hints = {}             # label -> 1 | 2
         self._trial_splitk = 0          # autotune: K slices to try on the small deep launches
         self._ran_splitk = set()
-        self.splitk_hints = {}          # label -> K slices (split-K, csrc/conv_mfma.hip) for launches with few GEMM rows
+        self.splitk_hints = {}          # label -> K slices (split-K, csrc/conv_mfma.hip; < 0: its two-launch form) for launches with few GEMM rows
         is_c = net_query.is_contracting
         self.n_down = sum(is_c) - 1                      # contracting Sequential blocks
         self.n_up = len(is_c) - sum(is_c) - 1            # expanding Sequential blocks
@@ -203,17 +203,17 @@ class RenderPlan(OverrideMixin):
             rt, ct = (tile_hint >> 4, tile_hint & 15) if tile_hint else (1, 1)
             waves = -(-rows // (16 * rt)) * (-(-ncols // 16) // ct)
             npad = -(-ncols // 16) * 16
-            ks = self._trial_splitk if (waves < 4096 and rows * npad * self._trial_splitk <= (1 << 24)) else 1
+            ks = self._trial_splitk if (waves < 4096 and rows * npad * abs(self._trial_splitk) <= (1 << 24)) else 1
         if bmap is not None:
             if not ok:
                 raise C.NLTError("a bias-map conv needs channel counts that are multiples of 4 (%s)" % label)
-            if ks > 1:
+            if abs(ks) > 1:
                 self._ran_splitk.add(label)
-            self._launch(label, nbytes, C.conv_forward_map, layer.mode, max(ks, 1), src0, c0, ld0, src1, c1, ld1, n, h, w,
+            self._launch(label, nbytes, C.conv_forward_map, layer.mode, ks or 1, src0, c0, ld0, src1, c1, ld1, n, h, w,
                          layer.packed(c0, c1), layer.bias.detach(), layer.n_ch_out, out, ldo, bmap, act=act is not None,
                          alpha=act.alpha if act is not None else 0.0, tile_hint=tile_hint, w_keras=layer.kernel.detach(), flops=flops)
             return
-        if ks > 1 and ok:
+        if abs(ks) > 1 and ok:
             self._ran_splitk.add(label)
             self._launch(label, nbytes, C.conv_forward_splitk, layer.mode, ks, src0, c0, ld0, src1, c1, ld1, n, h, w,
                          layer.packed(c0, c1), layer.bias.detach(), layer.n_ch_out, out, ldo, act=act is not None,
@@ -354,7 +354,12 @@ class RenderPlan(OverrideMixin):
         # weights through 4 rows) need thousands of waves each walking a short K slice to keep HBM busy: up to 128 slices
         mode = os.environ.get('NLT_SPLITK', 'all')                   # 'all' | 'fwd' (forward plans only) | 'off': A/B switch
         if mode == 'all' or (mode == 'fwd' and not backward):
-            trials += [('splitk', (16 * r + c, ks)) for (r, c) in ((1, 1), (1, 2), (2, 2), (1, 4)) for ks in (4, 8, 16, 32, 64, 128)]
+            # (ks > 0: one launch -- slices meet in LDS, groups of slices through a ticket counter; ks < 0: every slice a wave of its
+            # own and a second launch that adds them -- the faster form where 4-16 GEMM rows meet 32-128 slices, tools/bench_deep.py)
+            forms = os.environ.get('NLT_SPLITK_FORMS', 'both')     # 'both' | 'one' (launch) | 'two' (launches): A/B switch
+            cand = ((4, 8, 16, 32, 64, 128) if forms != 'two' else ()) + ((-16, -32, -64, -128) if forms == 'both' else ()) + \
+                   ((-4, -8, -16, -32, -64, -128) if forms == 'two' else ())
+            trials += [('splitk', (16 * r + c, ks)) for (r, c) in ((1, 1), (1, 2), (2, 2), (1, 4)) for ks in cand]
         saved_lds, saved_sk, saved_wino, saved_c32 = dict(self.lds_hints), dict(self.splitk_hints), dict(self.wino_hints), dict(self.c32_hints)
         for kind, hint in trials:
             self.tile_hints = {'*': hint} if kind == 'tile' else ({'*': hint[0]} if kind == 'splitk' else {})
@@ -979,7 +984,7 @@ class RenderPlan(OverrideMixin):
             rt, ct = (tile_hint >> 4, tile_hint & 15) if tile_hint else (1, 1)
             waves = -(-rows // (16 * rt)) * (-(-ncols // 16) // ct)
             npad = -(-ncols // 16) * 16
-            nks = self._trial_splitk if (waves < 4096 and rows * npad * self._trial_splitk <= (1 << 24)) else 1
+            nks = self._trial_splitk if (waves < 4096 and rows * npad * abs(self._trial_splitk) <= (1 << 24)) else 1
         taps = 1 if adj == C.DECONV_K2S2 else 4
         flops = 2 * rows * taps * layer.n_ch_out * ncols
         # LDS-tiled kernel (csrc/conv_tile.hip) for the launches the plan-time trials gave to it: the adjoint families it has
@@ -1005,7 +1010,7 @@ class RenderPlan(OverrideMixin):
                          layer.packed_adjoint_tile(lo, hi, tn), hi - lo, tn, out, ldo, mask_src=mask_src, ldm=ldm, mask_alpha=mask_alpha,
                          accumulate=accumulate, split=split, w_keras=ks, flops=flops)
             return
-        if nks > 1:
+        if abs(nks) > 1:
             self._ran_splitk.add(label)
         self._launch(label, nbytes, C.conv_backward_data, adj, dpre, layer.n_ch_out, ldp, n, oh, ow, packed, zero_bias, hi - lo,
                      out, ldo, mask_src=mask_src, ldm=ldm, mask_alpha=mask_alpha, accumulate=accumulate, tile_hint=tile_hint,

@@ -122,13 +122,16 @@ def test_conv_split_k_deep_levels():
     (C.DECONV_K2S1, 4, 4, 4, 512, 512, 0x22, 32),
     (C.CONV_K2S2, 4, 32, 32, 128, 256, 0x22, 8),        # mid-network: 1024 rows, two groups of four slices
     (C.CONV_K2S1, 2, 16, 16, 256, 256, 0x44, 6),        # the widest wave tile (48 KB of LDS for the meeting)
+    (C.CONV_K2S2, 4, 2, 2, 2048, 1024, 0x12, -128),     # the two-launch form (ksplit < 0): slices by independent waves + a summing launch
+    (C.DECONV_K2S2, 4, 2, 2, 1024, 512, 0x12, -16),
+    (C.CONV_K2S2, 4, 32, 32, 128, 256, 0x22, -8),
 ])
 def test_conv_split_k_in_launch_reduction_is_reproducible_and_fresh(mode, n, h, w, cin, cout, tile, ksplit):
     """The in-launch split-K reduction (csrc/conv_mfma.hip: groups of four slices meet in LDS, groups meet through the workspace,
     last-arriving workgroup finishes the tile): the SAME workspace serves launch after launch with new inputs while another stream
     keeps the memory system busy -- a reducer that read stale partial tiles (per-XCD L2s, per-CU L1) or a counter left non-zero
     would show here.  Each result against the single-slice launch (<= 2e-5 of the output scale); a repeated launch bit-identical."""
-    g = torch.Generator(device='cuda').manual_seed(ksplit * 7 + cin)
+    g = torch.Generator(device='cuda').manual_seed(abs(ksplit) * 7 + cin)
     k, s, tr = MODES[mode]
     wk = torch.randn((k, k, cout, cin) if tr else (k, k, cin, cout), device='cuda', generator=g) / (k * k * cin) ** 0.5
     packed = C.pack_conv_weights(mode, wk, cin, 0, cout)

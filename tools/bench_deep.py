@@ -9,17 +9,28 @@ import nlt_amd                                                   # noqa: E402
 from nlt_amd import capi as C                                    # noqa: E402
 
 
-def timeit(fn, reps=50):
-    for _ in range(5):
+def timeit(fn, reps=20):
+    """GPU-side time per launch: `reps` launches captured in one hipGraph (eager back-to-back launches through ctypes cost ~7 us of
+    host time each and would measure that instead)."""
+    fn()
+    torch.cuda.synchronize()
+    s = torch.cuda.Stream()
+    with torch.cuda.stream(s):
         fn()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            for _ in range(reps):
+                fn()
+    torch.cuda.synchronize()
+    g.replay()
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
-    for _ in range(reps):
-        fn()
+    for _ in range(3):
+        g.replay()
     e1.record()
     torch.cuda.synchronize()
-    return e0.elapsed_time(e1) / reps
+    return e0.elapsed_time(e1) / (3 * reps)
 
 
 shapes = [('L8.q.s2', C.CONV_K2S2, 4, 2, 2, 2048, 1024), ('L8.q.s1', C.CONV_K2S1, 4, 1, 1, 1024, 1024),
@@ -38,7 +49,7 @@ for name, mode, n, h, w, cin, cout in shapes:
     for tile in (17, 18, 20, 34):
         t = timeit(lambda: C.conv_forward(mode, x, cin, cin, None, 0, 0, n, h, w, wk, packed, bias, cout, out, cout, tile_hint=tile))
         res.append(('t%d' % tile, t))
-        for ks in (4, 16, 64, 128):
+        for ks in (4, 16, 32, 64, 128):
             t = timeit(lambda: C.conv_forward_splitk(mode, ks, x, cin, cin, None, 0, 0, n, h, w, packed, bias, cout, out, cout, tile_hint=tile))
             res.append(('t%d/k%d' % (tile, ks), t))
     best = min(res, key=lambda r: r[1])
