@@ -937,6 +937,8 @@ def repack_table(entries, device):
     tab = np.zeros(len(entries), dtype=np.dtype(REPACK_FIELDS))
     blocks = 0
     for i, e in enumerate(entries):
+        if e['dst'].numel() % 4 or e['dst'].data_ptr() % 16:          # (the refresh launch stores quads)
+            raise NLTError("repack_table: a packed buffer must be 16-byte aligned and a multiple of 4 floats long")
         tab[i] = (e['src'].data_ptr(), e['dst'].data_ptr(), e['dst'].numel(), blocks, e['kind'], e['mode'], e['c0'], e['c1'],
                   e['cout'], e['tn'], e['lo'], e['full'])
         blocks += (e['dst'].numel() + 255) // 256

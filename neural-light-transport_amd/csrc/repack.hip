@@ -13,33 +13,49 @@ __device__ __forceinline__ float frag(const nlt_repack_desc& e, long idx) {
   return nlt_mfma_fragment<MODE>(e.src, idx, e.c0, e.c1, e.cout, N, (N + 15) >> 4, e.full, e.lo);
 }
 
-__global__ __launch_bounds__(256) void repack_all_kernel(const nlt_repack_desc* __restrict__ d, int nd) {
+template <int MODE>
+__device__ __forceinline__ f32x4 frag4(const nlt_repack_desc& e, long idx) {
+  return (f32x4){frag<MODE>(e, idx), frag<MODE>(e, idx + 1), frag<MODE>(e, idx + 2), frag<MODE>(e, idx + 3)};
+}
+
+// One wave per 256 packed elements; a lane fills FOUR consecutive ones (in every layout they are the four channels of one
+// (tile, lane) slot: the index arithmetic -- a binary search and several divisions by runtime values -- is done once per quad) with
+// one 16-byte store.  r01-r05: one element and one 4-byte store per thread, 40 us per train step at config 4.
+__global__ __launch_bounds__(64) void repack_all_kernel(const nlt_repack_desc* __restrict__ d, int nd) {
   int lo = 0, hi = nd;                                                 // last descriptor with first_block <= blockIdx.x
   while (hi - lo > 1) {
     const int mid = (lo + hi) >> 1;
     if (d[mid].first_block <= (long)blockIdx.x) lo = mid; else hi = mid;
   }
   const nlt_repack_desc e = d[lo];
-  const long idx = ((long)blockIdx.x - e.first_block) * 256 + threadIdx.x;
-  if (idx >= e.total) return;
-  float v;
-  if (e.kind == NLT_REPACK_WINO) v = nlt_wino_fragment(e.src, idx, e.c0, e.cout, e.tn >> 4, e.full, e.lo, e.mode == NLT_DECONV_K2S1);
-  else if (e.kind == NLT_REPACK_TILE && e.mode == NLT_DECONV_K2S2) v = nlt_tile_fragment_d2(e.src, idx, e.c0, e.cout, e.tn >> 4, e.full, e.lo);
-  else if (e.kind == NLT_REPACK_TILE)
-    v = nlt_tile_fragment(e.src, idx, e.c0, e.cout, e.tn >> 4, e.full, e.lo, e.mode == NLT_DECONV_K2S1 || e.mode == NLT_DECONV_K2S2);
-  else if (e.mode == NLT_CONV1X1) v = frag<NLT_CONV1X1>(e, idx);
-  else if (e.mode == NLT_CONV_K2S2) v = frag<NLT_CONV_K2S2>(e, idx);
-  else if (e.mode == NLT_CONV_K2S1) v = frag<NLT_CONV_K2S1>(e, idx);
-  else if (e.mode == NLT_DECONV_K2S2) v = frag<NLT_DECONV_K2S2>(e, idx);
-  else v = frag<NLT_DECONV_K2S1>(e, idx);
-  e.dst[idx] = v;
+  const long idx = ((long)blockIdx.x - e.first_block) * 256 + threadIdx.x * 4;
+  if (idx >= e.total) return;                                          // (totals are multiples of 256)
+  f32x4 v;
+  if (e.kind == NLT_REPACK_WINO) {
+    const bool tr = e.mode == NLT_DECONV_K2S1;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) v[j] = nlt_wino_fragment(e.src, idx + j, e.c0, e.cout, e.tn >> 4, e.full, e.lo, tr);
+  } else if (e.kind == NLT_REPACK_TILE && e.mode == NLT_DECONV_K2S2) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) v[j] = nlt_tile_fragment_d2(e.src, idx + j, e.c0, e.cout, e.tn >> 4, e.full, e.lo);
+  } else if (e.kind == NLT_REPACK_TILE) {
+    const bool tr = e.mode == NLT_DECONV_K2S1 || e.mode == NLT_DECONV_K2S2;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) v[j] = nlt_tile_fragment(e.src, idx + j, e.c0, e.cout, e.tn >> 4, e.full, e.lo, tr);
+  }
+  else if (e.mode == NLT_CONV1X1) v = frag4<NLT_CONV1X1>(e, idx);
+  else if (e.mode == NLT_CONV_K2S2) v = frag4<NLT_CONV_K2S2>(e, idx);
+  else if (e.mode == NLT_CONV_K2S1) v = frag4<NLT_CONV_K2S1>(e, idx);
+  else if (e.mode == NLT_DECONV_K2S2) v = frag4<NLT_DECONV_K2S2>(e, idx);
+  else v = frag4<NLT_DECONV_K2S1>(e, idx);
+  *reinterpret_cast<f32x4*>(e.dst + idx) = v;
 }
 
 }  // namespace
 
 extern "C" int nlt_repack_weights(const nlt_repack_desc* descs_device, int n_desc, long total_blocks, void* stream) {
   if (!descs_device || n_desc <= 0 || total_blocks <= 0 || total_blocks >= (1l << 31)) return NLT_ERR_BAD_ARG;
-  hipLaunchKernelGGL(repack_all_kernel, dim3((unsigned)total_blocks), dim3(256), 0, static_cast<hipStream_t>(stream),
+  hipLaunchKernelGGL(repack_all_kernel, dim3((unsigned)total_blocks), dim3(64), 0, static_cast<hipStream_t>(stream),
                      descs_device, n_desc);
   NLT_CHECK_LAUNCH();
   return NLT_OK;

@@ -550,32 +550,38 @@ class RenderPlan(OverrideMixin):
             tkey = ('fwd', base.data_ptr(), cvis.data_ptr(), lvis.data_ptr(), nn_rgb.data_ptr(), nn_base.data_ptr(),
                     bool(skip_connect_base), algo, inference, fused, C._stream(), pred_out is not None,
                     ovr['serial'] if use_ovr else 0)
-            tapes = b.setdefault('tapes', {})
-            if len(tapes) > 16:                     # ever-changing input addresses (a loader that allocates per step): forget
-                tapes.clear()
-            ent = tapes.get(tkey, 0)
-            if isinstance(ent, tuple):
-                if self._replayable(b, ent, reg):
-                    reg.touch_keys(ent[4])              # (a replay reads its fragment buffers without asking: tell a running census)
-                    C.replay(ent)
-                    self.tape_replays += 1
-                    return self._finish_pred(b), b
-                ent = 1
-            tapes[tkey] = 1
-            if ent == 1:
-                C.tape_begin()
-                reg.begin_record()
-                try:
-                    out = self._forward_body(b, base, cvis, lvis, nn_rgb, nn_base, obs_weights, obs_override, skip_connect_base,
-                                             algo, fused, inference, ovr)
-                except BaseException:
-                    C.tape_abort()
-                    reg.end_record()
-                    raise
-                tapes[tkey] = C.tape_end(reg.version, reg.end_record()) or 1  # (None: a workspace grew while recording -> record again)
-                return out
+            return self._run_taped(b, reg, tkey, lambda: self._forward_body(
+                b, base, cvis, lvis, nn_rgb, nn_base, obs_weights, obs_override, skip_connect_base, algo, fused, inference, ovr))
         return self._forward_body(b, base, cvis, lvis, nn_rgb, nn_base, obs_weights, obs_override, skip_connect_base, algo,
                                   fused, inference, ovr)
+
+    def _run_taped(self, b, reg, tkey, body):
+        """`body()` under the launch tape of this (inputs, plan state) key: first sight runs it, second sight records it, later
+        sights replay the record (csrc/tape.hip) -- as long as the buffers and packed fragments it baked in are still the ones."""
+        tapes = b.setdefault('tapes', {})
+        if len(tapes) > 16:                     # ever-changing input addresses (a loader that allocates per step): forget
+            tapes.clear()
+        ent = tapes.get(tkey, 0)
+        if isinstance(ent, tuple):
+            if self._replayable(b, ent, reg):
+                reg.touch_keys(ent[4])              # (a replay reads its fragment buffers without asking: tell a running census)
+                C.replay(ent)
+                self.tape_replays += 1
+                return self._finish_pred(b), b
+            ent = 1
+        tapes[tkey] = 1
+        if ent == 1:
+            C.tape_begin()
+            reg.begin_record()
+            try:
+                out = body()
+            except BaseException:
+                C.tape_abort()
+                reg.end_record()
+                raise
+            tapes[tkey] = C.tape_end(reg.version, reg.end_record()) or 1  # (None: a workspace grew while recording -> record again)
+            return out
+        return body()
 
     def _forward_resident(self, res, skip_connect_base, algo):
         """Inference forward whose inputs are still in the resident uint8 store: same plan, the front launch is
@@ -600,29 +606,8 @@ class RenderPlan(OverrideMixin):
         tkey = None
         if self.use_tape and self.timer is None and not self._tuning and reg is not None:
             tkey = ('fwd_u8',) + res.key() + (bool(skip_connect_base), algo, C._stream(), self._pred_out is not None)
-            tapes = b.setdefault('tapes', {})
-            if len(tapes) > 16:
-                tapes.clear()
-            ent = tapes.get(tkey, 0)
-            if isinstance(ent, tuple):
-                if self._replayable(b, ent, reg):
-                    reg.touch_keys(ent[4])
-                    C.replay(ent)
-                    self.tape_replays += 1
-                    return self._finish_pred(b), b
-                ent = 1
-            tapes[tkey] = 1
-            if ent == 1:
-                C.tape_begin()
-                reg.begin_record()
-                try:
-                    out = self._forward_fused(b, None, None, None, None, None, skip_connect_base, algo, resident=res)
-                except BaseException:
-                    C.tape_abort()
-                    reg.end_record()
-                    raise
-                tapes[tkey] = C.tape_end(reg.version, reg.end_record()) or 1
-                return out
+            return self._run_taped(b, reg, tkey, lambda: self._forward_fused(b, None, None, None, None, None, skip_connect_base, algo,
+                                                                             resident=res))
         return self._forward_fused(b, None, None, None, None, None, skip_connect_base, algo, resident=res)
 
     def _forward_body(self, b, base, cvis, lvis, nn_rgb, nn_base, obs_weights, obs_override, skip_connect_base, algo, fused,

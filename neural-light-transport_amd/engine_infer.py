@@ -183,29 +183,7 @@ class OverrideMixin:
         if self.use_tape and dev.type == 'cuda' and self.timer is None and not self._tuning and reg is not None:
             tkey = ('ovr_u8', res.diffuse.data_ptr(), res.cvis.data_ptr(), res.lvis.data_ptr(), res.ids.data_ptr(), n,
                     bool(skip_connect_base), algo, C._stream(), self._pred_out is not None, ovr['serial'])
-            tapes = b.setdefault('tapes', {})
-            if len(tapes) > 16:
-                tapes.clear()
-            ent = tapes.get(tkey, 0)
-            if isinstance(ent, tuple):
-                if self._replayable(b, ent, reg):
-                    reg.touch_keys(ent[4])
-                    C.replay(ent)
-                    self.tape_replays += 1
-                    return self._finish_pred(b), b
-                ent = 1
-            tapes[tkey] = 1
-            if ent == 1:
-                C.tape_begin()
-                reg.begin_record()
-                try:
-                    out = body()
-                except BaseException:
-                    C.tape_abort()
-                    reg.end_record()
-                    raise
-                tapes[tkey] = C.tape_end(reg.version, reg.end_record()) or 1
-                return out
+            return self._run_taped(b, reg, tkey, body)
         return body()
 
     def _forward_ovr(self, b, base, cvis, lvis, st, skip_connect_base, algo, resident=None):
