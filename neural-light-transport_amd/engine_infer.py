@@ -17,6 +17,10 @@ the K of every stride-2 encoder conv, a quarter (bottleneck) to two thirds of th
 The two fused expanding blocks (csrc/dec_block.hip) and the back kernel (csrc/fused.hip) have map variants as well
 (nlt_dec_block_forward_map, nlt_back_forward_map): the given half of no interleaved feature buffer is ever written or read.
 
+What qualifies (`can_fuse_override`): one [1,h,w,C] map per level, an expand()ed view of one, or a materialised [N,h,w,C] tensor whose
+frames are copies of one map (the reference's tf.tile(x, (bs, 1, 1, 1)), nlt/nlt_test.py:83-86; checked on the device once per tensor
+set).  Store-resident batches (Dataset.load_batch(resident=True)) are read in place (`_forward_resident_ovr`, nlt_front_ovr_forward_u8).
+
 Same re-association as the folded front kernel (sum over [q | ovr] channels split into two sums): <= 1e-6 rel-L2 from the
 layer-by-layer plan, <= 1e-4 from the oracle (tests/test_gpu_infer.py).
 """
@@ -65,19 +69,38 @@ class OverrideMixin:
         if len(obs_override) != D + 1 or (h | w) & 3:
             return False
         hh, ww = h, w
+        tiled = False
         for l, t in enumerate(obs_override):                # one map per level, shared by every frame
             if not (torch.is_tensor(t) and t.dim() == 4 and t.dtype == torch.float32 and tuple(t.shape[1:]) == (hh, ww, cl[l])
-                    and (t.shape[0] == 1 or t.stride(0) == 0) and (not arrays or t.device == arrays[0].device)):
+                    and t.shape[0] >= 1 and (not arrays or t.device == arrays[0].device)):
                 return False
+            tiled = tiled or (t.shape[0] != 1 and t.stride(0) != 0)
             hh, ww = hh // 2, ww // 2
         last = q.layers[D + U].convs()
         prev = q.layers[D + U - 1].convs()
         acts = [a for blk in (q.layers[1], q.layers[2], q.layers[D + U]) for _, a in blk.convs()]
         (qa2, _), _ = q.layers[2].convs()
-        return (cl[0] == 16 and cl[1] == 16 and cl[2] == 32 and last[0][0].n_ch_out == 4 and last[1][0].n_ch_out == 4
+        if not (cl[0] == 16 and cl[1] == 16 and cl[2] == 32 and last[0][0].n_ch_out == 4 and last[1][0].n_ch_out == 4
                 and prev[1][0].n_ch_out == 8 and q.layers[-1].n_ch_out == 3
                 and all(a is not None for a in acts) and len({a.alpha for a in acts}) == 1 and 0.0 <= acts[0].alpha <= 1.0
-                and all(c % 4 == 0 for c in cl) and C.front4_supported(*arrays))
+                and all(c % 4 == 0 for c in cl) and C.front4_supported(*arrays)):
+            return False
+        # a MATERIALISED [N,h,w,C] override -- what the reference's own call site hands over: tf.tile(x, (bs, 1, 1, 1)),
+        # nlt/nlt_test.py:83-86 -- takes this plan when its frames are copies of one map (checked on the device once per tensor set)
+        return not tiled or self._frames_identical(obs_override)
+
+    def _frames_identical(self, obs_override):
+        key = tuple((t.data_ptr(), t._version, tuple(t.shape), t.stride(0)) for t in obs_override)
+        with OverrideMixin._lock:
+            c = getattr(self.q, '_ovr_same', None)
+            if c is not None and c[0] == key:
+                return c[1]
+        if obs_override[0].is_cuda and torch.cuda.is_current_stream_capturing():
+            return False                                    # (the verdict is a device -> host read: not inside a graph capture)
+        same = bool(torch.stack([(t[1:] == t[:1]).all() for t in obs_override if t.shape[0] > 1 and t.stride(0) != 0]).all())
+        with OverrideMixin._lock:                           # (the tensors are kept: their addresses cannot be handed out again)
+            self.q._ovr_same = (key, same, list(obs_override))
+        return same
 
     def _ovr_stamp(self, obs_override):
         q = self.q

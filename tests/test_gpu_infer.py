@@ -306,3 +306,41 @@ def test_infer_on_store_resident_batches_equals_infer_on_the_assembled_float_bat
     pm.plan.fuse_override = False
     gen = pm.call(res[0], 'test', obs_override=agg)
     assert rel_l2(gen[3]['pred'].cpu(), first[0].cpu()) <= 1e-5
+
+
+def test_a_tiled_override_takes_the_fused_plan_and_a_per_frame_one_does_not():
+    """The reference's call site hands Model.call `tf.tile(feat, (bs, 1, 1, 1))` (nlt/nlt_test.py:83-86): a materialised [N,h,w,C]
+    tensor whose frames are copies.  The plan checks that on the device (once per tensor set) and takes the fused query-only plan --
+    same texels, bit for bit, as with the [1,h,w,C] maps; frames that differ keep the general plan (and its answer)."""
+    uv, cam, n = 128, 64, 3
+    om, pm = make_pair(depth=256, uv=uv, im=cam, seed=61)
+    pm.build('cuda')
+    tr = [O.synth_batch(2, uv, uv, cam, cam, cam, cam, k=1, seed=62)]
+    batch, nn = O.synth_batch(n, uv, uv, cam, cam, cam, cam, k=1, seed=63)
+    agg = [a.cuda() for a in _agg_from_oracle(om, tr)]
+    db = to_device_batch(batch, nn)
+    one = pm.call(db, 'test', obs_override=agg)[3]['pred'].clone()
+    serial = pm.plan._ovr['serial']
+    tiled = [a.repeat(n, 1, 1, 1) for a in agg]
+    got = pm.call(db, 'test', obs_override=tiled)[3]['pred'].clone()
+    assert pm.plan._ovr['serial'] != serial                   # (other tensors: the state was rebuilt -- on the fused plan)
+    assert torch.equal(got, one)
+    r0 = pm.plan.tape_replays
+    for _ in range(3):
+        again = pm.call(db, 'test', obs_override=tiled)[3]['pred']
+    assert pm.plan.tape_replays > r0 and torch.equal(again, one)
+    # frames that differ: the general plan, checked against the oracle
+    serial = pm.plan._ovr['serial']
+    scale = torch.linspace(1.0, 1.3, n, device='cuda').view(n, 1, 1, 1)
+    per_frame = [t * scale for t in tiled]
+    out = pm.call(db, 'test', obs_override=per_frame)[3]['pred']
+    assert pm.plan._ovr['serial'] == serial
+    with torch.no_grad():
+        ref = om.call(batch, 'test', obs_override=[t.cpu() for t in per_frame], nn_list=nn)[3]['pred']
+    assert rel_l2(out.cpu(), ref) <= TOL
+    # an in-place edit of one frame of the tiled tensors is seen (tensor version): back to the general plan
+    tiled[0][1].mul_(1.5)
+    out2 = pm.call(db, 'test', obs_override=tiled)[3]['pred']
+    with torch.no_grad():
+        ref2 = om.call(batch, 'test', obs_override=[t.cpu() for t in tiled], nn_list=nn)[3]['pred']
+    assert rel_l2(out2.cpu(), ref2) <= TOL and rel_l2(out2.cpu(), one.cpu()) > 1e-4

@@ -304,6 +304,11 @@ def test_fused_override_plan_matches_oracle_and_the_general_plan(monkeypatch, de
     pm.plan.timer = Rec()
     got2 = pm.call(cpu_batch(batch, nn), 'test', obs_override=[f.expand(n, -1, -1, -1) for f in agg])
     assert torch.equal(got2[3]['pred'], got[3]['pred']) or n == 1
+    # ... and so is what the reference's own call site builds: tf.tile(x, (bs, 1, 1, 1)) (nlt/nlt_test.py:83-86), a materialised copy per frame
+    pm.plan.timer = Rec()
+    tiled = [f.repeat(n, 1, 1, 1) for f in agg]
+    got2t = pm.call(cpu_batch(batch, nn), 'test', obs_override=tiled)
+    assert 'F.front' in pm.plan.timer.records and torch.equal(got2t[3]['pred'], got[3]['pred'])
     pm.plan.timer = Rec()
     per_frame = [f.repeat(n, 1, 1, 1) * torch.linspace(1.0, 1.5, n).view(n, 1, 1, 1) for f in agg]
     with torch.no_grad():
@@ -390,7 +395,9 @@ def test_fused_override_plan_on_a_store_resident_batch(monkeypatch):
     want = ref + fl['base']
     want[:, 0, 0, :] = 0
     assert rel_l2(b, want) < 1e-5
-    # a per-frame override cannot take the store-resident path
-    assert not plan.resident_override_ok(res, [f.repeat(n, 1, 1, 1) for f in agg], 0.3)
+    # an override whose frames differ cannot take the store-resident path (copies of one map can: the reference's tf.tile)
+    assert plan.resident_override_ok(res, [f.repeat(n, 1, 1, 1) for f in agg], 0.3)
+    per_frame = [f.repeat(n, 1, 1, 1) * torch.linspace(1.0, 1.5, n).view(n, 1, 1, 1) for f in agg]
+    assert not plan.resident_override_ok(res, per_frame, 0.3)
     with pytest.raises(C.NLTError):
-        plan.forward(None, None, None, None, None, obs_override=[f.repeat(n, 1, 1, 1) for f in agg], inference=True, resident=res)
+        plan.forward(None, None, None, None, None, obs_override=per_frame, inference=True, resident=res)
