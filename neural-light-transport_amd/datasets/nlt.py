@@ -257,7 +257,8 @@ class Dataset:
         resident=True leaves the six UV-space texel buffers in the uint8 store and the uv2cam map in its fp16 store:
         entry 1 (base) is a ResidentTexels and entries 2, 3, 4, 5, 8, 9 are None -- `Model.call` feeds the stores to the
         fused front kernel (29 B per texel read instead of 116 written + 116 read at k = 4) and to the warp, and
-        materialises floats only where something asks for them (`ResidentTexels.materialize`: training, obs_override)."""
+        materialises floats only where something asks for them (`ResidentTexels.materialize`: training, a per-frame obs_override;
+        the inference mode -- one given map per level -- reads the stores in place too, nlt_front_ovr_forward_u8)."""
         s = self.store
         dev = s['cvis'].device
         n = len(ids)
