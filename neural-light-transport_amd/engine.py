@@ -114,6 +114,7 @@ class RenderPlan(OverrideMixin):
         self._trial_c32 = 0             # autotune: 1 = observations folded (mean in registers), 2 = unfolded
         self._ran_c32 = set()
         self.c32_hints = {}             # label -> 1 | 2
+        self.alias_obs = os.environ.get('NLT_ALIAS_OBS', '1') != '0'   # k = 1 inference: observation features live in fm[l]'s second half
         self._trial_splitk = 0          # autotune: K slices to try on the small deep launches
         self._ran_splitk = set()
         self.splitk_hints = {}          # label -> K slices (split-K, csrc/conv_mfma.hip; < 0: its two-launch form) for launches with few GEMM rows
@@ -757,6 +758,7 @@ class RenderPlan(OverrideMixin):
             C.wait_event(side, ev[0])
         hh, ww = h // 2, w // 2
         bf = self.precision == 'bf16' and not train
+        alias_obs = k == 1 and not train and not bf and self.alias_obs
         for l in range(2, D + 1):
             (qa, qact_a), (qb, qact_b) = q.layers[l].convs()
             (oa, oact_a), (ob, oact_b) = o.layers[l].convs()
@@ -772,6 +774,18 @@ class RenderPlan(OverrideMixin):
                     self._conv_bf('L%d.o.s1' % l, ob, oact_b, b['otmp'][l], c, c, None, 0, 0, n * k, h2_, w2_, b['obs'][l], c)
                     self._launch('L%d.o.mean' % l, 4 * n * h2_ * w2_ * c * (k + 1), C.obs_mean_bf16, b['obs'][l], n, k, h2_ * w2_, c,
                                  b['fm'][l].view(-1)[c:], 2 * c, moved=2 * n * h2_ * w2_ * c * (k + 1))
+                    return
+                if alias_obs:
+                    # ONE observation per frame, inference: the level's observation features ARE its "mean" -- the stride-1 conv
+                    # writes them straight into the second half of the interleaved map and the next level reads them there
+                    # (no obs[l] buffer traffic, no mean launch: one launch per level off the chain of the released shapes)
+                    if not s2_done:
+                        if l > 2:
+                            self._conv_enc('L%d.o.s2' % l, oa, oact_a, b['fm'][l - 1].view(-1)[cl[l - 1]:], cl[l - 1], 2 * cl[l - 1],
+                                           n, 1, hh, ww, b['otmp'][l], c, algo)
+                        else:
+                            self._conv_enc('L%d.o.s2' % l, oa, oact_a, b['obs'][1], cl[1], cl[1], n, 1, hh, ww, b['otmp'][l], c, algo)
+                    self._conv_enc('L%d.o.s1' % l, ob, oact_b, b['otmp'][l], c, c, n, 1, h2_, w2_, b['fm'][l].view(-1)[c:], 2 * c, algo)
                     return
                 if not s2_done:
                     self._conv_enc('L%d.o.s2' % l, oa, oact_a, b['obs'][l - 1], cl[l - 1], cl[l - 1], n, k, hh, ww, b['otmp'][l], c, algo)
