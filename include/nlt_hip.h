@@ -678,20 +678,6 @@ int nlt_conv_forward_splitk(int mode, int tile_hint, int ksplit, float* workspac
                             int cout, float* out, int ldo, int act, float alpha,
                             const float* mask_src, int ldm, int accumulate, void* stream);
 
-/* TWO convs of one encoder family (mode CONV_K2S2 or CONV_K2S1, single source each, same n / h / w / cout / activation) in ONE
- * launch: the query conv and the observation conv of a U-Net level at one observation per frame (nlt/models/nlt.py:150-170 runs
- * them as two Keras layers).  Member a: src_a (c_a channels, per-texel stride ld_a) -> out_a (stride ldo_a) with w_packed_a =
- * nlt_pack_conv_weights(mode, kernel_a, c_a, 0, cout), bias_a; member b likewise.  At the released shapes' deep levels each conv is
- * a few dozen workgroups: two launches on two streams pay an event hand-over per level, one launch shares the chip.  ksplit >= 1 as
- * nlt_conv_forward_splitk's one-launch form (workspace: nlt_conv_pair_workspace_floats() floats, zeroed once by the caller). */
-long nlt_conv_pair_workspace_floats(int mode, int n, int h, int w, int cout, int ksplit);
-int nlt_conv_forward_pair(int mode, int tile_hint, int ksplit, float* workspace,
-                          const float* src_a, int ld_a, int c_a, const float* w_packed_a, const float* bias_a,
-                          float* out_a, int ldo_a,
-                          const float* src_b, int ld_b, int c_b, const float* w_packed_b, const float* bias_b,
-                          float* out_b, int ldo_b,
-                          int n, int h, int w, int cout, int act, float alpha, void* stream);
-
 /*
  * The reference's INFERENCE mode: Model.call(batch, 'test', obs_override=feat_agg) (nlt/nlt_test.py:78-94,
  * nlt/models/nlt.py:154-155,172-174).  Every level's aggregated observation map is GIVEN -- one [1,h,w,C] map shared by all

@@ -104,9 +104,6 @@ SIGNATURES = {
     'nlt_conv_forward_splitk': (_c_int, [_c_int, _c_int, _c_int, _vp, _vp, _c_int, _c_int, _vp, _c_int, _c_int,
                                          _c_int, _c_int, _c_int, _vp, _vp, _c_int, _vp, _c_int, _c_int, _c_float,
                                          _vp, _c_int, _c_int, _vp]),
-    'nlt_conv_pair_workspace_floats': (_c_long, [_c_int] * 6),
-    'nlt_conv_forward_pair': (_c_int, [_c_int, _c_int, _c_int, _vp] + [_vp, _c_int, _c_int, _vp, _vp, _vp, _c_int] * 2 +
-                              [_c_int] * 4 + [_c_int, _c_float, _vp]),
     'nlt_conv_forward_map': (_c_int, [_c_int, _c_int, _c_int, _vp, _vp, _c_int, _c_int, _vp, _c_int, _c_int,
                                       _c_int, _c_int, _c_int, _vp, _vp, _c_int, _vp, _c_int, _c_int, _c_float,
                                       _vp, _c_int, _vp]),
@@ -890,21 +887,6 @@ def conv_forward_splitk(mode, ksplit, src0, c0, ld0, src1, c1, ld1, n, h, w, w_p
     _check(lib().nlt_conv_forward_splitk(mode, tile_hint, ksplit, _ptr(ws), _ptr(src0), ld0, c0, _ptr(src1), ld1, c1, n, h, w,
                                          _ptr(w_packed), _ptr(bias), cout, _ptr(out), ldo, 1 if act else 0, float(alpha),
                                          _ptr(mask_src), ldm, 1 if accumulate else 0, _stream()), 'nlt_conv_forward_splitk')
-
-
-def conv_forward_pair(mode, ksplit, src_a, c_a, ld_a, w_packed_a, bias_a, out_a, ldo_a, src_b, c_b, ld_b, w_packed_b, bias_b, out_b, ldo_b,
-                      n, h, w, cout, act=True, alpha=0.3, tile_hint=0, w_keras=None):
-    """Two single-source convs of one encoder family in one launch (include/nlt_hip.h: nlt_conv_forward_pair).  (w_keras = the two
-    Keras arrays: not read here; the host tests' CPU emulation computes from them.)"""
-    ws = None
-    if ksplit > 1:
-        need = lib().nlt_conv_pair_workspace_floats(mode, n, h, w, cout, ksplit)
-        if need <= 0:
-            raise NLTError("nlt_conv_pair_workspace_floats failed")
-        ws = _splitk_workspace(need, src_a.device)
-    _check(lib().nlt_conv_forward_pair(mode, tile_hint, max(ksplit, 1), _ptr(ws), _ptr(src_a), ld_a, c_a, _ptr(w_packed_a), _ptr(bias_a),
-                                       _ptr(out_a), ldo_a, _ptr(src_b), ld_b, c_b, _ptr(w_packed_b), _ptr(bias_b), _ptr(out_b), ldo_b,
-                                       n, h, w, cout, 1 if act else 0, float(alpha), _stream()), 'nlt_conv_forward_pair')
 
 
 def conv_forward_map(mode, ksplit, src0, c0, ld0, src1, c1, ld1, n, h, w, w_packed, bias, cout, out, ldo, bias_map,

@@ -65,29 +65,6 @@ extern "C" int nlt_conv_forward_splitk(int mode, int tile_hint, int ksplit, floa
   return nlt_conv_mfma_launch(mode, p, tile_hint, static_cast<hipStream_t>(stream), ksplit, workspace);
 }
 
-extern "C" long nlt_conv_pair_workspace_floats(int mode, int n, int h, int w, int cout, int ksplit) {
-  const long one = nlt_conv_splitk_workspace_floats(mode, n, h, w, cout, ksplit < 1 ? 1 : ksplit);
-  return one < 0 ? -1 : 2 * one - NLT_SPLITK_COUNTERS;             // one counter block, two members' partial tiles
-}
-
-extern "C" int nlt_conv_forward_pair(int mode, int tile_hint, int ksplit, float* workspace,
-                                     const float* src_a, int ld_a, int c_a, const float* w_packed_a, const float* bias_a,
-                                     float* out_a, int ldo_a,
-                                     const float* src_b, int ld_b, int c_b, const float* w_packed_b, const float* bias_b,
-                                     float* out_b, int ldo_b,
-                                     int n, int h, int w, int cout, int act, float alpha, void* stream) {
-  if (ksplit < 1 || (ksplit > 1 && (!workspace || !nlt_aligned16(workspace)))) return NLT_ERR_BAD_ARG;
-  if (mode != NLT_CONV_K2S2 && mode != NLT_CONV_K2S1) return NLT_ERR_UNSUPPORTED;
-  ConvP pa, pb;
-  int st = nlt_fill_conv_params(pa, mode, src_a, ld_a, c_a, nullptr, 0, 0, n, h, w, w_packed_a, bias_a, cout, out_a, ldo_a, act, alpha,
-                                nullptr, 0, 0);
-  if (st != NLT_OK) return st;
-  st = nlt_fill_conv_params(pb, mode, src_b, ld_b, c_b, nullptr, 0, 0, n, h, w, w_packed_b, bias_b, cout, out_b, ldo_b, act, alpha,
-                            nullptr, 0, 0);
-  if (st != NLT_OK) return st;
-  return nlt_conv_mfma_launch_pair(mode, pa, pb, tile_hint, static_cast<hipStream_t>(stream), ksplit, workspace);
-}
-
 extern "C" int nlt_conv_forward_map(int mode, int tile_hint, int ksplit, float* workspace,
                                     const float* src0, int ld0, int c0, const float* src1, int ld1, int c1,
                                     int n, int h, int w, const float* w_packed, const float* bias,

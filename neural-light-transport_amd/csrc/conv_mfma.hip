@@ -64,23 +64,21 @@ __device__ __forceinline__ void split_store(const ConvP& p, int otex, int oc, f3
   *d = v;
 }
 
-// `bid` = the workgroup's index inside ITS launch member (a pair launch runs two convs side by side, conv_mfma_pair_kernel);
-// cnt_off / slab_off = where this member's ticket counters / partial tiles start in the workspace.
 template <int MODE, int RT, int CT, int PF, int NW>           // NW = 0: no split, 4 independent waves; NW = 4 | 16: split-K workgroup
-__device__ __forceinline__ void conv_mfma_body(const ConvP& p, int mtiles, int ngroups, int ntiles, int ksplit, float* ws,
-                                               int bid, int cnt_off, long slab_off) {
+__global__ __launch_bounds__(NW ? 64 * NW : 256) void conv_mfma_kernel(ConvP p, int mtiles, int ngroups, int ntiles, int ksplit,
+                                                        float* ws) {
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   int ng, mt, ks, kg = 0, tile = 0;
   constexpr bool SPLIT = NW > 0;
   if constexpr (SPLIT) {                         // workgroup = (tile, group of NW K slices); wave = slice in the group
     const int kgroups = (ksplit + NW - 1) / NW;
-    tile = bid / kgroups;
-    kg = bid - tile * kgroups;
+    tile = blockIdx.x / kgroups;
+    kg = blockIdx.x - tile * kgroups;
     ng = tile % ngroups;
     mt = tile / ngroups;
     ks = kg * NW + wv;                            // (ks >= ksplit: an empty slice, zeros -- the wave still meets the barriers)
   } else {
-    int wave = bid * 4 + wv;
+    int wave = blockIdx.x * 4 + wv;
     ng = wave % ngroups; wave /= ngroups;
     mt = wave % mtiles;
     ks = wave / mtiles;                          // (two-launch split-K: every K slice a wave of its own)
@@ -236,8 +234,8 @@ __device__ __forceinline__ void conv_mfma_body(const ConvP& p, int mtiles, int n
     };
     meet();
     if (kgroups > 1) {
-      gu32* cnt = (gu32*)ws + cnt_off;                           // (agent-scope words: global address space, never flat)
-      float* slabs = ws + NLT_SPLITK_COUNTERS + slab_off;
+      gu32* cnt = (gu32*)ws;                                     // (agent-scope words: global address space, never flat)
+      float* slabs = ws + NLT_SPLITK_COUNTERS;
       const int npad = ntiles * 16;
       const size_t slab = (size_t)p.M * npad;
       if (!wv) {
@@ -327,30 +325,6 @@ __device__ __forceinline__ void conv_mfma_body(const ConvP& p, int mtiles, int n
       *o = v;
     }
   }
-}
-
-template <int MODE, int RT, int CT, int PF, int NW>
-__global__ __launch_bounds__(NW ? 64 * NW : 256) void conv_mfma_kernel(ConvP p, int mtiles, int ngroups, int ntiles, int ksplit,
-                                                        float* ws) {
-  conv_mfma_body<MODE, RT, CT, PF, NW>(p, mtiles, ngroups, ntiles, ksplit, ws, blockIdx.x, 0, 0);
-}
-
-// TWO convs of one family in one launch (r06): the query and the observation conv of an encoder level at one observation per
-// frame -- same mode, same output shape, different sources / weights / outputs and K.  At the released shapes' deep levels each of
-// them is a few dozen workgroups and a handful of microseconds; as two launches on two streams they pay an event hand-over per
-// level (137 us of a depth-1024 pass with NO kernel running, profiles/README.md r06_d), as one launch they share the chip.
-struct PairP {
-  ConvP p[2];
-  int ksplit[2], cnt_off[2];
-  long slab_off[2];
-  int mtiles, ngroups, ntiles, blocks0;
-};
-
-template <int MODE, int RT, int CT, int PF, int NW>
-__global__ __launch_bounds__(NW ? 64 * NW : 256) void conv_mfma_pair_kernel(PairP a, float* ws) {
-  const int m = (int)blockIdx.x >= a.blocks0;                   // (uniform: the member's parameters are scalar loads)
-  conv_mfma_body<MODE, RT, CT, PF, NW>(a.p[m], a.mtiles, a.ngroups, a.ntiles, a.ksplit[m], ws, (int)blockIdx.x - (m ? a.blocks0 : 0),
-                                       a.cnt_off[m], a.slab_off[m]);
 }
 
 // bias / accumulate / mask / LeakyReLU and the mode's output addressing of one output quad, exactly as the single-pass epilogue
@@ -493,62 +467,6 @@ int launch_tile(const ConvP& p, int ksplit, float* ws, hipStream_t s) {
   return NLT_OK;
 }
 
-template <int MODE, int RT, int CT>
-int launch_pair_tile(const ConvP& p0, const ConvP& p1, int ksplit, float* ws, hipStream_t s) {
-  PairP a;
-  a.p[0] = p0; a.p[1] = p1;
-  a.ntiles = (p0.N + 15) >> 4;
-  a.ngroups = a.ntiles / CT;
-  a.mtiles = (p0.M + 16 * RT - 1) / (16 * RT);
-  const long tiles = (long)a.mtiles * a.ngroups;
-  if (ksplit < 1 || !ws) ksplit = 1;
-  const int nw = ksplit <= 1 ? 0 : (ksplit >= 16 ? 16 : 4);
-  if (nw && ksplit > nw && 2 * tiles > NLT_SPLITK_COUNTERS) ksplit = nw;
-  int per_wave = 0;
-  long blocks[2], slab = 0;
-  for (int m = 0; m < 2; ++m) {
-    const int total = live_taps<MODE>(a.p[m]) * (chunks16(a.p[m].c0) + chunks16(a.p[m].c1));
-    a.ksplit[m] = ksplit > total ? total : ksplit;
-    if (nw == 0) a.ksplit[m] = 1;
-    const int pw = (total + a.ksplit[m] - 1) / a.ksplit[m];
-    if (pw > per_wave) per_wave = pw;
-    const long kgroups = nw ? (a.ksplit[m] + nw - 1) / nw : 1;
-    blocks[m] = nw ? tiles * kgroups : (tiles + 3) / 4;
-    a.cnt_off[m] = (int)(m * tiles);
-    a.slab_off[m] = slab;
-    slab += kgroups > 1 ? kgroups * (long)p0.M * a.ntiles * 16 : 0;
-  }
-  a.blocks0 = (int)blocks[0];
-  const unsigned grid = (unsigned)(blocks[0] + blocks[1]);
-  const bool pf3 = per_wave >= 24;
-  if (nw == 16) {
-    if (pf3 && RT * CT <= 2)
-      hipLaunchKernelGGL((conv_mfma_pair_kernel<MODE, RT, CT, (RT * CT <= 2 ? 3 : 2), 16>), dim3(grid), dim3(1024), 0, s, a, ws);
-    else
-      hipLaunchKernelGGL((conv_mfma_pair_kernel<MODE, RT, CT, 2, 16>), dim3(grid), dim3(1024), 0, s, a, ws);
-  } else if (nw == 4) {
-    if (pf3) hipLaunchKernelGGL((conv_mfma_pair_kernel<MODE, RT, CT, 3, 4>), dim3(grid), dim3(256), 0, s, a, ws);
-    else hipLaunchKernelGGL((conv_mfma_pair_kernel<MODE, RT, CT, 2, 4>), dim3(grid), dim3(256), 0, s, a, ws);
-  } else {
-    if (pf3) hipLaunchKernelGGL((conv_mfma_pair_kernel<MODE, RT, CT, 3, 0>), dim3(grid), dim3(256), 0, s, a, ws);
-    else hipLaunchKernelGGL((conv_mfma_pair_kernel<MODE, RT, CT, 2, 0>), dim3(grid), dim3(256), 0, s, a, ws);
-  }
-  NLT_CHECK_LAUNCH();
-  return NLT_OK;
-}
-
-template <int MODE>
-int launch_pair_mode(const ConvP& p0, const ConvP& p1, int tile_hint, int ksplit, float* ws, hipStream_t s) {
-  const int ntiles = (p0.N + 15) >> 4;
-  int RT = tile_hint > 0 ? tile_hint >> 4 : 1, CT = tile_hint > 0 ? tile_hint & 15 : 1;
-  if (RT * CT > 4) { RT = 1; CT = (ntiles % 2 == 0) ? 2 : 1; }  // (a pair is for small launches: wave tiles of up to four fragments)
-  if (CT <= 0 || ntiles % CT) return NLT_ERR_UNSUPPORTED;
-#define NLT_TILE(R, C) if (RT == R && CT == C) return launch_pair_tile<MODE, R, C>(p0, p1, ksplit, ws, s);
-  NLT_TILE(1, 1) NLT_TILE(1, 2) NLT_TILE(2, 1) NLT_TILE(2, 2) NLT_TILE(1, 4) NLT_TILE(4, 1)
-#undef NLT_TILE
-  return NLT_ERR_UNSUPPORTED;
-}
-
 template <int MODE>
 int launch_mode(const ConvP& p, int tile_hint, int ksplit, float* ws, hipStream_t s) {
   const int ntiles = (p.N + 15) >> 4;
@@ -596,17 +514,6 @@ int nlt_conv_mfma_launch(int mode, const ConvP& p, int tile_hint, hipStream_t s,
     case NLT_DECONV_K2S1: return launch_mode<NLT_DECONV_K2S1>(p, tile_hint, ksplit, ws, s);
   }
   return NLT_ERR_BAD_ARG;
-}
-
-// two single-source convs of one encoder family (CONV_K2S2 / CONV_K2S1), same output shape, one launch
-int nlt_conv_mfma_launch_pair(int mode, const ConvP& p0, const ConvP& p1, int tile_hint, hipStream_t s, int ksplit, float* ws) {
-  if (!nlt_conv_mfma_supported(mode, p0) || !nlt_conv_mfma_supported(mode, p1)) return NLT_ERR_UNSUPPORTED;
-  if (p0.M != p1.M || p0.N != p1.N || p0.gh != p1.gh || p0.gw != p1.gw || ksplit < 0) return NLT_ERR_BAD_ARG;
-  switch (mode) {
-    case NLT_CONV_K2S2: return launch_pair_mode<NLT_CONV_K2S2>(p0, p1, tile_hint, ksplit, ws, s);
-    case NLT_CONV_K2S1: return launch_pair_mode<NLT_CONV_K2S1>(p0, p1, tile_hint, ksplit, ws, s);
-  }
-  return NLT_ERR_UNSUPPORTED;
 }
 
 extern "C" long nlt_packed_weight_floats(int mode, int c0, int c1, int cout) {

@@ -131,5 +131,4 @@ static inline bool nlt_wgrad_generic_only() {
 // Entry points implemented per algorithm file.
 int nlt_conv_direct_launch(int mode, const ConvP& p, hipStream_t s);
 int nlt_conv_mfma_launch(int mode, const ConvP& p, int tile_hint, hipStream_t s, int ksplit = 1, float* ws = nullptr);
-int nlt_conv_mfma_launch_pair(int mode, const ConvP& p0, const ConvP& p1, int tile_hint, hipStream_t s, int ksplit, float* ws);
 bool nlt_conv_mfma_supported(int mode, const ConvP& p);

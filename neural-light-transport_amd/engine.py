@@ -114,7 +114,6 @@ class RenderPlan(OverrideMixin):
         self._trial_c32 = 0             # autotune: 1 = observations folded (mean in registers), 2 = unfolded
         self._ran_c32 = set()
         self.c32_hints = {}             # label -> 1 | 2
-        self.pair_rows = int(os.environ.get('NLT_PAIR_ROWS', '1024'))   # k = 1 inference: levels of <= this many texels per batch run their two convs per stage as one launch (0: off)
         self.alias_obs = os.environ.get('NLT_ALIAS_OBS', '1') != '0'   # k = 1 inference: observation features live in fm[l]'s second half
         self._trial_splitk = 0          # autotune: K slices to try on the small deep launches
         self._ran_splitk = set()
@@ -225,30 +224,6 @@ class RenderPlan(OverrideMixin):
                        layer.packed(c0, c1) if ok else None, layer.bias.detach(), layer.n_ch_out, out, ldo,
                        act=act is not None, alpha=act.alpha if act is not None else 0.0,
                        algo=algo if ok else C.ALGO_DIRECT, tile_hint=tile_hint if ok else 0, flops=flops)
-
-    def _pair_ok(self, la, acta, lb, actb, c_a, c_b):
-        return (la.mode == lb.mode and la.mode in (C.CONV_K2S2, C.CONV_K2S1) and la.n_ch_out == lb.n_ch_out and la.n_ch_out % 4 == 0
-                and c_a % 4 == 0 and c_b % 4 == 0 and acta is not None and actb is not None and acta.alpha == actb.alpha)
-
-    def _conv_pair(self, label, la, acta, lb, actb, src_a, c_a, ld_a, out_a, ldo_a, src_b, c_b, ld_b, out_b, ldo_b, n, h, w):
-        """The observation conv (a) and the query conv (b) of an encoder level in ONE launch (nlt_conv_forward_pair): at one
-        observation per frame they have the same mode and output shape; wave tile / split-K by plan-time trial under the pair's label."""
-        la.build(c_a, src_a.device); lb.build(c_b, src_b.device)
-        oh, ow = la.out_hw(h, w)
-        cout, rows = la.n_ch_out, n * oh * ow
-        tile_hint = self.tile_hints.get(label, self.tile_hints.get('*', 0))
-        if tile_hint and (((cout + 15) // 16) % (tile_hint & 15) or (tile_hint >> 4) * (tile_hint & 15) > 4):
-            tile_hint = 0                # (pairs run wave tiles of up to four fragments; CT must divide the 16-column tiles)
-        ks = self.splitk_hints.get(label, 1)
-        if self._trial_splitk:
-            npad = -(-cout // 16) * 16
-            ks = self._trial_splitk if (self._trial_splitk > 1 and rows * npad * self._trial_splitk <= (1 << 24)) else 1
-        if ks > 1:
-            self._ran_splitk.add(label)
-        self._launch(label, 4 * (n * h * w * (c_a + c_b) + 2 * rows * cout), C.conv_forward_pair, la.mode, max(ks, 1),
-                     src_a, c_a, ld_a, la.packed(c_a, 0), la.bias.detach(), out_a, ldo_a,
-                     src_b, c_b, ld_b, lb.packed(c_b, 0), lb.bias.detach(), out_b, ldo_b, n, h, w, cout, act=True, alpha=acta.alpha,
-                     tile_hint=tile_hint, w_keras=(la.kernel.detach(), lb.kernel.detach()), flops=2 * rows * 4 * (c_a + c_b) * cout)
 
     def _wino(self, label, layer, act, src, cin, ld, frames, kobs, h, w, out, ldo, mean_out, ldm, flops, obs_weights=None):
         """The launch on the Winograd kernel if the plan (or the running trial) gave it to it; False otherwise.
@@ -784,15 +759,6 @@ class RenderPlan(OverrideMixin):
         hh, ww = h // 2, w // 2
         bf = self.precision == 'bf16' and not train
         alias_obs = k == 1 and not train and not bf and self.alias_obs
-        # ... and from the level whose maps have <= pair_rows texels per batch on, the two convs of a stage are ONE launch
-        # (`_conv_pair`): such launches are a few dozen workgroups each, and the query stream's event hand-over per level costs
-        # more than running them side by side saves
-        pair_from, joined = None, False
-        if alias_obs and self.pair_rows and algo == C.ALGO_AUTO and not self._trial_direct:
-            for l in range(3, D + 1):
-                if n * (h >> l) * (w >> l) <= self.pair_rows:
-                    pair_from = l
-                    break
         for l in range(2, D + 1):
             (qa, qact_a), (qb, qact_b) = q.layers[l].convs()
             (oa, oact_a), (ob, oact_b) = o.layers[l].convs()
@@ -835,19 +801,6 @@ class RenderPlan(OverrideMixin):
                     self._conv_enc('L%d.q.s2' % l, qa, qact_a, b['fm'][l - 1], cin, cin, n, 1, hh, ww, b['qtmp'][l], c, algo)
                 self._conv_enc('L%d.q.s1' % l, qb, qact_b, b['qtmp'][l], c, c, n, 1, h2_, w2_, b['fm'][l], 2 * c, algo)
 
-            if (pair_from is not None and l >= pair_from and self._pair_ok(oa, oact_a, qa, qact_a, cl[l - 1], cin)
-                    and self._pair_ok(ob, oact_b, qb, qact_b, c, c)):
-                if concurrent and not joined:
-                    joined = True
-                    C.record_event(ev[1], side)                     # the query path up to level l - 1 is done
-                    C.wait_event(main, ev[1])
-                half = b['fm'][l - 1].view(-1)[cl[l - 1]:]
-                self._conv_pair('L%d.qo.s2' % l, oa, oact_a, qa, qact_a, half, cl[l - 1], cin, b['otmp'][l], c,
-                                b['fm'][l - 1], cin, cin, b['qtmp'][l], c, n, hh, ww)
-                self._conv_pair('L%d.qo.s1' % l, ob, oact_b, qb, qact_b, b['otmp'][l], c, c, b['fm'][l].view(-1)[c:], 2 * c,
-                                b['qtmp'][l], c, c, b['fm'][l], 2 * c, n, h2_, w2_)
-                hh, ww = hh // 2, ww // 2
-                continue
             obs_path()
             if concurrent:
                 C.record_event(ev[l], main)                         # fm[l]'s observation half is complete

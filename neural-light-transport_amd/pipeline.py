@@ -43,7 +43,7 @@ import torch
 from . import _capi as C
 from .engine import RenderPlan
 
-_PLAN_SWITCHES = ('precision', 'fuse_ends', 'front_l2', 'fuse_dec', 'front_v4', 'two_streams', 'use_tape', 'use_wino', 'use_c32', 'fuse_override', 'alias_obs', 'pair_rows')
+_PLAN_SWITCHES = ('precision', 'fuse_ends', 'front_l2', 'fuse_dec', 'front_v4', 'two_streams', 'use_tape', 'use_wino', 'use_c32', 'fuse_override', 'alias_obs')
 
 
 def _copy_tuning(dst, src):

@@ -613,16 +613,6 @@ def front4_forward_u8(diffuse_store, rgb_store, cvis_store, lvis_store, ids, nn_
                    qtmp2, otmp2)
 
 
-def conv_forward_pair(mode, ksplit, src_a, c_a, ld_a, w_packed_a, bias_a, out_a, ldo_a, src_b, c_b, ld_b, w_packed_b, bias_b, out_b, ldo_b,
-                      n, h, w, cout, act=True, alpha=0.3, tile_hint=0, w_keras=None):
-    s, tr = _MODES[mode]
-    for src, c, ld, bias, out, ldo, wk in ((src_a, c_a, ld_a, bias_a, out_a, ldo_a, w_keras[0]), (src_b, c_b, ld_b, bias_b, out_b, ldo_b, w_keras[1])):
-        y = T.conv2d_same(_view(src, n, h, w, c, ld), wk, bias[:cout], s)
-        if act:
-            y = T.leaky_relu(y, alpha)
-        _view(out, n, y.shape[1], y.shape[2], cout, ldo).copy_(y)
-
-
 def conv_forward_map(mode, ksplit, src0, c0, ld0, src1, c1, ld1, n, h, w, w_packed, bias, cout, out, ldo, bias_map,
                      act=True, alpha=0.3, tile_hint=0, w_keras=None):
     x = _view(src0, n, h, w, c0, ld0)
@@ -672,7 +662,7 @@ def back_forward_map(x, q1, ldq, skip3, n, h2, w2, w_s2q, w_s1, b_s1, w_head, al
     pred.copy_(y)
 
 
-_FUSED = _FUSED + ('conv_forward_pair', 'conv_forward_map', 'front_ovr_forward', 'front_ovr_forward_u8', 'dec_block_forward_map', 'back_forward_map', 'front_pack_l2_weights', 'front2_forward', 'front4_supported', 'front4_forward', 'front4_forward_u8', 'front4_forward_train', 'dec_block_forward', 'act_forward', 'act_backward',
+_FUSED = _FUSED + ('conv_forward_map', 'front_ovr_forward', 'front_ovr_forward_u8', 'dec_block_forward_map', 'back_forward_map', 'front_pack_l2_weights', 'front2_forward', 'front4_supported', 'front4_forward', 'front4_forward_u8', 'front4_forward_train', 'dec_block_forward', 'act_forward', 'act_backward',
                   'pixelnorm_forward', 'pixelnorm_backward', 'norm_forward', 'norm_backward', 'pool2x2_forward', 'pool2x2_backward', 'sub_forward', 'finish_pred')
 
 

@@ -155,50 +155,6 @@ def test_conv_split_k_in_launch_reduction_is_reproducible_and_fresh(mode, n, h, 
         assert torch.equal(out, again), it
 
 
-@pytest.mark.parametrize('mode,n,h,w,ca,cb,cout,tile,ksplit', [
-    (C.CONV_K2S2, 4, 8, 8, 256, 512, 512, 0x12, 1),         # a level of the depth-1024 net: observation conv | query conv over [q | o]
-    (C.CONV_K2S2, 4, 8, 8, 256, 512, 512, 0x12, 8),         # split-K, two groups of four slices per member (tickets of both members)
-    (C.CONV_K2S2, 4, 4, 4, 512, 1024, 1024, 0x11, 32),      # 16-wave workgroups
-    (C.CONV_K2S1, 4, 4, 4, 512, 512, 512, 0x14, 4),         # slices meet in LDS only
-    (C.CONV_K2S1, 4, 1, 1, 1024, 1024, 1024, 0x12, 16),     # 1 x 1 grid: one live tap
-    (C.CONV_K2S1, 2, 16, 16, 128, 128, 128, 0x22, 1),
-    (C.CONV_K2S2, 3, 6, 10, 48, 96, 32, 0x44, 3),           # a wave tile a pair does not run: falls back to a narrow one
-])
-def test_conv_forward_pair_equals_two_launches(mode, n, h, w, ca, cb, cout, tile, ksplit):
-    """nlt_conv_forward_pair (two convs of one family in ONE launch, strided sources / outputs as the plan uses them) against the same
-    two convs launched one by one: bit-identical without split-K (same wave tile, same order of additions), <= 2e-5 of the output
-    scale with it; repeated launches on one workspace reproduce themselves."""
-    g = torch.Generator(device='cuda').manual_seed(ca * 3 + cout + ksplit)
-    k, s, tr = MODES[mode]
-    R = lambda *sh: torch.randn(sh, device='cuda', generator=g)
-    wa, wb = R(k, k, ca, cout) / (4 * ca) ** 0.5, R(k, k, cb, cout) / (4 * cb) ** 0.5
-    pa, pb = C.pack_conv_weights(mode, wa, ca, 0, cout), C.pack_conv_weights(mode, wb, cb, 0, cout)
-    ba, bb = R(cout), R(cout)
-    oh, ow = (h // 2, w // 2) if mode == C.CONV_K2S2 else (h, w)
-    for it in range(4):
-        xa_full = R(n, h, w, ca + 8)                                     # member a reads a channel slice of a wider map
-        xa = xa_full.view(-1)[8:]
-        xb = R(n, h, w, cb)
-        both = torch.full((n, oh, ow, 2 * cout), -7.0, device='cuda')    # the two outputs interleaved in one map, as fm[l]
-        C.conv_forward_pair(mode, ksplit, xa, ca, ca + 8, pa, ba, both.view(-1)[cout:], 2 * cout, xb, cb, cb, pb, bb, both, 2 * cout,
-                            n, h, w, cout, act=True, alpha=0.3, tile_hint=tile)
-        again = torch.empty_like(both)
-        C.conv_forward_pair(mode, ksplit, xa, ca, ca + 8, pa, ba, again.view(-1)[cout:], 2 * cout, xb, cb, cb, pb, bb, again, 2 * cout,
-                            n, h, w, cout, act=True, alpha=0.3, tile_hint=tile)
-        ra, rb = torch.empty(n, oh, ow, cout, device='cuda'), torch.empty(n, oh, ow, cout, device='cuda')
-        th = tile if (tile >> 4) * (tile & 15) <= 4 else 0
-        C.conv_forward(mode, xa, ca, ca + 8, None, 0, 0, n, h, w, wa, pa, ba, cout, ra, cout, act=True, alpha=0.3, algo=C.ALGO_MFMA, tile_hint=th)
-        C.conv_forward(mode, xb, cb, cb, None, 0, 0, n, h, w, wb, pb, bb, cout, rb, cout, act=True, alpha=0.3, algo=C.ALGO_MFMA, tile_hint=th)
-        torch.cuda.synchronize()
-        assert torch.equal(both, again), it
-        got_a, got_b = both[..., cout:], both[..., :cout]
-        if ksplit == 1 and th:
-            assert torch.equal(got_a, ra) and torch.equal(got_b, rb), it
-        else:
-            for got, ref in ((got_a, ra), (got_b, rb)):
-                assert float((got - ref).abs().max()) <= 2e-5 * max(float(ref.abs().max()), 1.0), it
-
-
 @pytest.mark.parametrize('algo', [C.ALGO_DIRECT, C.ALGO_MFMA])
 def test_conv_backward_data_epilogue(algo):
     """mask_src / accumulate: out = (old + conv(x)) * lrelu'(mask)."""
