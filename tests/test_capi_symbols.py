@@ -30,6 +30,21 @@ def test_every_header_symbol_is_exported_and_bound():
     assert syms == set(C.SIGNATURES), (syms ^ set(C.SIGNATURES))
 
 
+def test_the_documents_name_only_entry_points_that_exist():
+    """INTEGRATION.md (the reference-side binding guide), README.md and DESIGN.md must not send a maintainer to an entry point the
+    header no longer declares (r06 removed several with their experiments)."""
+    syms = header_symbols()
+    not_functions = {'nlt_hip', 'nlt_status', 'nlt_amd', 'nlt_test', 'nlt_test_infer', 'nlt_repack_desc', 'nlt_tape_call', 'nlt_common', 'nlt_oracle',
+                     'nlt_wino_fragment', 'nlt_mfma_fragment', 'nlt_tile_fragment'}     # (types, modules, device helpers of csrc/)
+    removed_and_said_so = {'nlt_back_backward_parts', 'nlt_front5_forward', 'nlt_conv_forward_pair'}    # (named as history, with "removed")
+    for doc in ('INTEGRATION.md', 'README.md', 'DESIGN.md'):
+        text = open(os.path.join(ROOT, doc)).read()
+        for name in set(re.findall(r'`(nlt_[a-z0-9_]+)`', text)) | set(re.findall(r'\b(nlt_[a-z0-9_]+)\(', text)):
+            if name in not_functions or name in syms or name.endswith('_'):
+                continue
+            assert doc != 'INTEGRATION.md' and name in removed_and_said_so, "%s names %s, which include/nlt_hip.h does not declare" % (doc, name)
+
+
 def test_metadata_calls_work_without_gpu():
     L = C.lib()
     assert b'gfx950' in L.nlt_version()
