@@ -2,6 +2,8 @@
 counts, dual-source virtual concat, channel-slice outputs, backward-data epilogue) against the
 CPU oracle's TF-semantics primitives.  fp32 tolerance: 2e-5 relative to the output scale
 (K <= 2048 fp32 accumulation, different summation order)."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -140,8 +142,8 @@ def test_conv_split_k_in_launch_reduction_is_reproducible_and_fresh(mode, n, h, 
     out, ref, again = (torch.empty(n, oh, ow, cout, device='cuda') for _ in range(3))
     side = torch.cuda.Stream()
     big = torch.empty(64 << 20, device='cuda')
-    for it in range(12):
-        x = torch.randn(n, h, w, cin, device='cuda', generator=g) * (1.0 + it)
+    for it in range(int(os.environ.get('NLT_STRESS_ITERS', '12'))):
+        x = torch.randn(n, h, w, cin, device='cuda', generator=g) * (1.0 + it % 7)
         torch.cuda.synchronize()
         with torch.cuda.stream(side):                     # streaming traffic on every XCD while the split launches run
             for _ in range(4):
@@ -153,6 +155,37 @@ def test_conv_split_k_in_launch_reduction_is_reproducible_and_fresh(mode, n, h, 
         scale = max(float(ref.abs().max()), 1.0)
         assert float((out - ref).abs().max()) <= 2e-5 * scale, (it, float((out - ref).abs().max()), scale)
         assert torch.equal(out, again), it
+
+
+def test_conv_split_k_launch_shapes_alternating_on_one_workspace():
+    """Launches of different shapes, slice counts and forms (one launch / two launches) share ONE workspace per stream: the ticket
+    counters of one launch are the partial-tile region of none, and every launch leaves its counters at zero -- 300 launches in random
+    order, each checked against the single-slice launch."""
+    g = torch.Generator(device='cuda').manual_seed(77)
+    cases = []
+    for mode, n, h, w, cin, cout, tile, ks in ((C.CONV_K2S1, 4, 1, 1, 1024, 1024, 0x12, 64), (C.CONV_K2S2, 4, 32, 32, 128, 256, 0x22, 8),
+                                                (C.DECONV_K2S2, 4, 2, 2, 1024, 512, 0x12, 16), (C.CONV_K2S2, 4, 2, 2, 2048, 1024, 0x12, -128),
+                                                (C.DECONV_K2S1, 4, 4, 4, 512, 512, 0x22, 32), (C.CONV_K2S1, 2, 16, 16, 256, 256, 0x44, 6),
+                                                (C.CONV_K2S2, 4, 64, 64, 64, 128, 0x22, 4), (C.CONV_K2S2, 4, 32, 32, 128, 256, 0x11, -8)):
+        k, s, tr = MODES[mode]
+        wk = torch.randn((k, k, cout, cin) if tr else (k, k, cin, cout), device='cuda', generator=g) / (k * k * cin) ** 0.5
+        oh, ow = (h // 2, w // 2) if mode == C.CONV_K2S2 else ((2 * h, 2 * w) if mode == C.DECONV_K2S2 else (h, w))
+        cases.append(dict(mode=mode, n=n, h=h, w=w, cin=cin, cout=cout, tile=tile, ks=ks, wk=wk, packed=C.pack_conv_weights(mode, wk, cin, 0, cout),
+                          bias=torch.randn(cout, device='cuda', generator=g), out=torch.empty(n, oh, ow, cout, device='cuda'),
+                          ref=torch.empty(n, oh, ow, cout, device='cuda')))
+    order = torch.randint(0, len(cases), (int(os.environ.get('NLT_STRESS_ITERS', '300')),), generator=torch.Generator().manual_seed(5)).tolist()
+    for it, ci in enumerate(order):
+        c = cases[ci]
+        x = torch.randn(c['n'], c['h'], c['w'], c['cin'], device='cuda', generator=g)
+        C.conv_forward_splitk(c['mode'], c['ks'], x, c['cin'], c['cin'], None, 0, 0, c['n'], c['h'], c['w'], c['packed'], c['bias'], c['cout'],
+                              c['out'], c['cout'], tile_hint=c['tile'])
+        C.conv_forward(c['mode'], x, c['cin'], c['cin'], None, 0, 0, c['n'], c['h'], c['w'], c['wk'], c['packed'], c['bias'], c['cout'],
+                       c['ref'], c['cout'], algo=C.ALGO_MFMA, tile_hint=c['tile'])
+        if it % 25 == 24 or it == len(order) - 1:
+            torch.cuda.synchronize()
+        err = (c['out'] - c['ref']).abs().max()
+        scale = c['ref'].abs().max().clamp(min=1.0)
+        assert float(err) <= 2e-5 * float(scale), (it, ci, float(err), float(scale))
 
 
 @pytest.mark.parametrize('algo', [C.ALGO_DIRECT, C.ALGO_MFMA])
